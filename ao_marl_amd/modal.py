@@ -1,0 +1,179 @@
+"""Init-time calibration of the control path: geometric imat -> actuator filtering -> diffractive
+imat -> influence-function matrix -> Btt modal basis -> Btt-filtered command matrix.
+
+Host NumPy / SciPy, like the reference (these steps are NumPy there too); the only device work is
+"push these commands, give me the slopes", delegated to a backend with
+    backend.dm_response(commands[K, nactu], geometric: bool) -> slopes[K, nslope]
+    backend.reload_dms()          # after the stack-array mirror lost actuators
+In the product the backend is the HIP simulator (ao_marl_amd/sim.py).
+
+Reference results each step must reproduce:
+  imat_geom            shesha/ao/imats.py:54-112
+  correct_dm           shesha/init/dm_init.py:817-889   (-> 88 / 1284 pzt actuators)
+  do_imat              shesha/ao/imats.py:115-167 (push-pull through the full WFS model)
+  compute_IFsparse     shesha/ao/basis.py:126-200
+  compute_btt          shesha/ao/basis.py:362-443
+  compute_cmat_with_Btt shesha/ao/basis.py:229-256, called from rlSupervisor.py:184,215-234
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import geometry as G
+from . import system
+
+
+def _push_matrix(s, dm_k, push):
+    sl = system.dm_command_slices(s)[dm_k]
+    n = sl[1] - sl[0]
+    cmds = np.zeros((n, s.nactu), dtype=np.float32)
+    cmds[np.arange(n), sl[0] + np.arange(n)] = push
+    return cmds
+
+
+def imat_geom(s, backend):
+    """Geometric interaction matrix [nslope, nactu] (slopes per unit command)."""
+    cols = []
+    for k, d in enumerate(s.dms):
+        r = backend.dm_response(_push_matrix(s, k, d.push4imat), geometric=True)
+        cols.append(r.T / np.float32(d.push4imat))
+    return np.concatenate(cols, axis=1).astype(np.float32)
+
+
+def correct_dm(s, sysm, imat, backend):
+    """Drop stack-array actuators whose geometric response is <= thresh * max (dm_init.py:857-859)."""
+    resp = np.sqrt(np.sum(imat.astype(np.float64)**2, axis=0))
+    kept = []
+    for k, (a, b) in enumerate(system.dm_command_slices(s)):
+        d = s.dms[k]
+        if d.type == "pzt":
+            tmp = resp[a:b]
+            ok = np.where(tmp > d.thresh * np.max(tmp))[0]
+            G.pzt_select(d, sysm.geom, ok)
+            kept.append(ok)
+        else:
+            kept.append(np.arange(b - a))
+    system.refresh_dms(s)
+    backend.reload_dms()
+    return kept
+
+
+def imat_diffractive(s, backend):
+    """Push-pull interaction matrix through the full image-formation + COG chain."""
+    cols = []
+    for k, d in enumerate(s.dms):
+        p = _push_matrix(s, k, d.push4imat)
+        plus = backend.dm_response(p, geometric=False)
+        minus = backend.dm_response(-p, geometric=False)
+        cols.append((plus - minus).T / np.float32(2 * d.push4imat))
+    return np.concatenate(cols, axis=1).astype(np.float32)
+
+
+def dm_pupil_window(sysm, d):
+    """Pupil mask on the DM support (basis.py:143-147): centred crop of the big pupil."""
+    ip = sysm.geom.ipupil
+    dm_dim = d.n2 - d.n1 + 1
+    t = (ip.shape[0] - dm_dim) // 2
+    return ip[t:ip.shape[0] - t, t:ip.shape[1] - t]
+
+
+def influence_matrix(s, sysm):
+    """IF [Npup, nactu] (sparse CSC): phase of a unit command of each actuator on the pupil."""
+    blocks = []
+    for d in s.dms:
+        dm_dim = d.n2 - d.n1 + 1
+        pup = dm_pupil_window(sysm, d) > 0
+        # DM arrays live in a dim x dim frame (dim >= dm_dim); production: dim == dm_dim
+        if d.dim != dm_dim:
+            raise NotImplementedError("DM support smaller than mpupil")
+        idx = -np.ones(pup.size, dtype=np.int64)
+        idx[pup.ravel()] = np.arange(int(pup.sum()))
+        npts = int(pup.sum())
+        if d.type == "pzt":
+            ss = d.influsize
+            k = np.arange(ss)
+            rows, cols, vals = [], [], []
+            f = d.influ  # [a (x offset), b (y offset), act]
+            for act in range(d.ntotact):
+                xs = d.i1[act] + k          # x pixel of offset a
+                ys = d.j1[act] + k
+                okx = (xs >= 0) & (xs < dm_dim)
+                oky = (ys >= 0) & (ys < dm_dim)
+                X, Y = np.meshgrid(xs[okx], ys[oky])       # [y, x]
+                p = idx[(X + dm_dim * Y).ravel()]
+                v = f[:, :, act][np.ix_(okx, oky)].T.ravel()  # -> [b(y), a(x)]
+                m = (p >= 0) & (v != 0)
+                rows.append(p[m])
+                cols.append(np.full(int(m.sum()), act))
+                vals.append(v[m])
+            blocks.append(sp.csc_matrix((np.concatenate(vals).astype(np.float64),
+                                         (np.concatenate(rows), np.concatenate(cols))),
+                                        shape=(npts, d.ntotact)))
+        else:
+            pl = d.influ.reshape(-1, 2)[pup.ravel()]
+            blocks.append(sp.csc_matrix(pl.astype(np.float64)))
+    return sp.hstack(blocks, format="csc")
+
+
+def compute_btt(IFpzt, IFtt):
+    """Btt (volts x modes) and P (modes x volts): piston/tip/tilt-free orthonormal (w.r.t. the
+    geometric covariance) basis of the stack-array mirror, plus normalised tip & tilt of the TT
+    mirror as the last two modes (basis.py:362-443)."""
+    N, n = IFpzt.shape
+    if n > N:
+        raise ValueError("Influence functions must be arrange as (Npts_pup x nactus)")
+    delta = (IFpzt.T @ IFpzt).toarray() / N
+    Tp = np.ones((N, 3))
+    Tp[:, :2] = IFtt
+    deltaT = IFpzt.T @ Tp / N
+    tau = np.linalg.solve(delta, deltaT)
+    tdt = tau.T @ delta @ tau
+    Gm = np.identity(n) - tau @ np.linalg.solve(tdt, tau.T @ delta)
+    gdg = Gm.T @ delta @ Gm
+    U, sv, _ = np.linalg.svd(gdg)
+    U, sv = U[:, :n - 3], sv[:n - 3]
+    B = (Gm @ U) / np.sqrt(sv)[None, :]
+    TT = IFtt.T @ IFtt / N
+    Btt = np.zeros((n + 2, n - 1))
+    Btt[:n, :n - 3] = B
+    Btt[n, n - 3] = 1. / np.sqrt(np.abs(TT[0, 0]))
+    Btt[n + 1, n - 2] = 1. / np.sqrt(np.abs(TT[1, 1]))
+    Delta = np.zeros((n + 2, n + 2))
+    Delta[:n, :n] = delta
+    Delta[n:, n:] = TT
+    P = Btt.T @ Delta
+    return Btt.astype(np.float32), P.astype(np.float32)
+
+
+def cmat_with_btt(D, Btt, nfilt):
+    """Command matrix filtering the `nfilt` highest-order Btt modes, TT kept
+    (basis.py:229-256)."""
+    nm = Btt.shape[1]
+    Bf = np.zeros((Btt.shape[0], nm - nfilt))
+    Bf[:, :nm - nfilt - 2] = Btt[:, :nm - (nfilt + 2)]
+    Bf[:, nm - nfilt - 2:] = Btt[:, nm - 2:]
+    Dm = D.astype(np.float64) @ Bf
+    Dmp = np.linalg.solve(Dm.T @ Dm, Dm.T)
+    return (Bf @ Dmp).astype(np.float32)
+
+
+class Calibration(object):
+    pass
+
+
+def calibrate(s, sysm, backend, nfilt=0, verbose=False):
+    """Full init sequence of the controller path; fills s.cmat and returns a Calibration with
+    imat_geom, kept actuators, imat, Btt (= modes2volts), P (= volts2modes), cmat."""
+    c = Calibration()
+    c.imat_geom = imat_geom(s, backend)
+    c.kept = correct_dm(s, sysm, c.imat_geom, backend)
+    if verbose:
+        print("correct_dm: kept", [len(k) for k in c.kept])
+    c.imat = imat_diffractive(s, backend)
+    IF = influence_matrix(s, sysm)
+    ntt = 2
+    c.Btt, c.P = compute_btt(IF[:, :-ntt].tocsc(), IF[:, -ntt:].toarray())
+    c.cmat = cmat_with_btt(c.imat, c.Btt, max(nfilt, 0))
+    s.cmat = np.ascontiguousarray(c.cmat)
+    c.modes2volts, c.volts2modes = c.Btt, c.P
+    c.IF = IF
+    return c

@@ -1,0 +1,309 @@
+"""ctypes loader + single-environment simulator over oracle/aoref.c.
+
+TEST INFRASTRUCTURE ONLY (see oracle/aoref.h): imported by tests/, tools/, bench.py's cpu_baseline
+leg and __graft_entry__.smoke() -- never by the product package.
+
+`OracleSim` sequences the C stage functions exactly like the native objects the reference drives
+(Atmos.move_atmos, Source.raytrace, Wfs.comp_image, Rtc.do_centroids/do_control/apply_control,
+Target.comp_image/comp_strehl -- SURVEY.md Appendix B), one environment, plain NumPy state.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libaoref.so")
+
+_f = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_u = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def build(force=False):
+    src = [os.path.join(HERE, "aoref.c"), os.path.join(HERE, "aoref.h")]
+    if (not force and os.path.exists(LIB) and
+            all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in src)):
+        return LIB
+    subprocess.check_call(["make", "-s", "-C", HERE, "libaoref.so"])
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        L.aoref_philox4x32_10.argtypes = [_u, _u, _u]
+        L.aoref_normals.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, _f]
+        L.aoref_uniforms.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, _f]
+        L.aoref_extrude.argtypes = [_f, C.c_int, _f, C.c_int, _f, _u, C.c_int, C.c_float, _f, _f]
+        L.aoref_raytrace.argtypes = [_f, C.c_int, C.c_int, _f, C.c_int, C.c_float, C.c_float,
+                                     C.c_int]
+        L.aoref_pzt_shape.argtypes = [_f, C.c_int, _f, _i, _i, _i, C.c_int, _f]
+        L.aoref_tt_shape.argtypes = [_f, C.c_int, _f, _f]
+        L.aoref_sh_image.argtypes = [_f, _f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i, _f,
+                                     _i, _f, C.c_float, C.c_float, _f]
+        L.aoref_sh_noise.argtypes = [_f, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint64]
+        L.aoref_cog.argtypes = [_f, C.c_int, C.c_int, C.c_float, C.c_float, _f]
+        L.aoref_fill_binimg.argtypes = [_f, C.c_int, C.c_int, _i, _i, C.c_int, _f]
+        L.aoref_slopes_geom.argtypes = [_f, _f, C.c_int, C.c_int, C.c_int, _i, _f, C.c_float, _f]
+        L.aoref_gemv.argtypes = [_f, C.c_int, C.c_int, _f, _f]
+        L.aoref_ls_control.argtypes = [_f, C.c_int, C.c_int, _f, C.c_float, _f, _f]
+        L.aoref_psf.argtypes = [_f, _f, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.aoref_phase_var.argtypes = [_f, _f, C.c_int]
+        L.aoref_phase_var.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def normals(seed, stream, counter, n):
+    out = np.empty(n, dtype=np.float32)
+    lib().aoref_normals(seed & 0xFFFFFFFF, stream, counter, n, out)
+    return out
+
+
+def uniforms(seed, stream, counter, n):
+    out = np.empty(n, dtype=np.float32)
+    lib().aoref_uniforms(seed & 0xFFFFFFFF, stream, counter, n, out)
+    return out
+
+
+def delay_weights(delay):
+    """voltage = a*com + b*com1 + c*com2 for a pure delay of `delay` frames (0 <= delay <= 2)."""
+    d = float(delay)
+    if d <= 1.0:
+        return (1.0 - d, d, 0.0)
+    return (0.0, 2.0 - d, d - 1.0)
+
+
+class OracleSim(object):
+    """One environment of the AO loop on the CPU oracle; `s` is an ao_marl_amd.system.SimArrays."""
+
+    def __init__(self, s, seed=1234):
+        self.s = s
+        self.L = lib()
+        self.screens = [np.zeros((d, d), dtype=np.float32) for d in s.screen_dim]
+        self.wfs_phase = np.zeros((s.n, s.n), dtype=np.float32)
+        self.tar_phase = np.zeros((s.pupdiam, s.pupdiam), dtype=np.float32)
+        self.bincube = np.zeros((s.nvalid, s.npix * s.npix), dtype=np.float32)
+        self.slopes = np.zeros(s.nslope, dtype=np.float32)
+        self.dm_shapes = [np.zeros((d.dim, d.dim), dtype=np.float32) for d in s.dms]
+        self._influ = []
+        for d in s.dms:
+            if d.type == "pzt":
+                self._influ.append(np.ascontiguousarray(d.influ.flatten("F"), dtype=np.float32))
+            else:
+                self._influ.append(np.ascontiguousarray(d.influ, dtype=np.float32))
+        self._alloc_ctrl()
+        self.ref_peak = float(np.sum(s.spupil, dtype=np.float64))**2
+        self.reset(seed)
+
+    def _alloc_ctrl(self):
+        n = self.s.nactu
+        self.com = np.zeros(n, dtype=np.float32)
+        self.com1 = np.zeros(n, dtype=np.float32)
+        self.com2 = np.zeros(n, dtype=np.float32)
+        self.err = np.zeros(n, dtype=np.float32)
+        self.voltage = np.zeros(n, dtype=np.float32)
+
+    # ---------------------------------------------------------------- reset (A1)
+    def reset(self, seed):
+        s = self.s
+        self.seed = int(seed)
+        self.accumx = np.zeros(s.nscreens, dtype=np.float32)
+        self.accumy = np.zeros(s.nscreens, dtype=np.float32)
+        self.ext_count = [0] * s.nscreens
+        self.frame = 0
+        for l in range(s.nscreens):
+            self.screens[l][:] = 0
+            d = 1 if s.deltax[l] > 0 else -1
+            for _ in range(2 * s.screen_dim[l]):
+                self._extrude(l, d)
+        self._alloc_ctrl()
+        for sh in self.dm_shapes:
+            sh[:] = 0
+        self.reset_strehl()
+
+    def reset_strehl(self):
+        hw = self.s.strehl_halfwin
+        self.le_img = np.zeros((2 * hw, 2 * hw), dtype=np.float64)
+        self.strehl_count = 0
+        self.strehl_se = 0.0
+        self.strehl_le = 0.0
+        self.strehl_se_full = 0.0
+        self.phase_var = 0.0
+        self.phase_var_sum = 0.0
+
+    # ---------------------------------------------------------------- atmosphere (A2)
+    def _extrude(self, l, d):
+        s = self.s
+        n = s.screen_dim[l]
+        ist = s.istx[l] if abs(d) == 1 else s.isty[l]
+        eps = normals(self.seed + l, 0, self.ext_count[l], n)
+        self.ext_count[l] += 1
+        tmp = np.empty(ist.size + n, dtype=np.float32)
+        self.L.aoref_extrude(self.screens[l].reshape(-1), n, s.A[l], ist.size, s.B[l], ist, d,
+                             float(s.amplitude[l]), eps, tmp)
+
+    def move_atmos(self):
+        s = self.s
+        for l in range(s.nscreens):
+            self.accumx[l] = np.float32(self.accumx[l] + s.deltax[l])
+            self.accumy[l] = np.float32(self.accumy[l] + s.deltay[l])
+            kx, ky = int(self.accumx[l]), int(self.accumy[l])
+            for _ in range(abs(kx)):
+                self._extrude(l, 1 if kx > 0 else -1)
+            self.accumx[l] = np.float32(self.accumx[l] - np.float32(kx))
+            for _ in range(abs(ky)):
+                self._extrude(l, 2 if ky > 0 else -2)
+            self.accumy[l] = np.float32(self.accumy[l] - np.float32(ky))
+
+    # ---------------------------------------------------------------- raytrace (A3, A9)
+    def _trace(self, out, atm_off, dm_off, atm, dms, reset):
+        ny, nx = out.shape
+        acc = 0 if reset else 1
+        if reset and not atm and not dms:
+            out[:] = 0
+        if atm:
+            for l in range(self.s.nscreens):
+                self.L.aoref_raytrace(out.reshape(-1), nx, ny, self.screens[l].reshape(-1),
+                                      self.s.screen_dim[l], atm_off[l][0], atm_off[l][1], acc)
+                acc = 1
+        if dms:
+            for k, sh in enumerate(self.dm_shapes):
+                self.L.aoref_raytrace(out.reshape(-1), nx, ny, sh.reshape(-1), sh.shape[0],
+                                      dm_off[k][0], dm_off[k][1], acc)
+                acc = 1
+
+    def raytrace_wfs(self, atm=True, dms=True, reset=True):
+        self._trace(self.wfs_phase, self.s.wfs_atm_off, self.s.wfs_dm_off, atm, dms, reset)
+
+    def raytrace_target(self, atm=True, dms=True, reset=True):
+        self._trace(self.tar_phase, self.s.tar_atm_off, self.s.tar_dm_off, atm, dms, reset)
+
+    # ---------------------------------------------------------------- WFS (A4, A5)
+    def comp_image(self, noise=True):
+        s = self.s
+        self.L.aoref_sh_image(self.wfs_phase.reshape(-1), s.mpupil.reshape(-1), s.nvalid, s.pdiam,
+                              s.nfft, s.npix, s.nrebin, s.phasemap, s.halfxy.reshape(-1), s.binmap,
+                              s.flux, float(s.nphot), s.wfs_lambda, self.bincube)
+        if noise and s.noise >= 0:
+            self.L.aoref_sh_noise(self.bincube, s.nvalid, s.npix * s.npix, s.noise,
+                                  self.seed & 0xFFFFFFFF, self.frame)
+        self.frame += 1
+
+    def binimg(self):
+        s = self.s
+        dim = s.npix * s.nxsub
+        img = np.zeros((dim, dim), dtype=np.float32)
+        self.L.aoref_fill_binimg(self.bincube, s.nvalid, s.npix, s.validsubsx, s.validsubsy, dim,
+                                 img)
+        return img
+
+    def do_centroids(self):
+        s = self.s
+        self.L.aoref_cog(self.bincube, s.nvalid, s.npix, s.cog_offset, s.cog_scale, self.slopes)
+
+    def slopes_geom(self):
+        s = self.s
+        out = np.zeros(s.nslope, dtype=np.float32)
+        self.L.aoref_slopes_geom(self.wfs_phase.reshape(-1), s.mpupil.reshape(-1), s.n, s.nvalid,
+                                 s.pdiam, s.phasemap, s.flux, s.subapd, out)
+        return out
+
+    # ---------------------------------------------------------------- controller (A6, A7, A8)
+    def do_control(self):
+        s = self.s
+        self.L.aoref_ls_control(s.cmat, s.nactu, s.nslope, self.slopes, s.gain, self.err, self.com)
+
+    def set_com(self, com):
+        com = np.asarray(com, dtype=np.float32)
+        if com.size != self.s.nactu:
+            raise ValueError("Dimension mismatch")  # rtcCompass.py:471-472
+        self.com[:] = com
+
+    def apply_control(self, comp_voltage=True):
+        if comp_voltage:
+            a, b, c = delay_weights(self.s.delay)
+            self.voltage[:] = (np.float32(a) * self.com + np.float32(b) * self.com1 +
+                               np.float32(c) * self.com2)
+            self.com2[:] = self.com1
+            self.com1[:] = self.com
+        else:
+            self.voltage[:] = self.com
+        self.comp_shapes(self.voltage)
+
+    def comp_shapes(self, volts):
+        off = 0
+        for k, d in enumerate(self.s.dms):
+            v = np.ascontiguousarray(volts[off:off + d.ntotact], dtype=np.float32)
+            if d.type == "pzt":
+                self.L.aoref_pzt_shape(self.dm_shapes[k].reshape(-1), d.dim, self._influ[k],
+                                       d.influpos, d.ninflu, d.influstart, d.influsize, v)
+            else:
+                self.L.aoref_tt_shape(self.dm_shapes[k].reshape(-1), d.dim,
+                                      self._influ[k].reshape(-1), v)
+            off += d.ntotact
+
+    # ---------------------------------------------------------------- target (A10)
+    def comp_strehl(self, full=False):
+        s = self.s
+        hw = s.strehl_halfwin
+        win = np.zeros((2 * hw, 2 * hw), dtype=np.float32)
+        pf, pw = C.c_float(0), C.c_float(0)
+        self.L.aoref_psf(self.tar_phase.reshape(-1), s.spupil.reshape(-1), s.pupdiam, s.npsf,
+                         s.tar_lambda, hw, None, win.ctypes.data_as(C.c_void_p), C.byref(pf),
+                         C.byref(pw))
+        self.le_img += win
+        self.strehl_count += 1
+        self.strehl_se = pw.value / self.ref_peak
+        self.strehl_se_full = pf.value / self.ref_peak
+        self.strehl_le = float(self.le_img.max()) / self.strehl_count / self.ref_peak
+        self.phase_var = float(self.L.aoref_phase_var(self.tar_phase.reshape(-1),
+                                                      s.spupil.reshape(-1), s.pupdiam))
+        self.phase_var_sum += self.phase_var
+        return self.get_strehl()
+
+    def get_strehl(self):
+        avg = self.phase_var_sum / self.strehl_count if self.strehl_count > 0 else 0.0
+        return [self.strehl_se, self.strehl_le, self.phase_var, avg]
+
+    # ---------------------------------------------------------------- composite frames
+    def next_part_one(self):
+        """rlSupervisor.py:1015-1051 + :954-987 for the integrator controller."""
+        self.move_atmos()
+        if self.s.delay != 0 or True:
+            # pure_delay_0 ("modification_online") is False in every shipped config
+            self.raytrace_target()
+        self.raytrace_wfs(atm=True, dms=False, reset=True)
+        self.raytrace_wfs(atm=False, dms=True, reset=False)
+        self.comp_image()
+        self.do_centroids()
+        self.do_control()
+
+    def next_part_two(self, com_rl=None):
+        """rlSupervisor.py:900-947: optional overwrite of the command, apply, PSF + Strehl."""
+        if com_rl is not None:
+            self.set_com(com_rl)
+        self.apply_control()
+        self.comp_strehl()
+
+    # ---------------------------------------------------------------- calibration backend
+    def dm_response(self, commands, geometric):
+        """slopes for each row of `commands` [K, nactu] with the atmosphere switched off."""
+        out = np.zeros((commands.shape[0], self.s.nslope), dtype=np.float32)
+        for k in range(commands.shape[0]):
+            self.comp_shapes(commands[k])
+            self.raytrace_wfs(atm=False, dms=True, reset=True)
+            if geometric:
+                out[k] = self.slopes_geom()
+            else:
+                self.comp_image(noise=False)
+                self.do_centroids()
+                out[k] = self.slopes
+        return out
