@@ -1,0 +1,801 @@
+// aomarl_capi.hip -- C ABI (include/aomarl.h) over the gfx950 kernels in aomarl_kernels.hip.
+// Host side only sequences kernel launches on the caller's stream; no device<->host copies after
+// aomarl_create / aomarl_set_* (aomarl_reset uploads env_count seeds, 4 bytes each).
+#include "aomarl_kernels.hip"
+
+#include <math.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+#define HIPCHK(x)                                                                            \
+  do {                                                                                       \
+    hipError_t _e = (x);                                                                     \
+    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e),    \
+                                      __FILE__, __LINE__);                                   \
+  } while (0)
+#define LAUNCHCHK()                                                                          \
+  do {                                                                                       \
+    hipError_t _e = hipGetLastError();                                                       \
+    if (_e != hipSuccess) return fail("kernel launch failed: %s (%s:%d)",                    \
+                                      hipGetErrorString(_e), __FILE__, __LINE__);            \
+  } while (0)
+
+struct aomarl_ctx {
+  DevSys sys;
+  std::vector<void *> owned;       // device allocations
+  // host copies needed for scheduling
+  int nlayers = 0, ndm = 0;
+  int dim[AOMARL_MAX_LAYERS], ns[AOMARL_MAX_LAYERS], abclass[AOMARL_MAX_LAYERS];
+  float deltax[AOMARL_MAX_LAYERS], deltay[AOMARL_MAX_LAYERS];
+  int nclass = 0;
+  int maxdim = 0, maxK = 0;
+  float gain = 0.f, delay = 0.f;
+  bool spot_fast = false;
+  // controller matrices
+  float *cmat = nullptr;           // [nactu][ld_s]
+  int ld_cmat = 0;
+  int nmodes = 0, nact = 0, ld_v2m = 0, ld_m2v = 0;
+  float *v2m = nullptr, *m2v = nullptr, *freedom = nullptr;
+  int32_t *amodes = nullptr;
+  uint32_t *seed_stage = nullptr;  // device staging for reset seeds
+  int seed_stage_n = 0;
+};
+
+const char *aomarl_last_error(void) { return g_err; }
+int aomarl_abi_version(void) { return AOMARL_ABI_VERSION; }
+
+template <typename T>
+static int upload(aomarl_ctx *c, const T *host, size_t n, T **dev) {
+  *dev = nullptr;
+  if (n == 0) return 0;
+  if (!host) return fail("null host array in descriptor");
+  void *p = nullptr;
+  HIPCHK(hipMalloc(&p, n * sizeof(T)));
+  c->owned.push_back(p);
+  HIPCHK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+  *dev = (T *)p;
+  return 0;
+}
+
+static bool is_int(float v) { return floorf(v) == v; }
+
+int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
+  if (!d || !out) return fail("aomarl_create: null argument");
+  if (d->abi_version != AOMARL_ABI_VERSION)
+    return fail("aomarl_create: ABI version %d, library is %d", d->abi_version, AOMARL_ABI_VERSION);
+  if (d->nlayers < 0 || d->nlayers > AOMARL_MAX_LAYERS) return fail("nlayers out of range");
+  if (d->ndm < 1 || d->ndm > AOMARL_MAX_DMS) return fail("ndm out of range");
+  if (d->n <= 0 || d->pupdiam <= 0 || d->n < d->pupdiam) return fail("bad pupil sizes");
+  if (d->npsf & (d->npsf - 1)) return fail("npsf must be a power of two");
+  if (!(d->strehl_halfwin == 4 || d->strehl_halfwin == 8 || d->strehl_halfwin == 16))
+    return fail("strehl_halfwin must be 4, 8 or 16");
+  aomarl_ctx *c = new aomarl_ctx();
+  DevSys &s = c->sys;
+  memset(&s, 0, sizeof(s));
+  int rc = 0;
+#define UP(T, host, n, dev)                                      \
+  do {                                                           \
+    T *_p;                                                       \
+    rc = upload<T>(c, host, n, &_p);                             \
+    if (rc) { aomarl_destroy(c); return rc; }                    \
+    dev = _p;                                                    \
+  } while (0)
+  s.n = d->n; s.pupdiam = d->pupdiam;
+  UP(float, d->mpupil, (size_t)d->n * d->n, s.mpupil);
+  UP(float, d->spupil, (size_t)d->pupdiam * d->pupdiam, s.spupil);
+  s.nvalid = d->nvalid; s.pdiam = d->pdiam; s.nfft = d->nfft; s.npix = d->npix;
+  s.nrebin = d->nrebin; s.nxsub = d->nxsub;
+  const int pd2 = d->pdiam * d->pdiam;
+  UP(int32_t, d->phasemap, (size_t)pd2 * d->nvalid, s.phasemap);
+  // every sub-aperture must be a contiguous pdiam x pdiam tile of the phase grid
+  std::vector<int32_t> sub(d->nvalid);
+  for (int i = 0; i < d->nvalid; i++) {
+    int p0 = d->phasemap[i];
+    int x0 = p0 % d->n, y0 = p0 / d->n;
+    if (x0 + d->pdiam > d->n || y0 + d->pdiam > d->n) { aomarl_destroy(c); return fail("phasemap tile outside the phase grid"); }
+    for (int k = 0; k < pd2; k++)
+      if (d->phasemap[(size_t)k * d->nvalid + i] != p0 + (k % d->pdiam) + d->n * (k / d->pdiam)) {
+        aomarl_destroy(c);
+        return fail("phasemap of sub-aperture %d is not a contiguous tile", i);
+      }
+    sub[i] = x0 | (y0 << 16);
+  }
+  UP(int32_t, sub.data(), sub.size(), s.sub_xy);
+  std::vector<float> hrev(pd2);
+  for (int k = 0; k < pd2; k++) hrev[k] = (float)((double)d->halfxy[k] / (2.0 * M_PI));
+  UP(float, hrev.data(), hrev.size(), s.halfxy);
+  UP(int32_t, d->binmap, (size_t)d->nrebin * d->nrebin * d->npix * d->npix, s.binmap);
+  UP(float, d->flux, (size_t)d->nvalid, s.flux);
+  UP(int32_t, d->validsubsx, (size_t)d->nvalid, s.validx);
+  UP(int32_t, d->validsubsy, (size_t)d->nvalid, s.validy);
+  s.nphot = d->nphot; s.wfs_inv_lambda = 1.0f / d->wfs_lambda; s.noise = d->noise;
+  s.cog_offset = d->cog_offset; s.cog_scale = d->cog_scale; s.subapd = d->subapd;
+  c->spot_fast = (d->pdiam == 16 && d->nfft == 64 && d->nrebin == 2 && d->npix == 16);
+  if (c->spot_fast) {
+    // the kernel hard-codes the binmap of this sampling: LR (Y, X) <- HR rows/cols
+    // (2Y-16 .. 2Y-15) mod 64 ; check the map handed in says the same
+    for (int px = 0; px < 256 && c->spot_fast; px++) {
+      int Y = px / 16, X = px % 16;
+      bool seen[4] = {false, false, false, false};
+      for (int r = 0; r < 4; r++) {
+        int hr = d->binmap[r * 256 + px];
+        int ky = hr / 64, kx = hr % 64;
+        int dy = (ky - (2 * Y - 16) + 64) % 64, dx = (kx - (2 * X - 16) + 64) % 64;
+        if (dy > 1 || dx > 1) { c->spot_fast = false; break; }
+        seen[dy * 2 + dx] = true;
+      }
+      if (!(seen[0] && seen[1] && seen[2] && seen[3])) c->spot_fast = false;
+    }
+  }
+  if (!c->spot_fast) {
+    aomarl_destroy(c);
+    return fail("unsupported WFS sampling (pdiam=%d nfft=%d nrebin=%d npix=%d): the spot kernel "
+                "is specialised for 16/64/2/16", d->pdiam, d->nfft, d->nrebin, d->npix);
+  }
+  // layers
+  c->nlayers = s.nlayers = d->nlayers;
+  long long off = 0;
+  const float *seenA[AOMARL_MAX_LAYERS]; const float *seenB[AOMARL_MAX_LAYERS];
+  const float *devAB[AOMARL_MAX_LAYERS]; int ldab[AOMARL_MAX_LAYERS];
+  s.wfs_all_int = 1; s.tar_all_int = 1;
+  for (int l = 0; l < d->nlayers; l++) {
+    const aomarl_layer_desc &L = d->layers[l];
+    DevLayer &D = s.layers[l];
+    if (L.dim <= 0 || L.dim > 65535 || L.nstencil <= 0) { aomarl_destroy(c); return fail("bad layer %d", l); }
+    D.dim = L.dim; D.ns = L.nstencil; D.screen_off = off; off += (long long)L.dim * L.dim;
+    c->dim[l] = L.dim; c->ns[l] = L.nstencil; c->deltax[l] = L.deltax; c->deltay[l] = L.deltay;
+    if (L.dim > c->maxdim) c->maxdim = L.dim;
+    if (L.dim + L.nstencil > c->maxK) c->maxK = L.dim + L.nstencil;
+    std::vector<uint32_t> ix(L.nstencil), iy(L.nstencil);
+    for (int k = 0; k < L.nstencil; k++) {
+      if (L.istx[k] >= (uint32_t)(L.dim * L.dim) || L.isty[k] >= (uint32_t)(L.dim * L.dim)) { aomarl_destroy(c); return fail("stencil index out of range"); }
+      ix[k] = (L.istx[k] % L.dim) | ((L.istx[k] / L.dim) << 16);
+      iy[k] = (L.isty[k] % L.dim) | ((L.isty[k] / L.dim) << 16);
+    }
+    UP(uint32_t, ix.data(), ix.size(), D.istx);
+    UP(uint32_t, iy.data(), iy.size(), D.isty);
+    // [A | B] concatenated, shared between layers that were given the same host matrices
+    int cls = -1;
+    for (int m = 0; m < c->nclass; m++)
+      if (seenA[m] == L.A && seenB[m] == L.B) cls = m;
+    if (cls < 0) {
+      cls = c->nclass++;
+      seenA[cls] = L.A; seenB[cls] = L.B;
+      int K = L.nstencil + L.dim;
+      int ld = (K + 3) & ~3;
+      std::vector<float> ab((size_t)L.dim * ld, 0.f);
+      for (int r = 0; r < L.dim; r++) {
+        memcpy(&ab[(size_t)r * ld], L.A + (size_t)r * L.nstencil, sizeof(float) * L.nstencil);
+        memcpy(&ab[(size_t)r * ld + L.nstencil], L.B + (size_t)r * L.dim, sizeof(float) * L.dim);
+      }
+      float *p;
+      UP(float, ab.data(), ab.size(), p);
+      devAB[cls] = p; ldab[cls] = ld;
+    }
+    c->abclass[l] = cls;
+    D.AB = devAB[cls]; D.ldab = ldab[cls];
+    D.amp = L.amplitude;
+    D.wxo = L.wfs_xoff; D.wyo = L.wfs_yoff; D.txo = L.tar_xoff; D.tyo = L.tar_yoff;
+    D.wox = (int)L.wfs_xoff; D.woy = (int)L.wfs_yoff; D.tox = (int)L.tar_xoff; D.toy = (int)L.tar_yoff;
+    if (!is_int(L.wfs_xoff) || !is_int(L.wfs_yoff)) s.wfs_all_int = 0;
+    if (!is_int(L.tar_xoff) || !is_int(L.tar_yoff)) s.tar_all_int = 0;
+    if (s.wfs_all_int && (D.wox < 0 || D.woy < 0 || D.wox + d->n > L.dim || D.woy + d->n > L.dim)) { aomarl_destroy(c); return fail("WFS window leaves screen %d", l); }
+    if (s.tar_all_int && (D.tox < 0 || D.toy < 0 || D.tox + d->pupdiam > L.dim || D.toy + d->pupdiam > L.dim)) { aomarl_destroy(c); return fail("target window leaves screen %d", l); }
+  }
+  s.screen_stride = off;
+  // DMs
+  c->ndm = s.ndm = d->ndm;
+  long long soff = 0; int coff = 0;
+  for (int k = 0; k < d->ndm; k++) {
+    const aomarl_dm_desc &M = d->dms[k];
+    DevDm &D = s.dms[k];
+    D.type = M.type; D.dim = M.dim; D.nact = M.nact; D.ss = M.influsize;
+    D.shape_off = soff; soff += (long long)M.dim * M.dim;
+    D.com_off = coff; coff += M.nact;
+    if (M.type == AOMARL_DM_PZT) {
+      UP(float, M.influ, (size_t)M.nact * M.influsize * M.influsize, D.influ);
+      UP(int32_t, M.influpos, (size_t)M.ninflupos, D.influpos);
+      UP(int32_t, M.ninflu, (size_t)M.dim * M.dim, D.ninflu);
+      UP(int32_t, M.influstart, (size_t)M.dim * M.dim, D.influstart);
+      // bounds of the gather tables (a bad table would fault on the device)
+      long long tot = 0;
+      for (long long p = 0; p < (long long)M.dim * M.dim; p++) {
+        if (M.influstart[p] != tot || M.ninflu[p] < 0) { aomarl_destroy(c); return fail("DM %d: influstart/ninflu inconsistent", k); }
+        tot += M.ninflu[p];
+      }
+      if (tot != M.ninflupos) { aomarl_destroy(c); return fail("DM %d: sum(ninflu) != len(influpos)", k); }
+      for (long long q = 0; q < M.ninflupos; q++)
+        if (M.influpos[q] < 0 || M.influpos[q] >= M.nact * M.influsize * M.influsize) { aomarl_destroy(c); return fail("DM %d: influpos out of range", k); }
+    } else if (M.type == AOMARL_DM_TT) {
+      if (M.nact != 2) { aomarl_destroy(c); return fail("tip-tilt DM must have 2 actuators"); }
+      UP(float, M.influ, (size_t)M.dim * M.dim * 2, D.influ);
+    } else {
+      aomarl_destroy(c);
+      return fail("DM %d: unknown type %d", k, M.type);
+    }
+    D.wxo = M.wfs_xoff; D.wyo = M.wfs_yoff; D.txo = M.tar_xoff; D.tyo = M.tar_yoff;
+    D.wox = (int)M.wfs_xoff; D.woy = (int)M.wfs_yoff; D.tox = (int)M.tar_xoff; D.toy = (int)M.tar_yoff;
+    if (!is_int(M.wfs_xoff) || !is_int(M.wfs_yoff)) s.wfs_all_int = 0;
+    if (!is_int(M.tar_xoff) || !is_int(M.tar_yoff)) s.tar_all_int = 0;
+    if (s.wfs_all_int && (D.wox < 0 || D.woy < 0 || D.wox + d->n > M.dim || D.woy + d->n > M.dim)) { aomarl_destroy(c); return fail("WFS window leaves DM %d", k); }
+    if (s.tar_all_int && (D.tox < 0 || D.toy < 0 || D.tox + d->pupdiam > M.dim || D.toy + d->pupdiam > M.dim)) { aomarl_destroy(c); return fail("target window leaves DM %d", k); }
+  }
+  s.shape_stride = soff;
+  if (coff != d->nactu) { aomarl_destroy(c); return fail("sum of DM actuators (%d) != nactu (%d)", coff, d->nactu); }
+  if (d->nslope != 2 * d->nvalid) { aomarl_destroy(c); return fail("nslope must be 2*nvalid"); }
+  s.nactu = d->nactu; s.nslope = d->nslope;
+  // target
+  s.tar_inv_lambda = 1.0f / d->tar_lambda; s.npsf = d->npsf; s.hw = d->strehl_halfwin;
+  std::vector<float> tw((size_t)d->npsf * 2);
+  for (int j = 0; j < d->npsf; j++) {
+    double a = 2.0 * M_PI * (double)j / (double)d->npsf;
+    tw[2 * j] = (float)cos(a); tw[2 * j + 1] = (float)sin(a);
+  }
+  UP(float, tw.data(), tw.size(), s.psf_tw);
+  double sp = 0.;
+  for (size_t p = 0; p < (size_t)d->pupdiam * d->pupdiam; p++) sp += d->spupil[p];
+  s.ref_peak = (float)(sp * sp);
+  c->gain = d->gain; c->delay = d->delay;
+  if (c->delay < 0.f || c->delay > 2.f) { aomarl_destroy(c); return fail("delay must be in [0, 2]"); }
+#undef UP
+  *out = c;
+  return 0;
+}
+
+int aomarl_destroy(aomarl_ctx *c) {
+  if (!c) return 0;
+  for (void *p : c->owned) (void)hipFree(p);
+  if (c->seed_stage) (void)hipFree(c->seed_stage);
+  delete c;
+  return 0;
+}
+
+static int replace_dev(aomarl_ctx *c, float **slot, const std::vector<float> &h) {
+  if (*slot) {
+    for (size_t i = 0; i < c->owned.size(); i++)
+      if (c->owned[i] == *slot) { c->owned.erase(c->owned.begin() + i); break; }
+    (void)hipFree(*slot);
+    *slot = nullptr;
+  }
+  return upload<float>(c, h.data(), h.size(), slot);
+}
+
+int aomarl_set_cmat(aomarl_ctx *c, const float *cmat) {
+  if (!c || !cmat) return fail("aomarl_set_cmat: null argument");
+  const int na = c->sys.nactu, nsl = c->sys.nslope;
+  const int ld = (nsl + 3) & ~3;
+  std::vector<float> h((size_t)na * ld, 0.f);
+  for (int r = 0; r < na; r++) memcpy(&h[(size_t)r * ld], cmat + (size_t)r * nsl, sizeof(float) * nsl);
+  c->ld_cmat = ld;
+  return replace_dev(c, &c->cmat, h);
+}
+
+int aomarl_set_gain(aomarl_ctx *c, float gain) {
+  if (!c) return fail("null ctx");
+  c->gain = gain;
+  return 0;
+}
+
+int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m2v,
+                     const float *freedom, int nact, const int32_t *amodes) {
+  if (!c || !v2m || !m2v) return fail("aomarl_set_modal: null argument");
+  const int na = c->sys.nactu;
+  if (nmodes <= 0 || nmodes > na) return fail("nmodes out of range");
+  c->nmodes = nmodes;
+  c->ld_v2m = (na + 3) & ~3;
+  c->ld_m2v = (nmodes + 3) & ~3;
+  std::vector<float> a((size_t)nmodes * c->ld_v2m, 0.f), b((size_t)na * c->ld_m2v, 0.f);
+  for (int r = 0; r < nmodes; r++) memcpy(&a[(size_t)r * c->ld_v2m], v2m + (size_t)r * na, sizeof(float) * na);
+  for (int r = 0; r < na; r++) memcpy(&b[(size_t)r * c->ld_m2v], m2v + (size_t)r * nmodes, sizeof(float) * nmodes);
+  int rc = replace_dev(c, &c->v2m, a);
+  if (rc) return rc;
+  rc = replace_dev(c, &c->m2v, b);
+  if (rc) return rc;
+  std::vector<float> f(nmodes, 0.f);
+  if (freedom) memcpy(f.data(), freedom, sizeof(float) * nmodes);
+  rc = replace_dev(c, &c->freedom, f);
+  if (rc) return rc;
+  c->nact = 0;
+  if (nact > 0) {
+    if (!amodes) return fail("action_modes is null");
+    for (int j = 0; j < nact; j++)
+      if (amodes[j] < 0 || amodes[j] >= nmodes) return fail("action mode %d out of range", amodes[j]);
+    if (c->amodes) {
+      for (size_t i = 0; i < c->owned.size(); i++)
+        if (c->owned[i] == c->amodes) { c->owned.erase(c->owned.begin() + i); break; }
+      (void)hipFree(c->amodes);
+      c->amodes = nullptr;
+    }
+    rc = upload<int32_t>(c, amodes, nact, &c->amodes);
+    if (rc) return rc;
+    c->nact = nact;
+  }
+  return 0;
+}
+
+// ---- workspace layout (floats)
+struct Work {
+  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, total;
+  int ldz, ldn, ldm, nblk;
+};
+
+static Work work_layout(const aomarl_ctx *c, int nenv) {
+  Work w;
+  const DevSys &s = c->sys;
+  const size_t ncol = (size_t)nenv * (c->nlayers > 0 ? c->nlayers : 1);
+  w.ldz = (c->maxK + 3) & ~3;
+  w.ldn = (c->maxdim + 3) & ~3;
+  w.ldm = (s.nactu + 3) & ~3;
+  const int W = 2 * s.hw, RB = 256 / W;
+  w.nblk = (s.pupdiam + RB - 1) / RB;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+  w.Z = take(ncol * w.ldz);
+  w.NEWL = take(ncol * w.ldn);
+  w.ZREF = take(ncol);
+  w.MODES = take((size_t)nenv * w.ldm);
+  w.TR = take((size_t)nenv * s.pupdiam * W * 2);
+  w.TPART = take((size_t)nenv * w.nblk * 4);
+  w.PEND = take((size_t)nenv * (W * W + 4));
+  w.total = o;
+  return w;
+}
+
+size_t aomarl_workspace_floats(const aomarl_ctx *c, int nenv) {
+  return c ? work_layout(c, nenv).total : 0;
+}
+size_t aomarl_screen_stride(const aomarl_ctx *c) { return c ? (size_t)c->sys.screen_stride : 0; }
+size_t aomarl_dmshape_stride(const aomarl_ctx *c) { return c ? (size_t)c->sys.shape_stride : 0; }
+
+static int check_range(const aomarl_ctx *c, const aomarl_state *st, int b, int n) {
+  if (!c || !st) return fail("null ctx/state");
+  if (b < 0 || n < 0 || b + n > st->nenv) return fail("env range [%d, %d) outside [0, %d)", b, b + n, st->nenv);
+  if (st->ld_actu < c->sys.nactu) return fail("ld_actu (%d) < nactu (%d)", st->ld_actu, c->sys.nactu);
+  if (!st->screens || !st->origin || !st->seeds || !st->ext_count || !st->com || !st->com1 ||
+      !st->com2 || !st->err || !st->voltage || !st->slopes || !st->dm_shape || !st->strehl ||
+      !st->le_img || !st->frame || !st->work)
+    return fail("aomarl_state has a null mandatory buffer");
+  return 0;
+}
+
+static DevState dev_state(const aomarl_state *st) {
+  DevState d;
+  d.nenv = st->nenv; d.ld_actu = st->ld_actu;
+  d.screens = st->screens; d.origin = st->origin; d.seeds = st->seeds; d.ext_count = st->ext_count;
+  d.com = st->com; d.com1 = st->com1; d.com2 = st->com2; d.err = st->err; d.voltage = st->voltage;
+  d.slopes = st->slopes; d.dm_shape = st->dm_shape; d.bincube = st->bincube;
+  d.wfs_phase = st->wfs_phase; d.tar_phase = st->tar_phase; d.strehl = st->strehl;
+  d.le_img = st->le_img; d.frame = st->frame; d.work = st->work;
+  return d;
+}
+
+// ---------------------------------------------------------------- atmosphere
+int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, const int32_t *layer,
+                   const int32_t *dir, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0 || nops == 0) return 0;
+  if (nops < 0 || nops > c->nlayers) return fail("nops out of range");
+  for (int i = 0; i < nops; i++) {
+    if (layer[i] < 0 || layer[i] >= c->nlayers) return fail("extrude: bad layer");
+    if (!(dir[i] == 1 || dir[i] == -1 || dir[i] == 2 || dir[i] == -2)) return fail("extrude: bad direction");
+    for (int j = 0; j < i; j++)
+      if (layer[j] == layer[i]) return fail("extrude: a layer appears twice in one round");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  DevState ds = dev_state(st);
+  Work w = work_layout(c, st->nenv);
+  // one sub-round per [A|B] class
+  for (int cls = 0; cls < c->nclass; cls++) {
+    RoundOps ops;
+    ops.nops = 0;
+    int ref = -1;
+    for (int i = 0; i < nops; i++)
+      if (c->abclass[layer[i]] == cls) { ops.layer[ops.nops] = layer[i]; ops.dir[ops.nops] = dir[i]; ops.nops++; ref = layer[i]; }
+    if (ops.nops == 0) continue;
+    const int dimc = c->dim[ref], nsc = c->ns[ref], K = dimc + nsc;
+    const int ncol = n * ops.nops;
+    float *Z = st->work + w.Z, *NEWL = st->work + w.NEWL, *ZREF = st->work + w.ZREF;
+    hipLaunchKernelGGL(k_extrude_gather, dim3(ncol, (K + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
+                       ops, Z, w.ldz, ZREF);
+    LAUNCHCHK();
+    launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
+                   0.0f, NEWL, w.ldn, s);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol, (dimc + 255) / 256), dim3(256), 0, s, c->sys,
+                       ds, b, ops, NEWL, w.ldn, ZREF);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_extrude_commit, dim3((ncol + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
+                       ncol, ops);
+    LAUNCHCHK();
+  }
+  return 0;
+}
+
+// plan of one env: signed pixel shifts per layer after adding the per-frame deltas
+struct Plan { int kx[AOMARL_MAX_LAYERS], ky[AOMARL_MAX_LAYERS]; };
+
+static bool plan_eq(const Plan &a, const Plan &b, int nl) {
+  for (int l = 0; l < nl; l++)
+    if (a.kx[l] != b.kx[l] || a.ky[l] != b.ky[l]) return false;
+  return true;
+}
+
+static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p, void *stream) {
+  // layer l's queue: |kx| x-extrusions then |ky| y-extrusions; round r = r-th op of each layer
+  int maxr = 0;
+  for (int l = 0; l < c->nlayers; l++) {
+    int len = abs(p.kx[l]) + abs(p.ky[l]);
+    if (len > maxr) maxr = len;
+  }
+  for (int r = 0; r < maxr; r++) {
+    int32_t layer[AOMARL_MAX_LAYERS], dir[AOMARL_MAX_LAYERS];
+    int nops = 0;
+    for (int l = 0; l < c->nlayers; l++) {
+      int ax = abs(p.kx[l]), ay = abs(p.ky[l]);
+      if (r < ax) { layer[nops] = l; dir[nops] = p.kx[l] > 0 ? 1 : -1; nops++; }
+      else if (r < ax + ay) { layer[nops] = l; dir[nops] = p.ky[l] > 0 ? 2 : -2; nops++; }
+    }
+    int rc = aomarl_extrude(c, st, b, n, nops, layer, dir, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int aomarl_move_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
+                      void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!accumx || !accumy) return fail("move_atmos: null accumulators");
+  const int nl = c->nlayers;
+  int g0 = b;
+  Plan cur;
+  for (int e = b; e <= b + n; e++) {
+    Plan p;
+    if (e < b + n) {
+      for (int l = 0; l < nl; l++) {
+        float ax = accumx[(size_t)e * nl + l] + c->deltax[l];
+        float ay = accumy[(size_t)e * nl + l] + c->deltay[l];
+        int kx = (int)ax, ky = (int)ay;
+        p.kx[l] = kx; p.ky[l] = ky;
+        accumx[(size_t)e * nl + l] = ax - (float)kx;
+        accumy[(size_t)e * nl + l] = ay - (float)ky;
+      }
+    }
+    if (e == b) { cur = p; continue; }
+    if (e == b + n || !plan_eq(p, cur, nl)) {
+      rc = run_plan(c, st, g0, e - g0, cur, stream);
+      if (rc) return rc;
+      g0 = e; cur = p;
+    }
+  }
+  return 0;
+}
+
+int aomarl_reset_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_strehl_reset, dim3(n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *seeds, float *accumx,
+                 float *accumy, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!seeds || !accumx || !accumy) return fail("reset: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DevState ds = dev_state(st);
+  if (c->seed_stage_n < n) {
+    if (c->seed_stage) (void)hipFree(c->seed_stage);
+    HIPCHK(hipMalloc((void **)&c->seed_stage, sizeof(uint32_t) * (size_t)st->nenv));
+    c->seed_stage_n = st->nenv;
+  }
+  HIPCHK(hipMemcpyAsync(c->seed_stage, seeds, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_reset_env, dim3(n), dim3(256), 0, s, c->sys, ds, b, n, c->seed_stage, st->ld_actu);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, st->screens + (size_t)b * c->sys.screen_stride,
+                     (long long)n * c->sys.screen_stride, 0.f);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, st->dm_shape + (size_t)b * c->sys.shape_stride,
+                     (long long)n * c->sys.shape_stride, 0.f);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_fill_f32, dim3(64), dim3(256), 0, s, st->slopes + (size_t)b * c->sys.nslope,
+                     (long long)n * c->sys.nslope, 0.f);
+  LAUNCHCHK();
+  rc = aomarl_reset_strehl(c, st, b, n, stream);
+  if (rc) return rc;
+  for (int e = b; e < b + n; e++)
+    for (int l = 0; l < c->nlayers; l++) { accumx[(size_t)e * c->nlayers + l] = 0.f; accumy[(size_t)e * c->nlayers + l] = 0.f; }
+  // refresh_screen: 2*dim extrusions along x, sign of deltax (atmosCompass.py:141-145)
+  int maxr = 0;
+  for (int l = 0; l < c->nlayers; l++) if (2 * c->dim[l] > maxr) maxr = 2 * c->dim[l];
+  for (int r = 0; r < maxr; r++) {
+    int32_t layer[AOMARL_MAX_LAYERS], dir[AOMARL_MAX_LAYERS];
+    int nops = 0;
+    for (int l = 0; l < c->nlayers; l++)
+      if (r < 2 * c->dim[l]) { layer[nops] = l; dir[nops] = c->deltax[l] > 0.f ? 1 : -1; nops++; }
+    rc = aomarl_extrude(c, st, b, n, nops, layer, dir, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int aomarl_get_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, float *dst, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (layer < 0 || layer >= c->nlayers || !dst) return fail("get_screen: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_get_screen, dim3(256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, layer, dst);
+  LAUNCHCHK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- DMs
+int aomarl_comp_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *volts, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  const float *v = volts ? volts : st->voltage + (size_t)b * st->ld_actu;
+  const int ldv = volts ? c->sys.nactu : st->ld_actu;
+  DevState ds = dev_state(st);
+  for (int k = 0; k < c->ndm; k++) {
+    const int np = c->sys.dms[k].dim * c->sys.dms[k].dim;
+    hipLaunchKernelGGL(k_dm_shape, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, c->sys, ds, b, k, v, ldv);
+    LAUNCHCHK();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- raytrace (unfused API)
+int aomarl_raytrace_wfs(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!st->wfs_phase) return fail("raytrace_wfs needs st->wfs_phase");
+  if (n == 0) return 0;
+  const int np = c->sys.n * c->sys.n;
+  hipLaunchKernelGGL(k_raytrace<false>, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, flags);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_raytrace_target(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!st->tar_phase) return fail("raytrace_target needs st->tar_phase");
+  if (n == 0) return 0;
+  const int np = c->sys.pupdiam * c->sys.pupdiam;
+  hipLaunchKernelGGL(k_raytrace<true>, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, flags);
+  LAUNCHCHK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- WFS
+__global__ void k_inc_u32(uint32_t *p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += 1u;
+}
+
+int aomarl_comp_image(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  const bool from_buf = flags & AOMARL_IMG_FROM_PHASE_BUFFER;
+  const bool noise = (flags & AOMARL_IMG_NOISE) && c->sys.noise >= 0.f;
+  const bool cube = flags & AOMARL_IMG_WRITE_BINCUBE;
+  const int cog = (flags & AOMARL_IMG_COG) ? 1 : 0;
+  if (from_buf && !st->wfs_phase) return fail("comp_image: FROM_PHASE_BUFFER needs st->wfs_phase");
+  if (!from_buf && !c->sys.wfs_all_int)
+    return fail("comp_image: fused raytrace needs integer layer offsets; use raytrace_wfs + FROM_PHASE_BUFFER");
+  if (cube && !st->bincube) return fail("comp_image: WRITE_BINCUBE needs st->bincube");
+  if (!cube && !cog) return fail("comp_image: nothing to produce (neither bincube nor slopes)");
+  const int na = (flags & AOMARL_IMG_NO_ATMOS) ? 1 : 0, nd = (flags & AOMARL_IMG_NO_DMS) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  DevState ds = dev_state(st);
+  dim3 grid((c->sys.nvalid + 3) / 4, n), blk(256);
+#define SPOT(FB, NZ, WC) hipLaunchKernelGGL((k_wfs_spot<FB, NZ, WC>), grid, blk, 0, s, c->sys, ds, b, na, nd, cog)
+  if (from_buf) {
+    if (noise) { if (cube) SPOT(true, true, true); else SPOT(true, true, false); }
+    else { if (cube) SPOT(true, false, true); else SPOT(true, false, false); }
+  } else {
+    if (noise) { if (cube) SPOT(false, true, true); else SPOT(false, true, false); }
+    else { if (cube) SPOT(false, false, true); else SPOT(false, false, false); }
+  }
+#undef SPOT
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_inc_u32, dim3((n + 255) / 256), dim3(256), 0, s, st->frame + b, n);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_do_centroids(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!st->bincube) return fail("do_centroids needs st->bincube");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_cog, dim3((c->sys.nvalid + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_slopes_geom(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!st->wfs_phase) return fail("slopes_geom needs st->wfs_phase");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_slopes_geom, dim3((c->sys.nvalid + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b);
+  LAUNCHCHK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- controller
+int aomarl_do_control(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!c->cmat) return fail("do_control: no command matrix (aomarl_set_cmat)");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int na = c->sys.nactu, nsl = c->sys.nslope;
+  // err[env][a] = - sum_s slopes[env][s] cmat[a][s]
+  launch_gemm_nt(n, na, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->cmat, c->ld_cmat, 0.0f,
+                 st->err + (size_t)b * st->ld_actu, st->ld_actu, s);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_set_com(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *com, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!com) return fail("set_com: null command");
+  if (n == 0) return 0;
+  const int na = c->sys.nactu;
+  hipLaunchKernelGGL(k_copy_rows, dim3((na + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
+                     st->com + (size_t)b * st->ld_actu, st->ld_actu, com, na, na);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_volts2modes(aomarl_ctx *c, int nrows, const float *vec, float *modes, void *stream) {
+  if (!c || !c->v2m) return fail("volts2modes: no modal basis (aomarl_set_modal)");
+  if (!vec || !modes) return fail("volts2modes: null argument");
+  launch_gemm_nt(nrows, c->nmodes, c->sys.nactu, 1.0f, vec, c->sys.nactu, c->v2m, c->ld_v2m, 0.0f,
+                 modes, c->nmodes, (hipStream_t)stream);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_rl_control(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *action, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!c->v2m || !c->m2v) return fail("rl_control: no modal basis (aomarl_set_modal)");
+  if (c->nact <= 0) return fail("rl_control: no action modes set");
+  if (!action) return fail("rl_control: null action");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  Work w = work_layout(c, st->nenv);
+  float *modes = st->work + w.MODES;
+  const int na = c->sys.nactu, nm = c->nmodes;
+  float *com = st->com + (size_t)b * st->ld_actu;
+  launch_gemm_nt(n, nm, na, 1.0f, com, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, modes, w.ldm, s);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_modal_add, dim3((c->nact + 255) / 256, n), dim3(256), 0, s, modes, w.ldm, action, c->nact, c->amodes, c->freedom);
+  LAUNCHCHK();
+  launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, com, st->ld_actu, s);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_apply_control(aomarl_ctx *c, aomarl_state *st, int b, int n, int comp_voltage, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  const float d = c->delay;
+  float wa, wb, wc;
+  if (d <= 1.f) { wa = 1.f - d; wb = d; wc = 0.f; } else { wa = 0.f; wb = 2.f - d; wc = d - 1.f; }
+  const int na = c->sys.nactu;
+  hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, dev_state(st), na, st->ld_actu, wa, wb, wc, b, comp_voltage);
+  LAUNCHCHK();
+  return aomarl_comp_dm_shape(c, st, b, n, nullptr, stream);
+}
+
+// ---------------------------------------------------------------- target
+static int target_psf_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, bool from_buf, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Work w = work_layout(c, st->nenv);
+  const int W = 2 * c->sys.hw, RB = 256 / W;
+  float *TR = st->work + w.TR + (size_t)b * c->sys.pupdiam * W * 2;
+  float *TP = st->work + w.TPART + (size_t)b * w.nblk * 4;
+  float *PEND = st->work + w.PEND + (size_t)b * (W * W + 4);
+  size_t sm = sizeof(float) * (2 * RB * TGT_XC + 3 * 256) + (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
+  DevState ds = dev_state(st);
+  if (from_buf)
+    hipLaunchKernelGGL(k_target_rows<true>, dim3(w.nblk, n), dim3(256), sm, s, c->sys, ds, b, TR, TP, w.nblk);
+  else
+    hipLaunchKernelGGL(k_target_rows<false>, dim3(w.nblk, n), dim3(256), sm, s, c->sys, ds, b, TR, TP, w.nblk);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_target_finish, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_target_psf(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!c->sys.tar_all_int) {
+    rc = aomarl_raytrace_target(c, st, b, n, AOMARL_TRACE_ATMOS | AOMARL_TRACE_DMS | AOMARL_TRACE_RESET, stream);
+    if (rc) return rc;
+    return target_psf_impl(c, st, b, n, true, stream);
+  }
+  return target_psf_impl(c, st, b, n, false, stream);
+}
+
+int aomarl_comp_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  Work w = work_layout(c, st->nenv);
+  const int W = 2 * c->sys.hw;
+  float *PEND = st->work + w.PEND + (size_t)b * (W * W + 4);
+  hipLaunchKernelGGL(k_strehl_commit, dim3(n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, PEND);
+  LAUNCHCHK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- composites
+int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
+                         int image_flags, void *stream) {
+  int rc = aomarl_move_atmos(c, st, b, n, accumx, accumy, stream);
+  if (rc) return rc;
+  rc = aomarl_target_psf(c, st, b, n, stream);
+  if (rc) return rc;
+  int fl = (image_flags | AOMARL_IMG_COG | AOMARL_IMG_NOISE) & ~(AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS);
+  if (!c->sys.wfs_all_int) {
+    rc = aomarl_raytrace_wfs(c, st, b, n, AOMARL_TRACE_ATMOS | AOMARL_TRACE_DMS | AOMARL_TRACE_RESET, stream);
+    if (rc) return rc;
+    fl |= AOMARL_IMG_FROM_PHASE_BUFFER;
+  }
+  rc = aomarl_comp_image(c, st, b, n, fl, stream);
+  if (rc) return rc;
+  return aomarl_do_control(c, st, b, n, stream);
+}
+
+int aomarl_next_part_two(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *action, void *stream) {
+  int rc;
+  if (action) {
+    rc = aomarl_rl_control(c, st, b, n, action, stream);
+    if (rc) return rc;
+  }
+  rc = aomarl_apply_control(c, st, b, n, 1, stream);
+  if (rc) return rc;
+  return aomarl_comp_strehl(c, st, b, n, stream);
+}
+
+int aomarl_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb,
+                   float beta, float *C, int ldc, void *stream) {
+  if (!A || !B || !C) return fail("gemm_nt: null pointer");
+  if (M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) return fail("gemm_nt: bad sizes");
+  launch_gemm_nt(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, (hipStream_t)stream);
+  LAUNCHCHK();
+  return 0;
+}

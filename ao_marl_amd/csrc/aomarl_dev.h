@@ -1,0 +1,114 @@
+// aomarl_dev.h -- device-side description shared by the kernels of libaomarl_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aomarl.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DevLayer {
+  int dim, ns;
+  long long screen_off;          // floats from the env's screen base
+  const uint32_t *istx, *isty;   // packed (x | y << 16) logical stencil coordinates
+  const float *AB;               // [dim][ldab]: row r = [A[r][0..ns) | B[r][0..dim)]
+  int ldab;
+  float amp;
+  float wxo, wyo, txo, tyo;      // float offsets
+  int wox, woy, tox, toy;        // integer parts
+};
+
+struct DevDm {
+  int type, dim, nact, ss;
+  long long shape_off;           // floats from the env's dm_shape base
+  int com_off;                   // first command index
+  const float *influ;
+  const int32_t *influpos, *ninflu, *influstart;
+  float wxo, wyo, txo, tyo;
+  int wox, woy, tox, toy;
+};
+
+struct DevSys {
+  int n, pupdiam;
+  const float *mpupil, *spupil;
+  int nvalid, pdiam, nfft, npix, nrebin, nxsub;
+  const int32_t *phasemap;
+  const int32_t *sub_xy;         // [nvalid] packed (x0 | y0 << 16): top-left phase pixel
+  const float *halfxy;
+  const int32_t *binmap;
+  const float *flux;
+  const int32_t *validx, *validy;
+  float nphot, wfs_inv_lambda, noise, cog_offset, cog_scale, subapd;
+  int nlayers;
+  DevLayer layers[AOMARL_MAX_LAYERS];
+  int ndm;
+  DevDm dms[AOMARL_MAX_DMS];
+  float tar_inv_lambda;
+  int npsf, hw;
+  const float *psf_tw;           // [npsf][2] cos, sin of 2 pi j / npsf
+  float ref_peak;
+  int nactu, nslope;
+  int wfs_all_int, tar_all_int;  // every offset of that path is an integer
+  long long screen_stride, shape_stride;
+};
+
+struct DevState {
+  int nenv, ld_actu;
+  float *screens;
+  int32_t *origin;
+  uint32_t *seeds, *ext_count;
+  float *com, *com1, *com2, *err, *voltage, *slopes, *dm_shape, *bincube, *wfs_phase, *tar_phase;
+  float *strehl, *le_img;
+  uint32_t *frame;
+  float *work;
+};
+
+// ---------------------------------------------------------------- Philox4x32-10 + normals
+// (same definition as the oracle: key = {seed, "AOMR"}, ctr = {block, counter_lo, counter_hi,
+//  stream}; 4 outputs -> 4 uniforms or 2 Box-Muller pairs)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) {
+  return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// element `idx` of the normal stream (seed, stream, counter)
+__device__ __forceinline__ float philox_normal(uint32_t seed, uint32_t stream, uint32_t cnt_lo,
+                                               uint32_t cnt_hi, uint32_t idx) {
+  uint32_t x[4];
+  philox4x32_10(idx >> 2, cnt_lo, cnt_hi, stream, seed, 0x414F4D52u, x);
+  int h = (idx >> 1) & 1;
+  float u0 = u01(x[2 * h]), u1 = u01(x[2 * h + 1]);
+  float r = sqrtf(-2.0f * logf(u0));
+  float a = 6.28318530717958647692f * u1;
+  return (idx & 1) ? r * sinf(a) : r * cosf(a);
+}
+
+__device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, uint32_t cnt_lo,
+                                                uint32_t cnt_hi, uint32_t idx) {
+  uint32_t x[4];
+  philox4x32_10(idx >> 2, cnt_lo, cnt_hi, stream, seed, 0x414F4D52u, x);
+  return u01(x[idx & 3]);
+}
+
+// ring-buffered screen: logical (x, y) -> physical float index
+__device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
+  int px = x + ox;
+  px -= (px >= n) ? n : 0;
+  int py = y + oy;
+  py -= (py >= n) ? n : 0;
+  return py * n + px;
+}

@@ -1,0 +1,804 @@
+// aomarl_kernels.hip -- CDNA4 (gfx950) kernels of the AO environment hot path.
+// wave = 64 lanes; fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) for the DFT and GEMM work.
+#include "aomarl_dev.h"
+
+#define WAVE 64
+
+// =============================================================================================
+// fp32 GEMM  C[M][N] = alpha * A[M][K] . B[N][K]^T + beta * C     (both operands K-contiguous)
+// 256 threads = 4 waves in 2x2, block tile 64x64, one v_mfma_f32_32x32x2_f32 accumulator/wave.
+// =============================================================================================
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alpha,
+                                                 const float *__restrict__ A, int lda,
+                                                 const float *__restrict__ B, int ldb, float beta,
+                                                 float *__restrict__ C, int ldc) {
+  __shared__ float As[64][17];
+  __shared__ float Bs[64][17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const int lr = tid >> 2, lc = (tid & 3) * 4;
+  const int gm = m0 + lr, gn = n0 + lr;
+  const float *pa = A + (long long)gm * lda;
+  const float *pb = B + (long long)gn * ldb;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+    const int gk = k0 + lc;
+    if (gm < M) {
+      if (ALIGNED && gk + 3 < K) {
+        float4 t = *reinterpret_cast<const float4 *>(pa + gk);
+        va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (gk + j < K) va[j] = pa[gk + j];
+      }
+    }
+    if (gn < N) {
+      if (ALIGNED && gk + 3 < K) {
+        float4 t = *reinterpret_cast<const float4 *>(pb + gk);
+        vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (gk + j < K) vb[j] = pb[gk + j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      As[lr][lc + j] = va[j];
+      Bs[lr][lc + j] = vb[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      float a = As[wm * 32 + (lane & 31)][2 * ks + (lane >> 5)];
+      float b = Bs[wn * 32 + (lane & 31)][2 * ks + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      float *c = C + (long long)row * ldc + col;
+      float v = alpha * acc[r];
+      if (beta != 0.f) v += beta * (*c);
+      *c = v;
+    }
+  }
+}
+
+void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
+                    int ldb, float beta, float *C, int ldc, hipStream_t s) {
+  if (M <= 0 || N <= 0) return;
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
+            (((uintptr_t)B & 15) == 0);
+  if (al)
+    hipLaunchKernelGGL(k_gemm_nt<true>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
+                       C, ldc);
+  else
+    hipLaunchKernelGGL(k_gemm_nt<false>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb,
+                       beta, C, ldc);
+}
+
+// =============================================================================================
+// atmosphere: Fried-Clark extrusion on ring-buffered screens
+// =============================================================================================
+struct RoundOps {
+  int nops;
+  int layer[AOMARL_MAX_LAYERS];
+  int dir[AOMARL_MAX_LAYERS];
+};
+
+// Z[col][0..ns) = screen[stencil] - zref ; Z[col][ns..ns+n) = amplitude * N(0,1)
+__global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st, int env_begin,
+                                                        RoundOps ops, float *__restrict__ Z,
+                                                        int ldz, float *__restrict__ ZREF) {
+  const int col = blockIdx.x;
+  const int e = env_begin + col / ops.nops, op = col % ops.nops;
+  const int li = ops.layer[op], dir = ops.dir[op];
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim, ns = L.ns;
+  const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
+  const bool top_right = (dir == 1 || dir == -2);
+  const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, ox, oy, n)];
+  const uint32_t *ist = (dir == 1 || dir == -1) ? L.istx : L.isty;
+  const uint32_t seed = st.seeds[e] + (uint32_t)li;
+  const uint32_t cnt = st.ext_count[e * sys.nlayers + li];
+  const int j = blockIdx.y * blockDim.x + threadIdx.x;
+  if (j < ns) {
+    uint32_t xy = ist[j];
+    Z[(long long)col * ldz + j] = base[ring_idx(xy & 0xFFFF, xy >> 16, ox, oy, n)] - zref;
+  } else if (j < ns + n) {
+    Z[(long long)col * ldz + j] = L.amp * philox_normal(seed, 0u, cnt, 0u, (uint32_t)(j - ns));
+  }
+  if (j == 0) ZREF[col] = zref;
+}
+
+__global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st, int env_begin,
+                                                         RoundOps ops,
+                                                         const float *__restrict__ NEWL, int ldn,
+                                                         const float *__restrict__ ZREF) {
+  const int col = blockIdx.x;
+  const int e = env_begin + col / ops.nops, op = col % ops.nops;
+  const int li = ops.layer[op], dir = ops.dir[op];
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim;
+  float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
+  const int r = blockIdx.y * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float v = NEWL[(long long)col * ldn + r] + ZREF[col];
+  int px, py;
+  if (dir == 1) {
+    px = ox;
+    py = r + oy; py -= (py >= n) ? n : 0;
+  } else if (dir == -1) {
+    px = ox - 1; px += (px < 0) ? n : 0;
+    py = n - 1 - r + oy; py -= (py >= n) ? n : 0;
+  } else if (dir == 2) {
+    py = oy;
+    px = r + ox; px -= (px >= n) ? n : 0;
+  } else {
+    py = oy - 1; py += (py < 0) ? n : 0;
+    px = n - 1 - r + ox; px -= (px >= n) ? n : 0;
+  }
+  base[py * n + px] = v;
+}
+
+__global__ void k_extrude_commit(DevSys sys, DevState st, int env_begin, int ncol, RoundOps ops) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const int e = env_begin + col / ops.nops, op = col % ops.nops;
+  const int li = ops.layer[op], dir = ops.dir[op];
+  const int n = sys.layers[li].dim;
+  int *o = st.origin + (e * sys.nlayers + li) * 2;
+  if (dir == 1) o[0] = (o[0] + 1 >= n) ? 0 : o[0] + 1;
+  else if (dir == -1) o[0] = (o[0] - 1 < 0) ? n - 1 : o[0] - 1;
+  else if (dir == 2) o[1] = (o[1] + 1 >= n) ? 0 : o[1] + 1;
+  else o[1] = (o[1] - 1 < 0) ? n - 1 : o[1] - 1;
+  st.ext_count[e * sys.nlayers + li] += 1u;
+}
+
+__global__ void k_fill_f32(float *p, long long n, float v) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_reset_env(DevSys sys, DevState st, int env_begin, int env_count,
+                            const uint32_t *__restrict__ seeds_dev, int ld_actu) {
+  // small per-env state: origin, counters, integrator vectors
+  const int e = env_begin + blockIdx.x;
+  if (threadIdx.x == 0) {
+    st.seeds[e] = seeds_dev[blockIdx.x];
+    st.frame[e] = 0u;
+  }
+  for (int i = threadIdx.x; i < sys.nlayers; i += blockDim.x) {
+    st.origin[(e * sys.nlayers + i) * 2] = 0;
+    st.origin[(e * sys.nlayers + i) * 2 + 1] = 0;
+    st.ext_count[e * sys.nlayers + i] = 0u;
+  }
+  for (int i = threadIdx.x; i < ld_actu; i += blockDim.x) {
+    long long o = (long long)e * ld_actu + i;
+    st.com[o] = 0.f; st.com1[o] = 0.f; st.com2[o] = 0.f; st.err[o] = 0.f; st.voltage[o] = 0.f;
+  }
+}
+
+__global__ void k_get_screen(DevSys sys, DevState st, int env_begin, int li, float *dst) {
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim;
+  const int e = env_begin + blockIdx.y;
+  const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n * n; p += gridDim.x * blockDim.x) {
+    int y = p / n, x = p - y * n;
+    dst[(long long)blockIdx.y * n * n + p] = base[ring_idx(x, y, ox, oy, n)];
+  }
+}
+
+// =============================================================================================
+// deformable mirrors
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_dm_shape(DevSys sys, DevState st, int env_begin, int k,
+                                                  const float *__restrict__ volts, int ldv) {
+  const DevDm &D = sys.dms[k];
+  const int e = env_begin + blockIdx.y;
+  const float *com = volts + (long long)blockIdx.y * ldv + D.com_off;
+  float *shape = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= D.dim * D.dim) return;
+  if (D.type == AOMARL_DM_PZT) {
+    const int ss2 = D.ss * D.ss;
+    const int s0 = D.influstart[p], c = D.ninflu[p];
+    float acc = 0.f;
+    for (int t = 0; t < c; t++) {
+      int pos = D.influpos[s0 + t];
+      acc += D.influ[pos] * com[pos / ss2];
+    }
+    shape[p] = acc;
+  } else {
+    const float2 f = reinterpret_cast<const float2 *>(D.influ)[p];
+    shape[p] = com[0] * f.x + com[1] * f.y;
+  }
+}
+
+// =============================================================================================
+// raytrace into a phase buffer (generic, bilinear) -- unfused API path
+// =============================================================================================
+__device__ __forceinline__ float bilinear_plain(const float *in, int N, float fx, float fy) {
+  int ix = (int)floorf(fx), iy = (int)floorf(fy);
+  float wx = fx - (float)ix, wy = fy - (float)iy;
+  if (ix < 0 || iy < 0 || ix >= N || iy >= N) return 0.f;
+  int ix1 = ix + 1 < N ? ix + 1 : ix, iy1 = iy + 1 < N ? iy + 1 : iy;
+  float v00 = in[iy * N + ix], v01 = in[iy * N + ix1], v10 = in[iy1 * N + ix], v11 = in[iy1 * N + ix1];
+  return (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+}
+
+__device__ __forceinline__ float bilinear_ring(const float *in, int N, int ox, int oy, float fx,
+                                               float fy) {
+  int ix = (int)floorf(fx), iy = (int)floorf(fy);
+  float wx = fx - (float)ix, wy = fy - (float)iy;
+  if (ix < 0 || iy < 0 || ix >= N || iy >= N) return 0.f;
+  int ix1 = ix + 1 < N ? ix + 1 : ix, iy1 = iy + 1 < N ? iy + 1 : iy;
+  float v00 = in[ring_idx(ix, iy, ox, oy, N)], v01 = in[ring_idx(ix1, iy, ox, oy, N)];
+  float v10 = in[ring_idx(ix, iy1, ox, oy, N)], v11 = in[ring_idx(ix1, iy1, ox, oy, N)];
+  return (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+}
+
+template <bool TARGET>
+__global__ __launch_bounds__(256) void k_raytrace(DevSys sys, DevState st, int env_begin,
+                                                  int flags) {
+  const int nn = TARGET ? sys.pupdiam : sys.n;
+  const int e = env_begin + blockIdx.y;
+  float *out = (TARGET ? st.tar_phase : st.wfs_phase) + (long long)e * nn * nn;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nn * nn) return;
+  const int y = p / nn, x = p - y * nn;
+  float v = (flags & AOMARL_TRACE_RESET) ? 0.f : out[p];
+  if (flags & AOMARL_TRACE_ATMOS) {
+    for (int l = 0; l < sys.nlayers; l++) {
+      const DevLayer &L = sys.layers[l];
+      const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+      const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
+      v += bilinear_ring(base, L.dim, ox, oy, (float)x + (TARGET ? L.txo : L.wxo),
+                         (float)y + (TARGET ? L.tyo : L.wyo));
+    }
+  }
+  if (flags & AOMARL_TRACE_DMS) {
+    for (int k = 0; k < sys.ndm; k++) {
+      const DevDm &D = sys.dms[k];
+      const float *sh = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+      v += bilinear_plain(sh, D.dim, (float)x + (TARGET ? D.txo : D.wxo),
+                          (float)y + (TARGET ? D.tyo : D.wyo));
+    }
+  }
+  out[p] = v;
+}
+
+// =============================================================================================
+// Shack-Hartmann spot image + centre of gravity.
+// One wavefront per (environment, sub-aperture); specialised for the production sampling
+// pdiam = 16 phase pixels, Nfft = 64, nrebin = 2, npix = 16 (SURVEY Appendix A / golden fixtures).
+//
+// The 16x16 complex pupil tile is staged in LDS; the zero-padded 64x64 FFT is never formed:
+// only the 32x32 central frequencies feed the 16x16 binned image, and the input has 16 non-zero
+// rows/columns, so the transform is the pruned DFT  X = E^T . a . E  with E[16][32] =
+// exp(-2 pi i x k / 64), k in [-16, 16): two small complex GEMMs (96 v_mfma_f32_16x16x4_f32).
+// |X|^2, the 2x2 binning (binmap), the flux normalisation, optional noise and the COG are done on
+// the accumulator registers.
+// =============================================================================================
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
+  if (!(lam > 0.f)) return 0.f;
+  if (lam < 30.f) {
+    float p = expf(-lam), c = p;
+    int k = 0;
+    while (u > c && k < 200) {
+      k++;
+      p *= lam / (float)k;
+      c += p;
+    }
+    return (float)k;
+  }
+  float v = floorf(lam + sqrtf(lam) * zn + 0.5f);
+  return v < 0.f ? 0.f : v;
+}
+
+template <bool FROM_BUF, bool NOISE, bool WRITE_CUBE>
+__global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int env_begin,
+                                                  int no_atmos, int no_dms, int do_cog) {
+  __shared__ float sAr[4][16][17];
+  __shared__ float sAi[4][16][17];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv;             // sub-aperture
+  const int e = env_begin + blockIdx.y;
+  if (i >= sys.nvalid) return;                   // whole wave exits together
+  const int q = lane >> 4, c = lane & 15;
+
+  // ---- twiddles: idx = 4q + s (pixel), freq = 16 b + c - 16
+  float Cc[2][4], Ss[2][4], nS[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      int m = ((4 * q + s) * (16 * b + c - 16)) & 63;
+      float sn, cs;
+      sincospif((float)m * (1.0f / 32.0f), &sn, &cs);
+      Cc[b][s] = cs; Ss[b][s] = sn; nS[b][s] = -sn;
+    }
+
+  // ---- stage 0: phase -> complex amplitude tile in LDS (4 pixels per lane)
+  const int xy0 = sys.sub_xy[i];
+  const int gx0 = xy0 & 0xFFFF, gy0 = xy0 >> 16;
+  const int ty = lane >> 2, tx0 = (lane & 3) * 4;
+  const int gy = gy0 + ty;
+  float ph[4] = {0.f, 0.f, 0.f, 0.f};
+  if (FROM_BUF) {
+    const float *pb = st.wfs_phase + (long long)e * sys.n * sys.n + gy * sys.n + gx0 + tx0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) ph[j] = pb[j];
+  } else {
+    if (!no_atmos) {
+      for (int l = 0; l < sys.nlayers; l++) {
+        const DevLayer &L = sys.layers[l];
+        const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+        const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
+        int py = gy + L.woy + oy; py -= (py >= L.dim) ? L.dim : 0;
+        int px = gx0 + tx0 + L.wox + ox; px -= (px >= L.dim) ? L.dim : 0;
+        const float *row = base + py * L.dim;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          int xx = px + j; xx -= (xx >= L.dim) ? L.dim : 0;
+          ph[j] += row[xx];
+        }
+      }
+    }
+    if (!no_dms) {
+      for (int k = 0; k < sys.ndm; k++) {
+        const DevDm &D = sys.dms[k];
+        const float *sh = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off +
+                          (gy + D.woy) * D.dim + gx0 + tx0 + D.wox;
+#pragma unroll
+        for (int j = 0; j < 4; j++) ph[j] += sh[j];
+      }
+    }
+  }
+  {
+    const float *mk = sys.mpupil + gy * sys.n + gx0 + tx0;
+    const float *hx = sys.halfxy + ty * 16 + tx0;   // halfxy already divided by 2 pi
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float t = ph[j] * sys.wfs_inv_lambda - hx[j];  // revolutions
+      t -= rintf(t);
+      float sn, cs;
+      sincospif(2.0f * t, &sn, &cs);
+      float m = mk[j];
+      sAr[wv][ty][tx0 + j] = m * cs;
+      sAi[wv][ty][tx0 + j] = m * sn;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): LDS writes of this wave are done
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- stage 1: T[y][kx] = sum_x a[y][x] E[x][kx]   (y = c on M, x = 4q+s on K)
+  f32x4 Tr[2], Ti[2];
+#pragma unroll
+  for (int b = 0; b < 2; b++) { Tr[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; Ti[b] = Tr[b]; }
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const float ar = sAr[wv][c][4 * q + s], ai = sAi[wv][c][4 * q + s];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      Tr[b] = mfma16(ar, Cc[b][s], Tr[b]);
+      Ti[b] = mfma16(ai, Cc[b][s], Ti[b]);
+      Tr[b] = mfma16(ai, Ss[b][s], Tr[b]);
+      Ti[b] = mfma16(ar, nS[b][s], Ti[b]);
+    }
+  }
+  // ---- stage 2: X[ky][kx] = sum_y E[ky][y] T[y][kx]; accumulator reg s of lane group q holds
+  //      y = 4q + s, which is exactly the K index the twiddle registers were built for.
+  f32x4 Xr[2][2], Xi[2][2];
+#pragma unroll
+  for (int bm = 0; bm < 2; bm++)
+#pragma unroll
+    for (int bn = 0; bn < 2; bn++) { Xr[bm][bn] = (f32x4){0.f, 0.f, 0.f, 0.f}; Xi[bm][bn] = Xr[bm][bn]; }
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int bm = 0; bm < 2; bm++)
+#pragma unroll
+      for (int bn = 0; bn < 2; bn++) {
+        Xr[bm][bn] = mfma16(Cc[bm][s], Tr[bn][s], Xr[bm][bn]);
+        Xi[bm][bn] = mfma16(Cc[bm][s], Ti[bn][s], Xi[bm][bn]);
+        Xr[bm][bn] = mfma16(Ss[bm][s], Ti[bn][s], Xr[bm][bn]);
+        Xi[bm][bn] = mfma16(nS[bm][s], Tr[bn][s], Xi[bm][bn]);
+      }
+  // ---- |X|^2 and 2x2 binning: reg r <-> ky = 16 bm + 4 q + r - 16, lane c <-> kx = 16 bn + c - 16
+  //      LR pixel Y = 8 bm + 2 q + (r >> 1), X = 8 bn + (c >> 1)
+  float v[2][2][2];
+#pragma unroll
+  for (int bm = 0; bm < 2; bm++)
+#pragma unroll
+    for (int bn = 0; bn < 2; bn++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float a0 = Xr[bm][bn][2 * h], b0 = Xi[bm][bn][2 * h];
+        float a1 = Xr[bm][bn][2 * h + 1], b1 = Xi[bm][bn][2 * h + 1];
+        float t = (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1);
+        t += __shfl_xor(t, 1);
+        v[bm][bn][h] = t;
+      }
+  // ---- total flux (each LR pixel is held by two lanes: count even lanes only)
+  const bool owner = (c & 1) == 0;
+  float tot = 0.f;
+#pragma unroll
+  for (int bm = 0; bm < 2; bm++)
+#pragma unroll
+    for (int bn = 0; bn < 2; bn++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) tot += v[bm][bn][h];
+  tot = owner ? tot : 0.f;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+  const float g = tot > 0.f ? sys.nphot * sys.flux[i] / tot : 0.f;
+  float s0 = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+  for (int bm = 0; bm < 2; bm++)
+#pragma unroll
+    for (int bn = 0; bn < 2; bn++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int Y = 8 * bm + 2 * q + h, X = 8 * bn + (c >> 1);
+        float val = v[bm][bn][h] * g;
+        if (NOISE) {
+          const uint32_t idx = (uint32_t)i * 256u + (uint32_t)(Y * 16 + X);
+          const uint32_t sd = st.seeds[e], fr = st.frame[e];
+          float u = philox_uniform(sd, 1u, fr, 0u, idx);
+          float zn = philox_normal(sd, 2u, fr, 0u, idx);
+          val = poisson_draw(val, u, zn);
+          if (sys.noise > 0.f) val += sys.noise * philox_normal(sd, 3u, fr, 0u, idx);
+        }
+        if (WRITE_CUBE && owner)
+          st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
+        s0 += val;
+        sx += val * (float)X;
+        sy += val * (float)Y;
+      }
+  if (do_cog) {
+    s0 = owner ? s0 : 0.f; sx = owner ? sx : 0.f; sy = owner ? sy : 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      s0 += __shfl_xor(s0, o);
+      sx += __shfl_xor(sx, o);
+      sy += __shfl_xor(sy, o);
+    }
+    if (lane == 0) {
+      float *sl = st.slopes + (long long)e * sys.nslope;
+      if (s0 != 0.f) {
+        sl[i] = (sx / s0 - sys.cog_offset) * sys.cog_scale;
+        sl[sys.nvalid + i] = (sy / s0 - sys.cog_offset) * sys.cog_scale;
+      } else {
+        sl[i] = 0.f;
+        sl[sys.nvalid + i] = 0.f;
+      }
+    }
+  }
+}
+
+// COG from a stored bincube (Rtc.do_centroids on its own): one wave per sub-aperture
+__global__ __launch_bounds__(256) void k_cog(DevSys sys, DevState st, int env_begin) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv;
+  const int e = env_begin + blockIdx.y;
+  if (i >= sys.nvalid) return;
+  const int np2 = sys.npix * sys.npix;
+  const float *im = st.bincube + ((long long)e * sys.nvalid + i) * np2;
+  float s0 = 0.f, sx = 0.f, sy = 0.f;
+  for (int p = lane; p < np2; p += 64) {
+    float val = im[p];
+    int y = p / sys.npix, x = p - y * sys.npix;
+    s0 += val; sx += val * (float)x; sy += val * (float)y;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s0 += __shfl_xor(s0, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o);
+  }
+  if (lane == 0) {
+    float *sl = st.slopes + (long long)e * sys.nslope;
+    if (s0 != 0.f) {
+      sl[i] = (sx / s0 - sys.cog_offset) * sys.cog_scale;
+      sl[sys.nvalid + i] = (sy / s0 - sys.cog_offset) * sys.cog_scale;
+    } else {
+      sl[i] = 0.f; sl[sys.nvalid + i] = 0.f;
+    }
+  }
+}
+
+// geometric slopes from st->wfs_phase (calibration only): one wave per sub-aperture
+__global__ __launch_bounds__(256) void k_slopes_geom(DevSys sys, DevState st, int env_begin) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv;
+  const int e = env_begin + blockIdx.y;
+  if (i >= sys.nvalid) return;
+  const int pd = sys.pdiam, n = sys.n;
+  const int xy0 = sys.sub_xy[i];
+  const int gx0 = xy0 & 0xFFFF, gy0 = xy0 >> 16;
+  const float *ph = st.wfs_phase + (long long)e * n * n;
+  float gx = 0.f, gyv = 0.f;
+  for (int k = lane; k < pd * pd; k += 64) {
+    int y = k / pd, x = k - y * pd;
+    int xm = x > 0 ? x - 1 : x, xp = x < pd - 1 ? x + 1 : x;
+    int ym = y > 0 ? y - 1 : y, yp = y < pd - 1 ? y + 1 : y;
+    float m = sys.mpupil[(gy0 + y) * n + gx0 + x];
+    float dx = (ph[(gy0 + y) * n + gx0 + xp] - ph[(gy0 + y) * n + gx0 + xm]) / (float)(xp - xm);
+    float dy = (ph[(gy0 + yp) * n + gx0 + x] - ph[(gy0 + ym) * n + gx0 + x]) / (float)(yp - ym);
+    gx += m * dx; gyv += m * dy;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { gx += __shfl_xor(gx, o); gyv += __shfl_xor(gyv, o); }
+  if (lane == 0) {
+    const float alpha = 0.206265f / sys.subapd;
+    const float den = (float)pd * sys.flux[i];
+    float *sl = st.slopes + (long long)e * sys.nslope;
+    sl[i] = alpha * gx / den;
+    sl[sys.nvalid + i] = alpha * gyv / den;
+  }
+}
+
+// =============================================================================================
+// controller glue
+// =============================================================================================
+// com += gain * err     (err = -cmat.s was produced by the GEMM with alpha = -1)
+__global__ void k_integrate(float *__restrict__ com, const float *__restrict__ err, int nactu,
+                            int ld, float gain, int env_begin) {
+  const int e = env_begin + blockIdx.y;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < nactu) com[(long long)e * ld + a] += gain * err[(long long)e * ld + a];
+}
+
+// voltage = a com + b com1 + c com2 ; com2 <- com1 ; com1 <- com
+__global__ void k_delay(DevState st, int nactu, int ld, float a, float b, float c, int env_begin,
+                        int comp_voltage) {
+  const int e = env_begin + blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nactu) return;
+  const long long o = (long long)e * ld + i;
+  const float c0 = st.com[o];
+  if (comp_voltage) {
+    const float c1 = st.com1[o], c2 = st.com2[o];
+    st.voltage[o] = a * c0 + b * c1 + c * c2;
+    st.com2[o] = c1;
+    st.com1[o] = c0;
+  } else {
+    st.voltage[o] = c0;
+  }
+}
+
+__global__ void k_copy_rows(float *__restrict__ dst, int ldd, const float *__restrict__ src,
+                            int lds, int ncols) {
+  const int r = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncols) dst[(long long)r * ldd + i] = src[(long long)r * lds + i];
+}
+
+// modes[e][action_modes[j]] += action[e][j] * freedom[action_modes[j]]
+__global__ void k_modal_add(float *__restrict__ modes, int ldm, const float *__restrict__ action,
+                            int nact, const int32_t *__restrict__ amodes,
+                            const float *__restrict__ freedom) {
+  const int r = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nact) {
+    int m = amodes[j];
+    modes[(long long)r * ldm + m] += action[(long long)r * nact + j] * freedom[m];
+  }
+}
+
+// =============================================================================================
+// science target: fused raytrace + windowed PSF (separable DFT) + phase variance
+// stage 1: R[y][kx] = sum_x a(y, x) exp(-2 pi i kx x / Npsf), kx in [-hw, hw)
+// =============================================================================================
+#define TGT_XC 64
+template <bool FROM_BUF>
+__global__ __launch_bounds__(256) void k_target_rows(DevSys sys, DevState st, int env_begin,
+                                                     float *__restrict__ TR,
+                                                     float *__restrict__ TPART, int nblk) {
+  extern __shared__ float smem[];
+  const int W = 2 * sys.hw, RB = 256 / W, pd = sys.pupdiam, np = sys.npsf;
+  float *sar = smem;                      // [RB][TGT_XC]
+  float *sai = sar + RB * TGT_XC;
+  float *red = sai + RB * TGT_XC;         // [3][256]
+  float2 *stw = reinterpret_cast<float2 *>(red + 3 * 256);   // [np] (only if it fits)
+  const bool tw_lds = np <= 4096;
+  const int tid = threadIdx.x;
+  const int e = env_begin + blockIdx.y;
+  const int y0 = blockIdx.x * RB;
+  const float2 *gtw = reinterpret_cast<const float2 *>(sys.psf_tw);
+  if (tw_lds)
+    for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
+  const float2 *tw = tw_lds ? stw : gtw;
+  // pivot for the variance sums: phase at the pupil-grid centre
+  float pivot;
+  {
+    const int cx = pd / 2, cy = pd / 2;
+    float v = 0.f;
+    if (FROM_BUF) {
+      v = st.tar_phase[(long long)e * pd * pd + cy * pd + cx];
+    } else {
+      for (int l = 0; l < sys.nlayers; l++) {
+        const DevLayer &L = sys.layers[l];
+        const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+        const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
+        v += base[ring_idx(cx + L.tox, cy + L.toy, ox, oy, L.dim)];
+      }
+      for (int k = 0; k < sys.ndm; k++) {
+        const DevDm &D = sys.dms[k];
+        v += st.dm_shape[(long long)e * sys.shape_stride + D.shape_off + (cy + D.toy) * D.dim + cx + D.tox];
+      }
+    }
+    pivot = v;
+  }
+  const int kxi = tid % W, ys = tid / W;
+  const int kxf = kxi - sys.hw;
+  float accr = 0.f, acci = 0.f;
+  float sd = 0.f, sd2 = 0.f, sm = 0.f;
+  for (int x0 = 0; x0 < pd; x0 += TGT_XC) {
+    __syncthreads();
+    for (int p = tid; p < RB * TGT_XC; p += 256) {
+      const int yy = p / TGT_XC, xx = p - yy * TGT_XC;
+      const int y = y0 + yy, x = x0 + xx;
+      float ar = 0.f, ai = 0.f;
+      if (y < pd && x < pd) {
+        const float m = sys.spupil[y * pd + x];
+        if (m != 0.f) {
+          float v = 0.f;
+          if (FROM_BUF) {
+            v = st.tar_phase[(long long)e * pd * pd + y * pd + x];
+          } else {
+            for (int l = 0; l < sys.nlayers; l++) {
+              const DevLayer &L = sys.layers[l];
+              const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+              const int ox = st.origin[(e * sys.nlayers + l) * 2];
+              const int oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
+              v += base[ring_idx(x + L.tox, y + L.toy, ox, oy, L.dim)];
+            }
+            for (int k = 0; k < sys.ndm; k++) {
+              const DevDm &D = sys.dms[k];
+              v += st.dm_shape[(long long)e * sys.shape_stride + D.shape_off +
+                               (y + D.toy) * D.dim + x + D.tox];
+            }
+          }
+          float t = v * sys.tar_inv_lambda;
+          t -= rintf(t);
+          float sn, cs;
+          sincospif(2.0f * t, &sn, &cs);
+          ar = m * cs; ai = m * sn;
+          const float d = v - pivot;
+          sd += d; sd2 += d * d; sm += 1.f;
+        }
+      }
+      sar[p] = ar; sai[p] = ai;
+    }
+    __syncthreads();
+    if (ys < RB) {
+      const int xmax = (pd - x0) < TGT_XC ? (pd - x0) : TGT_XC;
+      for (int xx = 0; xx < xmax; xx++) {
+        const float ar = sar[ys * TGT_XC + xx], ai = sai[ys * TGT_XC + xx];
+        const float2 w = tw[(kxf * (x0 + xx)) & (np - 1)];   // (cos, sin); e^{-i t} = cos - i sin
+        accr += ar * w.x + ai * w.y;
+        acci += ai * w.x - ar * w.y;
+      }
+    }
+  }
+  if (ys < RB && y0 + ys < pd) {
+    float *o = TR + (((long long)blockIdx.y * pd + (y0 + ys)) * W + kxi) * 2;
+    o[0] = accr; o[1] = acci;
+  }
+  // block partial sums for the variance
+  red[tid] = sd; red[256 + tid] = sd2; red[512 + tid] = sm;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+      red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; red[512 + tid] += red[512 + tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float *pp = TPART + ((long long)blockIdx.y * nblk + blockIdx.x) * 4;
+    pp[0] = red[0]; pp[1] = red[256]; pp[2] = red[512]; pp[3] = 0.f;
+  }
+}
+
+// stage 2: G[ky][kx] = sum_y R[y][kx] exp(-2 pi i ky y / Npsf); |G|^2 -> pending window;
+// variance from the block partials -> pending[W*W]
+__global__ __launch_bounds__(256) void k_target_finish(DevSys sys, const float *__restrict__ TR,
+                                                       const float *__restrict__ TPART, int nblk,
+                                                       float *__restrict__ PEND) {
+  const int W = 2 * sys.hw, pd = sys.pupdiam, np = sys.npsf;
+  const int b = blockIdx.x;     // env within the batch
+  const float2 *tw = reinterpret_cast<const float2 *>(sys.psf_tw);
+  const float2 *R = reinterpret_cast<const float2 *>(TR) + (long long)b * pd * W;
+  float *pend = PEND + (long long)b * (W * W + 4);
+  for (int o = threadIdx.x; o < W * W; o += blockDim.x) {
+    const int ky = o / W, kx = o - ky * W;
+    const int kyf = ky - sys.hw;
+    float gr = 0.f, gi = 0.f;
+    for (int y = 0; y < pd; y++) {
+      const float2 r = R[y * W + kx];
+      const float2 w = tw[(kyf * y) & (np - 1)];
+      gr += r.x * w.x + r.y * w.y;
+      gi += r.y * w.x - r.x * w.y;
+    }
+    pend[o] = gr * gr + gi * gi;
+  }
+  if (threadIdx.x == 0) {
+    double sd = 0., sd2 = 0., sm = 0.;
+    for (int k = 0; k < nblk; k++) {
+      const float *pp = TPART + ((long long)b * nblk + k) * 4;
+      sd += pp[0]; sd2 += pp[1]; sm += pp[2];
+    }
+    double var = 0.;
+    if (sm > 0.) { double mean = sd / sm; var = sd2 / sm - mean * mean; }
+    pend[W * W] = (float)var;
+  }
+}
+
+// publish the pending PSF: LE accumulation, Strehl SE / LE, variance bookkeeping
+__global__ __launch_bounds__(256) void k_strehl_commit(DevSys sys, DevState st, int env_begin,
+                                                       const float *__restrict__ PEND) {
+  __shared__ float r0[256], r1[256];
+  __shared__ int ri[256];
+  const int W = 2 * sys.hw;
+  const int e = env_begin + blockIdx.x;
+  const float *pend = PEND + (long long)blockIdx.x * (W * W + 4);
+  float *le = st.le_img + (long long)e * W * W;
+  float mse = 0.f, mle = 0.f;
+  int arg = 0;
+  for (int o = threadIdx.x; o < W * W; o += blockDim.x) {
+    const float p = pend[o];
+    const float l = le[o] + p;
+    le[o] = l;
+    if (p > mse) { mse = p; arg = o; }
+    mle = fmaxf(mle, l);
+  }
+  r0[threadIdx.x] = mse; r1[threadIdx.x] = mle; ri[threadIdx.x] = arg;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) {
+      if (r0[threadIdx.x + o] > r0[threadIdx.x]) { r0[threadIdx.x] = r0[threadIdx.x + o]; ri[threadIdx.x] = ri[threadIdx.x + o]; }
+      r1[threadIdx.x] = fmaxf(r1[threadIdx.x], r1[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float *s = st.strehl + (long long)e * 8;
+    const float cnt = s[4] + 1.f;
+    const float var = pend[W * W];
+    const int ay = ri[0] / W, ax = ri[0] - ay * W;
+    s[0] = r0[0] / sys.ref_peak;
+    s[1] = r1[0] / cnt / sys.ref_peak;
+    s[2] = var;
+    s[3] = s[3] + var;
+    s[4] = cnt;
+    s[5] = (ay == 0 || ax == 0 || ay == W - 1 || ax == W - 1) ? 1.f : 0.f;
+  }
+}
+
+__global__ void k_strehl_reset(DevSys sys, DevState st, int env_begin) {
+  const int W = 2 * sys.hw;
+  const int e = env_begin + blockIdx.x;
+  for (int o = threadIdx.x; o < W * W; o += blockDim.x) st.le_img[(long long)e * W * W + o] = 0.f;
+  if (threadIdx.x < 8) st.strehl[(long long)e * 8 + threadIdx.x] = 0.f;
+}

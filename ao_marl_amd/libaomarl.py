@@ -1,0 +1,225 @@
+"""ctypes binding of the C ABI in include/aomarl.h (libaomarl_hip.so, built in-tree by
+ao_marl_amd/csrc/Makefile or __graft_entry__.build()).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing the
+product path raises.  The CPU oracle under oracle/ is never used from here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libaomarl_hip.so")
+MAX_LAYERS, MAX_DMS, ABI_VERSION = 8, 4, 1
+
+DM_PZT, DM_TT = 0, 1
+TRACE_ATMOS, TRACE_DMS, TRACE_RESET = 1, 2, 4
+IMG_FROM_PHASE_BUFFER, IMG_NOISE, IMG_WRITE_BINCUBE, IMG_COG, IMG_NO_ATMOS, IMG_NO_DMS = \
+    1, 2, 4, 8, 16, 32
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint32)
+
+
+class DmDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("dim", C.c_int32), ("nact", C.c_int32),
+                ("influsize", C.c_int32), ("ninflupos", C.c_int64), ("influ", _fp),
+                ("influpos", _ip), ("ninflu", _ip), ("influstart", _ip),
+                ("wfs_xoff", C.c_float), ("wfs_yoff", C.c_float), ("tar_xoff", C.c_float),
+                ("tar_yoff", C.c_float)]
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("nstencil", C.c_int32), ("A", _fp), ("B", _fp),
+                ("istx", _up), ("isty", _up), ("deltax", C.c_float), ("deltay", C.c_float),
+                ("amplitude", C.c_float), ("wfs_xoff", C.c_float), ("wfs_yoff", C.c_float),
+                ("tar_xoff", C.c_float), ("tar_yoff", C.c_float)]
+
+
+class Desc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("n", C.c_int32), ("pupdiam", C.c_int32),
+                ("mpupil", _fp), ("spupil", _fp),
+                ("nvalid", C.c_int32), ("pdiam", C.c_int32), ("nfft", C.c_int32),
+                ("npix", C.c_int32), ("nrebin", C.c_int32), ("nxsub", C.c_int32),
+                ("phasemap", _ip), ("halfxy", _fp), ("binmap", _ip), ("flux", _fp),
+                ("validsubsx", _ip), ("validsubsy", _ip),
+                ("nphot", C.c_float), ("wfs_lambda", C.c_float), ("noise", C.c_float),
+                ("cog_offset", C.c_float), ("cog_scale", C.c_float), ("subapd", C.c_float),
+                ("nlayers", C.c_int32), ("layers", LayerDesc * MAX_LAYERS),
+                ("ndm", C.c_int32), ("dms", DmDesc * MAX_DMS),
+                ("tar_lambda", C.c_float), ("npsf", C.c_int32), ("strehl_halfwin", C.c_int32),
+                ("nactu", C.c_int32), ("nslope", C.c_int32), ("gain", C.c_float),
+                ("delay", C.c_float)]
+
+
+class State(C.Structure):
+    _fields_ = [("nenv", C.c_int32), ("ld_actu", C.c_int32), ("screens", C.c_void_p),
+                ("origin", C.c_void_p), ("seeds", C.c_void_p), ("ext_count", C.c_void_p),
+                ("com", C.c_void_p), ("com1", C.c_void_p), ("com2", C.c_void_p),
+                ("err", C.c_void_p), ("voltage", C.c_void_p), ("slopes", C.c_void_p),
+                ("dm_shape", C.c_void_p), ("bincube", C.c_void_p), ("wfs_phase", C.c_void_p),
+                ("tar_phase", C.c_void_p), ("strehl", C.c_void_p), ("le_img", C.c_void_p),
+                ("frame", C.c_void_p), ("work", C.c_void_p)]
+
+
+# every symbol include/aomarl.h declares: (name, restype, argtypes)
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_range = [_vp, C.POINTER(State), _i, _i]
+SYMBOLS = [
+    ("aomarl_last_error", C.c_char_p, []),
+    ("aomarl_abi_version", _i, []),
+    ("aomarl_create", _i, [C.POINTER(Desc), C.POINTER(_vp)]),
+    ("aomarl_destroy", _i, [_vp]),
+    ("aomarl_set_cmat", _i, [_vp, _fp]),
+    ("aomarl_set_gain", _i, [_vp, _f]),
+    ("aomarl_set_modal", _i, [_vp, _i, _fp, _fp, _fp, _i, _ip]),
+    ("aomarl_workspace_floats", C.c_size_t, [_vp, _i]),
+    ("aomarl_screen_stride", C.c_size_t, [_vp]),
+    ("aomarl_dmshape_stride", C.c_size_t, [_vp]),
+    ("aomarl_reset", _i, _range + [_up, _fp, _fp, _vp]),
+    ("aomarl_move_atmos", _i, _range + [_fp, _fp, _vp]),
+    ("aomarl_extrude", _i, _range + [_i, _ip, _ip, _vp]),
+    ("aomarl_get_screen", _i, _range + [_i, _vp, _vp]),
+    ("aomarl_raytrace_wfs", _i, _range + [_i, _vp]),
+    ("aomarl_raytrace_target", _i, _range + [_i, _vp]),
+    ("aomarl_comp_image", _i, _range + [_i, _vp]),
+    ("aomarl_do_centroids", _i, _range + [_vp]),
+    ("aomarl_slopes_geom", _i, _range + [_vp]),
+    ("aomarl_do_control", _i, _range + [_vp]),
+    ("aomarl_set_com", _i, _range + [_vp, _vp]),
+    ("aomarl_rl_control", _i, _range + [_vp, _vp]),
+    ("aomarl_apply_control", _i, _range + [_i, _vp]),
+    ("aomarl_comp_dm_shape", _i, _range + [_vp, _vp]),
+    ("aomarl_target_psf", _i, _range + [_vp]),
+    ("aomarl_comp_strehl", _i, _range + [_vp]),
+    ("aomarl_reset_strehl", _i, _range + [_vp]),
+    ("aomarl_volts2modes", _i, [_vp, _i, _vp, _vp, _vp]),
+    ("aomarl_next_part_one", _i, _range + [_fp, _fp, _i, _vp]),
+    ("aomarl_next_part_two", _i, _range + [_vp, _vp]),
+    ("aomarl_gemm_nt", _i, [_i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp]),
+]
+
+_lib = None
+
+
+class AomarlError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libaomarl_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(HERE, "csrc")
+    cmd = ["make", "-s", "-C", src_dir]
+    if force:
+        cmd.insert(1, "-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AomarlError(
+                "libaomarl_hip.so is missing (%s). Build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` or `make -C ao_marl_amd/csrc`. There is no CPU "
+                "fallback for the product path." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise AomarlError("libaomarl_hip.so does not export %s" % name)
+        fn.restype, fn.argtypes = res, args
+    if L.aomarl_abi_version() != ABI_VERSION:
+        raise AomarlError("libaomarl_hip.so ABI %d != binding %d" %
+                          (L.aomarl_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise AomarlError(load().aomarl_last_error().decode("utf-8", "replace"))
+
+
+def fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def uptr(a):
+    return a.ctypes.data_as(_up)
+
+
+def make_desc(s):
+    """SimArrays -> (Desc, keepalive list of the NumPy arrays the Desc points to)."""
+    keep = []
+
+    def f32(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        keep.append(a)
+        return fptr(a)
+
+    def i32(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        keep.append(a)
+        return iptr(a)
+
+    def u32(a):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        keep.append(a)
+        return uptr(a)
+
+    d = Desc()
+    d.abi_version = ABI_VERSION
+    d.n, d.pupdiam = s.n, s.pupdiam
+    d.mpupil, d.spupil = f32(s.mpupil), f32(s.spupil)
+    d.nvalid, d.pdiam, d.nfft, d.npix, d.nrebin, d.nxsub = (s.nvalid, s.pdiam, s.nfft, s.npix,
+                                                           s.nrebin, s.nxsub)
+    d.phasemap, d.halfxy, d.binmap, d.flux = i32(s.phasemap), f32(s.halfxy), i32(s.binmap), f32(s.flux)
+    d.validsubsx, d.validsubsy = i32(s.validsubsx), i32(s.validsubsy)
+    d.nphot, d.wfs_lambda, d.noise = float(s.nphot), s.wfs_lambda, s.noise
+    d.cog_offset, d.cog_scale, d.subapd = s.cog_offset, s.cog_scale, s.subapd
+    if s.nscreens > MAX_LAYERS or len(s.dms) > MAX_DMS:
+        raise AomarlError("too many layers / DMs for the C ABI")
+    d.nlayers = s.nscreens
+    shared = {}
+    for l in range(s.nscreens):
+        L = d.layers[l]
+        L.dim, L.nstencil = s.screen_dim[l], int(s.istx[l].size)
+        # layers that share the same A/B arrays must hand over the same pointers
+        key = (id(s.A[l]), id(s.B[l]))
+        if key not in shared:
+            shared[key] = (f32(s.A[l]), f32(s.B[l]))
+        L.A, L.B = shared[key]
+        L.istx, L.isty = u32(s.istx[l]), u32(s.isty[l])
+        L.deltax, L.deltay = float(s.deltax[l]), float(s.deltay[l])
+        L.amplitude = float(s.amplitude[l])
+        L.wfs_xoff, L.wfs_yoff = s.wfs_atm_off[l]
+        L.tar_xoff, L.tar_yoff = s.tar_atm_off[l]
+    d.ndm = len(s.dms)
+    for k, m in enumerate(s.dms):
+        D = d.dms[k]
+        D.dim, D.nact = m.dim, m.ntotact
+        if m.type == "pzt":
+            D.type, D.influsize = DM_PZT, m.influsize
+            D.influ = f32(m.influ.flatten("F"))
+            D.influpos, D.ninflu, D.influstart = i32(m.influpos), i32(m.ninflu), i32(m.influstart)
+            D.ninflupos = int(m.influpos.size)
+        else:
+            D.type, D.influsize = DM_TT, m.dim
+            D.influ = f32(m.influ)
+        D.wfs_xoff, D.wfs_yoff = s.wfs_dm_off[k]
+        D.tar_xoff, D.tar_yoff = s.tar_dm_off[k]
+    d.tar_lambda, d.npsf, d.strehl_halfwin = s.tar_lambda, s.npsf, s.strehl_halfwin
+    d.nactu, d.nslope, d.gain, d.delay = s.nactu, s.nslope, s.gain, s.delay
+    return d, keep

@@ -1,0 +1,359 @@
+"""HipSim: the batched, device-resident AO simulator (product path).
+
+Owns one `aomarl_ctx` (static geometry on the GPU) and the per-environment state as torch tensors
+whose `data_ptr()`s are handed to the C ABI (include/aomarl.h).  PyTorch is plumbing here: device
+memory, streams -- every arithmetic step of the AO frame runs in the hand-written gfx950 kernels
+of libaomarl_hip.so.  No CPU fallback exists: without the library or a GPU this raises.
+
+Method names mirror the native objects the reference drives:
+reset / move_atmos / raytrace_* / comp_image / do_centroids / do_control / set_com / rl_control /
+apply_control / target_psf + comp_strehl, plus the two composites next_part_one / next_part_two
+(rlSupervisor.py:1015-1051, 900-947).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import libaomarl as la
+from . import system
+
+
+def _ld4(n):
+    return (n + 3) & ~3
+
+
+class HipSim(object):
+    def __init__(self, s, nenv, device="cuda:0", keep_bincube=False, keep_phase=False):
+        if not torch.cuda.is_available():
+            raise la.AomarlError("HipSim needs a GPU (torch.cuda.is_available() is False); the "
+                                 "product path has no CPU fallback")
+        self.lib = la.load()
+        self.s = s
+        self.nenv = int(nenv)
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.keep_bincube, self.keep_phase = keep_bincube, keep_phase
+        self.ctx = C.c_void_p()
+        self._create_ctx()
+        self._alloc()
+        if s.cmat is not None:
+            self.set_cmat(s.cmat)
+
+    # ------------------------------------------------------------------ plumbing
+    def _create_ctx(self):
+        desc, keep = la.make_desc(self.s)
+        ctx = C.c_void_p()
+        la.check(self.lib.aomarl_create(C.byref(desc), C.byref(ctx)))
+        if self.ctx:
+            self.lib.aomarl_destroy(self.ctx)
+        self.ctx = ctx
+        del keep
+
+    def _alloc(self):
+        s, n, dev = self.s, self.nenv, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.ld_actu = _ld4(s.nactu)
+        self.screen_stride = int(self.lib.aomarl_screen_stride(self.ctx))
+        self.shape_stride = int(self.lib.aomarl_dmshape_stride(self.ctx))
+        W = 2 * s.strehl_halfwin
+        t = {}
+        t["screens"] = torch.zeros(n, self.screen_stride, **f32)
+        t["origin"] = torch.zeros(n, max(s.nscreens, 1), 2, **i32)
+        t["seeds"] = torch.zeros(n, **i32)
+        t["ext_count"] = torch.zeros(n, max(s.nscreens, 1), **i32)
+        for k in ("com", "com1", "com2", "err", "voltage"):
+            t[k] = torch.zeros(n, self.ld_actu, **f32)
+        t["slopes"] = torch.zeros(n, s.nslope, **f32)
+        t["dm_shape"] = torch.zeros(n, self.shape_stride, **f32)
+        t["bincube"] = torch.zeros(n, s.nvalid, s.npix * s.npix, **f32) if self.keep_bincube \
+            else None
+        t["wfs_phase"] = torch.zeros(n, s.n, s.n, **f32) if self.keep_phase else None
+        t["tar_phase"] = torch.zeros(n, s.pupdiam, s.pupdiam, **f32) if self.keep_phase else None
+        t["strehl"] = torch.zeros(n, 8, **f32)
+        t["le_img"] = torch.zeros(n, W * W, **f32)
+        t["frame"] = torch.zeros(n, **i32)
+        t["work"] = torch.zeros(int(self.lib.aomarl_workspace_floats(self.ctx, n)), **f32)
+        self.t = t
+        st = la.State()
+        st.nenv, st.ld_actu = n, self.ld_actu
+        for k, v in t.items():
+            setattr(st, k, v.data_ptr() if v is not None else None)
+        self.st = st
+        self.accumx = np.zeros((n, max(s.nscreens, 1)), dtype=np.float32)
+        self.accumy = np.zeros((n, max(s.nscreens, 1)), dtype=np.float32)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                torch.cuda.synchronize(self.device)
+                self.lib.aomarl_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    def _range(self, env_begin, env_count):
+        if env_count is None:
+            env_count = self.nenv - env_begin
+        return env_begin, env_count
+
+    # ------------------------------------------------------------------ views
+    @property
+    def com(self):
+        return self.t["com"][:, :self.s.nactu]
+
+    @property
+    def err(self):
+        return self.t["err"][:, :self.s.nactu]
+
+    @property
+    def voltage(self):
+        return self.t["voltage"][:, :self.s.nactu]
+
+    @property
+    def slopes(self):
+        return self.t["slopes"]
+
+    @property
+    def strehl(self):
+        """[nenv, 4]: SR SE, SR LE, phase variance, mean phase variance (targetCompass.py:139-159)."""
+        s = self.t["strehl"]
+        avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
+        return torch.stack([s[:, 0], s[:, 1], s[:, 2], avg], dim=1)
+
+    def dm_shape(self, k):
+        d = self.s.dms[k]
+        off = sum(x.dim * x.dim for x in self.s.dms[:k])
+        return self.t["dm_shape"][:, off:off + d.dim * d.dim].view(self.nenv, d.dim, d.dim)
+
+    def screen(self, layer, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        d = self.s.screen_dim[layer]
+        out = torch.empty(n, d, d, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_get_screen(self.ctx, C.byref(self.st), b, n, layer,
+                                            out.data_ptr(), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ configuration
+    def set_cmat(self, cmat):
+        cmat = np.ascontiguousarray(cmat, dtype=np.float32)
+        if cmat.shape != (self.s.nactu, self.s.nslope):
+            raise ValueError("cmat must be [nactu, nslope]")
+        la.check(self.lib.aomarl_set_cmat(self.ctx, la.fptr(cmat)))
+
+    def set_gain(self, gain):
+        la.check(self.lib.aomarl_set_gain(self.ctx, float(gain)))
+
+    def set_modal(self, v2m, m2v, freedom=None, action_modes=None):
+        v2m = np.ascontiguousarray(v2m, dtype=np.float32)
+        m2v = np.ascontiguousarray(m2v, dtype=np.float32)
+        nm = v2m.shape[0]
+        if v2m.shape != (nm, self.s.nactu) or m2v.shape != (self.s.nactu, nm):
+            raise ValueError("v2m must be [nmodes, nactu] and m2v [nactu, nmodes]")
+        fr = np.zeros(nm, dtype=np.float32) if freedom is None else \
+            np.ascontiguousarray(freedom, dtype=np.float32)
+        am = np.zeros(0, dtype=np.int32) if action_modes is None else \
+            np.ascontiguousarray(np.asarray(action_modes) % nm, dtype=np.int32)
+        la.check(self.lib.aomarl_set_modal(self.ctx, nm, la.fptr(v2m), la.fptr(m2v), la.fptr(fr),
+                                           int(am.size), la.iptr(am) if am.size else None))
+        self.nmodes, self.nact = nm, int(am.size)
+
+    def reload_dms(self):
+        """After actuator filtering changed s.dms: rebuild the static description + state."""
+        torch.cuda.synchronize(self.device)
+        self._create_ctx()
+        self._alloc()
+
+    # ------------------------------------------------------------------ per-frame API
+    def reset(self, seeds, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.int64) &
+                                                     0xFFFFFFFF, (n,)), dtype=np.uint32)
+        la.check(self.lib.aomarl_reset(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
+                                       la.fptr(self.accumx), la.fptr(self.accumy),
+                                       self._stream()))
+
+    def move_atmos(self, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_move_atmos(self.ctx, C.byref(self.st), b, n,
+                                            la.fptr(self.accumx), la.fptr(self.accumy),
+                                            self._stream()))
+
+    def extrude(self, layers, dirs, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        l = np.ascontiguousarray(layers, dtype=np.int32)
+        d = np.ascontiguousarray(dirs, dtype=np.int32)
+        la.check(self.lib.aomarl_extrude(self.ctx, C.byref(self.st), b, n, int(l.size),
+                                         la.iptr(l), la.iptr(d), self._stream()))
+
+    def _need_phase(self):
+        if self.t["wfs_phase"] is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self.t["wfs_phase"] = torch.zeros(self.nenv, self.s.n, self.s.n, **f32)
+            self.t["tar_phase"] = torch.zeros(self.nenv, self.s.pupdiam, self.s.pupdiam, **f32)
+            self.st.wfs_phase = self.t["wfs_phase"].data_ptr()
+            self.st.tar_phase = self.t["tar_phase"].data_ptr()
+
+    def _need_bincube(self):
+        if self.t["bincube"] is None:
+            self.t["bincube"] = torch.zeros(self.nenv, self.s.nvalid, self.s.npix * self.s.npix,
+                                            dtype=torch.float32, device=self.device)
+            self.st.bincube = self.t["bincube"].data_ptr()
+
+    def raytrace_wfs(self, atm=True, dms=True, reset=True, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        self._need_phase()
+        fl = (la.TRACE_ATMOS if atm else 0) | (la.TRACE_DMS if dms else 0) | \
+            (la.TRACE_RESET if reset else 0)
+        la.check(self.lib.aomarl_raytrace_wfs(self.ctx, C.byref(self.st), b, n, fl,
+                                              self._stream()))
+
+    def raytrace_target(self, atm=True, dms=True, reset=True, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        self._need_phase()
+        fl = (la.TRACE_ATMOS if atm else 0) | (la.TRACE_DMS if dms else 0) | \
+            (la.TRACE_RESET if reset else 0)
+        la.check(self.lib.aomarl_raytrace_target(self.ctx, C.byref(self.st), b, n, fl,
+                                                 self._stream()))
+
+    def comp_image(self, from_phase_buffer=False, noise=True, write_bincube=False, cog=True,
+                   atm=True, dms=True, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        fl = 0
+        if from_phase_buffer:
+            self._need_phase()
+            fl |= la.IMG_FROM_PHASE_BUFFER
+        if noise:
+            fl |= la.IMG_NOISE
+        if write_bincube:
+            self._need_bincube()
+            fl |= la.IMG_WRITE_BINCUBE
+        if cog:
+            fl |= la.IMG_COG
+        if not atm:
+            fl |= la.IMG_NO_ATMOS
+        if not dms:
+            fl |= la.IMG_NO_DMS
+        la.check(self.lib.aomarl_comp_image(self.ctx, C.byref(self.st), b, n, fl, self._stream()))
+
+    def do_centroids(self, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_do_centroids(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def slopes_geom(self, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_slopes_geom(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def do_control(self, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_do_control(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def set_com(self, com, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        com = torch.as_tensor(com, dtype=torch.float32, device=self.device).contiguous()
+        if com.shape != (n, self.s.nactu):
+            raise ValueError("Dimension mismatch")   # rtcCompass.py:471-472
+        la.check(self.lib.aomarl_set_com(self.ctx, C.byref(self.st), b, n, com.data_ptr(),
+                                         self._stream()))
+
+    def rl_control(self, action, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        action = torch.as_tensor(action, dtype=torch.float32, device=self.device).contiguous()
+        if action.shape != (n, self.nact):
+            raise ValueError("action must be [env_count, %d]" % self.nact)
+        la.check(self.lib.aomarl_rl_control(self.ctx, C.byref(self.st), b, n, action.data_ptr(),
+                                            self._stream()))
+
+    def apply_control(self, comp_voltage=True, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_apply_control(self.ctx, C.byref(self.st), b, n,
+                                               1 if comp_voltage else 0, self._stream()))
+
+    def comp_dm_shape(self, volts=None, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        ptr = None
+        if volts is not None:
+            volts = torch.as_tensor(volts, dtype=torch.float32, device=self.device).contiguous()
+            if volts.shape != (n, self.s.nactu):
+                raise ValueError("volts must be [env_count, nactu]")
+            ptr = volts.data_ptr()
+        la.check(self.lib.aomarl_comp_dm_shape(self.ctx, C.byref(self.st), b, n, ptr,
+                                               self._stream()))
+
+    def target_psf(self, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        if not all(float(o).is_integer() for t in (self.s.tar_atm_off + self.s.tar_dm_off)
+                   for o in t):
+            self._need_phase()
+        la.check(self.lib.aomarl_target_psf(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def comp_strehl(self, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_comp_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def reset_strehl(self, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_reset_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def volts2modes(self, vec):
+        vec = vec.contiguous()
+        out = torch.empty(vec.shape[0], self.nmodes, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_volts2modes(self.ctx, vec.shape[0], vec.data_ptr(),
+                                             out.data_ptr(), self._stream()))
+        return out
+
+    def next_part_one(self, write_bincube=False, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        fl = 0
+        if write_bincube:
+            self._need_bincube()
+            fl |= la.IMG_WRITE_BINCUBE
+        la.check(self.lib.aomarl_next_part_one(self.ctx, C.byref(self.st), b, n,
+                                               la.fptr(self.accumx), la.fptr(self.accumy), fl,
+                                               self._stream()))
+
+    def next_part_two(self, action=None, env_begin=0, env_count=None):
+        b, n = self._range(env_begin, env_count)
+        ptr = None
+        if action is not None:
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device).contiguous()
+            if action.shape != (n, self.nact):
+                raise ValueError("action must be [env_count, %d]" % self.nact)
+            ptr = action.data_ptr()
+        la.check(self.lib.aomarl_next_part_two(self.ctx, C.byref(self.st), b, n, ptr,
+                                               self._stream()))
+
+    def gemm_nt(self, A, B, alpha=1.0, beta=0.0, Cout=None):
+        """C = alpha * A @ B.T + beta * C on the library's fp32 MFMA GEMM (tests)."""
+        A, B = A.contiguous(), B.contiguous()
+        M, K = A.shape
+        N = B.shape[0]
+        if Cout is None:
+            Cout = torch.zeros(M, N, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_gemm_nt(M, N, K, alpha, A.data_ptr(), A.stride(0), B.data_ptr(),
+                                         B.stride(0), beta, Cout.data_ptr(), Cout.stride(0),
+                                         self._stream()))
+        return Cout
+
+    # ------------------------------------------------------------------ calibration backend
+    def dm_response(self, commands, geometric):
+        """slopes [K, nslope] for commands [K, nactu], atmosphere off (modal.calibrate backend)."""
+        commands = np.ascontiguousarray(commands, dtype=np.float32)
+        K = commands.shape[0]
+        out = np.zeros((K, self.s.nslope), dtype=np.float32)
+        for k0 in range(0, K, self.nenv):
+            n = min(self.nenv, K - k0)
+            v = torch.from_numpy(commands[k0:k0 + n]).to(self.device)
+            self.comp_dm_shape(v, 0, n)
+            if geometric:
+                self.raytrace_wfs(atm=False, dms=True, reset=True, env_begin=0, env_count=n)
+                self.slopes_geom(0, n)
+            else:
+                self.comp_image(noise=False, cog=True, atm=False, dms=True, env_begin=0,
+                                env_count=n)
+            out[k0:k0 + n] = self.slopes[:n].cpu().numpy()
+        return out

@@ -1,0 +1,223 @@
+/*
+ * aomarl.h -- C ABI of the MI355X-native AO environment hot path (libaomarl_hip.so).
+ *
+ * DROP-IN BOUNDARY.  The reference (Tomeu7/AO-MARL) reaches its per-frame arithmetic through the
+ * pybind11 modules `sutraWrap` / `carmaWrap` of COMPASS (shesha/sutra_wrap.py:4-38,46-72); there
+ * is no C header in its tree.  Each entry point below names the native call it replaces and the
+ * reference call site that drives it.  Differences by design:
+ *   - every call is BATCHED over environments [env_begin, env_begin+env_count) (independent
+ *     atmosphere seeds); batch size 1 reproduces the reference's single simulation;
+ *   - state lives in caller-owned device buffers (aomarl_state): no hidden device<->host copies
+ *     (the reference copies ~8 arrays per frame through np.array(d_xxx), rtcCompass.py:114,310);
+ *   - every call takes an explicit hipStream_t and returns an int status (0 = ok); the message of
+ *     the last failure on the calling thread is aomarl_last_error().
+ * Plain C types only: pointers + sizes, no torch/HIP types in signatures (stream is void*).
+ *
+ * Conventions: fp32; flat pixel index p = x + n*y (x fast); per-env vectors are rows [env][i].
+ */
+#ifndef AOMARL_H
+#define AOMARL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOMARL_MAX_LAYERS 8
+#define AOMARL_MAX_DMS 4
+#define AOMARL_ABI_VERSION 1
+
+enum { AOMARL_DM_PZT = 0, AOMARL_DM_TT = 1 };
+
+/* flags of aomarl_raytrace_* (sourceCompass.py:54-85: tel/atm/dms/reset arguments) */
+enum { AOMARL_TRACE_ATMOS = 1, AOMARL_TRACE_DMS = 2, AOMARL_TRACE_RESET = 4 };
+/* flags of aomarl_comp_image */
+enum {
+  AOMARL_IMG_FROM_PHASE_BUFFER = 1, /* read st->wfs_phase (else: fused integer-offset raytrace) */
+  AOMARL_IMG_NOISE = 2,             /* apply photon / read-out noise if desc.noise >= 0       */
+  AOMARL_IMG_WRITE_BINCUBE = 4,     /* store the 16x16 spot images (st->bincube)              */
+  AOMARL_IMG_COG = 8,               /* fused centre of gravity -> st->slopes                  */
+  AOMARL_IMG_NO_ATMOS = 16,         /* fused raytrace: DMs only (interaction matrix)          */
+  AOMARL_IMG_NO_DMS = 32            /* fused raytrace: atmosphere only                        */
+};
+
+typedef struct {
+  int32_t type;          /* AOMARL_DM_PZT | AOMARL_DM_TT                                   */
+  int32_t dim;           /* support is dim x dim (dm_init.py:146-147,168)                  */
+  int32_t nact;
+  int32_t influsize;     /* pzt: side of one influence patch (dm_init.py:373)              */
+  int64_t ninflupos;     /* pzt: len(influpos)                                             */
+  const float *influ;    /* pzt: [nact][ss][ss] = influ.flatten('F') of the (ss,ss,nact) cube
+                            tt : [dim*dim][2]   = C-order (dim,dim,2) cube (dm_init.py:661-694) */
+  const int32_t *influpos;   /* dm_init.py:800 */
+  const int32_t *ninflu;     /* [dim*dim]  dm_init.py:804 */
+  const int32_t *influstart; /* [dim*dim]  dm_init.py:805 */
+  float wfs_xoff, wfs_yoff;  /* wfs_init.py:196-204  */
+  float tar_xoff, tar_yoff;  /* target_init.py:119-141 */
+} aomarl_dm_desc;
+
+typedef struct {
+  int32_t dim;          /* screen is dim x dim (atmos_init.py:94-96)              */
+  int32_t nstencil;     /* iterkolmo.py:76-96                                      */
+  const float *A;       /* [dim][nstencil] row-major (iterkolmo.py:229)            */
+  const float *B;       /* [dim][dim]                (iterkolmo.py:239)            */
+  const uint32_t *istx; /* [nstencil] flat logical indices, mirrored if deltax < 0 */
+  const uint32_t *isty;
+  float deltax, deltay; /* pixels per frame (atmos_init.py:99-102)                 */
+  float amplitude;      /* r0_layer^(-5/6) * 0.5/(2 pi): screens in microns        */
+  float wfs_xoff, wfs_yoff; /* wfs_init.py:177-185   */
+  float tar_xoff, tar_yoff; /* target_init.py:104-113 */
+} aomarl_layer_desc;
+
+typedef struct {
+  int32_t abi_version; /* = AOMARL_ABI_VERSION */
+  /* pupil (geom_init.py:813-868) */
+  int32_t n, pupdiam;
+  const float *mpupil; /* [n*n]            */
+  const float *spupil; /* [pupdiam*pupdiam] */
+  /* Shack-Hartmann WFS (geom_init.py:168-321, 622-810; Sensors ctor wfs_init.py:107-110) */
+  int32_t nvalid, pdiam, nfft, npix, nrebin, nxsub;
+  const int32_t *phasemap; /* [pdiam^2][nvalid] */
+  const float *halfxy;     /* [pdiam^2]         */
+  const int32_t *binmap;   /* [nrebin^2][npix^2] */
+  const float *flux;       /* [nvalid] fluxPerSub of valid subaps (wfs_init.py:145) */
+  const int32_t *validsubsx, *validsubsy; /* [nvalid] pixel coords in binimg */
+  float nphot, wfs_lambda, noise, cog_offset, cog_scale, subapd;
+  /* atmosphere */
+  int32_t nlayers;
+  aomarl_layer_desc layers[AOMARL_MAX_LAYERS];
+  /* DMs of the controller, stack arrays first, tip-tilt last */
+  int32_t ndm;
+  aomarl_dm_desc dms[AOMARL_MAX_DMS];
+  /* science target */
+  float tar_lambda;
+  int32_t npsf;           /* FFT support of the PSF the window is cut from */
+  int32_t strehl_halfwin; /* PSF evaluated on frequencies [-hw, hw) in x and y */
+  /* controller (rtc_init.py:385-389, 506-513) */
+  int32_t nactu, nslope;
+  float gain, delay;
+} aomarl_desc;
+
+/* Device buffers owned by the caller (e.g. torch tensors); all [nenv] leading. */
+typedef struct {
+  int32_t nenv;
+  int32_t ld_actu;     /* row stride (floats) of com/com1/com2/err/voltage, >= nactu, % 4 == 0 */
+  float *screens;      /* [nenv][sum_l dim_l^2]  ring-buffered phase screens (microns)      */
+  int32_t *origin;     /* [nenv][nlayers][2]     ring origin (ox, oy)                       */
+  uint32_t *seeds;     /* [nenv]                 atmosphere base seed (layer k uses seed+k) */
+  uint32_t *ext_count; /* [nenv][nlayers]        extrusions drawn so far (RNG counter)      */
+  float *com, *com1, *com2, *err, *voltage; /* [nenv][nactu]                               */
+  float *slopes;       /* [nenv][nslope]         all x then all y (ao_env.py:665-666)       */
+  float *dm_shape;     /* [nenv][sum_k dim_k^2]                                             */
+  float *bincube;      /* [nenv][nvalid][npix^2] or NULL                                    */
+  float *wfs_phase;    /* [nenv][n*n]            or NULL (only the unfused API needs it)    */
+  float *tar_phase;    /* [nenv][pupdiam^2]      or NULL                                    */
+  float *strehl;       /* [nenv][8]: se, le, phase_var, phase_var_sum, count, peak_on_edge  */
+  float *le_img;       /* [nenv][(2hw)^2]        long-exposure PSF window                   */
+  uint32_t *frame;     /* [nenv]                 WFS noise frame counter                    */
+  float *work;         /* aomarl_workspace_floats(ctx, nenv) floats                         */
+} aomarl_state;
+
+typedef struct aomarl_ctx aomarl_ctx;
+
+const char *aomarl_last_error(void);
+int aomarl_abi_version(void);
+
+/* Build the static device-side description (replaces the Telescope/Atmos/Sensors/Dms/Target/
+ * Rtc constructors + load_arrays calls of shesha/init/xxx_init.py). Host pointers are copied. */
+int aomarl_create(const aomarl_desc *desc, aomarl_ctx **out);
+int aomarl_destroy(aomarl_ctx *ctx);
+/* d_control[0].set_cmat (basis.py:254): cmat is [nactu][nslope] row-major, host memory */
+int aomarl_set_cmat(aomarl_ctx *ctx, const float *cmat);
+int aomarl_set_gain(aomarl_ctx *ctx, float gain); /* d_control[0].set_gain (ao_env.py:957) */
+/* volts2modes [nmodes][nactu], modes2volts [nactu][nmodes] (rlSupervisor.py:170-172),
+ * freedom vector [nmodes] (rlSupervisor.py:277-278), action_modes[nact]: the modes an action
+ * component drives (rlSupervisor.py:677-691); host memory */
+int aomarl_set_modal(aomarl_ctx *ctx, int nmodes, const float *v2m, const float *m2v,
+                     const float *freedom, int nact, const int32_t *action_modes);
+size_t aomarl_workspace_floats(const aomarl_ctx *ctx, int nenv);
+size_t aomarl_screen_stride(const aomarl_ctx *ctx);   /* floats per env in st->screens  */
+size_t aomarl_dmshape_stride(const aomarl_ctx *ctx);  /* floats per env in st->dm_shape */
+
+/* RlSupervisor.reset (rlSupervisor.py:236-246): Atmos.set_seed/refresh_screen per layer
+ * (atmosCompass.py:137-145), integrator + DM shapes + Strehl meter zeroed.
+ * seeds: host [env_count]; accumx/accumy: host [nenv][nlayers], zeroed for the reset envs. */
+int aomarl_reset(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                 const uint32_t *seeds, float *accumx, float *accumy, void *stream);
+/* Atmos.move_atmos (atmosCompass.py:161). accumx/accumy: host [nenv][nlayers], updated. */
+int aomarl_move_atmos(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                      float *accumx, float *accumy, void *stream);
+/* one parallel round of extrusions: op i extrudes layer[i] in direction dir[i] (+-1 x, +-2 y) */
+int aomarl_extrude(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int nops,
+                   const int32_t *layer, const int32_t *dir, void *stream);
+/* copy the logical (un-rotated) screen of one layer to dst [env_count][dim*dim] (device) */
+int aomarl_get_screen(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int layer,
+                      float *dst, void *stream);
+
+/* Source.raytrace for the WFS guide star / the target (sourceCompass.py:76-85), materialising
+ * st->wfs_phase / st->tar_phase. The fast path (aomarl_comp_image without FROM_PHASE_BUFFER,
+ * aomarl_target_psf) fuses this and never writes the phase. */
+int aomarl_raytrace_wfs(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                        int flags, void *stream);
+int aomarl_raytrace_target(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                           int flags, void *stream);
+/* Wfs.comp_image (wfsCompass.py:343) [+ Rtc.do_centroids when AOMARL_IMG_COG] */
+int aomarl_comp_image(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int flags,
+                      void *stream);
+/* Rtc.do_centroids (rtcCompass.py:563) from st->bincube */
+int aomarl_do_centroids(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                        void *stream);
+/* Wfs.slopes_geom(0) from st->wfs_phase (imats.py:103) */
+int aomarl_slopes_geom(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                       void *stream);
+/* Rtc.do_control (rtcCompass.py:547): err = -cmat.s ; com += gain*err */
+int aomarl_do_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                      void *stream);
+/* d_control[0].set_com (rtcCompass.py:473): com_dev [env_count][nactu] device memory */
+int aomarl_set_com(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                   const float *com_dev, void *stream);
+/* RlSupervisor.rl_control -> correction_modal_basis (rlSupervisor.py:713-733, 784-818):
+ * m = v2m.com ; m[action_modes] += action*freedom[action_modes] ; com = m2v.m
+ * action_dev [env_count][nact] device memory */
+int aomarl_rl_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                      const float *action_dev, void *stream);
+/* Rtc.apply_control (rtcCompass.py:582): delay line -> voltage -> Dm.comp_shape per DM */
+int aomarl_apply_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                         int comp_voltage, void *stream);
+/* Dm.set_com + comp_shape (dmCompass.py:64-146): volts_dev [env_count][nactu] or NULL=voltage */
+int aomarl_comp_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                         const float *volts_dev, void *stream);
+/* fused target raytrace + PSF window + phase variance into a pending slot
+ * (RlSupervisor.raytrace_target, rlSupervisor.py:845-855) */
+int aomarl_target_psf(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                      void *stream);
+/* Target.comp_image + comp_strehl (targetCompass.py:193,205): publish the pending PSF */
+int aomarl_comp_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                       void *stream);
+int aomarl_reset_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                        void *stream);
+/* modes[env][nmodes] = v2m . vec[env][nactu]  (AoEnv.transform_state_to_zernike,
+ * ao_env.py:482-505); vec_dev / modes_dev device memory, row stride = nactu / nmodes */
+int aomarl_volts2modes(aomarl_ctx *ctx, int nrows, const float *vec_dev, float *modes_dev,
+                       void *stream);
+
+/* composites: one call per half frame, same order as the reference
+ * next_part_one: move_atmos, target trace(+PSF), WFS trace+image+COG, do_control
+ *                (rlSupervisor.py:1015-1051, 954-987)
+ * next_part_two: [rl_control], apply_control, comp_strehl (rlSupervisor.py:900-947);
+ *                action_dev may be NULL (integrator only, linear_control=True) */
+int aomarl_next_part_one(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                         float *accumx, float *accumy, int image_flags, void *stream);
+int aomarl_next_part_two(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                         const float *action_dev, void *stream);
+
+/* generic fp32 MFMA GEMM used by the calls above, exported for tests:
+ * C[M][N] = alpha * A[M][K] . B[N][K]^T + beta * C ; device pointers, row-major, ld in floats */
+int aomarl_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
+                   int ldb, float beta, float *C, int ldc, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,270 @@
+"""HIP path (through the C ABI) vs the CPU oracle, stage by stage and as a closed loop.
+Run on the GPU box: python -m pytest tests -m gpu.  Tolerances are fp32 round-off of different
+summation orders / algorithms (pruned MFMA DFT vs padded FFT, ring buffer vs shift, fused vs
+materialised raytrace); index-like outputs (brightest pixel, kept actuators) are exact."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from tests import helpers  # noqa: E402
+from oracle import aoref  # noqa: E402
+
+NAME = "production_sh_10x10_2m"
+SEEDS = [1234, 1250, 77]
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from ao_marl_amd.sim import HipSim
+    sysm, s, cal = helpers.calibrated(NAME)
+    sim = HipSim(s, nenv=len(SEEDS), keep_bincube=True, keep_phase=True)
+    sim.set_modal(cal.volts2modes, cal.modes2volts)
+    sim.reset(SEEDS)
+    oracles = [aoref.OracleSim(s, seed=sd) for sd in SEEDS]
+    return sysm, s, cal, sim, oracles
+
+
+def _push_oracle_state(sim, oracles):
+    """Copy the oracle's screens into the HIP state (origin 0) so later stages are compared on
+    identical inputs."""
+    s = sim.s
+    off = 0
+    for l, d in enumerate(s.screen_dim):
+        for e, o in enumerate(oracles):
+            sim.t["screens"][e, off:off + d * d] = torch.from_numpy(o.screens[l].reshape(-1))
+        off += d * d
+    sim.t["origin"].zero_()
+    for e, o in enumerate(oracles):
+        sim.t["ext_count"][e] = torch.tensor(o.ext_count, dtype=torch.int32)
+        sim.accumx[e] = o.accumx
+        sim.accumy[e] = o.accumy
+
+
+def test_gemm_nt_matches_torch(setup):
+    sim = setup[3]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for (M, N, K) in [(3, 90, 128), (64, 64, 16), (130, 257, 1957), (5, 7, 3), (256, 1286, 2400)]:
+        A = torch.randn(M, K, generator=g).cuda()
+        B = torch.randn(N, K, generator=g).cuda()
+        Cm = sim.gemm_nt(A, B, alpha=-1.0)
+        ref = -(A.double() @ B.double().T)
+        assert (Cm.double() - ref).abs().max().item() < 2e-4 * max(1.0, K**0.5)
+        C0 = torch.randn(M, N, generator=g).cuda()
+        C1 = sim.gemm_nt(A, B, alpha=0.5, beta=2.0, Cout=C0.clone())
+        ref = 0.5 * (A.double() @ B.double().T) + 2.0 * C0.double()
+        assert (C1.double() - ref).abs().max().item() < 2e-4 * max(1.0, K**0.5)
+
+
+def test_reset_screens_match_oracle(setup):
+    _, s, _, sim, oracles = setup
+    for l in range(s.nscreens):
+        scr = sim.screen(l).cpu().numpy()
+        for e, o in enumerate(oracles):
+            d = np.abs(scr[e] - o.screens[l]).max()
+            assert d < 2e-4, (l, e, d)   # 2n extrusions of fp32 recursion, screens ~ +-2 um
+            assert np.std(o.screens[l]) > 0.05
+
+
+def test_move_atmos_matches_oracle(setup):
+    _, s, _, sim, oracles = setup
+    _push_oracle_state(sim, oracles)
+    for _ in range(7):
+        sim.move_atmos()
+        for o in oracles:
+            o.move_atmos()
+    for l in range(s.nscreens):
+        scr = sim.screen(l).cpu().numpy()
+        for e, o in enumerate(oracles):
+            assert np.abs(scr[e] - o.screens[l]).max() < 2e-5
+    # the ring origin moved, the logical content did not wrap
+    assert int(sim.t["origin"].abs().sum()) > 0
+    assert np.array_equal(sim.accumx[0], oracles[0].accumx)
+    assert np.array_equal(sim.accumy[0], oracles[0].accumy)
+
+
+def test_all_four_extrusion_directions(setup):
+    _, s, _, sim, oracles = setup
+    _push_oracle_state(sim, oracles)
+    import copy
+    for d in (1, -1, 2, -2, 2, 1, -2, -1):
+        # stencils are mirrored for the configured wind sign only; use the matching ones
+        for o in oracles:
+            ist = s.istx[0] if abs(d) == 1 else s.isty[0]
+        n = s.screen_dim[0]
+        flip = (d == 1 and s.deltax[0] < 0) or (d == -1 and s.deltax[0] > 0) or \
+            (d == 2 and s.deltay[0] < 0) or (d == -2 and s.deltay[0] > 0)
+        if flip:
+            continue   # the stencil for that direction is not loaded (as in the reference)
+        sim.extrude([0], [d])
+        for o in oracles:
+            o._extrude(0, d)
+    scr = sim.screen(0).cpu().numpy()
+    for e, o in enumerate(oracles):
+        assert np.abs(scr[e] - o.screens[0]).max() < 2e-5
+
+
+def test_dm_shape_matches_oracle(setup):
+    _, s, _, sim, oracles = setup
+    rng = np.random.default_rng(3)
+    volts = rng.normal(0, 1.0, size=(len(oracles), s.nactu)).astype(np.float32)
+    sim.comp_dm_shape(torch.from_numpy(volts).cuda())
+    for e, o in enumerate(oracles):
+        o.comp_shapes(volts[e])
+        for k in range(len(s.dms)):
+            a = sim.dm_shape(k)[e].cpu().numpy()
+            assert np.abs(a - o.dm_shapes[k]).max() < 1e-6 * max(1.0, np.abs(o.dm_shapes[k]).max())
+
+
+def test_raytrace_and_spot_image_match_oracle(setup):
+    _, s, _, sim, oracles = setup
+    _push_oracle_state(sim, oracles)
+    rng = np.random.default_rng(4)
+    volts = rng.normal(0, 0.5, size=(len(oracles), s.nactu)).astype(np.float32)
+    sim.comp_dm_shape(torch.from_numpy(volts).cuda())
+    # unfused API: raytrace -> phase buffer -> image from buffer
+    sim.raytrace_wfs(atm=True, dms=False, reset=True)
+    sim.raytrace_wfs(atm=False, dms=True, reset=False)
+    sim.comp_image(from_phase_buffer=True, noise=False, write_bincube=True, cog=True)
+    cube_buf = sim.t["bincube"].cpu().numpy().copy()
+    sl_buf = sim.slopes.cpu().numpy().copy()
+    ph = sim.t["wfs_phase"].cpu().numpy()
+    # fused path
+    sim.comp_image(from_phase_buffer=False, noise=False, write_bincube=True, cog=True)
+    cube_fused = sim.t["bincube"].cpu().numpy().copy()
+    sl_fused = sim.slopes.cpu().numpy().copy()
+    sim.do_centroids()
+    sl_cog = sim.slopes.cpu().numpy().copy()
+    for e, o in enumerate(oracles):
+        o.comp_shapes(volts[e])
+        o.raytrace_wfs(atm=True, dms=False, reset=True)
+        o.raytrace_wfs(atm=False, dms=True, reset=False)
+        assert np.abs(ph[e] - o.wfs_phase).max() < 1e-5
+        o.comp_image(noise=False)
+        o.do_centroids()
+        scale = o.bincube.max()
+        assert np.abs(cube_buf[e] - o.bincube).max() < 2e-5 * scale
+        assert np.abs(cube_fused[e] - o.bincube).max() < 2e-5 * scale
+        # "bit-exact centroid indices": brightest pixel of every spot
+        assert np.array_equal(cube_fused[e].argmax(axis=1), o.bincube.argmax(axis=1))
+        assert np.allclose(cube_fused[e].sum(axis=1), s.nphot * s.flux, rtol=1e-5)
+        for sl in (sl_buf, sl_fused, sl_cog):
+            assert np.abs(sl[e] - o.slopes).max() < 1e-4   # arcsec (north-star tolerance)
+        assert np.abs(sl_fused[e] - o.slopes).max() < 2e-5
+
+
+def test_control_chain_matches_oracle(setup):
+    _, s, cal, sim, oracles = setup
+    rng = np.random.default_rng(5)
+    sl = rng.normal(0, 0.1, size=(len(oracles), s.nslope)).astype(np.float32)
+    c0 = rng.normal(0, 0.5, size=(len(oracles), s.nactu)).astype(np.float32)
+    sim.set_com(torch.from_numpy(c0).cuda())
+    sim.t["slopes"].copy_(torch.from_numpy(sl))
+    sim.t["com1"].zero_()
+    sim.t["com2"].zero_()
+    sim.do_control()
+    for rep in range(3):
+        sim.apply_control()
+    for e, o in enumerate(oracles):
+        o.set_com(c0[e])
+        o.slopes[:] = sl[e]
+        o.com1[:] = 0
+        o.com2[:] = 0
+        o.do_control()
+        for rep in range(3):
+            o.apply_control()
+        assert np.abs(sim.err[e].cpu().numpy() - o.err).max() < 2e-5
+        assert np.abs(sim.com[e].cpu().numpy() - o.com).max() < 2e-5
+        assert np.abs(sim.voltage[e].cpu().numpy() - o.voltage).max() < 2e-5
+        for k in range(len(s.dms)):
+            assert np.abs(sim.dm_shape(k)[e].cpu().numpy() - o.dm_shapes[k]).max() < 1e-5
+
+
+def test_rl_control_matches_numpy(setup):
+    _, s, cal, sim, _ = setup
+    rng = np.random.default_rng(6)
+    nm = cal.volts2modes.shape[0]
+    modes = np.r_[np.arange(0, 80), nm - 2, nm - 1]
+    freedom = rng.uniform(0.01, 0.1, size=nm).astype(np.float32)
+    sim.set_modal(cal.volts2modes, cal.modes2volts, freedom, modes)
+    c0 = rng.normal(0, 0.5, size=(sim.nenv, s.nactu)).astype(np.float32)
+    act = rng.uniform(-1, 1, size=(sim.nenv, modes.size)).astype(np.float32)
+    sim.set_com(torch.from_numpy(c0).cuda())
+    sim.rl_control(torch.from_numpy(act).cuda())
+    got = sim.com.cpu().numpy()
+    for e in range(sim.nenv):
+        # rlSupervisor.py:800-816 in NumPy
+        m = cal.volts2modes.dot(c0[e])
+        m[modes] += act[e] * freedom[modes]
+        want = cal.modes2volts.dot(m)
+        assert np.abs(got[e] - want).max() < 2e-5
+    v = sim.volts2modes(torch.from_numpy(c0).cuda()).cpu().numpy()
+    assert np.abs(v - c0 @ cal.volts2modes.T).max() < 2e-5
+    sim.set_modal(cal.volts2modes, cal.modes2volts)
+
+
+def test_target_psf_and_strehl_match_oracle(setup):
+    _, s, _, sim, oracles = setup
+    _push_oracle_state(sim, oracles)
+    rng = np.random.default_rng(7)
+    volts = rng.normal(0, 0.3, size=(len(oracles), s.nactu)).astype(np.float32)
+    sim.comp_dm_shape(torch.from_numpy(volts).cuda())
+    sim.reset_strehl()
+    for rep in range(2):
+        sim.target_psf()
+        sim.comp_strehl()
+    sim.raytrace_target()
+    tp = sim.t["tar_phase"].cpu().numpy()
+    st = sim.strehl.cpu().numpy()
+    for e, o in enumerate(oracles):
+        o.comp_shapes(volts[e])
+        o.reset_strehl()
+        o.raytrace_target()
+        assert np.abs(tp[e] - o.tar_phase).max() < 1e-5
+        for rep in range(2):
+            want = o.comp_strehl()
+        assert abs(st[e, 0] - want[0]) < 2e-5 * max(want[0], 1e-3) + 1e-7
+        assert abs(st[e, 1] - want[1]) < 2e-5 * max(want[1], 1e-3) + 1e-7
+        assert abs(st[e, 2] - want[2]) < 1e-4 * want[2] + 1e-9
+        assert abs(st[e, 3] - want[3]) < 1e-4 * want[3] + 1e-9
+
+
+def test_closed_loop_trace_matches_oracle(setup):
+    """40 frames of the integrator loop (next_part_two + next_part_one) from a common state."""
+    _, s, _, sim, oracles = setup
+    sim.reset(SEEDS)
+    for o, sd in zip(oracles, SEEDS):
+        o.reset(sd)
+    _push_oracle_state(sim, oracles)   # remove the reset's accumulated round-off
+    worst = 0.0
+    for it in range(40):
+        sim.next_part_two(None)
+        sim.next_part_one()
+        sl = sim.slopes.cpu().numpy()
+        cm = sim.com.cpu().numpy()
+        st = sim.strehl.cpu().numpy()
+        for e, o in enumerate(oracles):
+            o.next_part_two(None)
+            o.next_part_one()
+            worst = max(worst, np.abs(sl[e] - o.slopes).max())
+            assert np.abs(sl[e] - o.slopes).max() < 1e-4, it
+            assert np.abs(cm[e] - o.com).max() < 1e-4, it
+            assert abs(st[e, 0] - o.strehl_se) < 1e-4, it
+            assert abs(st[e, 1] - o.strehl_le) < 1e-4, it
+    assert sim.strehl[:, 0].min().item() > 0.3   # the loop closed
+    print("worst slope deviation over the trace: %.3g arcsec" % worst)
+
+
+def test_calibration_through_hip_backend_matches_oracle_backend(setup):
+    from ao_marl_amd import modal
+    from ao_marl_amd.sim import HipSim
+    sysm_o, s_o, cal_o = setup[0], setup[1], setup[2]
+    sysm, s = helpers.uncalibrated(NAME)
+    backend = HipSim(s, nenv=64, keep_phase=True)
+    cal = modal.calibrate(s, sysm, backend, nfilt=5)
+    assert [len(k) for k in cal.kept] == [88, 2]
+    assert np.array_equal(cal.kept[0], cal_o.kept[0])      # same actuators survive, exactly
+    assert np.abs(cal.imat - cal_o.imat).max() < 2e-5 * np.abs(cal_o.imat).max() + 1e-8
+    assert np.abs(cal.cmat - cal_o.cmat).max() < 2e-3 * np.abs(cal_o.cmat).max()
+    assert np.abs(cal.Btt - cal_o.Btt).max() < 1e-6
