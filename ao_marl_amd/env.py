@@ -1,0 +1,389 @@
+"""Vectorised AO environment: the reference's RlSupervisor + AoEnv + the environment half of
+TrainerRPC.env_step, for `nenv` independent atmosphere seeds resident on one GPU.
+
+Mirrors (same names, argument meaning, ordering, error behaviour):
+  RlSupervisor.reset / next_part_one / next_part_two / rl_control    rlSupervisor.py:236-246,
+                                                                      1015-1051, 900-947, 713-733
+  AoEnv.reset / linear_step / rl_step / calculate_reward             ao_env.py:316-359, 871-939,
+                                                                      585-860
+  TrainerRPC.env_step / divide_rewards_for_agents                    train_rpc.py:633-648, 402-416
+Every per-frame arithmetic step runs in libaomarl_hip.so (ao_marl_amd/sim.py); this file is
+sequencing + state bookkeeping on device tensors.  States are float32 (the reference concatenates
+float64 NumPy vectors, ao_env.py:909).
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import geometry as G
+from . import modal, params, system
+from .agents import AgentLayout
+from .sim import HipSim
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+# defaults of the reference's RL configuration (config/parameters.cfg:6-46, GlobalConfig.py:86-131)
+DEFAULT_ENV_RL = dict(
+        reward_type="avg_squared_modes_1000", max_steps_per_episode=1000, basis="zernike_space",
+        level="correction", state_dm_before_linear=True, state_dm_after_linear=False,
+        state_wfs=False, state_dm_residual=True, number_of_previous_dm=2,
+        number_of_previous_wfs=0, number_of_previous_dm_residuals=0, include_tip_tilt=True,
+        normalization_std_inside_environment=1.0, normalization_mean_inside_environment=0.0,
+        norm_scale_zernike_actions=10.0, modification_online=False,
+        n_zernike_start_end=[-1, -1], n_reverse_filtered_from_cmat=0, window_n_zernike=-1,
+        include_tip_tilt_windowed=False, tt_treated_as_mode=False, delayed_assignment=1)
+
+
+def load_norm(name):
+    """Normalisation statistics + action bounds recorded by the reference from real COMPASS."""
+    if name.endswith(".py"):
+        name = name[:-3]
+    path = os.path.join(DATA_DIR, "norm_%s.npz" % name)
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+                "no normalisation data for %r (%s); generate it with "
+                "VecAoEnv.obtain_normalization() or tools/import_norm_data.py" % (name, path))
+    z = np.load(path)
+    norm = {k: {st: z["%s_%s" % (k, st)] for st in ("mean", "std", "max", "min")}
+            for k in ("wfs", "dm", "dm_residual")}
+    return norm, z["zn_norm"].copy()
+
+
+class VecRlSupervisor(object):
+    """Batched counterpart of shesha's RlSupervisor for the integrator (+RL correction) path."""
+
+    def __init__(self, config, config_rl, nenv, *, initial_seed=1234, seed_stride=16,
+                 device="cuda:0", strehl_halfwin=8, keep_bincube=False):
+        self.config = config if not isinstance(config, str) else params.builtin(config)
+        self.config_rl = dict(DEFAULT_ENV_RL)
+        self.config_rl.update(config_rl or {})
+        if self.config_rl["level"] != "correction" or self.config_rl["basis"] != "zernike_space":
+            raise NotImplementedError                       # rlSupervisor.py:728-731, 831-834
+        self.pure_delay_0 = bool(self.config_rl["modification_online"])
+        if self.pure_delay_0:
+            raise NotImplementedError("modification_online (pure delay 0) is not on the hot path")
+        self.nenv, self.device = nenv, torch.device(device)
+        self.sysm = G.build_system(self.config)
+        self.s = system.from_system(self.sysm, ncontrol=0, strehl_halfwin=strehl_halfwin)
+        # calibration through the HIP backend (imat_geom, correct_dm, imat, Btt, filtered cmat)
+        cal_sim = HipSim(self.s, nenv=min(512, 2048), device=device, keep_phase=True)
+        self.n_reverse_filtered_from_cmat = int(self.config_rl["n_reverse_filtered_from_cmat"])
+        self.cal = modal.calibrate(self.s, self.sysm, cal_sim,
+                                   nfilt=max(self.n_reverse_filtered_from_cmat, 0))
+        del cal_sim
+        self.modes2volts, self.volts2modes = self.cal.modes2volts, self.cal.volts2modes
+        self.nmodes = self.volts2modes.shape[0]
+        self.n_modes_start_end = list(self.config_rl["n_zernike_start_end"])
+        self.include_tip_tilt = bool(self.config_rl["include_tip_tilt"])
+        self.sim = HipSim(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
+        self.freedom_vector = None
+        self._push_modal()
+        self.initial_seed, self.seed_stride = int(initial_seed), int(seed_stride)
+        self.current_seed = int(initial_seed)
+        self.iter = 0
+
+    # ---------------------------------------------------------------- configuration
+    def obtain_action_range_modal(self):
+        """rlSupervisor.py:677-691"""
+        lo, hi = self.n_modes_start_end
+        if lo >= 0:
+            rng = list(range(lo, hi))
+            if self.include_tip_tilt:
+                rng += [self.nmodes - 2, self.nmodes - 1]
+            return np.asarray(rng)
+        return np.arange(self.nmodes)
+
+    def load_freedom_vector(self, zn_norm):
+        """rlSupervisor.py:255-282: action bound per mode = zn_norm / norm_scale."""
+        fv = np.asarray(zn_norm, dtype=np.float32) / \
+            np.float32(self.config_rl["norm_scale_zernike_actions"])
+        if fv.shape != (self.nmodes,):
+            raise ValueError("freedom vector has %s entries, system has %d modes" %
+                             (fv.shape, self.nmodes))
+        self.freedom_vector = fv
+        self._push_modal()
+
+    def _push_modal(self):
+        self.action_range = self.obtain_action_range_modal()
+        self.sim.set_modal(self.volts2modes, self.modes2volts, self.freedom_vector,
+                           self.action_range)
+
+    def set_sim_seed(self, seed):
+        self.current_seed = int(seed)
+
+    def env_seeds(self):
+        return self.current_seed + self.seed_stride * np.arange(self.nenv)
+
+    # ---------------------------------------------------------------- loop
+    def reset(self):
+        """rlSupervisor.py:236-246 for every environment (seed e: current_seed + stride*e)."""
+        self.sim.reset(self.env_seeds())
+        self.iter = 0
+
+    def rl_control(self, action):
+        """rlSupervisor.py:713-733 (+ correction_modal_basis :784-818) on the device."""
+        std = self.config_rl["normalization_std_inside_environment"]
+        mean = self.config_rl["normalization_mean_inside_environment"]
+        if std != 1.0 or mean != 0.0:
+            action = action * std + mean
+        if self.freedom_vector is None:
+            raise RuntimeError("freedom vector not loaded (load_freedom_vector)")
+        self.sim.rl_control(action)
+
+    def next_part_two(self, action, linear_control=False, apply_control=True,
+                      compute_tar_psf=True):
+        """rlSupervisor.py:900-947"""
+        if not linear_control:
+            self.rl_control(action)
+        if apply_control:
+            self.sim.apply_control()
+        if compute_tar_psf:
+            self.sim.comp_strehl()
+
+    def next_part_one(self, move_atmos=True, do_control=True):
+        """rlSupervisor.py:1015-1051 -> next_part_one_integrator :954-987"""
+        if move_atmos and do_control:
+            self.sim.next_part_one()
+        else:
+            if move_atmos:
+                self.sim.move_atmos()
+            self.sim.target_psf()
+            self.sim.comp_image(noise=True, cog=True)
+            if do_control:
+                self.sim.do_control()
+        self.iter += 1
+
+    # ---------------------------------------------------------------- getters (device tensors)
+    def get_command(self):
+        return self.sim.com
+
+    def get_slopes(self):
+        return self.sim.slopes
+
+    def get_err(self):
+        return self.sim.err
+
+    def get_voltages(self):
+        return self.sim.voltage
+
+    def get_strehl(self):
+        return self.sim.strehl
+
+
+class VecAoEnv(object):
+    """Batched AoEnv (gym-like).  step(action) == TrainerRPC.env_step: rl_step(a), per-agent
+    rewards from the residual measured BEFORE the action reached the DM, then linear_step()."""
+
+    def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
+                 initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
+                 strehl_halfwin=8, norm=None, zn_norm=None):
+        cfg = dict(DEFAULT_ENV_RL)
+        cfg.update(config_rl or {})
+        self.config_rl = cfg
+        self.normalization_bool = normalization_bool
+        name = parameters_telescope[:-3] if parameters_telescope.endswith(".py") else \
+            parameters_telescope
+        self.supervisor = VecRlSupervisor(name, cfg, nenv, initial_seed=initial_seed,
+                                          seed_stride=seed_stride, device=device,
+                                          strehl_halfwin=strehl_halfwin)
+        sup = self.supervisor
+        self.nenv, self.device = nenv, sup.device
+        self.nmodes = sup.nmodes
+        if normalization_bool:
+            if norm is None or zn_norm is None:
+                norm, zn_norm = load_norm(name)
+            sup.load_freedom_vector(zn_norm)
+        self.windowed = cfg["window_n_zernike"] > -1 or cfg["tt_treated_as_mode"]
+        ar = sup.obtain_action_range_modal()
+        self._sel = None if (self.windowed or cfg["n_zernike_start_end"][0] < 0) else \
+            torch.as_tensor(ar % self.nmodes, dtype=torch.long, device=self.device)
+        self.dm_dim = self.nmodes if self._sel is None else int(self._sel.numel())
+        self.action_dim = len(ar)
+        self.wfs_dim = sup.s.nslope
+        # standardisation vectors (ao_env.py:470-480), sub-selected like load_norm_parameters does
+        self.norm = None
+        if normalization_bool:
+            self.norm = {}
+            for k in ("wfs", "dm", "dm_residual"):
+                m, sd = norm[k]["mean"], norm[k]["std"]
+                if k != "wfs" and self._sel is not None:
+                    m, sd = m[ar], sd[ar]
+                self.norm[k] = (torch.as_tensor(m, dtype=torch.float32, device=self.device),
+                                torch.as_tensor(sd, dtype=torch.float32, device=self.device))
+        # state layout
+        keys = []
+        for i in range(cfg["number_of_previous_wfs"], 0, -1):
+            keys.append(("wfs_history-%d" % i, self.wfs_dim))
+        if cfg["state_wfs"]:
+            keys.append(("wfs", self.wfs_dim))
+        for i in range(cfg["number_of_previous_dm"], 0, -1):
+            keys.append(("dm_history_%d" % i, self.dm_dim))
+        if cfg["state_dm_after_linear"]:
+            keys.append(("dm_after_linear", self.dm_dim))
+        if cfg["state_dm_before_linear"]:
+            keys.append(("dm_before_linear", self.dm_dim))
+        for i in range(cfg["number_of_previous_dm_residuals"], 0, -1):
+            keys.append(("dm_residual_history_%d" % i, self.dm_dim))
+        if cfg["state_dm_residual"]:
+            keys.append(("dm_residual", self.dm_dim))
+        self.state_keys = OrderedDict(keys)
+        self.state_dim = sum(self.state_keys.values())
+        self.reward_type = cfg["reward_type"]
+        # agents
+        self.layout = None
+        if n_agents_modal is not None:
+            self.set_agents(n_agents_modal)
+        self._hist_dm, self._hist_wfs, self._hist_res = [], [], []
+        self._last_res_modes = None
+
+    # ------------------------------------------------------------------ agents
+    def set_agents(self, n_agents_modal):
+        cfg = self.config_rl
+        self.layout = AgentLayout(self.nmodes, cfg["n_zernike_start_end"], n_agents_modal,
+                                  include_tip_tilt=cfg["include_tip_tilt"],
+                                  window_n_zernike=cfg["window_n_zernike"],
+                                  include_tip_tilt_windowed=cfg["include_tip_tilt_windowed"],
+                                  n_filtered=cfg["n_reverse_filtered_from_cmat"],
+                                  state_keys=tuple(self.state_keys), state_block=self.dm_dim)
+        assert self.layout.state_dim == self.state_dim or cfg["state_wfs"] or \
+            cfg["number_of_previous_wfs"] > 0
+        factor = float(self.reward_type.split("_")[-1])        # helper_rewards.py:18
+        M = torch.zeros(self.nmodes, self.layout.n_agents, device=self.device)
+        for j, (w, (a, b)) in enumerate(self.layout.agents.items()):
+            M[a:b, j] = -factor / (b - a)                      # -factor * mean(reward[a:b])
+        self._reward_mat = M
+        return self.layout
+
+    # ------------------------------------------------------------------ helpers
+    def _standardise(self, x, key):
+        if not self.normalization_bool:
+            return x
+        m, sd = self.norm[key]
+        return (x - m) / sd
+
+    def transform_state_to_zernike(self, volts, return_reward=False):
+        """ao_env.py:482-505"""
+        m = self.supervisor.sim.volts2modes(volts)
+        if (self.windowed and not return_reward) or self._sel is None:
+            return m
+        return m[:, self._sel]
+
+    # ------------------------------------------------------------------ gym-like API
+    def reset(self):
+        """ao_env.py:316-359"""
+        cfg = self.config_rl
+        self.supervisor.reset()
+        z = lambda d: torch.zeros(self.nenv, d, device=self.device)  # noqa: E731
+        self._hist_dm = [z(self.dm_dim) for _ in range(cfg["number_of_previous_dm"])]
+        self._hist_wfs = [z(self.wfs_dim) for _ in range(cfg["number_of_previous_wfs"])]
+        self._hist_res = [z(self.dm_dim) for _ in range(cfg["number_of_previous_dm_residuals"])]
+        return self.linear_step()
+
+    def linear_step(self, return_dict=False):
+        """ao_env.py:871-909"""
+        cfg, sup = self.config_rl, self.supervisor
+        s_dm_before = self.transform_state_to_zernike(sup.get_command())
+        sup.next_part_one()
+        s_dm_after = self.transform_state_to_zernike(sup.get_command()) \
+            if cfg["state_dm_after_linear"] else None
+        res_full = sup.sim.volts2modes(sup.get_err())
+        self._last_res_modes = res_full
+        s_res = res_full if (self.windowed or self._sel is None) else res_full[:, self._sel]
+        s_wfs = sup.get_slopes()
+        out = OrderedDict()
+        # add_wfs_to_state (ao_env.py:563-583)
+        n = len(self._hist_wfs)
+        for i, h in enumerate(self._hist_wfs):
+            out["wfs_history-%d" % (n - i)] = self._standardise(h, "wfs")
+        if cfg["number_of_previous_wfs"] > 0:
+            self._hist_wfs = self._hist_wfs[1:] + [s_wfs.clone()]
+        if cfg["state_wfs"]:
+            out["wfs"] = self._standardise(s_wfs, "wfs")
+        # add_dm_to_state (ao_env.py:535-561)
+        n = len(self._hist_dm)
+        for i, h in enumerate(self._hist_dm):
+            out["dm_history_%d" % (n - i)] = self._standardise(h, "dm")
+        if cfg["number_of_previous_dm"] > 0:
+            self._hist_dm = self._hist_dm[1:] + [s_dm_before]
+        if cfg["state_dm_after_linear"]:
+            out["dm_after_linear"] = self._standardise(s_dm_after, "dm")
+        if cfg["state_dm_before_linear"]:
+            out["dm_before_linear"] = self._standardise(s_dm_before, "dm")
+        # add_s_dm_residual_to_state (ao_env.py:507-533)
+        n = len(self._hist_res)
+        for i, h in enumerate(self._hist_res):
+            out["dm_residual_history_%d" % (n - i)] = self._standardise(h, "dm_residual")
+        if cfg["number_of_previous_dm"] > 0 and cfg["number_of_previous_dm_residuals"] > 0:
+            self._hist_res = self._hist_res[1:] + [s_res]
+        if cfg["state_dm_residual"]:
+            out["dm_residual"] = self._standardise(s_res, "dm_residual")
+        if return_dict:
+            return out
+        return torch.cat(list(out.values()), dim=1)
+
+    def calculate_reward(self):
+        """ao_env.py:585-860, the branches the shipped configurations use."""
+        st = self.supervisor.get_strehl()
+        rt = self.reward_type
+        if rt == "wavefront_phase_error":
+            return -st[:, 2]
+        if rt == "strehl_ratio_le":
+            return st[:, 1]
+        if rt == "strehl_ratio_se":
+            return st[:, 0]
+        if "avg_squared_modes_" in rt:
+            factor = float(rt.split("_")[-1])
+            m = self.transform_state_to_zernike(self.supervisor.get_err(), return_reward=True)
+            return -factor * (m * m).mean(dim=1)
+        raise NotImplementedError("This reward type not implemented")
+
+    def rl_step(self, action, linear_control=False, apply_control=True, compute_tar_psf=True,
+                compute_env_reward=False):
+        """ao_env.py:911-939. The reference computes the env-level reward and the trainer throws
+        it away (train_rpc.py:641); it is only evaluated here on request."""
+        self.supervisor.next_part_two(action, linear_control=linear_control,
+                                      apply_control=apply_control,
+                                      compute_tar_psf=compute_tar_psf)
+        r = self.calculate_reward() if compute_env_reward else None
+        return r, False, ""
+
+    def divide_rewards_for_agents(self):
+        """train_rpc.py:402-416 + helper_rewards.py:14-22: [nenv, n_agents].  get_err is read
+        after next_part_two and before the next linear_step, i.e. it is the residual of the
+        previous linear_step, whose modal projection is already at hand."""
+        if self.layout is None:
+            raise RuntimeError("no agent layout (set_agents)")
+        r = self._last_res_modes
+        return (r * r) @ self._reward_mat
+
+    def step(self, action, linear_control=False):
+        """TrainerRPC.env_step (train_rpc.py:633-648): (s_next, per-agent reward, done, info)."""
+        _, done, info = self.rl_step(action, linear_control)
+        r = self.divide_rewards_for_agents() if self.layout is not None else None
+        s_next = self.linear_step()
+        return s_next, r, done, info
+
+
+class DelayedMDP(object):
+    """Credit assignment under loop delay (environment/delayed_mdp.py:5-58): the tuple stored at
+    step t is (s_{t-delay}, a_{t-delay}, s'_t); batched tensors instead of single vectors."""
+
+    def __init__(self, delay, modification):
+        self.delay = delay
+        self.not_modification = int(not modification)
+        self._n = delay + self.not_modification
+        self.state_list, self.action_list, self.next_state_list = [], [], []
+
+    def check_update_possibility(self):
+        return len(self.action_list) >= self._n
+
+    def save(self, s, a, s_next):
+        for lst, v in ((self.state_list, s), (self.action_list, a), (self.next_state_list, s_next)):
+            lst.append(v)
+            if len(lst) > self._n:
+                lst.pop(0)
+
+    def credit_assignment(self):
+        return self.state_list[0], self.action_list[0], self.next_state_list[-1]

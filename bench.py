@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/sec (AO frames/sec) of the per-timestep hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of synthetic environments per GPU:
+    batched 14-agent SAC actor forward  ->  next_part_two (Btt correction, delay, DM shapes,
+    Strehl)  ->  per-agent rewards  ->  next_part_one (phase-screen extrusion, target trace + PSF,
+    WFS trace + spot images + COG, integrator)  ->  state assembly.
+Workload (BASELINE.json configs[2]): production_sh_40x40_8m_3layers, 256 atmosphere seeds per
+GPU, 14 agents (13 x 98 Btt modes + tip-tilt), windowed states (w = 20).  Environments are
+independent, so N GPUs run N x 256 seeds with no data-path collective (weak scaling); the only
+collective is the MAX over ranks of the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step, timed live
+with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a C restatement of the
+COMPASS frame the reference drives, oracle/aoref.c) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOAD = "production_sh_40x40_8m_3layers"
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def stage_models(s, nenv, nmodes, nact):
+    """Algorithmic bytes / flops per launch of each stage (DESIGN.md section 4 derives them)."""
+    n2, p2 = s.n * s.n, s.pupdiam * s.pupdiam
+    nl = s.nscreens
+    shape_px = sum(d.dim * d.dim for d in s.dms)
+    # A4+A3+A5 fused: phase of every layer + DM planes in, 2 slopes per sub-aperture out;
+    # flops: pruned radix-2 FFT count for 16 non-zero rows -> 32x32 kept outputs of a 64^2 grid
+    fft_flops = 16 * 5 * 64 * 6 + 32 * 5 * 64 * 6
+    spot = dict(bound="mfma", unit="TFLOP/s", peak=FP32_MFMA_PEAK_TF,
+                work=nenv * s.nvalid * float(fft_flops + 256 * 20),
+                bytes=nenv * s.nvalid * 2048.0)
+    dm = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
+              work=nenv * (s.nactu * 4.0 + shape_px * 4.0))
+    tgt = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
+               work=nenv * ((nl + len(s.dms)) * p2 * 4.0))
+    return {"wfs_spot_cog": spot, "dm_shape": dm, "target_psf": tgt}
+
+
+class StageTimer(object):
+    def __init__(self):
+        self.pairs = {}
+
+    def wrap(self, obj, name, label):
+        fn = getattr(obj, name)
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.pairs.setdefault(label, []).append((e0, e1))
+            return r
+
+        setattr(obj, name, timed)
+
+    def mean_ms(self):
+        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.pairs.items()}
+
+    def clear(self):
+        self.pairs = {}
+
+
+def cpu_baseline(env, budget_s=15.0):
+    """The CPU oracle stepping ONE environment of the same configuration (same calibrated
+    command matrix) on this host; bounded to ~budget_s seconds of frames."""
+    from oracle import aoref
+    s = env.supervisor.s
+
+    class Sim(aoref.OracleSim):
+        def reset(self, seed):          # short refresh: frame cost does not depend on content
+            self.seed, self.frame = int(seed), 0
+            self.accumx = np.zeros(s.nscreens, dtype=np.float32)
+            self.accumy = np.zeros(s.nscreens, dtype=np.float32)
+            self.ext_count = [0] * s.nscreens
+            for l in range(s.nscreens):
+                for _ in range(8):
+                    self._extrude(l, 1 if s.deltax[l] > 0 else -1)
+            self._alloc_ctrl()
+            self.reset_strehl()
+
+    o = Sim(s, seed=1234)
+    o.next_part_two(None)
+    o.next_part_one()                   # warm caches / OpenMP pool
+    t0, frames = time.time(), 0
+    while True:
+        o.next_part_two(None)
+        o.next_part_one()
+        frames += 1
+        dt = time.time() - t0
+        if dt > budget_s or frames >= 200:
+            break
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": frames / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "%d integrator frames of 1 environment of %s (extrusion, 2 raytraces, "
+                      "1200 zero-padded 64x64 FFT spots, COG, cmat GEMV, delay, DM shapes, "
+                      "2048^2 FFT PSF) in %.1f s, OpenMP over rows/sub-apertures; SAC actor not "
+                      "included" % (frames, s.name, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=256, help="environments per GPU")
+    ap.add_argument("--config", default=WORKLOAD)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    device = "cuda:%d" % local_rank
+    torch.cuda.set_device(device)
+
+    from ao_marl_amd.agents import BatchedGaussianPolicy
+    from ao_marl_amd.env import VecAoEnv
+
+    small = "10x10" in args.config
+    if small:
+        rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+        n_modal = 1
+    else:
+        rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5,
+                  window_n_zernike=20, include_tip_tilt_windowed=True)
+        n_modal = 13
+    # independent shards: rank r owns seeds [r*envs, (r+1)*envs) of the global seed sequence
+    env = VecAoEnv(args.config, args.envs, rl, initial_seed=1234 + 16 * args.envs * rank,
+                   seed_stride=16, n_agents_modal=n_modal, device=device)
+    layout = env.layout
+    policy = BatchedGaussianPolicy(layout, last_layer_zero=False, seed=1234 + rank, device=device)
+    sim = env.supervisor.sim
+
+    timer = StageTimer()
+    env.supervisor.next_part_one_split = True
+    orig_np1 = env.supervisor.next_part_one
+
+    def split_part_one(move_atmos=True, do_control=True):
+        sim.move_atmos()
+        sim.target_psf()
+        sim.comp_image(noise=True, cog=True)
+        sim.do_control()
+        env.supervisor.iter += 1
+
+    env.supervisor.next_part_one = split_part_one
+    for name, label in (("move_atmos", "move_atmos"), ("target_psf", "target_psf"),
+                        ("comp_image", "wfs_spot_cog"), ("do_control", "do_control"),
+                        ("rl_control", "rl_control"), ("apply_control", "dm_shape"),
+                        ("comp_strehl", "strehl_commit")):
+        timer.wrap(sim, name, label)
+
+    state = env.reset()
+
+    def one_step(st):
+        a, _ = policy.select_action(st)
+        s_next, r, _, _ = env.step(a)
+        return s_next
+
+    for _ in range(args.warmup):
+        state = one_step(state)
+    timer.clear()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state = one_step(state)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = timer.mean_ms()
+    sr = sim.strehl[:, 1].mean().item()
+    if rank == 0:
+        models = stage_models(env.supervisor.s, args.envs, env.nmodes, layout.action_dim)
+        dom = max((k for k in stage_ms if k in models), key=lambda k: stage_ms[k])
+        m, ms = models[dom], stage_ms[dom]
+        scale = 1e-12 if m["unit"] == "TFLOP/s" else 1e-9
+        achieved = m["work"] / (ms * 1e-3) * scale
+        roof = {"kernel": dom, "bound": m["bound"], "achieved": achieved, "peak": m["peak"],
+                "unit": m["unit"], "frac": achieved / m["peak"], "traffic": None,
+                "avg_launch_ms": ms}
+        spot_ms = stage_ms["wfs_spot_cog"]
+        sp = models["wfs_spot_cog"]
+        out = {
+            "metric": "env steps/sec (AO frames/sec)", "value": args.envs * world * args.steps / elapsed,
+            "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "envs_per_gpu": args.envs,
+                       "agents": layout.n_agents, "state_dims": layout.state_shapes()[:1] +
+                       layout.state_shapes()[-1:], "action_dim": layout.action_dim,
+                       "parallelism": "independent env shards x%d" % world},
+            "roofline": roof,
+            "spot_kernel": {"avg_launch_ms": spot_ms,
+                            "algorithmic_tflops": sp["work"] / (spot_ms * 1e-3) * 1e-12,
+                            "frac_fp32_mfma_peak": sp["work"] / (spot_ms * 1e-3) * 1e-12 / FP32_MFMA_PEAK_TF,
+                            "algorithmic_gbs": sp["bytes"] / (spot_ms * 1e-3) * 1e-9,
+                            "frac_hbm_peak": sp["bytes"] / (spot_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS},
+            "stage_ms": stage_ms, "mean_strehl_le": sr,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(env)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,7 @@ void aoref_extrude(float *p, int n, const float *A, int ns, const float *B, cons
   size_t iref = (dir == 1 || dir == -2) ? (size_t)(n - 1) : (size_t)n * (n - 1);
   float zref = p[iref];
   for (int k = 0; k < ns; k++) z[k] = p[ist[k]] - zref;
+#pragma omp parallel for schedule(static)
   for (int r = 0; r < n; r++) {
     float acc = 0.f;
     const float *a = A + (size_t)r * ns;

@@ -175,8 +175,8 @@ def test_control_chain_matches_oracle(setup):
         for rep in range(3):
             o.apply_control()
         assert np.abs(sim.err[e].cpu().numpy() - o.err).max() < 2e-5
-        assert np.abs(sim.com[e].cpu().numpy() - o.com).max() < 2e-5
-        assert np.abs(sim.voltage[e].cpu().numpy() - o.voltage).max() < 2e-5
+        assert np.abs(sim.com[e].cpu().numpy() - o.com).max() < 2e-6 * np.abs(o.com).max() + 1e-5
+        assert np.abs(sim.voltage[e].cpu().numpy() - o.voltage).max() < 2e-6 * np.abs(o.com).max() + 1e-5
         for k in range(len(s.dms)):
             assert np.abs(sim.dm_shape(k)[e].cpu().numpy() - o.dm_shapes[k]).max() < 1e-5
 
@@ -198,7 +198,7 @@ def test_rl_control_matches_numpy(setup):
         m = cal.volts2modes.dot(c0[e])
         m[modes] += act[e] * freedom[modes]
         want = cal.modes2volts.dot(m)
-        assert np.abs(got[e] - want).max() < 2e-5
+        assert np.abs(got[e] - want).max() < 1e-6 * np.abs(want).max() + 1e-6
     v = sim.volts2modes(torch.from_numpy(c0).cuda()).cpu().numpy()
     assert np.abs(v - c0 @ cal.volts2modes.T).max() < 2e-5
     sim.set_modal(cal.volts2modes, cal.modes2volts)
@@ -249,7 +249,7 @@ def test_closed_loop_trace_matches_oracle(setup):
             o.next_part_one()
             worst = max(worst, np.abs(sl[e] - o.slopes).max())
             assert np.abs(sl[e] - o.slopes).max() < 1e-4, it
-            assert np.abs(cm[e] - o.com).max() < 1e-4, it
+            assert np.abs(cm[e] - o.com).max() < 1e-5 * np.abs(o.com).max() + 1e-4, it
             assert abs(st[e, 0] - o.strehl_se) < 1e-4, it
             assert abs(st[e, 1] - o.strehl_le) < 1e-4, it
     assert sim.strehl[:, 0].min().item() > 0.3   # the loop closed
