@@ -240,9 +240,14 @@ class BatchedGaussianPolicy(object):
 
 
 class BatchedQNetwork(object):
-    """Twin-Q critic forward for all agents (model_rpc.py:22-69), same stacking scheme."""
+    """Twin-Q critic forward for all agents (model_rpc.py:22-69), same stacking scheme.
 
-    def __init__(self, layout, hidden=256, num_layers=2, seed=4321, device="cuda:0"):
+    The reference passes `hidden_size_critic` as a one-element LIST (GlobalConfig.py:36), which
+    takes QNetwork's list branch: len(hidden_dim) - 1 = 0 extra hidden layers, i.e.
+    Linear(in+act, 256) - ReLU - Linear(256, 1) whatever `num_layers_critic` says.  That is the
+    default here (`extra_hidden=0`)."""
+
+    def __init__(self, layout, hidden=256, extra_hidden=0, seed=4321, device="cuda:0"):
         self.layout, self.device = layout, torch.device(device)
         ins, acts = layout.state_shapes(), layout.action_shapes()
         A = layout.n_agents
@@ -264,7 +269,7 @@ class BatchedQNetwork(object):
                 w = _xavier_uniform(g, hidden, ins[i] + acts[i]).T
                 Win[i, :ins[i]] = w[:ins[i]]
                 Win[i, self.in_max:self.in_max + acts[i]] = w[ins[i]:]
-            hid = [stack([hidden] * A, hidden, hidden) for _ in range(num_layers - 1)]
+            hid = [stack([hidden] * A, hidden, hidden) for _ in range(extra_hidden)]
             out = stack([hidden] * A, 1, hidden)
             self.q.append((Win.to(dev), hid, out))
 

@@ -1,0 +1,108 @@
+"""This repo's host-side logic == the reference's own functions (golden vectors produced by
+tools/gen_golden_host.py, which imports and runs the reference in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from ao_marl_amd import modal
+from ao_marl_amd.agents import AgentLayout, BatchedGaussianPolicy, BatchedQNetwork
+from ao_marl_amd.env import DelayedMDP
+
+
+def test_compute_btt_and_cmat_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "host_btt_10x10.npz"))
+    IF = sp.csc_matrix((z["IF_data"], z["IF_indices"], z["IF_indptr"]), shape=tuple(z["IF_shape"]))
+    Btt, P = modal.compute_btt(IF[:, :-2].tocsc(), IF[:, -2:].toarray())
+    # same formula, same LAPACK: identical up to round-off (mode signs included)
+    assert np.abs(Btt - z["Btt"]).max() < 5e-5 * np.abs(z["Btt"]).max()
+    assert np.abs(P - z["P"]).max() < 5e-5 * np.abs(z["P"]).max()
+    cmat = modal.cmat_with_btt(z["imat"], z["Btt"], 5)
+    assert np.abs(cmat - z["cmat"]).max() < 1e-4 * np.abs(z["cmat"]).max()
+    # the filtered command matrix keeps the first n-nfilt-2 modes + TT
+    assert cmat.shape == (90, 128)
+
+
+CASES = {"small": dict(nmodes=87, se=[0, 80], n_modal=1, window=-1, tt_w=False),
+         "large": dict(nmodes=1283, se=[0, 1274], n_modal=13, window=20, tt_w=True),
+         "large_notw": dict(nmodes=1283, se=[0, 1274], n_modal=13, window=20, tt_w=False)}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_agent_layout_matches_reference(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "host_agents.npz"))
+    c = CASES[name]
+    lay = AgentLayout(c["nmodes"], c["se"], c["n_modal"], include_tip_tilt=True,
+                      window_n_zernike=c["window"], include_tip_tilt_windowed=c["tt_w"],
+                      n_filtered=5)
+    total, local, total_existing = z["%s_total" % name]
+    assert (lay.total_controlled_modes, lay.local_controlled_modes, lay.nmodes) == \
+        (total, local, total_existing)
+    assert lay.state_shapes() == list(z["%s_state_shapes" % name])
+    for w, (a, b) in lay.agents.items():
+        assert [a, b] == list(z["%s_agent%d_modes" % (name, w)])
+        assert np.array_equal(lay.modes_chosen[w], z["%s_agent%d_chosen" % (name, w)]), (name, w)
+    if name == "large":
+        assert lay.state_shapes()[0] == 552 and lay.state_shapes()[-1] == 168
+        # reference quirk: the TT agent's window indices are absolute 0..39 in every block
+        assert list(lay.modes_chosen[14][2:42]) == list(range(40))
+
+
+def test_batched_sac_forward_matches_reference_modules(golden_dir):
+    blob = torch.load(os.path.join(golden_dir, "host_sac_forward.pt"), weights_only=True)
+    lay = AgentLayout(87, [0, 80], 1, include_tip_tilt=True)
+    assert lay.state_shapes() == [320, 8]
+    pol = BatchedGaussianPolicy(lay, device="cpu")
+    qn = BatchedQNetwork(lay, device="cpu")
+    n = 5
+    state = torch.zeros(n, lay.state_dim)
+    for i, w in enumerate(lay.agents):
+        pol.load_agent(i, blob["agent%d" % i]["policy"])
+        state[:, torch.as_tensor(lay.modes_chosen[w])] = blob["agent%d" % i]["x"]
+    # the two agents' state slices are disjoint in this layout, so one state serves both
+    mean, log_std = pol.forward(state)
+    for i in range(2):
+        ref = blob["agent%d" % i]
+        na = ref["mean"].shape[1]
+        assert torch.allclose(mean[i, :, :na], ref["mean"], atol=2e-5, rtol=1e-5)
+        assert torch.allclose(log_std[i, :, :na], ref["log_std"], atol=2e-5, rtol=1e-5)
+    a, mu = pol.select_action(state, eval_mode=True)
+    assert a.shape == (n, 82) and torch.equal(a, mu)
+    assert torch.allclose(mu[:, :80], torch.tanh(blob["agent0"]["mean"]), atol=2e-5)
+    assert torch.allclose(mu[:, 80:], torch.tanh(blob["agent1"]["mean"]), atol=2e-5)
+    # critic: load the reference weights into the stacked tensors
+    for i in range(2):
+        ref = blob["agent%d" % i]["critic"]
+        nin, na = [320, 8][i], [80, 2][i]
+        for qi, pre in enumerate(("Q1", "Q2")):
+            Win, hid, out = qn.q[qi]
+            w = ref["%s_input.weight" % pre].T
+            Win[i].zero_()
+            Win[i, :nin] = w[:nin]
+            Win[i, qn.in_max:qn.in_max + na] = w[nin:]
+            assert ref["%s_input.bias" % pre].abs().max() == 0   # weights_init_: bias 0
+            assert len(hid) == 0 and not any(k.startswith("hidden_") for k in ref)
+            out[i] = ref["%s_output.weight" % pre].T
+    xs = pol.split_states(state)
+    act = torch.zeros(2, n, qn.act_max)
+    act[0, :, :80] = blob["agent0"]["a"]
+    act[1, :, :2] = blob["agent1"]["a"]
+    q1, q2 = qn.forward(xs, act)
+    for i in range(2):
+        assert torch.allclose(q1[i], blob["agent%d" % i]["q1"], atol=2e-5, rtol=1e-5)
+        assert torch.allclose(q2[i], blob["agent%d" % i]["q2"], atol=2e-5, rtol=1e-5)
+
+
+def test_delayed_mdp_matches_reference(golden_dir):
+    rec = np.load(os.path.join(golden_dir, "host_delayed_mdp.npz"))["rec"]
+    got = []
+    for delay, modif in ((1, False), (0, False), (1, True)):
+        m = DelayedMDP(delay, modif)
+        for t in range(6):
+            if m.check_update_possibility():
+                s, a, sn = m.credit_assignment()
+                got.append((delay, int(modif), t, s, a, sn))
+            m.save(10 * t, 100 * t, 10 * (t + 1))
+    assert np.array_equal(np.asarray(got), rec)
