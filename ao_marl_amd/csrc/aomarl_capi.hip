@@ -9,6 +9,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <climits>
 #include <string>
 #include <vector>
 
@@ -46,6 +48,7 @@ struct aomarl_ctx {
   int maxdim = 0, maxK = 0;
   float gain = 0.f, delay = 0.f;
   bool spot_fast = false;
+  bool force_generic_dm = false, force_valu_target = false;
   // controller matrices
   float *cmat = nullptr;           // [nactu][ld_s]
   int ld_cmat = 0;
@@ -205,7 +208,8 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
     const aomarl_dm_desc &M = d->dms[k];
     DevDm &D = s.dms[k];
     D.type = M.type; D.dim = M.dim; D.nact = M.nact; D.ss = M.influsize;
-    D.shape_off = soff; soff += (long long)M.dim * M.dim;
+    D.shape_off = soff;
+    soff += (M.type == AOMARL_DM_TT) ? 4 : (long long)M.dim * M.dim;   // TT: 2 commands (+pad)
     D.com_off = coff; coff += M.nact;
     if (M.type == AOMARL_DM_PZT) {
       UP(float, M.influ, (size_t)M.nact * M.influsize * M.influsize, D.influ);
@@ -221,6 +225,61 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
       if (tot != M.ninflupos) { aomarl_destroy(c); return fail("DM %d: sum(ninflu) != len(influpos)", k); }
       for (long long q = 0; q < M.ninflupos; q++)
         if (M.influpos[q] < 0 || M.influpos[q] >= M.nact * M.influsize * M.influsize) { aomarl_destroy(c); return fail("DM %d: influpos out of range", k); }
+      // ---- separable-lattice fast path: recover (i1, j1) of every actuator from the gather
+      // tables (first pixel that references sample 0 of its patch), check that all patches are
+      // one rank-1 profile and that the actuators sit on a regular lattice.
+      {
+        const int ss = M.influsize, ss2 = ss * ss, na = M.nact;
+        std::vector<int> i1(na, INT32_MIN), j1(na, INT32_MIN);
+        for (long long p = 0; p < (long long)M.dim * M.dim; p++)
+          for (int t = 0; t < M.ninflu[p]; t++) {
+            int pos = M.influpos[M.influstart[p] + t];
+            int act = pos / ss2, rem = pos % ss2, a = rem / ss, b = rem % ss;   // b: x offset
+            int x = (int)(p % M.dim) - b, y = (int)(p / M.dim) - a;
+            if (i1[act] == INT32_MIN) { i1[act] = x; j1[act] = y; }
+            else if (i1[act] != x || j1[act] != y) { i1[act] = INT32_MAX; }
+          }
+        bool ok = na > 0 && ss <= 128;
+        for (int a = 0; a < na && ok; a++) ok = (i1[a] != INT32_MIN && i1[a] != INT32_MAX);
+        // identical patches
+        for (int a = 1; a < na && ok; a++)
+          ok = memcmp(M.influ + (size_t)a * ss2, M.influ, sizeof(float) * ss2) == 0;
+        std::vector<float> prof(ss, 0.f);
+        if (ok) {
+          int cdx = 0; float best = 0.f;
+          for (int t = 0; t < ss; t++) if (M.influ[t * ss + t] > best) { best = M.influ[t * ss + t]; cdx = t; }
+          ok = best > 0.f;
+          if (ok) {
+            const float sc = 1.0f / sqrtf(best);
+            float mx = 0.f;
+            for (int t = 0; t < ss; t++) prof[t] = M.influ[t * ss + cdx] * sc;
+            for (int a = 0; a < ss; a++)
+              for (int b = 0; b < ss; b++) mx = fmaxf(mx, fabsf(M.influ[a * ss + b] - prof[a] * prof[b]));
+            ok = mx <= 2e-6f * best;
+          }
+        }
+        int pitch = 0, imin = INT32_MAX, jmin = INT32_MAX, imax = INT32_MIN, jmax = INT32_MIN;
+        if (ok) {
+          auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+          for (int a = 0; a < na; a++) { imin = std::min(imin, i1[a]); jmin = std::min(jmin, j1[a]); imax = std::max(imax, i1[a]); jmax = std::max(jmax, j1[a]); }
+          for (int a = 0; a < na; a++) { pitch = gcd(pitch, i1[a] - imin); pitch = gcd(pitch, j1[a] - jmin); }
+          ok = pitch > 0 && ss <= 4 * pitch && (DMS_TX + ss - 1) / pitch + 2 <= DMS_GX && (DMS_TY + ss - 1) / pitch + 2 <= DMS_GY;
+        }
+        if (ok) {
+          const int gw = (imax - imin) / pitch + 1, gh = (jmax - jmin) / pitch + 1;
+          std::vector<int32_t> grid((size_t)gw * gh, -1);
+          for (int a = 0; a < na && ok; a++) {
+            int32_t &cell = grid[(size_t)((j1[a] - jmin) / pitch) * gw + (i1[a] - imin) / pitch];
+            if (cell != -1) ok = false;
+            cell = a;
+          }
+          if (ok) {
+            D.sep = 1; D.pitch = pitch; D.i1min = imin; D.j1min = jmin; D.gw = gw; D.gh = gh;
+            UP(int32_t, grid.data(), grid.size(), D.grid);
+            UP(float, prof.data(), prof.size(), D.prof);
+          }
+        }
+      }
     } else if (M.type == AOMARL_DM_TT) {
       if (M.nact != 2) { aomarl_destroy(c); return fail("tip-tilt DM must have 2 actuators"); }
       UP(float, M.influ, (size_t)M.dim * M.dim * 2, D.influ);
@@ -558,11 +617,35 @@ int aomarl_comp_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, const fl
   const int ldv = volts ? c->sys.nactu : st->ld_actu;
   DevState ds = dev_state(st);
   for (int k = 0; k < c->ndm; k++) {
-    const int np = c->sys.dms[k].dim * c->sys.dms[k].dim;
-    hipLaunchKernelGGL(k_dm_shape, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, c->sys, ds, b, k, v, ldv);
+    const DevDm &D = c->sys.dms[k];
+    const int np = D.dim * D.dim;
+    if (D.type == AOMARL_DM_TT)
+      hipLaunchKernelGGL(k_dm_shape, dim3(1, n), dim3(64), 0, (hipStream_t)stream, c->sys, ds, b, k, v, ldv);
+    else if (D.sep && !c->force_generic_dm)
+      hipLaunchKernelGGL(k_dm_shape_sep, dim3((D.dim + DMS_TX - 1) / DMS_TX, (D.dim + DMS_TY - 1) / DMS_TY, n),
+                         dim3(256), 0, (hipStream_t)stream, c->sys, ds, b, k, v, ldv);
+    else
+      hipLaunchKernelGGL(k_dm_shape, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, c->sys, ds, b, k, v, ldv);
     LAUNCHCHK();
   }
   return 0;
+}
+
+int aomarl_get_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, int k, float *dst, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (k < 0 || k >= c->ndm || !dst) return fail("get_dm_shape: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_get_dm_shape, dim3(256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, k, dst);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
+  if (!c || !name) return fail("set_option: null argument");
+  if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
+  if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
+  return fail("set_option: unknown option %s", name);
 }
 
 // ---------------------------------------------------------------- raytrace (unfused API)
@@ -726,8 +809,19 @@ static int target_psf_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, bool f
   float *TR = st->work + w.TR + (size_t)b * c->sys.pupdiam * W * 2;
   float *TP = st->work + w.TPART + (size_t)b * w.nblk * 4;
   float *PEND = st->work + w.PEND + (size_t)b * (W * W + 4);
-  size_t sm = sizeof(float) * (2 * RB * TGT_XC + 3 * 256) + (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
   DevState ds = dev_state(st);
+  if (c->sys.hw == 8 && !c->force_valu_target) {
+    size_t smm = sizeof(float) * (2 * 16 * 65 + 4 * 2 * 256) + (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
+    if (from_buf)
+      hipLaunchKernelGGL(k_target_rows_mfma<true>, dim3(w.nblk, n), dim3(256), smm, s, c->sys, ds, b, TR, TP, w.nblk);
+    else
+      hipLaunchKernelGGL(k_target_rows_mfma<false>, dim3(w.nblk, n), dim3(256), smm, s, c->sys, ds, b, TR, TP, w.nblk);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
+    LAUNCHCHK();
+    return 0;
+  }
+  size_t sm = sizeof(float) * (2 * RB * TGT_XC + 3 * 256) + (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
   if (from_buf)
     hipLaunchKernelGGL(k_target_rows<true>, dim3(w.nblk, n), dim3(256), sm, s, c->sys, ds, b, TR, TP, w.nblk);
   else

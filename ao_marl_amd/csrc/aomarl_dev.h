@@ -27,6 +27,12 @@ struct DevDm {
   const int32_t *influpos, *ninflu, *influstart;
   float wxo, wyo, txo, tyo;
   int wox, woy, tox, toy;
+  // stack-array fast path: every actuator shares one separable patch influ[a][b] = prof[a] prof[b]
+  // and sits on a regular lattice (i1min + pitch*gx, j1min + pitch*gy); grid[gy*gw+gx] = actuator
+  // index or -1.  0 = use the generic gather tables.
+  int sep, pitch, i1min, j1min, gw, gh;
+  const int32_t *grid;
+  const float *prof;
 };
 
 struct DevSys {

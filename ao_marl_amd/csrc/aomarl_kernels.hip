@@ -207,7 +207,20 @@ __global__ void k_get_screen(DevSys sys, DevState st, int env_begin, int li, flo
 
 // =============================================================================================
 // deformable mirrors
+// Stack-array shape: materialised per env (dim x dim).  Tip-tilt: NOT materialised -- the two
+// commands are kept in the DM's 4-float slot of st->dm_shape and every consumer evaluates
+// c0*f0[p] + c1*f1[p] from the static planes (L2/MALL-resident, shared by all environments).
 // =============================================================================================
+__device__ __forceinline__ float dm_value(const DevSys &sys, const DevState &st, int e, int k, int x,
+                                          int y) {
+  const DevDm &D = sys.dms[k];
+  const float *slot = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+  if (D.type == AOMARL_DM_PZT) return slot[y * D.dim + x];
+  const float2 f = reinterpret_cast<const float2 *>(D.influ)[y * D.dim + x];
+  return slot[0] * f.x + slot[1] * f.y;
+}
+
+// generic per-pixel gather over the reference's influpos / ninflu / influstart tables
 __global__ __launch_bounds__(256) void k_dm_shape(DevSys sys, DevState st, int env_begin, int k,
                                                   const float *__restrict__ volts, int ldv) {
   const DevDm &D = sys.dms[k];
@@ -215,19 +228,95 @@ __global__ __launch_bounds__(256) void k_dm_shape(DevSys sys, DevState st, int e
   const float *com = volts + (long long)blockIdx.y * ldv + D.com_off;
   float *shape = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (D.type == AOMARL_DM_TT) {
+    if (p < 2) shape[p] = com[p];
+    return;
+  }
   if (p >= D.dim * D.dim) return;
-  if (D.type == AOMARL_DM_PZT) {
-    const int ss2 = D.ss * D.ss;
-    const int s0 = D.influstart[p], c = D.ninflu[p];
-    float acc = 0.f;
-    for (int t = 0; t < c; t++) {
-      int pos = D.influpos[s0 + t];
-      acc += D.influ[pos] * com[pos / ss2];
+  const int ss2 = D.ss * D.ss;
+  const int s0 = D.influstart[p], c = D.ninflu[p];
+  float acc = 0.f;
+  for (int t = 0; t < c; t++) {
+    int pos = D.influpos[s0 + t];
+    acc += D.influ[pos] * com[pos / ss2];
+  }
+  shape[p] = acc;
+}
+
+// separable lattice fast path: tile of 64 x 32 pixels per block; the <= 9 x 8 lattice cells that
+// can reach the tile are staged in LDS; shape = sum_gy u(y - Yg) sum_gx u(x - Xg) C[gy][gx]
+#define DMS_TX 64
+#define DMS_TY 32
+#define DMS_GX 9
+#define DMS_GY 8
+__global__ __launch_bounds__(256) void k_dm_shape_sep(DevSys sys, DevState st, int env_begin, int k,
+                                                      const float *__restrict__ volts, int ldv) {
+  __shared__ float sC[DMS_GY][DMS_GX + 1];
+  __shared__ float sU[128];
+  const DevDm &D = sys.dms[k];
+  const int e = env_begin + blockIdx.z;
+  const float *com = volts + (long long)blockIdx.z * ldv + D.com_off;
+  float *shape = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * DMS_TX, y0 = blockIdx.y * DMS_TY;
+  const int ss = D.ss, pitch = D.pitch;
+  // first lattice column / row that can touch the tile: X_g + ss - 1 >= x0
+  auto first = [&](int p0, int pmin) {
+    int num = p0 - pmin - (ss - 1);
+    int g = num >= 0 ? (num + pitch - 1) / pitch : -((-num) / pitch);
+    return g;
+  };
+  const int gxb = first(x0, D.i1min), gyb = first(y0, D.j1min);
+  if (tid < ss) sU[tid] = D.prof[tid];
+  if (tid < DMS_GY * DMS_GX) {
+    const int r = tid / DMS_GX, cc = tid - r * DMS_GX;
+    const int gx = gxb + cc, gy = gyb + r;
+    float v = 0.f;
+    if (gx >= 0 && gx < D.gw && gy >= 0 && gy < D.gh) {
+      int a = D.grid[gy * D.gw + gx];
+      if (a >= 0) v = com[a];
     }
-    shape[p] = acc;
-  } else {
-    const float2 f = reinterpret_cast<const float2 *>(D.influ)[p];
-    shape[p] = com[0] * f.x + com[1] * f.y;
+    sC[r][cc] = v;
+  }
+  __syncthreads();
+  const int x = x0 + (tid & 63);
+  float wx[DMS_GX];
+#pragma unroll
+  for (int cc = 0; cc < DMS_GX; cc++) {
+    int a = x - (D.i1min + pitch * (gxb + cc));
+    wx[cc] = (a >= 0 && a < ss) ? sU[a] : 0.f;
+  }
+  float rs[DMS_GY];
+#pragma unroll
+  for (int r = 0; r < DMS_GY; r++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < DMS_GX; cc++) acc += wx[cc] * sC[r][cc];
+    rs[r] = acc;
+  }
+  if (x >= D.dim) return;
+#pragma unroll
+  for (int j = 0; j < DMS_TY / 4; j++) {
+    const int y = y0 + (tid >> 6) + 4 * j;
+    if (y >= D.dim) continue;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < DMS_GY; r++) {
+      int a = y - (D.j1min + pitch * (gyb + r));
+      float wy = (a >= 0 && a < ss) ? sU[a] : 0.f;
+      acc += wy * rs[r];
+    }
+    shape[y * D.dim + x] = acc;
+  }
+}
+
+// materialise any DM's shape into dst [env_count][dim*dim] (getter for tests / host API)
+__global__ void k_get_dm_shape(DevSys sys, DevState st, int env_begin, int k, float *dst) {
+  const DevDm &D = sys.dms[k];
+  const int e = env_begin + blockIdx.y;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < D.dim * D.dim; p += gridDim.x * blockDim.x) {
+    int y = p / D.dim, x = p - y * D.dim;
+    dst[(long long)blockIdx.y * D.dim * D.dim + p] = dm_value(sys, st, e, k, x, y);
   }
 }
 
@@ -276,9 +365,20 @@ __global__ __launch_bounds__(256) void k_raytrace(DevSys sys, DevState st, int e
   if (flags & AOMARL_TRACE_DMS) {
     for (int k = 0; k < sys.ndm; k++) {
       const DevDm &D = sys.dms[k];
-      const float *sh = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
-      v += bilinear_plain(sh, D.dim, (float)x + (TARGET ? D.txo : D.wxo),
-                          (float)y + (TARGET ? D.tyo : D.wyo));
+      const float fx = (float)x + (TARGET ? D.txo : D.wxo), fy = (float)y + (TARGET ? D.tyo : D.wyo);
+      const int ix = (int)floorf(fx), iy = (int)floorf(fy);
+      if (ix >= 0 && iy >= 0 && ix < D.dim && iy < D.dim) {
+        const float wx = fx - (float)ix, wy = fy - (float)iy;
+        const int ix1 = ix + 1 < D.dim ? ix + 1 : ix, iy1 = iy + 1 < D.dim ? iy + 1 : iy;
+        float v00 = dm_value(sys, st, e, k, ix, iy);
+        if (wx == 0.f && wy == 0.f) {
+          v += v00;
+        } else {
+          float v01 = dm_value(sys, st, e, k, ix1, iy), v10 = dm_value(sys, st, e, k, ix, iy1);
+          float v11 = dm_value(sys, st, e, k, ix1, iy1);
+          v += (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+        }
+      }
     }
   }
   out[p] = v;
@@ -321,10 +421,17 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
                                                   int no_atmos, int no_dms, int do_cog) {
   __shared__ float sAr[4][16][17];
   __shared__ float sAi[4][16][17];
+  __shared__ float2 sTw[64];                     // (cos, sin)(2 pi m / 64)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wv;             // sub-aperture
   const int e = env_begin + blockIdx.y;
-  if (i >= sys.nvalid) return;                   // whole wave exits together
+  if (threadIdx.x < 64) {
+    float sn, cs;
+    sincospif((float)threadIdx.x * (1.0f / 32.0f), &sn, &cs);
+    sTw[threadIdx.x] = make_float2(cs, sn);
+  }
+  __syncthreads();
+  if (i >= sys.nvalid) return;                   // whole wave exits together (no barrier below)
   const int q = lane >> 4, c = lane & 15;
 
   // ---- twiddles: idx = 4q + s (pixel), freq = 16 b + c - 16
@@ -333,10 +440,8 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
   for (int b = 0; b < 2; b++)
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-      int m = ((4 * q + s) * (16 * b + c - 16)) & 63;
-      float sn, cs;
-      sincospif((float)m * (1.0f / 32.0f), &sn, &cs);
-      Cc[b][s] = cs; Ss[b][s] = sn; nS[b][s] = -sn;
+      const float2 w = sTw[((4 * q + s) * (16 * b + c - 16)) & 63];
+      Cc[b][s] = w.x; Ss[b][s] = w.y; nS[b][s] = -w.y;
     }
 
   // ---- stage 0: phase -> complex amplitude tile in LDS (4 pixels per lane)
@@ -368,10 +473,17 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
     if (!no_dms) {
       for (int k = 0; k < sys.ndm; k++) {
         const DevDm &D = sys.dms[k];
-        const float *sh = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off +
-                          (gy + D.woy) * D.dim + gx0 + tx0 + D.wox;
+        const float *slot = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+        const int o = (gy + D.woy) * D.dim + gx0 + tx0 + D.wox;
+        if (D.type == AOMARL_DM_PZT) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) ph[j] += sh[j];
+          for (int j = 0; j < 4; j++) ph[j] += slot[o + j];
+        } else {
+          const float c0 = slot[0], c1 = slot[1];
+          const float2 *f = reinterpret_cast<const float2 *>(D.influ) + o;
+#pragma unroll
+          for (int j = 0; j < 4; j++) ph[j] += c0 * f[j].x + c1 * f[j].y;
+        }
       }
     }
   }
@@ -382,8 +494,7 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
     for (int j = 0; j < 4; j++) {
       float t = ph[j] * sys.wfs_inv_lambda - hx[j];  // revolutions
       t -= rintf(t);
-      float sn, cs;
-      sincospif(2.0f * t, &sn, &cs);
+      const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_cosf(t);   // v_sin/v_cos
       float m = mk[j];
       sAr[wv][ty][tx0 + j] = m * cs;
       sAi[wv][ty][tx0 + j] = m * sn;
@@ -643,10 +754,8 @@ __global__ __launch_bounds__(256) void k_target_rows(DevSys sys, DevState st, in
         const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
         v += base[ring_idx(cx + L.tox, cy + L.toy, ox, oy, L.dim)];
       }
-      for (int k = 0; k < sys.ndm; k++) {
-        const DevDm &D = sys.dms[k];
-        v += st.dm_shape[(long long)e * sys.shape_stride + D.shape_off + (cy + D.toy) * D.dim + cx + D.tox];
-      }
+      for (int k = 0; k < sys.ndm; k++)
+        v += dm_value(sys, st, e, k, cx + sys.dms[k].tox, cy + sys.dms[k].toy);
     }
     pivot = v;
   }
@@ -674,11 +783,8 @@ __global__ __launch_bounds__(256) void k_target_rows(DevSys sys, DevState st, in
               const int oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
               v += base[ring_idx(x + L.tox, y + L.toy, ox, oy, L.dim)];
             }
-            for (int k = 0; k < sys.ndm; k++) {
-              const DevDm &D = sys.dms[k];
-              v += st.dm_shape[(long long)e * sys.shape_stride + D.shape_off +
-                               (y + D.toy) * D.dim + x + D.tox];
-            }
+            for (int k = 0; k < sys.ndm; k++)
+              v += dm_value(sys, st, e, k, x + sys.dms[k].tox, y + sys.dms[k].toy);
           }
           float t = v * sys.tar_inv_lambda;
           t -= rintf(t);
@@ -752,6 +858,208 @@ __global__ __launch_bounds__(256) void k_target_finish(DevSys sys, const float *
     double var = 0.;
     if (sm > 0.) { double mean = sd / sm; var = sd2 / sm - mean * mean; }
     pend[W * W] = (float)var;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// MFMA version (hw == 8 -> 16 kept frequencies per axis = one 16-wide MFMA tile).
+// Block = 16 pupil rows; the complex amplitude of a 16 x 64 chunk is staged in LDS; the 4 waves
+// split the chunk's 64 columns (K) and accumulate R[16 y][16 kx] with v_mfma_f32_16x16x4_f32:
+//   Rr += ar*C + ai*S ; Ri += ai*C - ar*S ,  C/S[x][kx] = cos/sin(2 pi kx x / Npsf)
+// ---------------------------------------------------------------------------------------------
+template <bool FROM_BUF>
+__global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState st, int env_begin,
+                                                          float *__restrict__ TR,
+                                                          float *__restrict__ TPART, int nblk) {
+  extern __shared__ float smem[];
+  const int pd = sys.pupdiam, np = sys.npsf;
+  float *sar = smem;                       // [16][65]
+  float *sai = sar + 16 * 65;
+  float *red = sai + 16 * 65;              // [4 waves][2][256] partial tiles; reused for sums
+  float2 *stw = reinterpret_cast<float2 *>(red + 4 * 2 * 256);   // [np] if it fits
+  const bool tw_lds = np <= 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, c = lane & 15;
+  const int e = env_begin + blockIdx.y;
+  const int y0 = blockIdx.x * 16;
+  const float2 *gtw = reinterpret_cast<const float2 *>(sys.psf_tw);
+  if (tw_lds)
+    for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
+  const float2 *tw = tw_lds ? stw : gtw;
+  float pivot;
+  {
+    const int cx = pd / 2, cy = pd / 2;
+    float v = 0.f;
+    if (FROM_BUF) {
+      v = st.tar_phase[(long long)e * pd * pd + cy * pd + cx];
+    } else {
+      for (int l = 0; l < sys.nlayers; l++) {
+        const DevLayer &L = sys.layers[l];
+        const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+        const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
+        v += base[ring_idx(cx + L.tox, cy + L.toy, ox, oy, L.dim)];
+      }
+      for (int k = 0; k < sys.ndm; k++)
+        v += dm_value(sys, st, e, k, cx + sys.dms[k].tox, cy + sys.dms[k].toy);
+    }
+    pivot = v;
+  }
+  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  float sd = 0.f, sd2 = 0.f, sm = 0.f;
+  const int fy = tid >> 4, fx0 = (tid & 15) * 4;     // fill: row fy, 4 consecutive columns
+  const int y = y0 + fy;
+  const int kxf = c - 8;
+  for (int x0 = 0; x0 < pd; x0 += 64) {
+    __syncthreads();
+    {
+      float ph[4] = {0.f, 0.f, 0.f, 0.f};
+      float mk[4] = {0.f, 0.f, 0.f, 0.f};
+      const int xb = x0 + fx0;
+      if (y < pd) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) mk[j] = (xb + j < pd) ? sys.spupil[y * pd + xb + j] : 0.f;
+        if (FROM_BUF) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (xb + j < pd) ph[j] = st.tar_phase[(long long)e * pd * pd + y * pd + xb + j];
+        } else if (xb < pd) {
+          for (int l = 0; l < sys.nlayers; l++) {
+            const DevLayer &L = sys.layers[l];
+            const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+            const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
+            int py = y + L.toy + oy; py -= (py >= L.dim) ? L.dim : 0;
+            int px = xb + L.tox + ox; px -= (px >= L.dim) ? L.dim : 0;
+            const float *row = base + py * L.dim;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              int xx = px + j; xx -= (xx >= L.dim) ? L.dim : 0;
+              ph[j] += row[xx];        // columns past pd stay inside the screen (window + 4 < dim)
+            }
+          }
+          for (int k = 0; k < sys.ndm; k++) {
+            const DevDm &D = sys.dms[k];
+            const float *slot = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+            const int o = (y + D.toy) * D.dim + xb + D.tox;
+            if (D.type == AOMARL_DM_PZT) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) ph[j] += slot[o + j];
+            } else {
+              const float c0 = slot[0], c1 = slot[1];
+              const float2 *f = reinterpret_cast<const float2 *>(D.influ) + o;
+#pragma unroll
+              for (int j = 0; j < 4; j++) ph[j] += c0 * f[j].x + c1 * f[j].y;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float ar = 0.f, ai = 0.f;
+        if (mk[j] != 0.f) {
+          float t = ph[j] * sys.tar_inv_lambda;
+          t -= rintf(t);
+          ar = mk[j] * __builtin_amdgcn_cosf(t);
+          ai = mk[j] * __builtin_amdgcn_sinf(t);
+          const float d = ph[j] - pivot;
+          sd += d; sd2 += d * d; sm += 1.f;
+        }
+        sar[fy * 65 + fx0 + j] = ar;
+        sai[fy * 65 + fx0 + j] = ai;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int xl = 16 * wv + 4 * s + q;
+      const float ar = sar[c * 65 + xl], ai = sai[c * 65 + xl];
+      const float2 w = tw[(kxf * (x0 + xl)) & (np - 1)];
+      Rr = mfma16(ar, w.x, Rr);
+      Ri = mfma16(ai, w.x, Ri);
+      Rr = mfma16(ai, w.y, Rr);
+      Ri = mfma16(ar, -w.y, Ri);
+    }
+  }
+  __syncthreads();
+  // cross-wave reduction of the 4 partial tiles; acc reg r of lane (q, c): y = 4q + r, kx = c
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    red[(wv * 2 + 0) * 256 + (4 * q + r) * 16 + c] = Rr[r];
+    red[(wv * 2 + 1) * 256 + (4 * q + r) * 16 + c] = Ri[r];
+  }
+  __syncthreads();
+  {
+    const int yy = tid >> 4, kx = tid & 15;
+    if (y0 + yy < pd) {
+      float vr = 0.f, vi = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; w4++) { vr += red[(w4 * 2) * 256 + tid]; vi += red[(w4 * 2 + 1) * 256 + tid]; }
+      float *o = TR + (((long long)blockIdx.y * pd + (y0 + yy)) * 16 + kx) * 2;
+      o[0] = vr; o[1] = vi;
+    }
+  }
+  __syncthreads();
+  red[tid] = sd; red[256 + tid] = sd2; red[512 + tid] = sm;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+      red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; red[512 + tid] += red[512 + tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float *pp = TPART + ((long long)blockIdx.y * nblk + blockIdx.x) * 4;
+    pp[0] = red[0]; pp[1] = red[256]; pp[2] = red[512]; pp[3] = 0.f;
+  }
+}
+
+// stage 2 on MFMA: G[ky][kx] = sum_y E[ky][y] R[y][kx]; 4 waves split y, one block per env
+__global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const float *__restrict__ TR,
+                                                            const float *__restrict__ TPART, int nblk,
+                                                            float *__restrict__ PEND) {
+  __shared__ float red[4 * 2 * 256];
+  const int pd = sys.pupdiam, np = sys.npsf;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, c = lane & 15;
+  const float2 *tw = reinterpret_cast<const float2 *>(sys.psf_tw);
+  const float2 *R = reinterpret_cast<const float2 *>(TR) + (long long)b * pd * 16;
+  float *pend = PEND + (long long)b * (256 + 4);
+  const int kyf = c - 8;
+  f32x4 Gr = {0.f, 0.f, 0.f, 0.f}, Gi = {0.f, 0.f, 0.f, 0.f};
+  const int per = ((pd + 15) / 16) * 4;              // rows per wave, multiple of 4
+  const int yb = wv * per, ye = min(pd, yb + per);
+  for (int yy = yb; yy < ye; yy += 4) {
+    const int y = yy + q;
+    float2 r = make_float2(0.f, 0.f), w = make_float2(0.f, 0.f);
+    if (y < ye) {
+      r = R[y * 16 + c];                               // B operand: R[y = yy + q][kx = c]
+      w = tw[(kyf * y) & (np - 1)];                    // A operand: E[ky = c - 8][y = yy + q]
+    }
+    Gr = mfma16(w.x, r.x, Gr);
+    Gi = mfma16(w.x, r.y, Gi);
+    Gr = mfma16(w.y, r.y, Gr);
+    Gi = mfma16(-w.y, r.x, Gi);
+  }
+#pragma unroll
+  for (int r4 = 0; r4 < 4; r4++) {
+    red[(wv * 2 + 0) * 256 + (4 * q + r4) * 16 + c] = Gr[r4];
+    red[(wv * 2 + 1) * 256 + (4 * q + r4) * 16 + c] = Gi[r4];
+  }
+  __syncthreads();
+  {
+    float gr = 0.f, gi = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; w4++) { gr += red[(w4 * 2) * 256 + tid]; gi += red[(w4 * 2 + 1) * 256 + tid]; }
+    pend[tid] = gr * gr + gi * gi;                     // tid = ky * 16 + kx
+  }
+  if (tid == 0) {
+    double sd = 0., sd2 = 0., sm = 0.;
+    for (int k = 0; k < nblk; k++) {
+      const float *pp = TPART + ((long long)b * nblk + k) * 4;
+      sd += pp[0]; sd2 += pp[1]; sm += pp[2];
+    }
+    double var = 0.;
+    if (sm > 0.) { double mean = sd / sm; var = sd2 / sm - mean * mean; }
+    pend[256] = (float)var;
   }
 }
 

@@ -93,6 +93,8 @@ SYMBOLS = [
     ("aomarl_rl_control", _i, _range + [_vp, _vp]),
     ("aomarl_apply_control", _i, _range + [_i, _vp]),
     ("aomarl_comp_dm_shape", _i, _range + [_vp, _vp]),
+    ("aomarl_get_dm_shape", _i, _range + [_i, _vp, _vp]),
+    ("aomarl_set_option", _i, [_vp, C.c_char_p, _i]),
     ("aomarl_target_psf", _i, _range + [_vp]),
     ("aomarl_comp_strehl", _i, _range + [_vp]),
     ("aomarl_reset_strehl", _i, _range + [_vp]),

@@ -125,10 +125,18 @@ class HipSim(object):
         avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
         return torch.stack([s[:, 0], s[:, 1], s[:, 2], avg], dim=1)
 
-    def dm_shape(self, k):
+    def dm_shape(self, k, env_begin=0, env_count=None):
+        """Shape of DM k, [env_count, dim, dim] (materialised on demand: tip-tilt mirrors are
+        never stored, their consumers evaluate the two planes on the fly)."""
+        b, n = self._range(env_begin, env_count)
         d = self.s.dms[k]
-        off = sum(x.dim * x.dim for x in self.s.dms[:k])
-        return self.t["dm_shape"][:, off:off + d.dim * d.dim].view(self.nenv, d.dim, d.dim)
+        out = torch.empty(n, d.dim, d.dim, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_get_dm_shape(self.ctx, C.byref(self.st), b, n, k,
+                                              out.data_ptr(), self._stream()))
+        return out
+
+    def set_option(self, name, value):
+        la.check(self.lib.aomarl_set_option(self.ctx, name.encode(), int(value)))
 
     def screen(self, layer, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)

@@ -109,7 +109,7 @@ typedef struct {
   uint32_t *ext_count; /* [nenv][nlayers]        extrusions drawn so far (RNG counter)      */
   float *com, *com1, *com2, *err, *voltage; /* [nenv][nactu]                               */
   float *slopes;       /* [nenv][nslope]         all x then all y (ao_env.py:665-666)       */
-  float *dm_shape;     /* [nenv][sum_k dim_k^2]                                             */
+  float *dm_shape;     /* [nenv][aomarl_dmshape_stride]: dim^2 per stack array, 4 per tip-tilt */
   float *bincube;      /* [nenv][nvalid][npix^2] or NULL                                    */
   float *wfs_phase;    /* [nenv][n*n]            or NULL (only the unfused API needs it)    */
   float *tar_phase;    /* [nenv][pupdiam^2]      or NULL                                    */
@@ -188,6 +188,13 @@ int aomarl_apply_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int e
 /* Dm.set_com + comp_shape (dmCompass.py:64-146): volts_dev [env_count][nactu] or NULL=voltage */
 int aomarl_comp_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                          const float *volts_dev, void *stream);
+/* materialise the shape of DM k into dst [env_count][dim*dim] (device memory). Stack-array shapes
+ * live in st->dm_shape; tip-tilt shapes are never stored (consumers evaluate c0*f0 + c1*f1) */
+int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int k,
+                        float *dst, void *stream);
+/* implementation switches for tests / A-B measurements: "force_generic_dm" (per-pixel gather
+ * tables instead of the separable-lattice kernel), "force_valu_target" (VALU PSF rows kernel) */
+int aomarl_set_option(aomarl_ctx *ctx, const char *name, int value);
 /* fused target raytrace + PSF window + phase variance into a pending slot
  * (RlSupervisor.raytrace_target, rlSupervisor.py:845-855) */
 int aomarl_target_psf(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,

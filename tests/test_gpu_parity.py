@@ -105,16 +105,21 @@ def test_all_four_extrusion_directions(setup):
         assert np.abs(scr[e] - o.screens[0]).max() < 2e-5
 
 
-def test_dm_shape_matches_oracle(setup):
+@pytest.mark.parametrize("generic", [0, 1])
+def test_dm_shape_matches_oracle(setup, generic):
+    """Both stack-array kernels: the separable-lattice fast path and the generic gather over the
+    reference's influpos tables."""
     _, s, _, sim, oracles = setup
     rng = np.random.default_rng(3)
     volts = rng.normal(0, 1.0, size=(len(oracles), s.nactu)).astype(np.float32)
+    sim.set_option("force_generic_dm", generic)
     sim.comp_dm_shape(torch.from_numpy(volts).cuda())
+    sim.set_option("force_generic_dm", 0)
     for e, o in enumerate(oracles):
         o.comp_shapes(volts[e])
         for k in range(len(s.dms)):
             a = sim.dm_shape(k)[e].cpu().numpy()
-            assert np.abs(a - o.dm_shapes[k]).max() < 1e-6 * max(1.0, np.abs(o.dm_shapes[k]).max())
+            assert np.abs(a - o.dm_shapes[k]).max() < 2e-6 * max(1.0, np.abs(o.dm_shapes[k]).max())
 
 
 def test_raytrace_and_spot_image_match_oracle(setup):
@@ -204,8 +209,11 @@ def test_rl_control_matches_numpy(setup):
     sim.set_modal(cal.volts2modes, cal.modes2volts)
 
 
-def test_target_psf_and_strehl_match_oracle(setup):
+@pytest.mark.parametrize("valu", [0, 1])
+def test_target_psf_and_strehl_match_oracle(setup, valu):
+    """Both PSF-row kernels (fp32 MFMA and the VALU fallback)."""
     _, s, _, sim, oracles = setup
+    sim.set_option("force_valu_target", valu)
     _push_oracle_state(sim, oracles)
     rng = np.random.default_rng(7)
     volts = rng.normal(0, 0.3, size=(len(oracles), s.nactu)).astype(np.float32)
@@ -228,6 +236,7 @@ def test_target_psf_and_strehl_match_oracle(setup):
         assert abs(st[e, 1] - want[1]) < 2e-5 * max(want[1], 1e-3) + 1e-7
         assert abs(st[e, 2] - want[2]) < 1e-4 * want[2] + 1e-9
         assert abs(st[e, 3] - want[3]) < 1e-4 * want[3] + 1e-9
+    sim.set_option("force_valu_target", 0)
 
 
 def test_closed_loop_trace_matches_oracle(setup):
@@ -265,6 +274,6 @@ def test_calibration_through_hip_backend_matches_oracle_backend(setup):
     cal = modal.calibrate(s, sysm, backend, nfilt=5)
     assert [len(k) for k in cal.kept] == [88, 2]
     assert np.array_equal(cal.kept[0], cal_o.kept[0])      # same actuators survive, exactly
-    assert np.abs(cal.imat - cal_o.imat).max() < 2e-5 * np.abs(cal_o.imat).max() + 1e-8
+    assert np.abs(cal.imat - cal_o.imat).max() < 1e-4 * np.abs(cal_o.imat).max()
     assert np.abs(cal.cmat - cal_o.cmat).max() < 2e-3 * np.abs(cal_o.cmat).max()
     assert np.abs(cal.Btt - cal_o.Btt).max() < 1e-6
