@@ -55,7 +55,7 @@ class VecRlSupervisor(object):
     """Batched counterpart of shesha's RlSupervisor for the integrator (+RL correction) path."""
 
     def __init__(self, config, config_rl, nenv, *, initial_seed=1234, seed_stride=16,
-                 device="cuda:0", strehl_halfwin=8, keep_bincube=False):
+                 device="cuda:0", strehl_halfwin=8, keep_bincube=False, sim_factory=None):
         self.config = config if not isinstance(config, str) else params.builtin(config)
         self.config_rl = dict(DEFAULT_ENV_RL)
         self.config_rl.update(config_rl or {})
@@ -67,8 +67,12 @@ class VecRlSupervisor(object):
         self.nenv, self.device = nenv, torch.device(device)
         self.sysm = G.build_system(self.config)
         self.s = system.from_system(self.sysm, ncontrol=0, strehl_halfwin=strehl_halfwin)
-        # calibration through the HIP backend (imat_geom, correct_dm, imat, Btt, filtered cmat)
-        cal_sim = HipSim(self.s, nenv=min(512, 2048), device=device, keep_phase=True)
+        # `sim_factory(s, nenv, device=..., **kw)` builds the simulator; the product default is
+        # the HIP one.  (tests/ inject a CPU-oracle-backed stand-in to pin this file's host logic
+        # against the reference's traces on a GPU-less box.)
+        make = sim_factory if sim_factory is not None else HipSim
+        # calibration through the backend (imat_geom, correct_dm, imat, Btt, filtered cmat)
+        cal_sim = make(self.s, nenv=min(512, 2048), device=device, keep_phase=True)
         self.n_reverse_filtered_from_cmat = int(self.config_rl["n_reverse_filtered_from_cmat"])
         self.cal = modal.calibrate(self.s, self.sysm, cal_sim,
                                    nfilt=max(self.n_reverse_filtered_from_cmat, 0))
@@ -77,7 +81,7 @@ class VecRlSupervisor(object):
         self.nmodes = self.volts2modes.shape[0]
         self.n_modes_start_end = list(self.config_rl["n_zernike_start_end"])
         self.include_tip_tilt = bool(self.config_rl["include_tip_tilt"])
-        self.sim = HipSim(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
+        self.sim = make(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
         self.freedom_vector = None
         self._push_modal()
         self.initial_seed, self.seed_stride = int(initial_seed), int(seed_stride)
@@ -178,16 +182,20 @@ class VecAoEnv(object):
 
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
-                 strehl_halfwin=8, norm=None, zn_norm=None):
+                 strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
         self.normalization_bool = normalization_bool
-        name = parameters_telescope[:-3] if parameters_telescope.endswith(".py") else \
-            parameters_telescope
-        self.supervisor = VecRlSupervisor(name, cfg, nenv, initial_seed=initial_seed,
+        if isinstance(parameters_telescope, params.ParamSet):
+            config, name = parameters_telescope, parameters_telescope.simul_name
+        else:
+            name = parameters_telescope[:-3] if parameters_telescope.endswith(".py") else \
+                parameters_telescope
+            config = name
+        self.supervisor = VecRlSupervisor(config, cfg, nenv, initial_seed=initial_seed,
                                           seed_stride=seed_stride, device=device,
-                                          strehl_halfwin=strehl_halfwin)
+                                          strehl_halfwin=strehl_halfwin, sim_factory=sim_factory)
         sup = self.supervisor
         self.nenv, self.device = nenv, sup.device
         self.nmodes = sup.nmodes

@@ -1,0 +1,116 @@
+"""OracleVecSim: the HipSim interface over the CPU oracle (torch CPU tensors, a Python loop over
+environments).  TEST INFRASTRUCTURE: lets tests/ drive ao_marl_amd.env (host logic) without a GPU
+and check it against traces of the reference's own Python; never used by the product."""
+import numpy as np
+import torch
+
+from oracle import aoref
+
+
+class _Sim(aoref.OracleSim):
+    def __init__(self, s, lazy):
+        self._lazy = lazy
+        aoref.OracleSim.__init__(self, s, seed=0)
+
+    def reset(self, seed):
+        if self._lazy:              # construction: no screen generation yet
+            self.seed, self.frame = int(seed), 0
+            self.accumx = np.zeros(self.s.nscreens, dtype=np.float32)
+            self.accumy = np.zeros(self.s.nscreens, dtype=np.float32)
+            self.ext_count = [0] * self.s.nscreens
+            self._alloc_ctrl()
+            self.reset_strehl()
+            self._lazy = False
+            return
+        aoref.OracleSim.reset(self, seed)
+
+
+class OracleVecSim(object):
+    def __init__(self, s, nenv, device="cpu", keep_bincube=False, keep_phase=False):
+        self.s, self.nenv, self.device = s, int(nenv), torch.device("cpu")
+        self._build()
+
+    def _build(self):
+        self.sims = [_Sim(self.s, True) for _ in range(self.nenv)]
+        self.v2m = self.m2v = self.freedom = self.amodes = None
+
+    # configuration
+    def set_cmat(self, cmat):
+        self.s.cmat = np.ascontiguousarray(cmat, dtype=np.float32)
+
+    def set_gain(self, g):
+        self.s.gain = float(g)
+
+    def set_modal(self, v2m, m2v, freedom=None, action_modes=None):
+        self.v2m, self.m2v = np.asarray(v2m, np.float32), np.asarray(m2v, np.float32)
+        self.nmodes = self.v2m.shape[0]
+        self.freedom = None if freedom is None else np.asarray(freedom, np.float32)
+        self.amodes = None if action_modes is None else np.asarray(action_modes) % self.nmodes
+        self.nact = 0 if self.amodes is None else int(self.amodes.size)
+
+    def reload_dms(self):
+        self._build()
+
+    # state views
+    def _stack(self, name):
+        return torch.from_numpy(np.stack([getattr(o, name) for o in self.sims]).astype(np.float32))
+
+    com = property(lambda self: self._stack("com"))
+    err = property(lambda self: self._stack("err"))
+    voltage = property(lambda self: self._stack("voltage"))
+    slopes = property(lambda self: self._stack("slopes"))
+
+    @property
+    def strehl(self):
+        return torch.tensor([o.get_strehl() for o in self.sims], dtype=torch.float32)
+
+    # per-frame API
+    def reset(self, seeds):
+        seeds = np.broadcast_to(np.asarray(seeds), (self.nenv,))
+        for o, sd in zip(self.sims, seeds):
+            o.reset(int(sd))
+
+    def rl_control(self, action):
+        a = np.asarray(action, dtype=np.float32)
+        for e, o in enumerate(self.sims):
+            m = self.v2m.dot(o.com)                                  # rlSupervisor.py:800
+            m[self.amodes] += a[e] * self.freedom[self.amodes]       # :813
+            o.set_com(self.m2v.dot(m))                               # :816, :733
+
+    def apply_control(self):
+        for o in self.sims:
+            o.apply_control()
+
+    def comp_strehl(self):
+        for o in self.sims:
+            o.comp_strehl()
+
+    def next_part_one(self):
+        for o in self.sims:
+            o.next_part_one()
+
+    def move_atmos(self):
+        for o in self.sims:
+            o.move_atmos()
+
+    def target_psf(self):
+        for o in self.sims:
+            o.raytrace_target()
+
+    def comp_image(self, noise=True, cog=True, **kw):
+        for o in self.sims:
+            o.raytrace_wfs(atm=True, dms=False, reset=True)
+            o.raytrace_wfs(atm=False, dms=True, reset=False)
+            o.comp_image(noise=noise)
+            if cog:
+                o.do_centroids()
+
+    def do_control(self):
+        for o in self.sims:
+            o.do_control()
+
+    def volts2modes(self, vec):
+        return torch.from_numpy(np.asarray(vec, dtype=np.float32) @ self.v2m.T)
+
+    def dm_response(self, commands, geometric):
+        return self.sims[0].dm_response(np.ascontiguousarray(commands, dtype=np.float32), geometric)

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""G10: the reference's OWN RlSupervisor + AoEnv, unmodified, executed over the oracle facade
+(tools/ref_facade.py) -> golden (state, per-agent reward, slopes, command, Strehl) traces.
+
+Build container only.  The parameter file is tools/par/production_aomarl_sh_10x10_2m_single.py (the 10x10
+system reduced to its controller-0 path, because the GEO reference controller of the stock files is
+not in the oracle); it is staged, together with copies of the reference's 10x10 normalisation DATA
+under that name, in a scratch directory laid out like the reference expects.
+Writes tests/golden/trace_10x10_single.npz.
+"""
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import _ref_shims  # noqa: E402
+import ref_facade  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+REF = _ref_shims.REF
+NAME = "production_aomarl_sh_10x10_2m_single"
+NORM = "src/reinforcement_learning/helper_functions/preprocessing/normalization"
+
+
+def stage(tmp):
+    os.makedirs(os.path.join(tmp, "data/par/par4rl/production"))
+    shutil.copy(os.path.join(HERE, "par", NAME + ".py"), os.path.join(tmp, "data/par/par4rl/production"))
+    for sub in ("state_normalization", "normalization_action_zernike"):
+        os.makedirs(os.path.join(tmp, NORM, sub))
+    shutil.copy(os.path.join(REF, NORM, "state_normalization",
+                             "normalization_production_sh_10x10_2m_zernike_space.pickle"),
+                os.path.join(tmp, NORM, "state_normalization",
+                             "normalization_%s_zernike_space.pickle" % NAME))
+    shutil.copy(os.path.join(REF, NORM, "normalization_action_zernike",
+                             "zn_norm_production_sh_10x10_2m.npy"),
+                os.path.join(tmp, NORM, "normalization_action_zernike", "zn_norm_%s.npy" % NAME))
+    os.makedirs(os.path.join(tmp, "output/debug"))
+
+
+def main(nframes=30, seed=1234):
+    ref_facade.install()
+    _ref_shims.install()
+    tmp = tempfile.mkdtemp(prefix="aomarl_ref_")
+    stage(tmp)
+    os.chdir(tmp)
+    from src.reinforcement_learning.config.GlobalConfig import Config
+    from src.reinforcement_learning.environment.ao_env import AoEnv
+    from src.reinforcement_learning.rpc_training.helper_rpc.helper_rewards import \
+        get_separated_rewards
+    from src.reinforcement_learning.rpc_training.train_rpc import TrainerRPC
+    cfg = Config(os.path.join(REF, "src/reinforcement_learning"))
+    cfg.env_rl.update({"parameters_telescope": NAME + ".py", "n_zernike_start_end": [0, 80],
+                       "n_reverse_filtered_from_cmat": 5, "include_tip_tilt": "True",
+                       "verbose": False})
+    cfg.strings_to_bools()
+    cfg.autoencoder["path"] = None
+    env = AoEnv(config_rl=cfg, normalization_bool=True, initial_seed=seed)
+    env.supervisor.set_sim_seed(seed)
+    sup = env.supervisor
+    fake = types.SimpleNamespace(env=env, world_size=3)
+    agents, total, local, total_existing = TrainerRPC.create_agents_dictionary_original(fake, cfg)
+    rng = np.random.default_rng(99)
+    rec = {k: [] for k in ("state", "reward", "slopes", "com", "err", "voltage", "strehl",
+                           "action")}
+    s = env.reset()
+    rec["state"].append(np.asarray(s, dtype=np.float64))
+    rec["slopes"].append(sup.rtc.get_slopes(0))
+    rec["com"].append(sup.rtc.get_command(0))
+    rec["err"].append(sup.rtc.get_err(0))
+    for it in range(nframes):
+        # zero actions for the first third (pure integrator through rl_control), then U(-1, 1)
+        a = np.zeros(82, dtype=np.float32) if it < nframes // 3 else \
+            rng.uniform(-1, 1, size=82).astype(np.float32)
+        # TrainerRPC.env_step (train_rpc.py:633-648)
+        _, done, info = env.rl_step(a, False)
+        modes = sup.volts2modes.dot(sup.rtc.get_err(0))
+        r = get_separated_rewards(np.square(modes), cfg.env_rl["reward_type"], agents)
+        s = env.linear_step(False)
+        rec["action"].append(a)
+        rec["state"].append(np.asarray(s, dtype=np.float64))
+        rec["reward"].append(np.array([r[w] for w in agents], dtype=np.float64))
+        rec["slopes"].append(sup.rtc.get_slopes(0))
+        rec["com"].append(sup.rtc.get_command(0))
+        rec["err"].append(sup.rtc.get_err(0))
+        rec["voltage"].append(sup.rtc.get_voltages(0))
+        rec["strehl"].append(np.asarray(sup.target.get_strehl(0), dtype=np.float64))
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["modes2volts"], out["volts2modes"] = sup.modes2volts, sup.volts2modes
+    out["cmat"] = np.array(sup.rtc._rtc.d_control[0].d_cmat)
+    out["imat"] = np.array(sup.rtc._rtc.d_control[0].d_imat)
+    out["freedom_vector"] = sup.freedom_vector
+    out["seed"] = np.array(seed)
+    out["agents"] = np.array([agents[w] for w in agents])
+    out["nactu"] = np.array(out["com"].shape[1])
+    dst = os.path.join(ROOT, "tests", "golden", "trace_10x10_single.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, {k: v.shape for k, v in out.items()})
+    print("SR se/le last:", out["strehl"][-1][:2], "state absmax", np.abs(out["state"]).max())
+    os.chdir(ROOT)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
