@@ -49,6 +49,8 @@ struct aomarl_ctx {
   float gain = 0.f, delay = 0.f;
   bool spot_fast = false;
   bool force_generic_dm = false, force_valu_target = false;
+  int spot_blocks_per_env = 0;
+  bool force_generic_spot = false, force_generic_target = false;
   // controller matrices
   float *cmat = nullptr;           // [nactu][ld_s]
   int ld_cmat = 0;
@@ -84,6 +86,7 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
   if (d->nlayers < 0 || d->nlayers > AOMARL_MAX_LAYERS) return fail("nlayers out of range");
   if (d->ndm < 1 || d->ndm > AOMARL_MAX_DMS) return fail("ndm out of range");
   if (d->n <= 0 || d->pupdiam <= 0 || d->n < d->pupdiam) return fail("bad pupil sizes");
+  if (d->pupdiam % 4 || d->n % 4) return fail("pupil grid sizes must be multiples of 4");
   if (d->npsf & (d->npsf - 1)) return fail("npsf must be a power of two");
   if (!(d->strehl_halfwin == 4 || d->strehl_halfwin == 8 || d->strehl_halfwin == 16))
     return fail("strehl_halfwin must be 4, 8 or 16");
@@ -389,7 +392,7 @@ int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m
 
 // ---- workspace layout (floats)
 struct Work {
-  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, total;
+  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, GEMM, gemm_floats, total;
   int ldz, ldn, ldm, nblk;
 };
 
@@ -411,6 +414,11 @@ static Work work_layout(const aomarl_ctx *c, int nenv) {
   w.TR = take((size_t)nenv * s.pupdiam * W * 2);
   w.TPART = take((size_t)nenv * w.nblk * 4);
   w.PEND = take((size_t)nenv * (W * W + 4));
+  {
+    size_t mn = std::max(ncol * (size_t)w.ldn, (size_t)nenv * (size_t)w.ldm);
+    w.gemm_floats = 8 * mn;
+    w.GEMM = take(w.gemm_floats);
+  }
   w.total = o;
   return w;
 }
@@ -474,7 +482,7 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
                        ops, Z, w.ldz, ZREF);
     LAUNCHCHK();
     launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
-                   0.0f, NEWL, w.ldn, s);
+                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM, w.gemm_floats);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol, (dimc + 255) / 256), dim3(256), 0, s, c->sys,
                        ds, b, ops, NEWL, w.ldn, ZREF);
@@ -595,7 +603,10 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
     rc = aomarl_extrude(c, st, b, n, nops, layer, dir, stream);
     if (rc) return rc;
   }
-  return 0;
+  // pending PSF of the fresh atmosphere with flat DMs: comp_strehl before the first
+  // next_part_one is well defined
+  if (!c->sys.tar_all_int && !st->tar_phase) return 0;
+  return aomarl_target_psf(c, st, b, n, stream);
 }
 
 int aomarl_get_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, float *dst, void *stream) {
@@ -645,6 +656,9 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!c || !name) return fail("set_option: null argument");
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
+  if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
+  if (!strcmp(name, "force_generic_spot")) { c->force_generic_spot = value != 0; return 0; }
+  if (!strcmp(name, "force_generic_target")) { c->force_generic_target = value != 0; return 0; }
   return fail("set_option: unknown option %s", name);
 }
 
@@ -693,9 +707,25 @@ int aomarl_comp_image(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, 
   const int na = (flags & AOMARL_IMG_NO_ATMOS) ? 1 : 0, nd = (flags & AOMARL_IMG_NO_DMS) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   DevState ds = dev_state(st);
-  dim3 grid((c->sys.nvalid + 3) / 4, n), blk(256);
+  // persistent waves: enough blocks per environment to fill the chip ~2x (256 CUs x 32 waves)
+  int gx = (16384 + 4 * n - 1) / (4 * n);
+  gx = std::max(1, std::min(gx, (c->sys.nvalid + 3) / 4));
+  if (c->spot_blocks_per_env > 0) gx = std::min(c->spot_blocks_per_env, (c->sys.nvalid + 3) / 4);
+  dim3 grid(gx, n), blk(256);
 #define SPOT(FB, NZ, WC) hipLaunchKernelGGL((k_wfs_spot<FB, NZ, WC>), grid, blk, 0, s, c->sys, ds, b, na, nd, cog)
-  if (from_buf) {
+#define FAST(NL, NZ, WC) hipLaunchKernelGGL((k_wfs_spot_fast<NL, NZ, WC>), grid, blk, 0, s, c->sys, ds, b, cog)
+  const bool fast_ok = !from_buf && !na && !nd && !c->force_generic_spot && c->ndm == 2 &&
+                       c->sys.dms[0].type == AOMARL_DM_PZT && c->sys.dms[1].type == AOMARL_DM_TT &&
+                       (c->nlayers == 1 || c->nlayers == 3);
+  if (fast_ok) {
+    if (c->nlayers == 1) {
+      if (noise) { if (cube) FAST(1, true, true); else FAST(1, true, false); }
+      else { if (cube) FAST(1, false, true); else FAST(1, false, false); }
+    } else {
+      if (noise) { if (cube) FAST(3, true, true); else FAST(3, true, false); }
+      else { if (cube) FAST(3, false, true); else FAST(3, false, false); }
+    }
+  } else if (from_buf) {
     if (noise) { if (cube) SPOT(true, true, true); else SPOT(true, true, false); }
     else { if (cube) SPOT(true, false, true); else SPOT(true, false, false); }
   } else {
@@ -703,6 +733,7 @@ int aomarl_comp_image(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, 
     else { if (cube) SPOT(false, false, true); else SPOT(false, false, false); }
   }
 #undef SPOT
+#undef FAST
   LAUNCHCHK();
   hipLaunchKernelGGL(k_inc_u32, dim3((n + 255) / 256), dim3(256), 0, s, st->frame + b, n);
   LAUNCHCHK();
@@ -738,8 +769,9 @@ int aomarl_do_control(aomarl_ctx *c, aomarl_state *st, int b, int n, void *strea
   hipStream_t s = (hipStream_t)stream;
   const int na = c->sys.nactu, nsl = c->sys.nslope;
   // err[env][a] = - sum_s slopes[env][s] cmat[a][s]
+  Work w = work_layout(c, st->nenv);
   launch_gemm_nt(n, na, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->cmat, c->ld_cmat, 0.0f,
-                 st->err + (size_t)b * st->ld_actu, st->ld_actu, s);
+                 st->err + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats);
   LAUNCHCHK();
   hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b);
   LAUNCHCHK();
@@ -758,11 +790,16 @@ int aomarl_set_com(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *c
   return 0;
 }
 
-int aomarl_volts2modes(aomarl_ctx *c, int nrows, const float *vec, float *modes, void *stream) {
+int aomarl_volts2modes(aomarl_ctx *c, aomarl_state *st, int nrows, const float *vec, int ldvec,
+                       float *modes, void *stream) {
   if (!c || !c->v2m) return fail("volts2modes: no modal basis (aomarl_set_modal)");
   if (!vec || !modes) return fail("volts2modes: null argument");
-  launch_gemm_nt(nrows, c->nmodes, c->sys.nactu, 1.0f, vec, c->sys.nactu, c->v2m, c->ld_v2m, 0.0f,
-                 modes, c->nmodes, (hipStream_t)stream);
+  if (ldvec < c->sys.nactu) return fail("volts2modes: ldvec < nactu");
+  float *ws = nullptr;
+  size_t wsn = 0;
+  if (st && st->work) { Work w = work_layout(c, st->nenv); ws = st->work + w.GEMM; wsn = w.gemm_floats; }
+  launch_gemm_nt(nrows, c->nmodes, c->sys.nactu, 1.0f, vec, ldvec, c->v2m, c->ld_v2m, 0.0f,
+                 modes, c->nmodes, (hipStream_t)stream, ws, wsn);
   LAUNCHCHK();
   return 0;
 }
@@ -779,11 +816,11 @@ int aomarl_rl_control(aomarl_ctx *c, aomarl_state *st, int b, int n, const float
   float *modes = st->work + w.MODES;
   const int na = c->sys.nactu, nm = c->nmodes;
   float *com = st->com + (size_t)b * st->ld_actu;
-  launch_gemm_nt(n, nm, na, 1.0f, com, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, modes, w.ldm, s);
+  launch_gemm_nt(n, nm, na, 1.0f, com, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, modes, w.ldm, s, st->work + w.GEMM, w.gemm_floats);
   LAUNCHCHK();
   hipLaunchKernelGGL(k_modal_add, dim3((c->nact + 255) / 256, n), dim3(256), 0, s, modes, w.ldm, action, c->nact, c->amodes, c->freedom);
   LAUNCHCHK();
-  launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, com, st->ld_actu, s);
+  launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, com, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats);
   LAUNCHCHK();
   return 0;
 }
@@ -810,6 +847,20 @@ static int target_psf_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, bool f
   float *TP = st->work + w.TPART + (size_t)b * w.nblk * 4;
   float *PEND = st->work + w.PEND + (size_t)b * (W * W + 4);
   DevState ds = dev_state(st);
+  const bool tfast = c->sys.hw == 8 && !c->force_valu_target && !c->force_generic_target && !from_buf &&
+                     c->ndm == 2 && c->sys.dms[0].type == AOMARL_DM_PZT && c->sys.dms[1].type == AOMARL_DM_TT &&
+                     (c->nlayers == 1 || c->nlayers == 3);
+  if (tfast) {
+    size_t smm = sizeof(float) * (4 * 16 * 65 + 4 * 2 * 256) + (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
+    if (c->nlayers == 1)
+      hipLaunchKernelGGL(k_target_rows_fast<1>, dim3(w.nblk, n), dim3(256), smm, s, c->sys, ds, b, TR, TP, w.nblk);
+    else
+      hipLaunchKernelGGL(k_target_rows_fast<3>, dim3(w.nblk, n), dim3(256), smm, s, c->sys, ds, b, TR, TP, w.nblk);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
+    LAUNCHCHK();
+    return 0;
+  }
   if (c->sys.hw == 8 && !c->force_valu_target) {
     size_t smm = sizeof(float) * (2 * 16 * 65 + 4 * 2 * 256) + (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
     if (from_buf)

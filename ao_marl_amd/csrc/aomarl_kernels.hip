@@ -4,6 +4,26 @@
 
 #define WAVE 64
 
+// 4 consecutive floats at a dword-aligned (not necessarily 16-byte aligned) address: one
+// global_load_dwordx4 (gfx950 supports unaligned vector access; the compiler emits it for this type)
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+__device__ __forceinline__ void add4(float acc[4], const float *p) {
+  const f4u t = *reinterpret_cast<const f4u *>(p);
+  acc[0] += t.v[0]; acc[1] += t.v[1]; acc[2] += t.v[2]; acc[3] += t.v[3];
+}
+// 4 consecutive logical pixels of a ring-buffered screen row starting at physical column px
+__device__ __forceinline__ void add4_ring(float acc[4], const float *row, int px, int dim) {
+  if (px + 3 < dim) {
+    add4(acc, row + px);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int xx = px + j; xx -= (xx >= dim) ? dim : 0;
+      acc[j] += row[xx];
+    }
+  }
+}
+
 // =============================================================================================
 // fp32 GEMM  C[M][N] = alpha * A[M][K] . B[N][K]^T + beta * C     (both operands K-contiguous)
 // 256 threads = 4 waves in 2x2, block tile 64x64, one v_mfma_f32_32x32x2_f32 accumulator/wave.
@@ -12,11 +32,15 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alpha,
                                                  const float *__restrict__ A, int lda,
                                                  const float *__restrict__ B, int ldb, float beta,
-                                                 float *__restrict__ C, int ldc) {
+                                                 float *__restrict__ C, int ldc, int kchunk,
+                                                 float *__restrict__ P) {
+  // blockIdx.z = K split: the block reduces k in [z*kchunk, min(K, (z+1)*kchunk)); with more than
+  // one split the raw partial tile goes to P[z][M][N] and k_gemm_reduce finishes (deterministic)
   __shared__ float As[64][17];
   __shared__ float Bs[64][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -24,27 +48,27 @@ __global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alph
   const int gm = m0 + lr, gn = n0 + lr;
   const float *pa = A + (long long)gm * lda;
   const float *pb = B + (long long)gn * ldb;
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  for (int k0 = kb; k0 < ke; k0 += 16) {
     float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
     const int gk = k0 + lc;
     if (gm < M) {
-      if (ALIGNED && gk + 3 < K) {
+      if (ALIGNED && gk + 3 < ke) {
         float4 t = *reinterpret_cast<const float4 *>(pa + gk);
         va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w;
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (gk + j < K) va[j] = pa[gk + j];
+          if (gk + j < ke) va[j] = pa[gk + j];
       }
     }
     if (gn < N) {
-      if (ALIGNED && gk + 3 < K) {
+      if (ALIGNED && gk + 3 < ke) {
         float4 t = *reinterpret_cast<const float4 *>(pb + gk);
         vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (gk + j < K) vb[j] = pb[gk + j];
+          if (gk + j < ke) vb[j] = pb[gk + j];
       }
     }
 #pragma unroll
@@ -62,30 +86,64 @@ __global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alph
     __syncthreads();
   }
   const int col = n0 + wn * 32 + (lane & 31);
+  const bool split = gridDim.z > 1;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (row < M && col < N) {
-      float *c = C + (long long)row * ldc + col;
-      float v = alpha * acc[r];
-      if (beta != 0.f) v += beta * (*c);
-      *c = v;
+      if (split) {
+        P[((long long)blockIdx.z * M + row) * N + col] = acc[r];
+      } else {
+        float *c = C + (long long)row * ldc + col;
+        float v = alpha * acc[r];
+        if (beta != 0.f) v += beta * (*c);
+        *c = v;
+      }
     }
   }
 }
 
+__global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float *__restrict__ P,
+                              float beta, float *__restrict__ C, int ldc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * N) return;
+  const int row = (int)(i / N), col = (int)(i - (long long)row * N);
+  float s = 0.f;
+  for (int z = 0; z < nsplit; z++) s += P[(long long)z * M * N + i];
+  float *c = C + (long long)row * ldc + col;
+  float v = alpha * s;
+  if (beta != 0.f) v += beta * (*c);
+  *c = v;
+}
+
+// ws / ws_floats: optional split-K workspace (NULL: never split)
 void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
-                    int ldb, float beta, float *C, int ldc, hipStream_t s) {
+                    int ldb, float beta, float *C, int ldc, hipStream_t s, float *ws = nullptr,
+                    size_t ws_floats = 0) {
   if (M <= 0 || N <= 0) return;
-  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  const int bx = (N + 63) / 64, by = (M + 63) / 64;
+  int nsplit = 1;
+  if (ws && bx * by < 384) {
+    nsplit = (512 + bx * by - 1) / (bx * by);
+    if (nsplit > 8) nsplit = 8;
+    while (nsplit > 1 && (K / nsplit < 128 || (size_t)nsplit * M * N > ws_floats)) nsplit--;
+  }
+  int kchunk = ((K + nsplit - 1) / nsplit + 15) & ~15;
+  nsplit = (K + kchunk - 1) / kchunk;
+  dim3 grid(bx, by, nsplit);
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
   if (al)
     hipLaunchKernelGGL(k_gemm_nt<true>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
-                       C, ldc);
+                       C, ldc, kchunk, ws);
   else
     hipLaunchKernelGGL(k_gemm_nt<false>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb,
-                       beta, C, ldc);
+                       beta, C, ldc, kchunk, ws);
+  if (nsplit > 1) {
+    const long long tot = (long long)M * N;
+    hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, M, N,
+                       nsplit, alpha, ws, beta, C, ldc);
+  }
 }
 
 // =============================================================================================
@@ -416,94 +474,16 @@ __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
   return v < 0.f ? 0.f : v;
 }
 
-template <bool FROM_BUF, bool NOISE, bool WRITE_CUBE>
-__global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int env_begin,
-                                                  int no_atmos, int no_dms, int do_cog) {
-  __shared__ float sAr[4][16][17];
-  __shared__ float sAi[4][16][17];
-  __shared__ float2 sTw[64];                     // (cos, sin)(2 pi m / 64)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wv;             // sub-aperture
-  const int e = env_begin + blockIdx.y;
-  if (threadIdx.x < 64) {
-    float sn, cs;
-    sincospif((float)threadIdx.x * (1.0f / 32.0f), &sn, &cs);
-    sTw[threadIdx.x] = make_float2(cs, sn);
-  }
-  __syncthreads();
-  if (i >= sys.nvalid) return;                   // whole wave exits together (no barrier below)
+// MFMA stages + binning + normalisation (+noise) + COG of one sub-aperture whose complex amplitude
+// tile is in sAr/sAi[wv]; shared by the generic and the fast spot kernels.
+template <bool NOISE, bool WRITE_CUBE>
+__device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &st, int e, int i,
+                                             int lane, int wv, const float (&Cc)[2][4],
+                                             const float (&Ss)[2][4], const float (&nS)[2][4],
+                                             float (*sAr)[16][17], float (*sAi)[16][17], int do_cog,
+                                             float flux_i) {
   const int q = lane >> 4, c = lane & 15;
-
-  // ---- twiddles: idx = 4q + s (pixel), freq = 16 b + c - 16
-  float Cc[2][4], Ss[2][4], nS[2][4];
-#pragma unroll
-  for (int b = 0; b < 2; b++)
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const float2 w = sTw[((4 * q + s) * (16 * b + c - 16)) & 63];
-      Cc[b][s] = w.x; Ss[b][s] = w.y; nS[b][s] = -w.y;
-    }
-
-  // ---- stage 0: phase -> complex amplitude tile in LDS (4 pixels per lane)
-  const int xy0 = sys.sub_xy[i];
-  const int gx0 = xy0 & 0xFFFF, gy0 = xy0 >> 16;
-  const int ty = lane >> 2, tx0 = (lane & 3) * 4;
-  const int gy = gy0 + ty;
-  float ph[4] = {0.f, 0.f, 0.f, 0.f};
-  if (FROM_BUF) {
-    const float *pb = st.wfs_phase + (long long)e * sys.n * sys.n + gy * sys.n + gx0 + tx0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) ph[j] = pb[j];
-  } else {
-    if (!no_atmos) {
-      for (int l = 0; l < sys.nlayers; l++) {
-        const DevLayer &L = sys.layers[l];
-        const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-        const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
-        int py = gy + L.woy + oy; py -= (py >= L.dim) ? L.dim : 0;
-        int px = gx0 + tx0 + L.wox + ox; px -= (px >= L.dim) ? L.dim : 0;
-        const float *row = base + py * L.dim;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          int xx = px + j; xx -= (xx >= L.dim) ? L.dim : 0;
-          ph[j] += row[xx];
-        }
-      }
-    }
-    if (!no_dms) {
-      for (int k = 0; k < sys.ndm; k++) {
-        const DevDm &D = sys.dms[k];
-        const float *slot = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
-        const int o = (gy + D.woy) * D.dim + gx0 + tx0 + D.wox;
-        if (D.type == AOMARL_DM_PZT) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) ph[j] += slot[o + j];
-        } else {
-          const float c0 = slot[0], c1 = slot[1];
-          const float2 *f = reinterpret_cast<const float2 *>(D.influ) + o;
-#pragma unroll
-          for (int j = 0; j < 4; j++) ph[j] += c0 * f[j].x + c1 * f[j].y;
-        }
-      }
-    }
-  }
-  {
-    const float *mk = sys.mpupil + gy * sys.n + gx0 + tx0;
-    const float *hx = sys.halfxy + ty * 16 + tx0;   // halfxy already divided by 2 pi
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float t = ph[j] * sys.wfs_inv_lambda - hx[j];  // revolutions
-      t -= rintf(t);
-      const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_cosf(t);   // v_sin/v_cos
-      float m = mk[j];
-      sAr[wv][ty][tx0 + j] = m * cs;
-      sAi[wv][ty][tx0 + j] = m * sn;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): LDS writes of this wave are done
-  __builtin_amdgcn_wave_barrier();
-
+  const bool owner = (c & 1) == 0;
   // ---- stage 1: T[y][kx] = sum_x a[y][x] E[x][kx]   (y = c on M, x = 4q+s on K)
   f32x4 Tr[2], Ti[2];
 #pragma unroll
@@ -519,8 +499,8 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
       Ti[b] = mfma16(ar, nS[b][s], Ti[b]);
     }
   }
-  // ---- stage 2: X[ky][kx] = sum_y E[ky][y] T[y][kx]; accumulator reg s of lane group q holds
-  //      y = 4q + s, which is exactly the K index the twiddle registers were built for.
+  // ---- stage 2: X[ky][kx] = sum_y E[ky][y] T[y][kx]; accumulator reg s of lane group q
+  //      holds y = 4q + s, exactly the K index the twiddle registers were built for.
   f32x4 Xr[2][2], Xi[2][2];
 #pragma unroll
   for (int bm = 0; bm < 2; bm++)
@@ -540,6 +520,7 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
   // ---- |X|^2 and 2x2 binning: reg r <-> ky = 16 bm + 4 q + r - 16, lane c <-> kx = 16 bn + c - 16
   //      LR pixel Y = 8 bm + 2 q + (r >> 1), X = 8 bn + (c >> 1)
   float v[2][2][2];
+  float tot = 0.f;
 #pragma unroll
   for (int bm = 0; bm < 2; bm++)
 #pragma unroll
@@ -551,20 +532,46 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
         float t = (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1);
         t += __shfl_xor(t, 1);
         v[bm][bn][h] = t;
+        tot += t;
       }
+  if (!NOISE && !WRITE_CUBE) {
+    // only the slopes are wanted and nothing depends on the normalised pixel values: the COG is
+    // invariant to the flux scale, so reduce (sum, sum x, sum y) of the raw image in ONE pass
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int bm = 0; bm < 2; bm++)
+#pragma unroll
+      for (int bn = 0; bn < 2; bn++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          sx += v[bm][bn][h] * (float)(8 * bn + (c >> 1));
+          sy += v[bm][bn][h] * (float)(8 * bm + 2 * q + h);
+        }
+    tot = owner ? tot : 0.f; sx = owner ? sx : 0.f; sy = owner ? sy : 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      tot += __shfl_xor(tot, o);
+      sx += __shfl_xor(sx, o);
+      sy += __shfl_xor(sy, o);
+    }
+    if (do_cog && lane == 0) {
+      float *sl = st.slopes + (long long)e * sys.nslope;
+      if (tot > 0.f) {
+        sl[i] = (sx / tot - sys.cog_offset) * sys.cog_scale;
+        sl[sys.nvalid + i] = (sy / tot - sys.cog_offset) * sys.cog_scale;
+      } else {
+        sl[i] = 0.f;
+        sl[sys.nvalid + i] = 0.f;
+      }
+    }
+    (void)flux_i;
+    return;
+  }
   // ---- total flux (each LR pixel is held by two lanes: count even lanes only)
-  const bool owner = (c & 1) == 0;
-  float tot = 0.f;
-#pragma unroll
-  for (int bm = 0; bm < 2; bm++)
-#pragma unroll
-    for (int bn = 0; bn < 2; bn++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) tot += v[bm][bn][h];
   tot = owner ? tot : 0.f;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
-  const float g = tot > 0.f ? sys.nphot * sys.flux[i] / tot : 0.f;
+  const float g = tot > 0.f ? sys.nphot * flux_i / tot : 0.f;
   float s0 = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
   for (int bm = 0; bm < 2; bm++)
@@ -606,6 +613,246 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
         sl[sys.nvalid + i] = 0.f;
       }
     }
+  }
+}
+
+// phase (sum of all sources) and pupil mask of the 4 pixels this lane owns in sub-aperture i
+template <bool FROM_BUF>
+__device__ __forceinline__ void spot_load(const DevSys &sys, const DevState &st, int e, int i,
+                                          int lane, int no_atmos, int no_dms, float ph[4],
+                                          float mk[4]) {
+  const int xy0 = sys.sub_xy[i];
+  const int gx0 = xy0 & 0xFFFF, gy0 = xy0 >> 16;
+  const int ty = lane >> 2, tx0 = (lane & 3) * 4;
+  const int gy = gy0 + ty;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { ph[j] = 0.f; mk[j] = 0.f; }
+  if (FROM_BUF) {
+    add4(ph, st.wfs_phase + (long long)e * sys.n * sys.n + gy * sys.n + gx0 + tx0);
+  } else {
+    if (!no_atmos) {
+      for (int l = 0; l < sys.nlayers; l++) {
+        const DevLayer &L = sys.layers[l];
+        const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+        const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
+        int py = gy + L.woy + oy; py -= (py >= L.dim) ? L.dim : 0;
+        int px = gx0 + tx0 + L.wox + ox; px -= (px >= L.dim) ? L.dim : 0;
+        add4_ring(ph, base + py * L.dim, px, L.dim);
+      }
+    }
+    if (!no_dms) {
+      for (int k = 0; k < sys.ndm; k++) {
+        const DevDm &D = sys.dms[k];
+        const float *slot = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+        const int o = (gy + D.woy) * D.dim + gx0 + tx0 + D.wox;
+        if (D.type == AOMARL_DM_PZT) {
+          add4(ph, slot + o);
+        } else {
+          const float c0 = slot[0], c1 = slot[1];
+          float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          add4(f, D.influ + 2 * o);
+          add4(f + 4, D.influ + 2 * o + 4);
+#pragma unroll
+          for (int j = 0; j < 4; j++) ph[j] += c0 * f[2 * j] + c1 * f[2 * j + 1];
+        }
+      }
+    }
+  }
+  add4(mk, sys.mpupil + gy * sys.n + gx0 + tx0);
+}
+
+// Persistent waves: block = 4 waves, wave w of block bx walks sub-apertures
+// (bx*4 + w) + k * gridDim.x*4 of environment blockIdx.y; the phase of the NEXT sub-aperture is
+// fetched into registers while the MFMAs of the current one run (hides the load latency chain).
+template <bool FROM_BUF, bool NOISE, bool WRITE_CUBE>
+__global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int env_begin,
+                                                  int no_atmos, int no_dms, int do_cog) {
+  __shared__ float sAr[4][16][17];
+  __shared__ float sAi[4][16][17];
+  __shared__ float2 sTw[64];                     // (cos, sin)(2 pi m / 64)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e = env_begin + blockIdx.y;
+  if (threadIdx.x < 64) {
+    float sn, cs;
+    sincospif((float)threadIdx.x * (1.0f / 32.0f), &sn, &cs);
+    sTw[threadIdx.x] = make_float2(cs, sn);
+  }
+  __syncthreads();                               // the only block-wide barrier
+  const int q = lane >> 4, c = lane & 15;
+  const int stride = gridDim.x * 4;
+  int i = blockIdx.x * 4 + wv;
+  if (i >= sys.nvalid) return;
+
+  // ---- twiddles: idx = 4q + s (pixel), freq = 16 b + c - 16
+  float Cc[2][4], Ss[2][4], nS[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const float2 w = sTw[((4 * q + s) * (16 * b + c - 16)) & 63];
+      Cc[b][s] = w.x; Ss[b][s] = w.y; nS[b][s] = -w.y;
+    }
+  const int ty = lane >> 2, tx0 = (lane & 3) * 4;
+  float hx[4] = {0.f, 0.f, 0.f, 0.f};
+  add4(hx, sys.halfxy + ty * 16 + tx0);          // halfxy already divided by 2 pi
+  const bool owner = (c & 1) == 0;
+
+  float ph[4], mk[4];
+  spot_load<FROM_BUF>(sys, st, e, i, lane, no_atmos, no_dms, ph, mk);
+  for (; i < sys.nvalid; i += stride) {
+    // ---- stage 0: complex amplitude tile -> LDS (4 pixels per lane)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float t = ph[j] * sys.wfs_inv_lambda - hx[j];  // revolutions
+      t -= rintf(t);
+      const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_cosf(t);   // v_sin/v_cos
+      sAr[wv][ty][tx0 + j] = mk[j] * cs;
+      sAi[wv][ty][tx0 + j] = mk[j] * sn;
+    }
+    // ---- prefetch the next sub-aperture of this wave
+    const int inext = i + stride;
+    if (inext < sys.nvalid) spot_load<FROM_BUF>(sys, st, e, inext, lane, no_atmos, no_dms, ph, mk);
+    __builtin_amdgcn_wave_barrier();
+
+    spot_compute<NOISE, WRITE_CUBE>(sys, st, e, i, lane, wv, Cc, Ss, nS, sAr, sAi, do_cog, sys.flux[i]);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast variant for the production layout: NL atmosphere layers, DMs = [stack array, tip-tilt],
+// every offset an integer, atmosphere and DMs both seen.  All loads of a tile are independent
+// (raw values land in separate registers, the sum is formed at first use), so one wait covers the
+// whole prefetch and it overlaps the MFMA block of the previous sub-aperture.  Per-environment
+// constants (ring origins, TT commands) are read once per wave.
+// ---------------------------------------------------------------------------------------------
+template <int NL>
+struct SpotEnv {
+  const float *lay[NL];
+  int px0[NL], py0[NL], dim[NL];
+  const float *pzt;
+  int pzt_dim, pzt_ox, pzt_oy;
+  const float *tt;
+  int tt_dim, tt_ox, tt_oy;
+  float c0, c1;
+};
+
+template <int NL>
+struct SpotRaw {
+  float L[NL][4];
+  float P[4], T[8], M[4];
+  float F;   // fluxPerSub of the sub-aperture
+};
+
+template <int NL>
+__device__ __forceinline__ void spot_fetch(const DevSys &sys, const SpotEnv<NL> &E, int xy0, int ty,
+                                           int tx0, int i, SpotRaw<NL> &r) {
+  const int gx = (xy0 & 0xFFFF) + tx0, gy = (xy0 >> 16) + ty;
+  r.F = sys.flux[i];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    int py = gy + E.py0[l]; py -= (py >= E.dim[l]) ? E.dim[l] : 0;
+    int px = gx + E.px0[l]; px -= (px >= E.dim[l]) ? E.dim[l] : 0;
+    const float *row = E.lay[l] + py * E.dim[l];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int xx = px + j; xx -= (xx >= E.dim[l]) ? E.dim[l] : 0;
+      r.L[l][j] = row[xx];
+    }
+  }
+  {
+    const f4u t = *reinterpret_cast<const f4u *>(E.pzt + (gy + E.pzt_oy) * E.pzt_dim + gx + E.pzt_ox);
+#pragma unroll
+    for (int j = 0; j < 4; j++) r.P[j] = t.v[j];
+  }
+  {
+    const float *f = E.tt + 2 * ((gy + E.tt_oy) * E.tt_dim + gx + E.tt_ox);
+    const f4u t0 = *reinterpret_cast<const f4u *>(f), t1 = *reinterpret_cast<const f4u *>(f + 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { r.T[j] = t0.v[j]; r.T[4 + j] = t1.v[j]; }
+  }
+  {
+    const f4u t = *reinterpret_cast<const f4u *>(sys.mpupil + gy * sys.n + gx);
+#pragma unroll
+    for (int j = 0; j < 4; j++) r.M[j] = t.v[j];
+  }
+}
+
+template <int NL, bool NOISE, bool WRITE_CUBE>
+__global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, int env_begin,
+                                                       int do_cog) {
+  __shared__ float sAr[4][16][17];
+  __shared__ float sAi[4][16][17];
+  __shared__ float2 sTw[64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e = env_begin + blockIdx.y;
+  if (threadIdx.x < 64) {
+    float sn, cs;
+    sincospif((float)threadIdx.x * (1.0f / 32.0f), &sn, &cs);
+    sTw[threadIdx.x] = make_float2(cs, sn);
+  }
+  __syncthreads();
+  const int q = lane >> 4, c = lane & 15;
+  const int stride = gridDim.x * 4;
+  int i = blockIdx.x * 4 + wv;
+  if (i >= sys.nvalid) return;
+  float Cc[2][4], Ss[2][4], nS[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const float2 w = sTw[((4 * q + s) * (16 * b + c - 16)) & 63];
+      Cc[b][s] = w.x; Ss[b][s] = w.y; nS[b][s] = -w.y;
+    }
+  const int ty = lane >> 2, tx0 = (lane & 3) * 4;
+  float hx[4] = {0.f, 0.f, 0.f, 0.f};
+  add4(hx, sys.halfxy + ty * 16 + tx0);
+  // ---- per-environment constants
+  SpotEnv<NL> E;
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const DevLayer &L = sys.layers[l];
+    E.lay[l] = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+    E.dim[l] = L.dim;
+    int px = L.wox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
+    int py = L.woy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
+    E.px0[l] = px; E.py0[l] = py;
+  }
+  {
+    const DevDm &D0 = sys.dms[0], &D1 = sys.dms[1];
+    E.pzt = st.dm_shape + (long long)e * sys.shape_stride + D0.shape_off;
+    E.pzt_dim = D0.dim; E.pzt_ox = D0.wox; E.pzt_oy = D0.woy;
+    const float *slot = st.dm_shape + (long long)e * sys.shape_stride + D1.shape_off;
+    E.c0 = slot[0]; E.c1 = slot[1];
+    E.tt = D1.influ; E.tt_dim = D1.dim; E.tt_ox = D1.wox; E.tt_oy = D1.woy;
+  }
+  SpotRaw<NL> raw;
+  int xy_cur = sys.sub_xy[i];
+  int xy_next = (i + stride < sys.nvalid) ? sys.sub_xy[i + stride] : 0;
+  spot_fetch<NL>(sys, E, xy_cur, ty, tx0, i, raw);
+  for (; i < sys.nvalid; i += stride) {
+    const float flux_i = raw.F;
+    // ---- stage 0: sum the sources, complex amplitude tile -> LDS
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float ph = raw.P[j] + (E.c0 * raw.T[2 * j] + E.c1 * raw.T[2 * j + 1]);
+#pragma unroll
+      for (int l = 0; l < NL; l++) ph += raw.L[l][j];
+      float t = ph * sys.wfs_inv_lambda - hx[j];
+      t -= rintf(t);
+      const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_cosf(t);
+      sAr[wv][ty][tx0 + j] = raw.M[j] * cs;
+      sAi[wv][ty][tx0 + j] = raw.M[j] * sn;
+    }
+    // ---- prefetch: data of the next sub-aperture, tile origin of the one after
+    const int inext = i + stride;
+    if (inext < sys.nvalid) {
+      spot_fetch<NL>(sys, E, xy_next, ty, tx0, inext, raw);
+      xy_next = (inext + stride < sys.nvalid) ? sys.sub_xy[inext + stride] : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    spot_compute<NOISE, WRITE_CUBE>(sys, st, e, i, lane, wv, Cc, Ss, nS, sAr, sAi, do_cog, flux_i);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -916,12 +1163,10 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
       float mk[4] = {0.f, 0.f, 0.f, 0.f};
       const int xb = x0 + fx0;
       if (y < pd) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) mk[j] = (xb + j < pd) ? sys.spupil[y * pd + xb + j] : 0.f;
+        // pd % 4 == 0 (checked at create): a group of 4 columns is entirely inside or outside
+        if (xb < pd) add4(mk, sys.spupil + y * pd + xb);
         if (FROM_BUF) {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (xb + j < pd) ph[j] = st.tar_phase[(long long)e * pd * pd + y * pd + xb + j];
+          if (xb < pd) add4(ph, st.tar_phase + (long long)e * pd * pd + y * pd + xb);
         } else if (xb < pd) {
           for (int l = 0; l < sys.nlayers; l++) {
             const DevLayer &L = sys.layers[l];
@@ -929,25 +1174,21 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
             const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
             int py = y + L.toy + oy; py -= (py >= L.dim) ? L.dim : 0;
             int px = xb + L.tox + ox; px -= (px >= L.dim) ? L.dim : 0;
-            const float *row = base + py * L.dim;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              int xx = px + j; xx -= (xx >= L.dim) ? L.dim : 0;
-              ph[j] += row[xx];        // columns past pd stay inside the screen (window + 4 < dim)
-            }
+            add4_ring(ph, base + py * L.dim, px, L.dim);
           }
           for (int k = 0; k < sys.ndm; k++) {
             const DevDm &D = sys.dms[k];
             const float *slot = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
             const int o = (y + D.toy) * D.dim + xb + D.tox;
             if (D.type == AOMARL_DM_PZT) {
-#pragma unroll
-              for (int j = 0; j < 4; j++) ph[j] += slot[o + j];
+              add4(ph, slot + o);
             } else {
               const float c0 = slot[0], c1 = slot[1];
-              const float2 *f = reinterpret_cast<const float2 *>(D.influ) + o;
+              float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              add4(f, D.influ + 2 * o);
+              add4(f + 4, D.influ + 2 * o + 4);
 #pragma unroll
-              for (int j = 0; j < 4; j++) ph[j] += c0 * f[j].x + c1 * f[j].y;
+              for (int j = 0; j < 4; j++) ph[j] += c0 * f[2 * j] + c1 * f[2 * j + 1];
             }
           }
         }
@@ -981,6 +1222,166 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
   }
   __syncthreads();
   // cross-wave reduction of the 4 partial tiles; acc reg r of lane (q, c): y = 4q + r, kx = c
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    red[(wv * 2 + 0) * 256 + (4 * q + r) * 16 + c] = Rr[r];
+    red[(wv * 2 + 1) * 256 + (4 * q + r) * 16 + c] = Ri[r];
+  }
+  __syncthreads();
+  {
+    const int yy = tid >> 4, kx = tid & 15;
+    if (y0 + yy < pd) {
+      float vr = 0.f, vi = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; w4++) { vr += red[(w4 * 2) * 256 + tid]; vi += red[(w4 * 2 + 1) * 256 + tid]; }
+      float *o = TR + (((long long)blockIdx.y * pd + (y0 + yy)) * 16 + kx) * 2;
+      o[0] = vr; o[1] = vi;
+    }
+  }
+  __syncthreads();
+  red[tid] = sd; red[256 + tid] = sd2; red[512 + tid] = sm;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+      red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; red[512 + tid] += red[512 + tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float *pp = TPART + ((long long)blockIdx.y * nblk + blockIdx.x) * 4;
+    pp[0] = red[0]; pp[1] = red[256]; pp[2] = red[512]; pp[3] = 0.f;
+  }
+}
+
+// Fast variant (production layout: NL layers, DMs = [stack array, tip-tilt], integer offsets):
+// per-environment constants hoisted, all loads of a chunk independent and issued one chunk ahead
+// of their use (software pipeline), double-buffered LDS tile -> one barrier per chunk.
+template <int NL>
+__global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState st, int env_begin,
+                                                          float *__restrict__ TR,
+                                                          float *__restrict__ TPART, int nblk) {
+  extern __shared__ float smem[];
+  const int pd = sys.pupdiam, np = sys.npsf;
+  float *sar = smem;                       // [2][16][65]
+  float *sai = sar + 2 * 16 * 65;
+  float *red = sai + 2 * 16 * 65;          // [4 waves][2][256]
+  float2 *stw = reinterpret_cast<float2 *>(red + 4 * 2 * 256);
+  const bool tw_lds = np <= 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, c = lane & 15;
+  const int e = env_begin + blockIdx.y;
+  const int y0 = blockIdx.x * 16;
+  const float2 *gtw = reinterpret_cast<const float2 *>(sys.psf_tw);
+  if (tw_lds)
+    for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
+  const float2 *tw = tw_lds ? stw : gtw;
+  // ---- per-environment constants
+  const float *lay[NL];
+  int lpx[NL], lpy[NL], ldim[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const DevLayer &L = sys.layers[l];
+    lay[l] = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+    ldim[l] = L.dim;
+    int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
+    int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
+    lpx[l] = px; lpy[l] = py;
+  }
+  const DevDm &D0 = sys.dms[0], &D1 = sys.dms[1];
+  const float *pzt = st.dm_shape + (long long)e * sys.shape_stride + D0.shape_off;
+  const float *ttslot = st.dm_shape + (long long)e * sys.shape_stride + D1.shape_off;
+  const float c0 = ttslot[0], c1 = ttslot[1];
+  const int fy = tid >> 4, fx0 = (tid & 15) * 4;
+  const int y = y0 + fy;
+  const bool row_ok = y < pd;
+  // pivot of the variance sums: phase at the grid centre
+  float pivot;
+  {
+    const int cx = pd / 2, cy = pd / 2;
+    float v = pzt[(cy + D0.toy) * D0.dim + cx + D0.tox];
+    const float2 f = reinterpret_cast<const float2 *>(D1.influ)[(cy + D1.toy) * D1.dim + cx + D1.tox];
+    v += c0 * f.x + c1 * f.y;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      int py = cy + lpy[l]; py -= (py >= ldim[l]) ? ldim[l] : 0;
+      int px = cx + lpx[l]; px -= (px >= ldim[l]) ? ldim[l] : 0;
+      v += lay[l][py * ldim[l] + px];
+    }
+    pivot = v;
+  }
+  // row pointers of this thread
+  const float *lrow[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    int py = (row_ok ? y : 0) + lpy[l]; py -= (py >= ldim[l]) ? ldim[l] : 0;
+    lrow[l] = lay[l] + py * ldim[l];
+  }
+  const float *prow = pzt + ((row_ok ? y : 0) + D0.toy) * D0.dim + D0.tox;
+  const float *trow = D1.influ + 2 * (((row_ok ? y : 0) + D1.toy) * D1.dim + D1.tox);
+  const float *mrow = sys.spupil + (row_ok ? y : 0) * pd;
+
+  float rL[NL][4], rP[4], rT[8], rM[4];
+  auto fetch = [&](int x0) {
+    const int xb = x0 + fx0;
+    const bool ok = row_ok && xb < pd;        // pd % 4 == 0: the 4 columns are in or out together
+    const int xs = ok ? xb : 0;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      int px = xs + lpx[l]; px -= (px >= ldim[l]) ? ldim[l] : 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int xx = px + j; xx -= (xx >= ldim[l]) ? ldim[l] : 0;
+        rL[l][j] = lrow[l][xx];
+      }
+    }
+    const f4u tp = *reinterpret_cast<const f4u *>(prow + xs);
+    const f4u t0 = *reinterpret_cast<const f4u *>(trow + 2 * xs);
+    const f4u t1 = *reinterpret_cast<const f4u *>(trow + 2 * xs + 4);
+    const f4u tm = *reinterpret_cast<const f4u *>(mrow + xs);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      rP[j] = tp.v[j]; rT[j] = t0.v[j]; rT[4 + j] = t1.v[j];
+      rM[j] = ok ? tm.v[j] : 0.f;
+    }
+  };
+
+  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  float sd = 0.f, sd2 = 0.f, sm = 0.f;
+  const int kxf = c - 8;
+  fetch(0);
+  int buf = 0;
+  for (int x0 = 0; x0 < pd; x0 += 64, buf ^= 1) {
+    float *bar = sar + buf * 16 * 65, *bai = sai + buf * 16 * 65;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float ph = rP[j] + (c0 * rT[2 * j] + c1 * rT[2 * j + 1]);
+#pragma unroll
+      for (int l = 0; l < NL; l++) ph += rL[l][j];
+      float ar = 0.f, ai = 0.f;
+      if (rM[j] != 0.f) {
+        float t = ph * sys.tar_inv_lambda;
+        t -= rintf(t);
+        ar = rM[j] * __builtin_amdgcn_cosf(t);
+        ai = rM[j] * __builtin_amdgcn_sinf(t);
+        const float d = ph - pivot;
+        sd += d; sd2 += d * d; sm += 1.f;
+      }
+      bar[fy * 65 + fx0 + j] = ar;
+      bai[fy * 65 + fx0 + j] = ai;
+    }
+    if (x0 + 64 < pd) fetch(x0 + 64);       // next chunk's loads fly during the barrier + MFMAs
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int xl = 16 * wv + 4 * s + q;
+      const float ar = bar[c * 65 + xl], ai = bai[c * 65 + xl];
+      const float2 w = tw[(kxf * (x0 + xl)) & (np - 1)];
+      Rr = mfma16(ar, w.x, Rr);
+      Ri = mfma16(ai, w.x, Ri);
+      Rr = mfma16(ai, w.y, Rr);
+      Ri = mfma16(ar, -w.y, Ri);
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     red[(wv * 2 + 0) * 256 + (4 * q + r) * 16 + c] = Rr[r];

@@ -308,10 +308,13 @@ class HipSim(object):
         la.check(self.lib.aomarl_reset_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))
 
     def volts2modes(self, vec):
-        vec = vec.contiguous()
+        """[rows, nactu] (any row stride, e.g. the padded views `com` / `err`) -> [rows, nmodes]."""
+        if vec.stride(1) != 1:
+            vec = vec.contiguous()
         out = torch.empty(vec.shape[0], self.nmodes, dtype=torch.float32, device=self.device)
-        la.check(self.lib.aomarl_volts2modes(self.ctx, vec.shape[0], vec.data_ptr(),
-                                             out.data_ptr(), self._stream()))
+        la.check(self.lib.aomarl_volts2modes(self.ctx, C.byref(self.st), vec.shape[0],
+                                             vec.data_ptr(), vec.stride(0), out.data_ptr(),
+                                             self._stream()))
         return out
 
     def next_part_one(self, write_bincube=False, env_begin=0, env_count=None):

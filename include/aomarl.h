@@ -204,10 +204,11 @@ int aomarl_comp_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env
                        void *stream);
 int aomarl_reset_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                         void *stream);
-/* modes[env][nmodes] = v2m . vec[env][nactu]  (AoEnv.transform_state_to_zernike,
- * ao_env.py:482-505); vec_dev / modes_dev device memory, row stride = nactu / nmodes */
-int aomarl_volts2modes(aomarl_ctx *ctx, int nrows, const float *vec_dev, float *modes_dev,
-                       void *stream);
+/* modes[row][nmodes] = v2m . vec[row][0..nactu)  (AoEnv.transform_state_to_zernike,
+ * ao_env.py:482-505); vec_dev row stride ldvec >= nactu, modes_dev row stride nmodes; st may be
+ * NULL (then no split-K workspace is used) */
+int aomarl_volts2modes(aomarl_ctx *ctx, aomarl_state *st, int nrows, const float *vec_dev,
+                       int ldvec, float *modes_dev, void *stream);
 
 /* composites: one call per half frame, same order as the reference
  * next_part_one: move_atmos, target trace(+PSF), WFS trace+image+COG, do_control

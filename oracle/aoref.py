@@ -128,6 +128,9 @@ class OracleSim(object):
         for sh in self.dm_shapes:
             sh[:] = 0
         self.reset_strehl()
+        # the science path sees the fresh atmosphere (a comp_strehl before the first
+        # next_part_one is then well defined; the product's reset does the same)
+        self.raytrace_target()
 
     def reset_strehl(self):
         hw = self.s.strehl_halfwin

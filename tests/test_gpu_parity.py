@@ -122,8 +122,12 @@ def test_dm_shape_matches_oracle(setup, generic):
             assert np.abs(a - o.dm_shapes[k]).max() < 2e-6 * max(1.0, np.abs(o.dm_shapes[k]).max())
 
 
-def test_raytrace_and_spot_image_match_oracle(setup):
+@pytest.mark.parametrize("generic", [0, 1])
+def test_raytrace_and_spot_image_match_oracle(setup, generic):
+    """Unfused API (raytrace -> buffer -> image), fused kernels (software-pipelined fast variant
+    and the generic one), standalone COG."""
     _, s, _, sim, oracles = setup
+    sim.set_option("force_generic_spot", generic)
     _push_oracle_state(sim, oracles)
     rng = np.random.default_rng(4)
     volts = rng.normal(0, 0.5, size=(len(oracles), s.nactu)).astype(np.float32)
@@ -141,6 +145,10 @@ def test_raytrace_and_spot_image_match_oracle(setup):
     sl_fused = sim.slopes.cpu().numpy().copy()
     sim.do_centroids()
     sl_cog = sim.slopes.cpu().numpy().copy()
+    # slopes-only path (no bincube): single-pass reduction of the raw image
+    sim.comp_image(from_phase_buffer=False, noise=False, write_bincube=False, cog=True)
+    sl_only = sim.slopes.cpu().numpy().copy()
+    sim.set_option("force_generic_spot", 0)
     for e, o in enumerate(oracles):
         o.comp_shapes(volts[e])
         o.raytrace_wfs(atm=True, dms=False, reset=True)
@@ -154,7 +162,7 @@ def test_raytrace_and_spot_image_match_oracle(setup):
         # "bit-exact centroid indices": brightest pixel of every spot
         assert np.array_equal(cube_fused[e].argmax(axis=1), o.bincube.argmax(axis=1))
         assert np.allclose(cube_fused[e].sum(axis=1), s.nphot * s.flux, rtol=1e-5)
-        for sl in (sl_buf, sl_fused, sl_cog):
+        for sl in (sl_buf, sl_fused, sl_cog, sl_only):
             assert np.abs(sl[e] - o.slopes).max() < 1e-4   # arcsec (north-star tolerance)
         assert np.abs(sl_fused[e] - o.slopes).max() < 2e-5
 
@@ -209,11 +217,12 @@ def test_rl_control_matches_numpy(setup):
     sim.set_modal(cal.volts2modes, cal.modes2volts)
 
 
-@pytest.mark.parametrize("valu", [0, 1])
+@pytest.mark.parametrize("valu", [0, 1, 2])
 def test_target_psf_and_strehl_match_oracle(setup, valu):
-    """Both PSF-row kernels (fp32 MFMA and the VALU fallback)."""
+    """All three PSF-row kernels: software-pipelined MFMA (0), VALU fallback (1), generic MFMA (2)."""
     _, s, _, sim, oracles = setup
-    sim.set_option("force_valu_target", valu)
+    sim.set_option("force_valu_target", 1 if valu == 1 else 0)
+    sim.set_option("force_generic_target", 1 if valu == 2 else 0)
     _push_oracle_state(sim, oracles)
     rng = np.random.default_rng(7)
     volts = rng.normal(0, 0.3, size=(len(oracles), s.nactu)).astype(np.float32)
@@ -237,6 +246,7 @@ def test_target_psf_and_strehl_match_oracle(setup, valu):
         assert abs(st[e, 2] - want[2]) < 1e-4 * want[2] + 1e-9
         assert abs(st[e, 3] - want[3]) < 1e-4 * want[3] + 1e-9
     sim.set_option("force_valu_target", 0)
+    sim.set_option("force_generic_target", 0)
 
 
 def test_closed_loop_trace_matches_oracle(setup):
@@ -246,6 +256,9 @@ def test_closed_loop_trace_matches_oracle(setup):
     for o, sd in zip(oracles, SEEDS):
         o.reset(sd)
     _push_oracle_state(sim, oracles)   # remove the reset's accumulated round-off
+    sim.target_psf()
+    for o in oracles:
+        o.raytrace_target()
     worst = 0.0
     for it in range(40):
         sim.next_part_two(None)
