@@ -49,7 +49,7 @@ struct aomarl_ctx {
   float gain = 0.f, delay = 0.f;
   bool spot_fast = false;
   bool force_generic_dm = false, force_valu_target = false;
-  int spot_blocks_per_env = 0;
+  int spot_blocks_per_env = 0, spot_lds_pad = 0;
   bool force_generic_spot = false, force_generic_target = false;
   // controller matrices
   float *cmat = nullptr;           // [nactu][ld_s]
@@ -148,10 +148,19 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
       if (!(seen[0] && seen[1] && seen[2] && seen[3])) c->spot_fast = false;
     }
   }
+  if (c->spot_fast) {
+    // the kernel folds the half-pixel ramp into half-integer DFT frequencies: it must be the
+    // reference's halfxy = pi (x + y) / Nfft (geom_init.py:689-692)
+    for (int k = 0; k < pd2 && c->spot_fast; k++) {
+      double want = M_PI * (double)((k % d->pdiam) + (k / d->pdiam)) / (double)d->nfft;
+      if (fabs((double)d->halfxy[k] - want) > 2e-6) c->spot_fast = false;
+    }
+  }
   if (!c->spot_fast) {
     aomarl_destroy(c);
-    return fail("unsupported WFS sampling (pdiam=%d nfft=%d nrebin=%d npix=%d): the spot kernel "
-                "is specialised for 16/64/2/16", d->pdiam, d->nfft, d->nrebin, d->npix);
+    return fail("unsupported WFS sampling (pdiam=%d nfft=%d nrebin=%d npix=%d, binmap, halfxy): the "
+                "spot kernel is specialised for 16/64/2/16 with the standard half-pixel ramp",
+                d->pdiam, d->nfft, d->nrebin, d->npix);
   }
   // layers
   c->nlayers = s.nlayers = d->nlayers;
@@ -657,6 +666,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
+  if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
   if (!strcmp(name, "force_generic_spot")) { c->force_generic_spot = value != 0; return 0; }
   if (!strcmp(name, "force_generic_target")) { c->force_generic_target = value != 0; return 0; }
   return fail("set_option: unknown option %s", name);
@@ -713,7 +723,7 @@ int aomarl_comp_image(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, 
   if (c->spot_blocks_per_env > 0) gx = std::min(c->spot_blocks_per_env, (c->sys.nvalid + 3) / 4);
   dim3 grid(gx, n), blk(256);
 #define SPOT(FB, NZ, WC) hipLaunchKernelGGL((k_wfs_spot<FB, NZ, WC>), grid, blk, 0, s, c->sys, ds, b, na, nd, cog)
-#define FAST(NL, NZ, WC) hipLaunchKernelGGL((k_wfs_spot_fast<NL, NZ, WC>), grid, blk, 0, s, c->sys, ds, b, cog)
+#define FAST(NL, NZ, WC) hipLaunchKernelGGL((k_wfs_spot_fast<NL, NZ, WC>), grid, blk, (size_t)c->spot_lds_pad, s, c->sys, ds, b, cog)
   const bool fast_ok = !from_buf && !na && !nd && !c->force_generic_spot && c->ndm == 2 &&
                        c->sys.dms[0].type == AOMARL_DM_PZT && c->sys.dms[1].type == AOMARL_DM_TT &&
                        (c->nlayers == 1 || c->nlayers == 3);

@@ -4,6 +4,25 @@
 
 #define WAVE 64
 
+// ---- cross-lane helpers on the VALU (DPP) instead of the LDS crossbar (ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// v + v[lane ^ 1]
+__device__ __forceinline__ float add_xor1(float v) { return v + dpp_f<0xB1>(v); }   // quad_perm [1,0,3,2]
+// sum over the 64 lanes, result uniform (returned in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x124>(v);     // row_ror:4
+  v += dpp_f<0x128>(v);     // row_ror:8   -> every lane holds its 16-lane row sum
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+}
+
 // 4 consecutive floats at a dword-aligned (not necessarily 16-byte aligned) address: one
 // global_load_dwordx4 (gfx950 supports unaligned vector access; the compiler emits it for this type)
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
@@ -475,90 +494,96 @@ __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
 }
 
 // MFMA stages + binning + normalisation (+noise) + COG of one sub-aperture whose complex amplitude
-// tile is in sAr/sAi[wv]; shared by the generic and the fast spot kernels.
+// tile b = mask * exp(i phi 2pi/lambda) is in sAr/sAi[wv]; shared by the generic and fast kernels.
+//
+// The 32 kept frequencies [-16, 15] of the 64-point transform of  a = b * exp(-i pi (x+y)/64)
+// (the reference's half-pixel ramp `halfxy`, geom_init.py:689-701) are the HALF-INTEGER
+// frequencies kappa = +-(k + 1/2), k = 0..15, of b itself:  kx = k  <->  +(k+1/2),
+// kx = -(k+1)  <->  -(k+1/2).  The +- pairs share cos and differ in the sign of sin, so with
+//   C[x][k] = cos(2 pi (2k+1) x / 128),  S[x][k] = sin(2 pi (2k+1) x / 128)      (16 x 16, real)
+// stage 1 needs the 4 real products  b_r C, b_i C, b_r S, b_i S  (16 MFMAs) and gives both
+// T+ = (PCr + PSi, PCi - PSr) and T- = (PCr - PSi, PCi + PSr); stage 2 does the same along y for
+// T+ and T- (32 MFMAs): 48 v_mfma_f32_16x16x4_f32 instead of 96 for the plain complex products.
+// Accumulator layout of stage 1 (row y = 4q + reg, col k = c) is again exactly the B-operand
+// K-order stage 2 wants, and the twiddle registers serve as B operand (stage 1) and A operand
+// (stage 2) alike, so nothing moves between the stages.
 template <bool NOISE, bool WRITE_CUBE>
 __device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &st, int e, int i,
-                                             int lane, int wv, const float (&Cc)[2][4],
-                                             const float (&Ss)[2][4], const float (&nS)[2][4],
+                                             int lane, int wv, const float (&Cc)[4],
+                                             const float (&Ss)[4],
                                              float (*sAr)[16][17], float (*sAi)[16][17], int do_cog,
                                              float flux_i) {
   const int q = lane >> 4, c = lane & 15;
   const bool owner = (c & 1) == 0;
-  // ---- stage 1: T[y][kx] = sum_x a[y][x] E[x][kx]   (y = c on M, x = 4q+s on K)
-  f32x4 Tr[2], Ti[2];
-#pragma unroll
-  for (int b = 0; b < 2; b++) { Tr[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; Ti[b] = Tr[b]; }
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- stage 1 (y = c on M, x = 4q + s on K, k = c on N)
+  f32x4 PCr = z4, PCi = z4, PSr = z4, PSi = z4;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    const float ar = sAr[wv][c][4 * q + s], ai = sAi[wv][c][4 * q + s];
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      Tr[b] = mfma16(ar, Cc[b][s], Tr[b]);
-      Ti[b] = mfma16(ai, Cc[b][s], Ti[b]);
-      Tr[b] = mfma16(ai, Ss[b][s], Tr[b]);
-      Ti[b] = mfma16(ar, nS[b][s], Ti[b]);
-    }
+    const float br = sAr[wv][c][4 * q + s], bi = sAi[wv][c][4 * q + s];
+    PCr = mfma16(br, Cc[s], PCr);
+    PCi = mfma16(bi, Cc[s], PCi);
+    PSr = mfma16(br, Ss[s], PSr);
+    PSi = mfma16(bi, Ss[s], PSi);
   }
-  // ---- stage 2: X[ky][kx] = sum_y E[ky][y] T[y][kx]; accumulator reg s of lane group q
-  //      holds y = 4q + s, exactly the K index the twiddle registers were built for.
-  f32x4 Xr[2][2], Xi[2][2];
+  f32x4 Tr[2], Ti[2];                 // [0]: kx = +(k+1/2)   [1]: kx = -(k+1/2)
+  Tr[0] = PCr + PSi; Ti[0] = PCi - PSr;
+  Tr[1] = PCr - PSi; Ti[1] = PCi + PSr;
+  // ---- stage 2 (ky' = c on M, y = 4q + s on K = accumulator reg s, kx' on N)
+  f32x4 Xr[2][2], Xi[2][2];           // [sy][sx], 0: +, 1: -
 #pragma unroll
-  for (int bm = 0; bm < 2; bm++)
+  for (int m = 0; m < 2; m++) {
+    f32x4 QCr = z4, QCi = z4, QSr = z4, QSi = z4;
 #pragma unroll
-    for (int bn = 0; bn < 2; bn++) { Xr[bm][bn] = (f32x4){0.f, 0.f, 0.f, 0.f}; Xi[bm][bn] = Xr[bm][bn]; }
-#pragma unroll
-  for (int s = 0; s < 4; s++)
-#pragma unroll
-    for (int bm = 0; bm < 2; bm++)
-#pragma unroll
-      for (int bn = 0; bn < 2; bn++) {
-        Xr[bm][bn] = mfma16(Cc[bm][s], Tr[bn][s], Xr[bm][bn]);
-        Xi[bm][bn] = mfma16(Cc[bm][s], Ti[bn][s], Xi[bm][bn]);
-        Xr[bm][bn] = mfma16(Ss[bm][s], Ti[bn][s], Xr[bm][bn]);
-        Xi[bm][bn] = mfma16(nS[bm][s], Tr[bn][s], Xi[bm][bn]);
-      }
-  // ---- |X|^2 and 2x2 binning: reg r <-> ky = 16 bm + 4 q + r - 16, lane c <-> kx = 16 bn + c - 16
-  //      LR pixel Y = 8 bm + 2 q + (r >> 1), X = 8 bn + (c >> 1)
+    for (int s = 0; s < 4; s++) {
+      QCr = mfma16(Cc[s], Tr[m][s], QCr);
+      QCi = mfma16(Cc[s], Ti[m][s], QCi);
+      QSr = mfma16(Ss[s], Tr[m][s], QSr);
+      QSi = mfma16(Ss[s], Ti[m][s], QSi);
+    }
+    Xr[0][m] = QCr + QSi; Xi[0][m] = QCi - QSr;
+    Xr[1][m] = QCr - QSi; Xi[1][m] = QCi + QSr;
+  }
+  // ---- |X|^2 and 2x2 binning.  Tile [sy][sx], reg r, lane (q, c): ky' = 4q + r, kx' = c;
+  //      + tiles: k = k' -> LR index 8 + (k' >> 1);  - tiles: k = -(k'+1) -> LR index 7 - (k' >> 1)
   float v[2][2][2];
   float tot = 0.f;
 #pragma unroll
-  for (int bm = 0; bm < 2; bm++)
+  for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-    for (int bn = 0; bn < 2; bn++)
+    for (int sx = 0; sx < 2; sx++)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        float a0 = Xr[bm][bn][2 * h], b0 = Xi[bm][bn][2 * h];
-        float a1 = Xr[bm][bn][2 * h + 1], b1 = Xi[bm][bn][2 * h + 1];
+        float a0 = Xr[sy][sx][2 * h], b0 = Xi[sy][sx][2 * h];
+        float a1 = Xr[sy][sx][2 * h + 1], b1 = Xi[sy][sx][2 * h + 1];
         float t = (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1);
-        t += __shfl_xor(t, 1);
-        v[bm][bn][h] = t;
+        t = add_xor1(t);
+        v[sy][sx][h] = t;
         tot += t;
       }
+  const int Xp = 8 + (c >> 1), Xm = 7 - (c >> 1);
   if (!NOISE && !WRITE_CUBE) {
     // only the slopes are wanted and nothing depends on the normalised pixel values: the COG is
     // invariant to the flux scale, so reduce (sum, sum x, sum y) of the raw image in ONE pass
-    float sx = 0.f, sy = 0.f;
+    float sx_ = 0.f, sy_ = 0.f;
 #pragma unroll
-    for (int bm = 0; bm < 2; bm++)
+    for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-      for (int bn = 0; bn < 2; bn++)
+      for (int sx = 0; sx < 2; sx++)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-          sx += v[bm][bn][h] * (float)(8 * bn + (c >> 1));
-          sy += v[bm][bn][h] * (float)(8 * bm + 2 * q + h);
+          const int Y = sy ? 7 - (2 * q + h) : 8 + 2 * q + h;
+          sx_ += v[sy][sx][h] * (float)(sx ? Xm : Xp);
+          sy_ += v[sy][sx][h] * (float)Y;
         }
-    tot = owner ? tot : 0.f; sx = owner ? sx : 0.f; sy = owner ? sy : 0.f;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      tot += __shfl_xor(tot, o);
-      sx += __shfl_xor(sx, o);
-      sy += __shfl_xor(sy, o);
-    }
+    tot = wave_sum(owner ? tot : 0.f);
+    sx_ = wave_sum(owner ? sx_ : 0.f);
+    sy_ = wave_sum(owner ? sy_ : 0.f);
     if (do_cog && lane == 0) {
       float *sl = st.slopes + (long long)e * sys.nslope;
       if (tot > 0.f) {
-        sl[i] = (sx / tot - sys.cog_offset) * sys.cog_scale;
-        sl[sys.nvalid + i] = (sy / tot - sys.cog_offset) * sys.cog_scale;
+        sl[i] = (sx_ / tot - sys.cog_offset) * sys.cog_scale;
+        sl[sys.nvalid + i] = (sy_ / tot - sys.cog_offset) * sys.cog_scale;
       } else {
         sl[i] = 0.f;
         sl[sys.nvalid + i] = 0.f;
@@ -568,19 +593,17 @@ __device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &
     return;
   }
   // ---- total flux (each LR pixel is held by two lanes: count even lanes only)
-  tot = owner ? tot : 0.f;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+  tot = wave_sum(owner ? tot : 0.f);
   const float g = tot > 0.f ? sys.nphot * flux_i / tot : 0.f;
   float s0 = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
-  for (int bm = 0; bm < 2; bm++)
+  for (int ty_ = 0; ty_ < 2; ty_++)
 #pragma unroll
-    for (int bn = 0; bn < 2; bn++)
+    for (int tx_ = 0; tx_ < 2; tx_++)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int Y = 8 * bm + 2 * q + h, X = 8 * bn + (c >> 1);
-        float val = v[bm][bn][h] * g;
+        const int Y = ty_ ? 7 - (2 * q + h) : 8 + 2 * q + h, X = tx_ ? Xm : Xp;
+        float val = v[ty_][tx_][h] * g;
         if (NOISE) {
           const uint32_t idx = (uint32_t)i * 256u + (uint32_t)(Y * 16 + X);
           const uint32_t sd = st.seeds[e], fr = st.frame[e];
@@ -596,13 +619,9 @@ __device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &
         sy += val * (float)Y;
       }
   if (do_cog) {
-    s0 = owner ? s0 : 0.f; sx = owner ? sx : 0.f; sy = owner ? sy : 0.f;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      s0 += __shfl_xor(s0, o);
-      sx += __shfl_xor(sx, o);
-      sy += __shfl_xor(sy, o);
-    }
+    s0 = wave_sum(owner ? s0 : 0.f);
+    sx = wave_sum(owner ? sx : 0.f);
+    sy = wave_sum(owner ? sy : 0.f);
     if (lane == 0) {
       float *sl = st.slopes + (long long)e * sys.nslope;
       if (s0 != 0.f) {
@@ -669,12 +688,12 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
                                                   int no_atmos, int no_dms, int do_cog) {
   __shared__ float sAr[4][16][17];
   __shared__ float sAi[4][16][17];
-  __shared__ float2 sTw[64];                     // (cos, sin)(2 pi m / 64)
+  __shared__ float2 sTw[128];                    // (cos, sin)(2 pi m / 128)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = env_begin + blockIdx.y;
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 128) {
     float sn, cs;
-    sincospif((float)threadIdx.x * (1.0f / 32.0f), &sn, &cs);
+    sincospif((float)threadIdx.x * (1.0f / 64.0f), &sn, &cs);
     sTw[threadIdx.x] = make_float2(cs, sn);
   }
   __syncthreads();                               // the only block-wide barrier
@@ -683,18 +702,14 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
   int i = blockIdx.x * 4 + wv;
   if (i >= sys.nvalid) return;
 
-  // ---- twiddles: idx = 4q + s (pixel), freq = 16 b + c - 16
-  float Cc[2][4], Ss[2][4], nS[2][4];
+  // ---- twiddles: idx = 4q + s (pixel), half-integer frequency k + 1/2 with k = c
+  float Cc[4], Ss[4];                            // cos / sin(2 pi (2c+1)(4q+s) / 128)
 #pragma unroll
-  for (int b = 0; b < 2; b++)
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const float2 w = sTw[((4 * q + s) * (16 * b + c - 16)) & 63];
-      Cc[b][s] = w.x; Ss[b][s] = w.y; nS[b][s] = -w.y;
-    }
+  for (int s = 0; s < 4; s++) {
+    const float2 w = sTw[((4 * q + s) * (2 * c + 1)) & 127];
+    Cc[s] = w.x; Ss[s] = w.y;
+  }
   const int ty = lane >> 2, tx0 = (lane & 3) * 4;
-  float hx[4] = {0.f, 0.f, 0.f, 0.f};
-  add4(hx, sys.halfxy + ty * 16 + tx0);          // halfxy already divided by 2 pi
   const bool owner = (c & 1) == 0;
 
   float ph[4], mk[4];
@@ -703,7 +718,8 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
     // ---- stage 0: complex amplitude tile -> LDS (4 pixels per lane)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      float t = ph[j] * sys.wfs_inv_lambda - hx[j];  // revolutions
+      float t = ph[j] * sys.wfs_inv_lambda;          // revolutions (the half-pixel ramp is folded
+                                                     // into the half-integer frequencies)
       t -= rintf(t);
       const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_cosf(t);   // v_sin/v_cos
       sAr[wv][ty][tx0 + j] = mk[j] * cs;
@@ -714,7 +730,7 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
     if (inext < sys.nvalid) spot_load<FROM_BUF>(sys, st, e, inext, lane, no_atmos, no_dms, ph, mk);
     __builtin_amdgcn_wave_barrier();
 
-    spot_compute<NOISE, WRITE_CUBE>(sys, st, e, i, lane, wv, Cc, Ss, nS, sAr, sAi, do_cog, sys.flux[i]);
+    spot_compute<NOISE, WRITE_CUBE>(sys, st, e, i, lane, wv, Cc, Ss, sAr, sAi, do_cog, sys.flux[i]);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -754,10 +770,16 @@ __device__ __forceinline__ void spot_fetch(const DevSys &sys, const SpotEnv<NL> 
     int py = gy + E.py0[l]; py -= (py >= E.dim[l]) ? E.dim[l] : 0;
     int px = gx + E.px0[l]; px -= (px >= E.dim[l]) ? E.dim[l] : 0;
     const float *row = E.lay[l] + py * E.dim[l];
+    if (px + 3 < E.dim[l]) {
+      const f4u t = *reinterpret_cast<const f4u *>(row + px);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      int xx = px + j; xx -= (xx >= E.dim[l]) ? E.dim[l] : 0;
-      r.L[l][j] = row[xx];
+      for (int j = 0; j < 4; j++) r.L[l][j] = t.v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int xx = px + j; xx -= (xx >= E.dim[l]) ? E.dim[l] : 0;
+        r.L[l][j] = row[xx];
+      }
     }
   }
   {
@@ -783,12 +805,12 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
                                                        int do_cog) {
   __shared__ float sAr[4][16][17];
   __shared__ float sAi[4][16][17];
-  __shared__ float2 sTw[64];
+  __shared__ float2 sTw[128];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = env_begin + blockIdx.y;
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 128) {
     float sn, cs;
-    sincospif((float)threadIdx.x * (1.0f / 32.0f), &sn, &cs);
+    sincospif((float)threadIdx.x * (1.0f / 64.0f), &sn, &cs);
     sTw[threadIdx.x] = make_float2(cs, sn);
   }
   __syncthreads();
@@ -796,17 +818,13 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
   const int stride = gridDim.x * 4;
   int i = blockIdx.x * 4 + wv;
   if (i >= sys.nvalid) return;
-  float Cc[2][4], Ss[2][4], nS[2][4];
+  float Cc[4], Ss[4];                            // cos / sin(2 pi (2c+1)(4q+s) / 128)
 #pragma unroll
-  for (int b = 0; b < 2; b++)
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const float2 w = sTw[((4 * q + s) * (16 * b + c - 16)) & 63];
-      Cc[b][s] = w.x; Ss[b][s] = w.y; nS[b][s] = -w.y;
-    }
+  for (int s = 0; s < 4; s++) {
+    const float2 w = sTw[((4 * q + s) * (2 * c + 1)) & 127];
+    Cc[s] = w.x; Ss[s] = w.y;
+  }
   const int ty = lane >> 2, tx0 = (lane & 3) * 4;
-  float hx[4] = {0.f, 0.f, 0.f, 0.f};
-  add4(hx, sys.halfxy + ty * 16 + tx0);
   // ---- per-environment constants
   SpotEnv<NL> E;
 #pragma unroll
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
       float ph = raw.P[j] + (E.c0 * raw.T[2 * j] + E.c1 * raw.T[2 * j + 1]);
 #pragma unroll
       for (int l = 0; l < NL; l++) ph += raw.L[l][j];
-      float t = ph * sys.wfs_inv_lambda - hx[j];
+      float t = ph * sys.wfs_inv_lambda;
       t -= rintf(t);
       const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_cosf(t);
       sAr[wv][ty][tx0 + j] = raw.M[j] * cs;
@@ -851,7 +869,7 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
       xy_next = (inext + stride < sys.nvalid) ? sys.sub_xy[inext + stride] : 0;
     }
     __builtin_amdgcn_wave_barrier();
-    spot_compute<NOISE, WRITE_CUBE>(sys, st, e, i, lane, wv, Cc, Ss, nS, sAr, sAi, do_cog, flux_i);
+    spot_compute<NOISE, WRITE_CUBE>(sys, st, e, i, lane, wv, Cc, Ss, sAr, sAi, do_cog, flux_i);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -1327,10 +1345,16 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       int px = xs + lpx[l]; px -= (px >= ldim[l]) ? ldim[l] : 0;
+      if (px + 3 < ldim[l]) {
+        const f4u t = *reinterpret_cast<const f4u *>(lrow[l] + px);
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        int xx = px + j; xx -= (xx >= ldim[l]) ? ldim[l] : 0;
-        rL[l][j] = lrow[l][xx];
+        for (int j = 0; j < 4; j++) rL[l][j] = t.v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          int xx = px + j; xx -= (xx >= ldim[l]) ? ldim[l] : 0;
+          rL[l][j] = lrow[l][xx];
+        }
       }
     }
     const f4u tp = *reinterpret_cast<const f4u *>(prow + xs);

@@ -208,8 +208,17 @@ def main():
         m, ms = models[dom], stage_ms[dom]
         scale = 1e-12 if m["unit"] == "TFLOP/s" else 1e-9
         achieved = m["work"] / (ms * 1e-3) * scale
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+        # MI355X_MICROARCH.md), measured off-line at 256 envs and scaled to this batch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_counters_256env.json")))
+            if dom in pmc and args.config == WORKLOAD:
+                traffic = pmc[dom]["hbm_traffic_bytes_per_launch"] * args.envs / pmc["_envs"]
+        except Exception:
+            traffic = None
         roof = {"kernel": dom, "bound": m["bound"], "achieved": achieved, "peak": m["peak"],
-                "unit": m["unit"], "frac": achieved / m["peak"], "traffic": None,
+                "unit": m["unit"], "frac": achieved / m["peak"], "traffic": traffic,
                 "avg_launch_ms": ms}
         spot_ms = stage_ms["wfs_spot_cog"]
         sp = models["wfs_spot_cog"]

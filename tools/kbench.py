@@ -27,6 +27,10 @@ for g in (4, 8, 16, 32, 64, 150, 300):
     sim.set_option("spot_blocks_per_env", g)
     print("spot gx=%-4d      %.3f ms" % (g, timeit(lambda: sim.comp_image(noise=False, cog=True))))
 sim.set_option("spot_blocks_per_env", 0)
+for pad in (0, 30000, 45000, 70000, 140000):
+    sim.set_option("spot_lds_pad", pad)
+    print("spot lds_pad=%-6d %.3f ms" % (pad, timeit(lambda: sim.comp_image(noise=False, cog=True))))
+sim.set_option("spot_lds_pad", 0)
 print("spot no_atmos     %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True, atm=False)))
 print("spot no_dms       %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True, dms=False)))
 print("spot none         %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True, atm=False, dms=False)))
