@@ -1,0 +1,70 @@
+"""Per-sub-aperture denoising autoencoder in the WFS path.
+
+Restates the forward of the reference's `DenoisingAutoencoderCNN2DSingleSubapeture`
+(src/autoencoder/autoencoder_models.py:130-197) functionally on a state dict in the reference's
+checkpoint layout (keys encoder1..3 / decoder1..3 .weight/.bias), and the data flow of
+`RlSupervisor.autoencoder_denoising` (rlSupervisor.py:876-891) without its host round trip:
+the bincube stays on the device, the denoised spots are written back in place and the centroider
+runs on them.
+
+Orientation: the reference feeds the network `np.moveaxis(np.array(d_bincube), -1, 0)`, i.e.
+[subap][x][y] (COMPASS arrays are first-index-fastest), the transpose of this repo's [y][x] tiles;
+the trained weights expect that, so tiles are transposed on the way in and out.
+
+PyTorch-ROCm (MIOpen convolutions, channels_last) is the engine here, as SURVEY section 7 step 8
+plans for the first version; 1 712 128 MAC per 16x16 image.
+"""
+import torch
+import torch.nn.functional as F
+
+KEYS = ("encoder1", "encoder2", "encoder3", "decoder1", "decoder2", "decoder3")
+
+
+class SubapDenoiser(object):
+    def __init__(self, state_dict, device="cuda:0", dtype=torch.float32, chunk=65536):
+        self.device, self.dtype, self.chunk = torch.device(device), dtype, int(chunk)
+        self.w = {}
+        for k in KEYS:
+            for p in ("weight", "bias"):
+                t = state_dict["%s.%s" % (k, p)].detach().to(self.device, dtype)
+                if p == "weight":
+                    t = t.contiguous(memory_format=torch.channels_last)
+                self.w["%s.%s" % (k, p)] = t
+        shapes = {k: tuple(self.w[k + ".weight"].shape) for k in KEYS}
+        want = {"encoder1": (16, 1, 3, 3), "encoder2": (32, 16, 3, 3), "encoder3": (64, 32, 3, 3),
+                "decoder1": (64, 32, 4, 4), "decoder2": (32, 16, 4, 4), "decoder3": (16, 1, 3, 3)}
+        if shapes != want:
+            raise ValueError("unexpected autoencoder layout %r" % (shapes,))
+
+    @classmethod
+    def load(cls, path, **kw):
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        return cls(sd, **kw)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: [N, 1, 16, 16] (reference orientation) -> same shape."""
+        w = self.w
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        x = F.relu(F.conv2d(x, w["encoder1.weight"], w["encoder1.bias"], padding=1))
+        x = F.max_pool2d(x, 2)
+        x = F.relu(F.conv2d(x, w["encoder2.weight"], w["encoder2.bias"], padding=1))
+        x = F.max_pool2d(x, 2)
+        x = F.relu(F.conv2d(x, w["encoder3.weight"], w["encoder3.bias"], padding=1))
+        x = F.relu(F.conv_transpose2d(x, w["decoder1.weight"], w["decoder1.bias"], stride=2,
+                                      padding=1))
+        x = F.relu(F.conv_transpose2d(x, w["decoder2.weight"], w["decoder2.bias"], stride=2,
+                                      padding=1))
+        x = F.conv_transpose2d(x, w["decoder3.weight"], w["decoder3.bias"], stride=1, padding=1)
+        return x.float()
+
+    @torch.no_grad()
+    def denoise_bincube_(self, bincube):
+        """In place on a [nenv, nvalid, 256] bincube of [y][x] tiles."""
+        n, nv, np2 = bincube.shape
+        flat = bincube.view(n * nv, 16, 16)
+        for i0 in range(0, n * nv, self.chunk):
+            t = flat[i0:i0 + self.chunk]
+            y = self.forward(t.transpose(1, 2).unsqueeze(1))
+            t.copy_(y.squeeze(1).transpose(1, 2))
+        return bincube

@@ -55,7 +55,10 @@ class VecRlSupervisor(object):
     """Batched counterpart of shesha's RlSupervisor for the integrator (+RL correction) path."""
 
     def __init__(self, config, config_rl, nenv, *, initial_seed=1234, seed_stride=16,
-                 device="cuda:0", strehl_halfwin=8, keep_bincube=False, sim_factory=None):
+                 device="cuda:0", strehl_halfwin=8, keep_bincube=False, sim_factory=None,
+                 autoencoder=None):
+        # autoencoder: a denoiser.SubapDenoiser (rlSupervisor.py:147, :977-978) or None
+        self.autoencoder = autoencoder
         self.config = config if not isinstance(config, str) else params.builtin(config)
         self.config_rl = dict(DEFAULT_ENV_RL)
         self.config_rl.update(config_rl or {})
@@ -148,7 +151,18 @@ class VecRlSupervisor(object):
 
     def next_part_one(self, move_atmos=True, do_control=True):
         """rlSupervisor.py:1015-1051 -> next_part_one_integrator :954-987"""
-        if move_atmos and do_control:
+        if self.autoencoder is not None:
+            # rlSupervisor.py:975-984 with the denoiser between image formation and centroiding;
+            # the bincube never leaves the device (the reference copies it to the host and back)
+            if move_atmos:
+                self.sim.move_atmos()
+            self.sim.target_psf()
+            self.sim.comp_image(noise=True, write_bincube=True, cog=False)
+            self.autoencoder.denoise_bincube_(self.sim.t["bincube"])
+            self.sim.do_centroids()
+            if do_control:
+                self.sim.do_control()
+        elif move_atmos and do_control:
             self.sim.next_part_one()
         else:
             if move_atmos:
@@ -182,7 +196,7 @@ class VecAoEnv(object):
 
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
-                 strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None):
+                 strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -195,7 +209,8 @@ class VecAoEnv(object):
             config = name
         self.supervisor = VecRlSupervisor(config, cfg, nenv, initial_seed=initial_seed,
                                           seed_stride=seed_stride, device=device,
-                                          strehl_halfwin=strehl_halfwin, sim_factory=sim_factory)
+                                          strehl_halfwin=strehl_halfwin, sim_factory=sim_factory,
+                                          autoencoder=autoencoder)
         sup = self.supervisor
         self.nenv, self.device = nenv, sup.device
         self.nmodes = sup.nmodes

@@ -1,0 +1,69 @@
+"""A17: the sub-aperture denoiser == the reference's module on the shipped weights (golden
+vectors from tools/gen_golden_host.py), orientation handling, and the fused device-side flow."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ao_marl_amd.denoiser import SubapDenoiser
+
+
+@pytest.fixture(scope="module")
+def blob(golden_dir):
+    return torch.load(os.path.join(golden_dir, "host_denoiser.pt"), weights_only=True)
+
+
+def test_forward_matches_reference_module(blob):
+    d = SubapDenoiser(blob["state_dict"], device="cpu")
+    assert sum(v.numel() for v in blob["state_dict"].values()) == 64449
+    y = d.forward(blob["x"])
+    assert torch.allclose(y, blob["y"], atol=2e-5, rtol=1e-5)
+
+
+def test_bincube_round_trip_uses_the_reference_orientation(blob):
+    """rlSupervisor.py:884-889: bincube (16,16,N) [x][y][i] -> moveaxis -> network -> back."""
+    d = SubapDenoiser(blob["state_dict"], device="cpu")
+    g = torch.Generator().manual_seed(1)
+    cube = torch.rand(2, 5, 256, generator=g) * 20          # [env][subap][y*16+x]
+    want = cube.clone()
+    for e in range(2):
+        compass = cube[e].view(5, 16, 16).permute(2, 1, 0).numpy()       # [x][y][i]
+        moved = np.moveaxis(compass, -1, 0)                               # [i][x][y]
+        out = d.forward(torch.from_numpy(np.ascontiguousarray(moved)).unsqueeze(1)).squeeze(1)
+        want[e] = out.permute(0, 2, 1).reshape(5, 256)                    # back to [y][x]
+    got = d.denoise_bincube_(cube.clone())
+    assert torch.allclose(got, want, atol=1e-5)
+    assert not torch.allclose(got, d.forward(cube.view(10, 1, 16, 16)).view(2, 5, 256), atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_denoised_wfs_path_matches_oracle(blob):
+    """config 5: noisy 40x40 sensor -> denoiser -> COG, device-resident, vs the oracle's noisy
+    images pushed through the same network on the CPU."""
+    from ao_marl_amd import geometry as G, params, system
+    from ao_marl_amd.sim import HipSim
+    from oracle import aoref
+    from tests.test_gpu_large import QuickOracle, _push
+    sysm = G.build_system(params.builtin("production_sh_40x40_8m_3layers_d0_noise"))
+    s = system.from_system(sysm)
+    s.cmat = np.zeros((s.nactu, s.nslope), dtype=np.float32)
+    sim = HipSim(s, nenv=2, keep_bincube=True)
+    oracles = [QuickOracle(s, seed=sd) for sd in (11, 12)]
+    sim.reset([11, 12])
+    sim.t["seeds"].copy_(torch.tensor([11, 12], dtype=torch.int32))
+    _push(sim, oracles)
+    dn_gpu = SubapDenoiser(blob["state_dict"], device="cuda:0")
+    dn_cpu = SubapDenoiser(blob["state_dict"], device="cpu")
+    sim.comp_image(noise=True, write_bincube=True, cog=False)
+    dn_gpu.denoise_bincube_(sim.t["bincube"])
+    sim.do_centroids()
+    sl = sim.slopes.cpu().numpy()
+    for e, o in enumerate(oracles):
+        o.raytrace_wfs(atm=True, dms=False, reset=True)
+        o.comp_image(noise=True)
+        cube = torch.from_numpy(o.bincube.copy()).unsqueeze(0)
+        o.bincube[:] = dn_cpu.denoise_bincube_(cube)[0].numpy()
+        o.do_centroids()
+        good = np.abs(sl[e] - o.slopes) < 2e-3
+        assert good.mean() > 0.995, good.mean()

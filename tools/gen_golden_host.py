@@ -128,6 +128,30 @@ def g8():
     print("G8", len(rec))
 
 
+def g9_denoiser():
+    """G8 of SURVEY: the shipped denoiser weights (data) + the reference module's forward on
+    seeded synthetic spot images."""
+    from src.autoencoder.autoencoder_models import DenoisingAutoencoderCNN2DSingleSubapeture
+    path = os.path.join(_ref_shims.REF, "output/autoencoder/autoencoder_weights/autoencoder_M9_rms_3")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    m = DenoisingAutoencoderCNN2DSingleSubapeture()
+    m.load_state_dict(sd)
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    yy, xx = torch.meshgrid(torch.arange(16.), torch.arange(16.), indexing="ij")
+    imgs = []
+    for k in range(8):
+        cx, cy = 7.5 + torch.randn(1, generator=g) * 1.5, 7.5 + torch.randn(1, generator=g) * 1.5
+        spot = 25 * torch.exp(-((xx - cx)**2 + (yy - cy)**2) / 3.0)
+        imgs.append(torch.poisson(spot, generator=g) + 3 * torch.randn(16, 16, generator=g))
+    x = torch.stack(imgs).unsqueeze(1)
+    with torch.no_grad():
+        y = m(x)
+    torch.save({"state_dict": {k: v.clone() for k, v in sd.items()}, "x": x, "y": y},
+               os.path.join(OUT, "host_denoiser.pt"))
+    print("G9 denoiser", tuple(x.shape), float(y.abs().max()), sum(v.numel() for v in sd.values()))
+
+
 if __name__ == "__main__":
     _ref_shims.install()
     os.makedirs(OUT, exist_ok=True)
@@ -135,3 +159,4 @@ if __name__ == "__main__":
     g6()
     g7()
     g8()
+    g9_denoiser()
