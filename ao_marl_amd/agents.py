@@ -190,6 +190,18 @@ class BatchedGaussianPolicy(object):
             lo[a:b] = torch.arange(b - a)
         self.sc_agent, self.sc_local = ag.to(dev), lo.to(dev)
         self.gen = torch.Generator(device=dev).manual_seed(seed)
+        self._native = None          # stacked nn.Linear-layout copies for the HIP batched GEMM
+        self.use_native = self.device.type == "cuda"
+
+    def _refresh_native(self):
+        """[A, out, in] (K-contiguous) copies + merged mean|log_std head for
+        libaomarl.linear_batched (fused bias + ReLU epilogue)."""
+        t = lambda w: w.transpose(1, 2).contiguous()   # noqa: E731
+        self._native = dict(
+                W1=t(self.W1), b1=self.b1[:, 0].contiguous(),
+                Wh=[t(w) for w in self.Wh], bh=[b[:, 0].contiguous() for b in self.bh],
+                Whead=torch.cat([t(self.Wm), t(self.Ws)], dim=1).contiguous(),
+                bhead=torch.cat([self.bm[:, 0], self.bs[:, 0]], dim=1).contiguous())
 
     def load_agent(self, i, state_dict):
         """Load one reference actor checkpoint (`model_state_dict`, train_rpc.py:1155-1161) into
@@ -207,6 +219,7 @@ class BatchedGaussianPolicy(object):
             self.Ws[i, :, :acts] = state_dict["log_std_linear.weight"].T.to(self.device)
             self.bm[i, 0, :acts] = state_dict["mean_linear.bias"].to(self.device)
             self.bs[i, 0, :acts] = state_dict["log_std_linear.bias"].to(self.device)
+        self._native = None
 
     def split_states(self, state):
         """[nenv, state_dim] -> [A, nenv, in_max] (TrainerRPC.divide_states_for_agents)."""
@@ -215,6 +228,18 @@ class BatchedGaussianPolicy(object):
 
     def forward(self, state):
         x = self.split_states(state.to(torch.float32))
+        if self.use_native:
+            from . import libaomarl as la
+            if self._native is None:
+                self._refresh_native()
+            n = self._native
+            x = la.linear_batched(x, n["W1"], n["b1"], relu=True)
+            for W, b in zip(n["Wh"], n["bh"]):
+                x = la.linear_batched(x, W, b, relu=True)
+            head = la.linear_batched(x, n["Whead"], n["bhead"], relu=False)
+            mean = head[:, :, :self.act_max]
+            log_std = head[:, :, self.act_max:].clamp(LOG_SIG_MIN, self.log_sig_max)
+            return mean, log_std
         x = torch.relu(torch.baddbmm(self.b1, x, self.W1))
         for W, b in zip(self.Wh, self.bh):
             x = torch.relu(torch.baddbmm(b, x, W))

@@ -954,3 +954,18 @@ int aomarl_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, co
   LAUNCHCHK();
   return 0;
 }
+
+int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int lda, long long strideA,
+                           const float *B, int ldb, long long strideB, const float *bias,
+                           long long strideBias, float *C, int ldc, long long strideC, int relu,
+                           void *stream) {
+  if (!A || !B || !C) return fail("gemm_nt_batched: null pointer");
+  if (batch < 0 || M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) return fail("gemm_nt_batched: bad sizes");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return fail("gemm_nt_batched: A and B must be 16-byte aligned");
+  hipLaunchKernelGGL(k_gemm_nt_batched, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0,
+                     (hipStream_t)stream, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias,
+                     C, ldc, strideC, relu);
+  LAUNCHCHK();
+  return 0;
+}

@@ -122,6 +122,78 @@ __global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alph
   }
 }
 
+// Batched variant for the SAC MLPs: C[b] = act(A[b] . B[b]^T + bias[b]) ; blockIdx.z = batch
+// (agent).  A [batch][M][lda], B [batch][N][ldb] (nn.Linear weight layout: [out][in]),
+// bias [batch][N] or NULL, C [batch][M][ldc]; relu != 0 applies max(., 0).
+__global__ __launch_bounds__(256) void k_gemm_nt_batched(int M, int N, int K,
+                                                         const float *__restrict__ A, int lda, long long sA,
+                                                         const float *__restrict__ B, int ldb, long long sB,
+                                                         const float *__restrict__ bias, long long sBias,
+                                                         float *__restrict__ C, int ldc, long long sC,
+                                                         int relu) {
+  __shared__ float As[64][17];
+  __shared__ float Bs[64][17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const int lr = tid >> 2, lc = (tid & 3) * 4;
+  const int gm = m0 + lr, gn = n0 + lr;
+  const float *pa = A + (long long)gm * lda;
+  const float *pb = B + (long long)gn * ldb;
+  const bool al = ((lda | ldb) & 3) == 0 && ((sA | sB) & 3) == 0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+    const int gk = k0 + lc;
+    if (gm < M) {
+      if (al && gk + 3 < K) {
+        float4 t = *reinterpret_cast<const float4 *>(pa + gk);
+        va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (gk + j < K) va[j] = pa[gk + j];
+      }
+    }
+    if (gn < N) {
+      if (al && gk + 3 < K) {
+        float4 t = *reinterpret_cast<const float4 *>(pb + gk);
+        vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (gk + j < K) vb[j] = pb[gk + j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      As[lr][lc + j] = va[j];
+      Bs[lr][lc + j] = vb[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      float a = As[wm * 32 + (lane & 31)][2 * ks + (lane >> 5)];
+      float b = Bs[wn * 32 + (lane & 31)][2 * ks + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+  const float bv = (bias && col < N) ? bias[(long long)blockIdx.z * sBias + col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      float v = acc[r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      C[(long long)row * ldc + col] = v;
+    }
+  }
+}
+
 __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float *__restrict__ P,
                               float beta, float *__restrict__ C, int ldc) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -102,6 +102,8 @@ SYMBOLS = [
     ("aomarl_next_part_one", _i, _range + [_fp, _fp, _i, _vp]),
     ("aomarl_next_part_two", _i, _range + [_vp, _vp]),
     ("aomarl_gemm_nt", _i, [_i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp]),
+    ("aomarl_gemm_nt_batched", _i, [_i, _i, _i, _i, _vp, _i, C.c_longlong, _vp, _i, C.c_longlong,
+                                    _vp, C.c_longlong, _vp, _i, C.c_longlong, _i, _vp]),
 ]
 
 _lib = None
@@ -225,3 +227,21 @@ def make_desc(s):
     d.tar_lambda, d.npsf, d.strehl_halfwin = s.tar_lambda, s.npsf, s.strehl_halfwin
     d.nactu, d.nslope, d.gain, d.delay = s.nactu, s.nslope, s.gain, s.delay
     return d, keep
+
+
+def linear_batched(x, weight, bias=None, relu=False, out=None):
+    """act(x @ weight^T + bias) for stacked layers on the library's batched fp32 MFMA GEMM.
+    x [B, M, K], weight [B, N, K] (nn.Linear layout), bias [B, N] or None -> [B, M, N]."""
+    import torch
+    L = load()
+    B, M, K = x.shape
+    N = weight.shape[1]
+    assert weight.shape == (B, N, K) and x.stride(2) == 1 and weight.stride(2) == 1
+    if out is None:
+        out = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
+    check(L.aomarl_gemm_nt_batched(
+            B, M, N, K, x.data_ptr(), x.stride(1), x.stride(0), weight.data_ptr(), weight.stride(1),
+            weight.stride(0), bias.data_ptr() if bias is not None else None,
+            bias.stride(0) if bias is not None else 0, out.data_ptr(), out.stride(1), out.stride(0),
+            1 if relu else 0, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out

@@ -225,6 +225,14 @@ int aomarl_next_part_two(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int e
 int aomarl_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
                    int ldb, float beta, float *C, int ldc, void *stream);
 
+/* batched fp32 MFMA GEMM with fused bias + ReLU for the stacked SAC MLPs (one batch entry per
+ * agent): C[b][M][N] = act(A[b][M][K] . B[b][N][K]^T + bias[b][N]); B is in nn.Linear layout
+ * ([out][in]); bias may be NULL; strides in floats; A, B 16-byte aligned */
+int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int lda, long long strideA,
+                           const float *B, int ldb, long long strideB, const float *bias,
+                           long long strideBias, float *C, int ldc, long long strideC, int relu,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,3 +290,27 @@ def test_calibration_through_hip_backend_matches_oracle_backend(setup):
     assert np.abs(cal.imat - cal_o.imat).max() < 1e-4 * np.abs(cal_o.imat).max()
     assert np.abs(cal.cmat - cal_o.cmat).max() < 2e-3 * np.abs(cal_o.cmat).max()
     assert np.abs(cal.Btt - cal_o.Btt).max() < 1e-6
+
+
+def test_batched_policy_native_gemm_matches_torch(setup):
+    """The stacked SAC actor on the library's batched MFMA GEMM (fused bias + ReLU) == torch.bmm."""
+    from ao_marl_amd.agents import AgentLayout, BatchedGaussianPolicy
+    lay = AgentLayout(1283, [0, 1274], 13, include_tip_tilt=True, window_n_zernike=20,
+                      include_tip_tilt_windowed=True, n_filtered=5)
+    pol = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=3, device="cuda:0")
+    with torch.no_grad():
+        pol.b1.normal_(0, 0.1)
+        pol.bm.normal_(0, 0.1)
+        pol.bs.normal_(0, 0.1)
+    st = torch.randn(37, lay.state_dim, device="cuda:0")
+    pol.use_native = True
+    m1, l1 = pol.forward(st)
+    pol.use_native = False
+    m0, l0 = pol.forward(st)
+    acts = lay.action_shapes()
+    for i, na in enumerate(acts):        # padded head columns are meaningless
+        assert torch.allclose(m1[i, :, :na], m0[i, :, :na], atol=2e-4, rtol=1e-4)
+        assert torch.allclose(l1[i, :, :na], l0[i, :, :na], atol=2e-4, rtol=1e-4)
+    pol.use_native = True
+    a, mu = pol.select_action(st)
+    assert a.shape == (37, 1276) and mu.abs().max() <= 1.0
