@@ -172,7 +172,7 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
     const aomarl_layer_desc &L = d->layers[l];
     DevLayer &D = s.layers[l];
     if (L.dim <= 0 || L.dim > 65535 || L.nstencil <= 0) { aomarl_destroy(c); return fail("bad layer %d", l); }
-    D.dim = L.dim; D.ns = L.nstencil; D.screen_off = off; off += (long long)L.dim * L.dim;
+    D.dim = L.dim; D.ns = L.nstencil; D.screen_off = off; off += (long long)L.dim * (L.dim + RING_PAD);
     c->dim[l] = L.dim; c->ns[l] = L.nstencil; c->deltax[l] = L.deltax; c->deltay[l] = L.deltay;
     if (L.dim > c->maxdim) c->maxdim = L.dim;
     if (L.dim + L.nstencil > c->maxK) c->maxK = L.dim + L.nstencil;
@@ -616,6 +616,16 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
   // next_part_one is well defined
   if (!c->sys.tar_all_int && !st->tar_phase) return 0;
   return aomarl_target_psf(c, st, b, n, stream);
+}
+
+int aomarl_set_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, const float *src, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (layer < 0 || layer >= c->nlayers || !src) return fail("set_screen: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_set_screen, dim3(256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, layer, src);
+  LAUNCHCHK();
+  return 0;
 }
 
 int aomarl_get_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, float *dst, void *stream) {

@@ -110,11 +110,15 @@ __device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, 
   return u01(x[idx & 3]);
 }
 
-// ring-buffered screen: logical (x, y) -> physical float index
+// ring-buffered screen: logical (x, y) -> physical float index.  Physical rows are
+// n + RING_PAD floats long: columns [n, n + RING_PAD) mirror columns [0, RING_PAD), so any 4
+// consecutive logical pixels starting at a physical column < n are 4 consecutive floats (no wrap
+// branch in the consumers); the extrusion scatter keeps the mirror up to date.
+#define RING_PAD 4
 __device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
   int px = x + ox;
   px -= (px >= n) ? n : 0;
   int py = y + oy;
   py -= (py >= n) ? n : 0;
-  return py * n + px;
+  return py * (n + RING_PAD) + px;
 }

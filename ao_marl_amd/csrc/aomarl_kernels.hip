@@ -32,15 +32,8 @@ __device__ __forceinline__ void add4(float acc[4], const float *p) {
 }
 // 4 consecutive logical pixels of a ring-buffered screen row starting at physical column px
 __device__ __forceinline__ void add4_ring(float acc[4], const float *row, int px, int dim) {
-  if (px + 3 < dim) {
-    add4(acc, row + px);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      int xx = px + j; xx -= (xx >= dim) ? dim : 0;
-      acc[j] += row[xx];
-    }
-  }
+  (void)dim;                     // rows carry RING_PAD mirror columns: never wraps
+  add4(acc, row + px);
 }
 
 // =============================================================================================
@@ -300,7 +293,9 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
     py = oy - 1; py += (py < 0) ? n : 0;
     px = n - 1 - r + ox; px -= (px >= n) ? n : 0;
   }
-  base[py * n + px] = v;
+  const int stride = n + RING_PAD;
+  base[py * stride + px] = v;
+  if (px < RING_PAD) base[py * stride + n + px] = v;     // mirror columns
 }
 
 __global__ void k_extrude_commit(DevSys sys, DevState st, int env_begin, int ncol, RoundOps ops) {
@@ -339,6 +334,22 @@ __global__ void k_reset_env(DevSys sys, DevState st, int env_begin, int env_coun
   for (int i = threadIdx.x; i < ld_actu; i += blockDim.x) {
     long long o = (long long)e * ld_actu + i;
     st.com[o] = 0.f; st.com1[o] = 0.f; st.com2[o] = 0.f; st.err[o] = 0.f; st.voltage[o] = 0.f;
+  }
+}
+
+// upload logical screens src [env_count][n*n] (origin reset to 0, mirror columns filled)
+__global__ void k_set_screen(DevSys sys, DevState st, int env_begin, int li, const float *src) {
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim, stride = n + RING_PAD;
+  const int e = env_begin + blockIdx.y;
+  float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n * stride; p += gridDim.x * blockDim.x) {
+    int y = p / stride, x = p - y * stride;
+    base[p] = src[(long long)blockIdx.y * n * n + y * n + (x >= n ? x - n : x)];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st.origin[(e * sys.nlayers + li) * 2] = 0;
+    st.origin[(e * sys.nlayers + li) * 2 + 1] = 0;
   }
 }
 
@@ -728,7 +739,7 @@ __device__ __forceinline__ void spot_load(const DevSys &sys, const DevState &st,
         const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
         int py = gy + L.woy + oy; py -= (py >= L.dim) ? L.dim : 0;
         int px = gx0 + tx0 + L.wox + ox; px -= (px >= L.dim) ? L.dim : 0;
-        add4_ring(ph, base + py * L.dim, px, L.dim);
+        add4_ring(ph, base + py * (L.dim + RING_PAD), px, L.dim);
       }
     }
     if (!no_dms) {
@@ -841,18 +852,9 @@ __device__ __forceinline__ void spot_fetch(const DevSys &sys, const SpotEnv<NL> 
   for (int l = 0; l < NL; l++) {
     int py = gy + E.py0[l]; py -= (py >= E.dim[l]) ? E.dim[l] : 0;
     int px = gx + E.px0[l]; px -= (px >= E.dim[l]) ? E.dim[l] : 0;
-    const float *row = E.lay[l] + py * E.dim[l];
-    if (px + 3 < E.dim[l]) {
-      const f4u t = *reinterpret_cast<const f4u *>(row + px);
+    const f4u t = *reinterpret_cast<const f4u *>(E.lay[l] + py * (E.dim[l] + RING_PAD) + px);
 #pragma unroll
-      for (int j = 0; j < 4; j++) r.L[l][j] = t.v[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        int xx = px + j; xx -= (xx >= E.dim[l]) ? E.dim[l] : 0;
-        r.L[l][j] = row[xx];
-      }
-    }
+    for (int j = 0; j < 4; j++) r.L[l][j] = t.v[j];
   }
   {
     const f4u t = *reinterpret_cast<const f4u *>(E.pzt + (gy + E.pzt_oy) * E.pzt_dim + gx + E.pzt_ox);
@@ -1264,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
             const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
             int py = y + L.toy + oy; py -= (py >= L.dim) ? L.dim : 0;
             int px = xb + L.tox + ox; px -= (px >= L.dim) ? L.dim : 0;
-            add4_ring(ph, base + py * L.dim, px, L.dim);
+            add4_ring(ph, base + py * (L.dim + RING_PAD), px, L.dim);
           }
           for (int k = 0; k < sys.ndm; k++) {
             const DevDm &D = sys.dms[k];
@@ -1394,7 +1396,7 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
     for (int l = 0; l < NL; l++) {
       int py = cy + lpy[l]; py -= (py >= ldim[l]) ? ldim[l] : 0;
       int px = cx + lpx[l]; px -= (px >= ldim[l]) ? ldim[l] : 0;
-      v += lay[l][py * ldim[l] + px];
+      v += lay[l][py * (ldim[l] + RING_PAD) + px];
     }
     pivot = v;
   }
@@ -1403,7 +1405,7 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     int py = (row_ok ? y : 0) + lpy[l]; py -= (py >= ldim[l]) ? ldim[l] : 0;
-    lrow[l] = lay[l] + py * ldim[l];
+    lrow[l] = lay[l] + py * (ldim[l] + RING_PAD);
   }
   const float *prow = pzt + ((row_ok ? y : 0) + D0.toy) * D0.dim + D0.tox;
   const float *trow = D1.influ + 2 * (((row_ok ? y : 0) + D1.toy) * D1.dim + D1.tox);
@@ -1417,17 +1419,9 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       int px = xs + lpx[l]; px -= (px >= ldim[l]) ? ldim[l] : 0;
-      if (px + 3 < ldim[l]) {
-        const f4u t = *reinterpret_cast<const f4u *>(lrow[l] + px);
+      const f4u t = *reinterpret_cast<const f4u *>(lrow[l] + px);
 #pragma unroll
-        for (int j = 0; j < 4; j++) rL[l][j] = t.v[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          int xx = px + j; xx -= (xx >= ldim[l]) ? ldim[l] : 0;
-          rL[l][j] = lrow[l][xx];
-        }
-      }
+      for (int j = 0; j < 4; j++) rL[l][j] = t.v[j];
     }
     const f4u tp = *reinterpret_cast<const f4u *>(prow + xs);
     const f4u t0 = *reinterpret_cast<const f4u *>(trow + 2 * xs);

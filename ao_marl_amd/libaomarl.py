@@ -83,6 +83,7 @@ SYMBOLS = [
     ("aomarl_move_atmos", _i, _range + [_fp, _fp, _vp]),
     ("aomarl_extrude", _i, _range + [_i, _ip, _ip, _vp]),
     ("aomarl_get_screen", _i, _range + [_i, _vp, _vp]),
+    ("aomarl_set_screen", _i, _range + [_i, _vp, _vp]),
     ("aomarl_raytrace_wfs", _i, _range + [_i, _vp]),
     ("aomarl_raytrace_target", _i, _range + [_i, _vp]),
     ("aomarl_comp_image", _i, _range + [_i, _vp]),

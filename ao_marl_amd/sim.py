@@ -146,6 +146,16 @@ class HipSim(object):
                                             out.data_ptr(), self._stream()))
         return out
 
+    def set_screen(self, layer, screens, env_begin=0, env_count=None):
+        """Overwrite one layer with logical screens [env_count, dim, dim] (ring origin reset)."""
+        b, n = self._range(env_begin, env_count)
+        d = self.s.screen_dim[layer]
+        src = torch.as_tensor(screens, dtype=torch.float32, device=self.device).contiguous()
+        if src.shape != (n, d, d):
+            raise ValueError("screens must be [env_count, %d, %d]" % (d, d))
+        la.check(self.lib.aomarl_set_screen(self.ctx, C.byref(self.st), b, n, layer,
+                                            src.data_ptr(), self._stream()))
+
     # ------------------------------------------------------------------ configuration
     def set_cmat(self, cmat):
         cmat = np.ascontiguousarray(cmat, dtype=np.float32)

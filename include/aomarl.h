@@ -103,7 +103,8 @@ typedef struct {
 typedef struct {
   int32_t nenv;
   int32_t ld_actu;     /* row stride (floats) of com/com1/com2/err/voltage, >= nactu, % 4 == 0 */
-  float *screens;      /* [nenv][sum_l dim_l^2]  ring-buffered phase screens (microns)      */
+  float *screens;      /* [nenv][aomarl_screen_stride] ring-buffered phase screens (microns);
+                          private layout, use aomarl_get_screen / aomarl_set_screen            */
   int32_t *origin;     /* [nenv][nlayers][2]     ring origin (ox, oy)                       */
   uint32_t *seeds;     /* [nenv]                 atmosphere base seed (layer k uses seed+k) */
   uint32_t *ext_count; /* [nenv][nlayers]        extrusions drawn so far (RNG counter)      */
@@ -151,6 +152,9 @@ int aomarl_move_atmos(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_
 /* one parallel round of extrusions: op i extrudes layer[i] in direction dir[i] (+-1 x, +-2 y) */
 int aomarl_extrude(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int nops,
                    const int32_t *layer, const int32_t *dir, void *stream);
+/* overwrite one layer with logical screens src [env_count][dim*dim] (device); ring origin -> 0 */
+int aomarl_set_screen(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int layer,
+                      const float *src, void *stream);
 /* copy the logical (un-rotated) screen of one layer to dst [env_count][dim*dim] (device) */
 int aomarl_get_screen(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int layer,
                       float *dst, void *stream);

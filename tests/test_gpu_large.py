@@ -47,13 +47,10 @@ class QuickOracle(aoref.OracleSim):
 
 def _push(sim, oracles):
     s = sim.s
-    off = 0
     for l, d in enumerate(s.screen_dim):
+        sim.set_screen(l, np.stack([o.screens[l] for o in oracles]))
         for e, o in enumerate(oracles):
-            sim.t["screens"][e, off:off + d * d] = torch.from_numpy(o.screens[l].reshape(-1))
             sim.t["ext_count"][e, l] = o.ext_count[l]
-        off += d * d
-    sim.t["origin"].zero_()
 
 
 def test_large_frames_match_oracle(large):

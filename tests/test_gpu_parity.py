@@ -30,12 +30,8 @@ def _push_oracle_state(sim, oracles):
     """Copy the oracle's screens into the HIP state (origin 0) so later stages are compared on
     identical inputs."""
     s = sim.s
-    off = 0
     for l, d in enumerate(s.screen_dim):
-        for e, o in enumerate(oracles):
-            sim.t["screens"][e, off:off + d * d] = torch.from_numpy(o.screens[l].reshape(-1))
-        off += d * d
-    sim.t["origin"].zero_()
+        sim.set_screen(l, np.stack([o.screens[l] for o in oracles]))
     for e, o in enumerate(oracles):
         sim.t["ext_count"][e] = torch.tensor(o.ext_count, dtype=torch.int32)
         sim.accumx[e] = o.accumx
