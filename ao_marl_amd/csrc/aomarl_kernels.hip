@@ -843,42 +843,78 @@ struct SpotRaw {
   float F;   // fluxPerSub of the sub-aperture
 };
 
+// All loads of one tile.  Addresses are  uniform base pointer (SGPR) + 32-bit lane offset, so
+// the compiler emits global_load ... v_off, s[base] with no 64-bit VALU arithmetic; ring wraps
+// cost one v_sub + v_min_u32 per axis (px, px - dim as unsigned: the smaller one is in range).
 template <int NL>
 __device__ __forceinline__ void spot_fetch(const DevSys &sys, const SpotEnv<NL> &E, int xy0, int ty,
                                            int tx0, int i, SpotRaw<NL> &r) {
-  const int gx = (xy0 & 0xFFFF) + tx0, gy = (xy0 >> 16) + ty;
+  const unsigned gx = (unsigned)((xy0 & 0xFFFF) + tx0), gy = (unsigned)((xy0 >> 16) + ty);
   r.F = sys.flux[i];
 #pragma unroll
   for (int l = 0; l < NL; l++) {
-    int py = gy + E.py0[l]; py -= (py >= E.dim[l]) ? E.dim[l] : 0;
-    int px = gx + E.px0[l]; px -= (px >= E.dim[l]) ? E.dim[l] : 0;
-    const f4u t = *reinterpret_cast<const f4u *>(E.lay[l] + py * (E.dim[l] + RING_PAD) + px);
+    const unsigned dim = (unsigned)E.dim[l];
+    unsigned py = gy + (unsigned)E.py0[l]; py = min(py, py - dim);
+    unsigned px = gx + (unsigned)E.px0[l]; px = min(px, px - dim);
+    const unsigned off = py * (dim + RING_PAD) + px;
+    const f4u t = *reinterpret_cast<const f4u *>(E.lay[l] + off);
 #pragma unroll
     for (int j = 0; j < 4; j++) r.L[l][j] = t.v[j];
   }
   {
-    const f4u t = *reinterpret_cast<const f4u *>(E.pzt + (gy + E.pzt_oy) * E.pzt_dim + gx + E.pzt_ox);
+    const unsigned off = (gy + (unsigned)E.pzt_oy) * (unsigned)E.pzt_dim + gx + (unsigned)E.pzt_ox;
+    const f4u t = *reinterpret_cast<const f4u *>(E.pzt + off);
 #pragma unroll
     for (int j = 0; j < 4; j++) r.P[j] = t.v[j];
   }
   {
-    const float *f = E.tt + 2 * ((gy + E.tt_oy) * E.tt_dim + gx + E.tt_ox);
-    const f4u t0 = *reinterpret_cast<const f4u *>(f), t1 = *reinterpret_cast<const f4u *>(f + 4);
+    const unsigned off = 2u * ((gy + (unsigned)E.tt_oy) * (unsigned)E.tt_dim + gx + (unsigned)E.tt_ox);
+    const f4u t0 = *reinterpret_cast<const f4u *>(E.tt + off);
+    const f4u t1 = *reinterpret_cast<const f4u *>(E.tt + off + 4u);
 #pragma unroll
     for (int j = 0; j < 4; j++) { r.T[j] = t0.v[j]; r.T[4 + j] = t1.v[j]; }
   }
   {
-    const f4u t = *reinterpret_cast<const f4u *>(sys.mpupil + gy * sys.n + gx);
+    const unsigned off = gy * (unsigned)sys.n + gx;
+    const f4u t = *reinterpret_cast<const f4u *>(sys.mpupil + off);
 #pragma unroll
     for (int j = 0; j < 4; j++) r.M[j] = t.v[j];
   }
 }
 
+// stage-1 MFMAs + T combinations of the tile in sAr/sAi (see spot_compute for the algebra)
+__device__ __forceinline__ void spot_stage1(int lane, const float (&Cc)[4], const float (&Ss)[4],
+                                            const float (*bAr)[17], const float (*bAi)[17],
+                                            f32x4 (&Tr)[2], f32x4 (&Ti)[2]) {
+  const int q = lane >> 4, c = lane & 15;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 PCr = z4, PCi = z4, PSr = z4, PSi = z4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const float br = bAr[c][4 * q + s], bi = bAi[c][4 * q + s];
+    PCr = mfma16(br, Cc[s], PCr);
+    PCi = mfma16(bi, Cc[s], PCi);
+    PSr = mfma16(br, Ss[s], PSr);
+    PSi = mfma16(bi, Ss[s], PSi);
+  }
+  Tr[0] = PCr + PSi; Ti[0] = PCi - PSr;
+  Tr[1] = PCr - PSi; Ti[1] = PCi + PSr;
+}
+
+// Software-pipelined fast kernel.  Per wave and iteration k (tile k of this wave):
+//   R1  stage-1 MFMAs of tile k (LDS buffer k&1), T combinations
+//   R2  stage-2 MFMAs of tile k  INTERLEAVED (sched_group_barrier) with independent work:
+//         amplitude of tile k+1 (sum of the prefetched sources, sin/cos) -> LDS buffer (k+1)&1,
+//         address arithmetic + issue of the loads of tile k+2
+//   R3  X combinations, |X|^2, binning, COG, store of tile k
+// so the VALU / VMEM / LDS-write work of the neighbouring tiles hides under the matrix pipe of
+// the current one instead of serialising with it.  The loop body is one basic block (indices are
+// clamped instead of branched on).
 template <int NL, bool NOISE, bool WRITE_CUBE>
 __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, int env_begin,
                                                        int do_cog) {
-  __shared__ float sAr[4][16][17];
-  __shared__ float sAi[4][16][17];
+  __shared__ float sAr[4][2][16][17];
+  __shared__ float sAi[4][2][16][17];
   __shared__ float2 sTw[128];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = env_begin + blockIdx.y;
@@ -890,8 +926,10 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
   __syncthreads();
   const int q = lane >> 4, c = lane & 15;
   const int stride = gridDim.x * 4;
-  int i = blockIdx.x * 4 + wv;
-  if (i >= sys.nvalid) return;
+  const int i0 = blockIdx.x * 4 + wv;
+  if (i0 >= sys.nvalid) return;
+  const int nit = (sys.nvalid - i0 + stride - 1) / stride;      // tiles of this wave
+  const int ilast = i0 + (nit - 1) * stride;
   float Cc[4], Ss[4];                            // cos / sin(2 pi (2c+1)(4q+s) / 128)
 #pragma unroll
   for (int s = 0; s < 4; s++) {
@@ -899,6 +937,7 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
     Cc[s] = w.x; Ss[s] = w.y;
   }
   const int ty = lane >> 2, tx0 = (lane & 3) * 4;
+  const bool owner = (c & 1) == 0;
   // ---- per-environment constants
   SpotEnv<NL> E;
 #pragma unroll
@@ -918,32 +957,143 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
     E.c0 = slot[0]; E.c1 = slot[1];
     E.tt = D1.influ; E.tt_dim = D1.dim; E.tt_ox = D1.wox; E.tt_oy = D1.woy;
   }
+  const float inv_lambda = sys.wfs_inv_lambda;
   SpotRaw<NL> raw;
-  int xy_cur = sys.sub_xy[i];
-  int xy_next = (i + stride < sys.nvalid) ? sys.sub_xy[i + stride] : 0;
-  spot_fetch<NL>(sys, E, xy_cur, ty, tx0, i, raw);
-  for (; i < sys.nvalid; i += stride) {
-    const float flux_i = raw.F;
-    // ---- stage 0: sum the sources, complex amplitude tile -> LDS
+  auto amplitude_to_lds = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       float ph = raw.P[j] + (E.c0 * raw.T[2 * j] + E.c1 * raw.T[2 * j + 1]);
 #pragma unroll
       for (int l = 0; l < NL; l++) ph += raw.L[l][j];
-      float t = ph * sys.wfs_inv_lambda;
+      float t = ph * inv_lambda;
       t -= rintf(t);
       const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_cosf(t);
-      sAr[wv][ty][tx0 + j] = raw.M[j] * cs;
-      sAi[wv][ty][tx0 + j] = raw.M[j] * sn;
+      sAr[wv][buf][ty][tx0 + j] = raw.M[j] * cs;
+      sAi[wv][buf][ty][tx0 + j] = raw.M[j] * sn;
     }
-    // ---- prefetch: data of the next sub-aperture, tile origin of the one after
-    const int inext = i + stride;
-    if (inext < sys.nvalid) {
-      spot_fetch<NL>(sys, E, xy_next, ty, tx0, inext, raw);
-      xy_next = (inext + stride < sys.nvalid) ? sys.sub_xy[inext + stride] : 0;
+  };
+  // ---- prologue: tile 0 -> LDS buffer 0, loads of tile 1 in flight
+  spot_fetch<NL>(sys, E, sys.sub_xy[i0], ty, tx0, i0, raw);
+  float flux_cur = raw.F;
+  amplitude_to_lds(0);
+  {
+    const int i1 = min(i0 + stride, ilast);
+    spot_fetch<NL>(sys, E, sys.sub_xy[i1], ty, tx0, i1, raw);
+  }
+  int xy2 = sys.sub_xy[min(i0 + 2 * stride, ilast)];
+  __builtin_amdgcn_wave_barrier();
+
+  for (int k = 0; k < nit; k++) {
+    const int i = i0 + k * stride;
+    const int buf = k & 1;
+    // ---- R1
+    f32x4 Tr[2], Ti[2];
+    spot_stage1(lane, Cc, Ss, sAr[wv][buf], sAi[wv][buf], Tr, Ti);
+    // ---- R2: stage-2 MFMAs ...
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Xr[2][2], Xi[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      f32x4 QCr = z4, QCi = z4, QSr = z4, QSi = z4;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        QCr = mfma16(Cc[s], Tr[m][s], QCr);
+        QCi = mfma16(Cc[s], Ti[m][s], QCi);
+        QSr = mfma16(Ss[s], Tr[m][s], QSr);
+        QSi = mfma16(Ss[s], Ti[m][s], QSi);
+      }
+      Xr[0][m] = QCr + QSi; Xi[0][m] = QCi - QSr;
+      Xr[1][m] = QCr - QSi; Xi[1][m] = QCi + QSr;
     }
-    __builtin_amdgcn_wave_barrier();
-    spot_compute<NOISE, WRITE_CUBE>(sys, st, e, i, lane, wv, Cc, Ss, sAr, sAi, do_cog, flux_i);
+    // ... with the neighbours' work: amplitude of tile k+1, loads of tile k+2
+    const float flux_next = raw.F;
+    amplitude_to_lds(buf ^ 1);
+    {
+      const int i2 = min(i + 2 * stride, ilast);
+      spot_fetch<NL>(sys, E, xy2, ty, tx0, i2, raw);
+      xy2 = sys.sub_xy[min(i + 3 * stride, ilast)];
+    }
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // 5 VALU
+      __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);     // 1 VMEM read or DS write
+    }
+    // ---- R3: |X|^2, 2x2 binning, flux / COG, store (same mapping as spot_compute)
+    float v[2][2][2];
+    float tot = 0.f;
+#pragma unroll
+    for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+      for (int sx = 0; sx < 2; sx++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          float a0 = Xr[sy][sx][2 * h], b0 = Xi[sy][sx][2 * h];
+          float a1 = Xr[sy][sx][2 * h + 1], b1 = Xi[sy][sx][2 * h + 1];
+          float t = (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1);
+          t = add_xor1(t);
+          v[sy][sx][h] = t;
+          tot += t;
+        }
+    const int Xp = 8 + (c >> 1), Xm = 7 - (c >> 1);
+    float *sl = st.slopes + (long long)e * sys.nslope;
+    if (!NOISE && !WRITE_CUBE) {
+      float sx_ = 0.f, sy_ = 0.f;
+#pragma unroll
+      for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+        for (int sx = 0; sx < 2; sx++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int Y = sy ? 7 - (2 * q + h) : 8 + 2 * q + h;
+            sx_ += v[sy][sx][h] * (float)(sx ? Xm : Xp);
+            sy_ += v[sy][sx][h] * (float)Y;
+          }
+      tot = wave_sum(owner ? tot : 0.f);
+      sx_ = wave_sum(owner ? sx_ : 0.f);
+      sy_ = wave_sum(owner ? sy_ : 0.f);
+      if (do_cog && lane == 0) {
+        const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+        sl[i] = tot > 0.f ? (sx_ * inv - sys.cog_offset) * sys.cog_scale : 0.f;
+        sl[sys.nvalid + i] = tot > 0.f ? (sy_ * inv - sys.cog_offset) * sys.cog_scale : 0.f;
+      }
+    } else {
+      tot = wave_sum(owner ? tot : 0.f);
+      const float g = tot > 0.f ? sys.nphot * flux_cur / tot : 0.f;
+      float s0 = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+      for (int ty_ = 0; ty_ < 2; ty_++)
+#pragma unroll
+        for (int tx_ = 0; tx_ < 2; tx_++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int Y = ty_ ? 7 - (2 * q + h) : 8 + 2 * q + h, X = tx_ ? Xm : Xp;
+            float val = v[ty_][tx_][h] * g;
+            if (NOISE) {
+              const uint32_t idx = (uint32_t)i * 256u + (uint32_t)(Y * 16 + X);
+              const uint32_t sd = st.seeds[e], fr = st.frame[e];
+              float u = philox_uniform(sd, 1u, fr, 0u, idx);
+              float zn = philox_normal(sd, 2u, fr, 0u, idx);
+              val = poisson_draw(val, u, zn);
+              if (sys.noise > 0.f) val += sys.noise * philox_normal(sd, 3u, fr, 0u, idx);
+            }
+            if (WRITE_CUBE && owner)
+              st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
+            s0 += val;
+            sx += val * (float)X;
+            sy += val * (float)Y;
+          }
+      if (do_cog) {
+        s0 = wave_sum(owner ? s0 : 0.f);
+        sx = wave_sum(owner ? sx : 0.f);
+        sy = wave_sum(owner ? sy : 0.f);
+        if (lane == 0) {
+          sl[i] = s0 != 0.f ? (sx / s0 - sys.cog_offset) * sys.cog_scale : 0.f;
+          sl[sys.nvalid + i] = s0 != 0.f ? (sy / s0 - sys.cog_offset) * sys.cog_scale : 0.f;
+        }
+      }
+    }
+    flux_cur = flux_next;
     __builtin_amdgcn_wave_barrier();
   }
 }

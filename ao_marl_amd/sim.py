@@ -34,6 +34,8 @@ class HipSim(object):
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.keep_bincube, self.keep_phase = keep_bincube, keep_phase
+        self.overlap_target = False
+        self._side = None
         self.ctx = C.c_void_p()
         self._create_ctx()
         self._alloc()
@@ -327,15 +329,40 @@ class HipSim(object):
                                              self._stream()))
         return out
 
-    def next_part_one(self, write_bincube=False, env_begin=0, env_count=None):
+    def next_part_one(self, write_bincube=False, env_begin=0, env_count=None, overlap=None):
+        """move_atmos -> {target trace + PSF  ||  WFS trace + image + COG -> do_control}.
+        The science path and the WFS path only read the screens and DM shapes, so with
+        `overlap` (default: self.overlap_target) the memory-bound PSF kernels run on a side HIP
+        stream next to the matrix-pipe-bound spot kernel and are joined before returning."""
         b, n = self._range(env_begin, env_count)
-        fl = 0
-        if write_bincube:
-            self._need_bincube()
-            fl |= la.IMG_WRITE_BINCUBE
-        la.check(self.lib.aomarl_next_part_one(self.ctx, C.byref(self.st), b, n,
-                                               la.fptr(self.accumx), la.fptr(self.accumy), fl,
-                                               self._stream()))
+        if overlap is None:
+            overlap = self.overlap_target
+        if not overlap:
+            fl = 0
+            if write_bincube:
+                self._need_bincube()
+                fl |= la.IMG_WRITE_BINCUBE
+            la.check(self.lib.aomarl_next_part_one(self.ctx, C.byref(self.st), b, n,
+                                                   la.fptr(self.accumx), la.fptr(self.accumy), fl,
+                                                   self._stream()))
+            return
+        self.move_atmos(b, n)
+        self.target_and_wfs(write_bincube=write_bincube, env_begin=b, env_count=n)
+        self.do_control(b, n)
+
+    def target_and_wfs(self, write_bincube=False, noise=True, cog=True, env_begin=0,
+                       env_count=None):
+        """target_psf on the side stream, comp_image on the current one, joined at the end."""
+        b, n = self._range(env_begin, env_count)
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self.target_psf(b, n)
+        self.comp_image(noise=noise, write_bincube=write_bincube, cog=cog, env_begin=b,
+                        env_count=n)
+        main.wait_stream(self._side)
 
     def next_part_two(self, action=None, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)

@@ -41,3 +41,6 @@ print("do_control        %.3f ms" % timeit(lambda: sim.do_control()))
 a = torch.zeros(nenv, nm, device="cuda")
 print("rl_control        %.3f ms" % timeit(lambda: sim.rl_control(a)))
 print("volts2modes       %.3f ms" % timeit(lambda: sim.volts2modes(sim.com)))
+
+print("target+wfs serial  %.3f ms" % timeit(lambda: (sim.target_psf(), sim.comp_image(noise=False, cog=True))))
+print("target||wfs        %.3f ms" % timeit(lambda: sim.target_and_wfs(noise=False)))
