@@ -50,7 +50,7 @@ struct aomarl_ctx {
   bool spot_fast = false;
   bool force_generic_dm = false, force_valu_target = false;
   int spot_blocks_per_env = 0, spot_lds_pad = 0;
-  bool force_generic_spot = false, force_generic_target = false;
+  bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
   // controller matrices
   float *cmat = nullptr;           // [nactu][ld_s]
   int ld_cmat = 0;
@@ -323,6 +323,53 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
   s.ref_peak = (float)(sp * sp);
   c->gain = d->gain; c->delay = d->delay;
   if (c->delay < 0.f || c->delay > 2.f) { aomarl_destroy(c); return fail("delay must be in [0, 2]"); }
+  // ---- fused frame kernel: the WFS tiles must BE the tiles of the pupil grid, at the same
+  // screen / DM pixels, the pupil must be binary
+  s.fused_ok = 0; s.ntiles = 0;
+  {
+    const int pd = d->pupdiam, pad = (d->n - pd) / 2;
+    bool ok = s.wfs_all_int && s.tar_all_int && d->ndm == 2 && d->dms[0].type == AOMARL_DM_PZT &&
+              d->dms[1].type == AOMARL_DM_TT && (d->nlayers == 1 || d->nlayers == 3) &&
+              d->strehl_halfwin == 8 && pd % 16 == 0 && pad >= 0 && d->n == pd + 2 * pad &&
+              (d->npsf & (d->npsf - 1)) == 0 && pd / 16 <= 256;
+    for (int l = 0; l < d->nlayers && ok; l++)
+      ok = s.layers[l].wox + pad == s.layers[l].tox && s.layers[l].woy + pad == s.layers[l].toy;
+    for (int k = 0; k < d->ndm && ok; k++)
+      ok = s.dms[k].wox + pad == s.dms[k].tox && s.dms[k].woy + pad == s.dms[k].toy;
+    for (int y = 0; y < pd && ok; y++)
+      for (int x = 0; x < pd && ok; x++) {
+        const float m = d->spupil[(size_t)y * pd + x];
+        ok = (m == 0.f || m == 1.f) && d->mpupil[(size_t)(y + pad) * d->n + x + pad] == m;
+      }
+    const int nt = pd / 16;
+    std::vector<int32_t> tsub((size_t)std::max(nt * nt, 1), -1);
+    std::vector<uint16_t> tmask((size_t)std::max(pd * nt, 1), 0);
+    if (ok) {
+      for (int y = 0; y < pd; y++)
+        for (int x = 0; x < pd; x++)
+          if (d->spupil[(size_t)y * pd + x] != 0.f) tmask[(size_t)y * nt + x / 16] |= (uint16_t)(1u << (x % 16));
+      for (int r = 0; r < nt; r++)
+        for (int t = 0; t < nt; t++) {
+          bool lit = false;
+          for (int yy = 0; yy < 16; yy++) lit = lit || tmask[(size_t)(16 * r + yy) * nt + t] != 0;
+          if (!lit) tsub[(size_t)r * nt + t] = -2;
+        }
+      for (int i = 0; i < d->nvalid && ok; i++) {
+        const int x0 = (sub[i] & 0xFFFF) - pad, y0 = (sub[i] >> 16) - pad;
+        ok = x0 >= 0 && y0 >= 0 && x0 % 16 == 0 && y0 % 16 == 0 && x0 < pd && y0 < pd;
+        if (ok) {
+          int32_t &cell = tsub[(size_t)(y0 / 16) * nt + x0 / 16];
+          ok = cell < 0;                 // one sub-aperture per tile (an unlit tile with a
+          cell = i;                      // sub-aperture is still imaged: zero flux, zero slopes)
+        }
+      }
+    }
+    if (ok) {
+      UP(int32_t, tsub.data(), tsub.size(), s.tile_sub);
+      UP(uint16_t, tmask.data(), tmask.size(), s.tile_mask);
+      s.fused_ok = 1; s.ntiles = nt;
+    }
+  }
 #undef UP
   *out = c;
   return 0;
@@ -677,6 +724,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
+  if (!strcmp(name, "force_unfused_frame")) { c->force_unfused_frame = value != 0; return 0; }
   if (!strcmp(name, "force_generic_spot")) { c->force_generic_spot = value != 0; return 0; }
   if (!strcmp(name, "force_generic_target")) { c->force_generic_target = value != 0; return 0; }
   return fail("set_option: unknown option %s", name);
@@ -928,13 +976,64 @@ int aomarl_comp_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stre
 }
 
 // ---------------------------------------------------------------- composites
+int aomarl_frame_fused_available(aomarl_ctx *c) {
+  return c && c->sys.fused_ok && !c->force_unfused_frame ? 1 : 0;
+}
+
+// science-path PSF (pending, like aomarl_target_psf) + WFS image / slopes (like aomarl_comp_image
+// without the NO_ATMOS / NO_DMS / FROM_PHASE_BUFFER variants) from one pass over the phase
+int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!c->sys.fused_ok) return fail("frame_fused: geometry not eligible (see aomarl_frame_fused_available)");
+  if (flags & (AOMARL_IMG_FROM_PHASE_BUFFER | AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS))
+    return fail("frame_fused: FROM_PHASE_BUFFER / NO_ATMOS / NO_DMS are not supported here");
+  const bool noise = (flags & AOMARL_IMG_NOISE) && c->sys.noise >= 0.f;
+  const bool cube = flags & AOMARL_IMG_WRITE_BINCUBE;
+  const int cog = (flags & AOMARL_IMG_COG) ? 1 : 0;
+  if (cube && !st->bincube) return fail("frame_fused: WRITE_BINCUBE needs st->bincube");
+  if (!cube && !cog) return fail("frame_fused: nothing to produce (neither bincube nor slopes)");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  Work w = work_layout(c, st->nenv);
+  const int W = 2 * c->sys.hw;
+  float *TR = st->work + w.TR + (size_t)b * c->sys.pupdiam * W * 2;
+  float *TP = st->work + w.TPART + (size_t)b * w.nblk * 4;
+  float *PEND = st->work + w.PEND + (size_t)b * (W * W + 4);
+  DevState ds = dev_state(st);
+  if (w.nblk != c->sys.ntiles) return fail("frame_fused: internal stripe count mismatch");
+  const size_t smm = sizeof(float) * (4 * 2 * 2 * 16 * 17 + 2 * 128) +
+                     (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
+  dim3 grid(c->sys.ntiles, n), blk(256);
+#define FUSED(NL, NZ, WC) hipLaunchKernelGGL((k_frame_fused<NL, NZ, WC>), grid, blk, smm, s, c->sys, ds, b, cog, TR, TP, w.nblk)
+  if (c->nlayers == 1) {
+    if (noise) { if (cube) FUSED(1, true, true); else FUSED(1, true, false); }
+    else { if (cube) FUSED(1, false, true); else FUSED(1, false, false); }
+  } else {
+    if (noise) { if (cube) FUSED(3, true, true); else FUSED(3, true, false); }
+    else { if (cube) FUSED(3, false, true); else FUSED(3, false, false); }
+  }
+#undef FUSED
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_inc_u32, dim3((n + 255) / 256), dim3(256), 0, s, st->frame + b, n);
+  LAUNCHCHK();
+  return 0;
+}
+
 int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
                          int image_flags, void *stream) {
   int rc = aomarl_move_atmos(c, st, b, n, accumx, accumy, stream);
   if (rc) return rc;
+  int fl = (image_flags | AOMARL_IMG_COG | AOMARL_IMG_NOISE) & ~(AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS);
+  if (aomarl_frame_fused_available(c) && !(fl & AOMARL_IMG_FROM_PHASE_BUFFER)) {
+    rc = aomarl_frame_fused(c, st, b, n, fl, stream);
+    if (rc) return rc;
+    return aomarl_do_control(c, st, b, n, stream);
+  }
   rc = aomarl_target_psf(c, st, b, n, stream);
   if (rc) return rc;
-  int fl = (image_flags | AOMARL_IMG_COG | AOMARL_IMG_NOISE) & ~(AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS);
   if (!c->sys.wfs_all_int) {
     rc = aomarl_raytrace_wfs(c, st, b, n, AOMARL_TRACE_ATMOS | AOMARL_TRACE_DMS | AOMARL_TRACE_RESET, stream);
     if (rc) return rc;

@@ -57,6 +57,11 @@ struct DevSys {
   int nactu, nslope;
   int wfs_all_int, tar_all_int;  // every offset of that path is an integer
   long long screen_stride, shape_stride;
+  // ---- fused frame kernel (WFS + science path share every phase pixel: the 16x16 sub-aperture
+  // tiles ARE the tiles of the pupil grid): available when the geometry lines up (see create)
+  int fused_ok, ntiles;          // ntiles = pupdiam / 16 tiles per axis
+  const int32_t *tile_sub;       // [ntiles][ntiles] (stripe, tile) -> sub-aperture index or -1
+  const uint16_t *tile_mask;     // [pupdiam][ntiles]: bit b = spupil[y][16 t + b] != 0
 };
 
 struct DevState {

@@ -793,7 +793,6 @@ __global__ __launch_bounds__(256) void k_wfs_spot(DevSys sys, DevState st, int e
     Cc[s] = w.x; Ss[s] = w.y;
   }
   const int ty = lane >> 2, tx0 = (lane & 3) * 4;
-  const bool owner = (c & 1) == 0;
 
   float ph[4], mk[4];
   spot_load<FROM_BUF>(sys, st, e, i, lane, no_atmos, no_dms, ph, mk);
@@ -1095,6 +1094,208 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
     }
     flux_cur = flux_next;
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// =============================================================================================
+// FUSED FRAME KERNEL: WFS spot images + COG  and  science-path PSF rows from ONE pass over the
+// phase.  The sub-aperture tiles (16 x 16 phase pixels starting at 2 + 16 k of the WFS grid) are
+// exactly the 16 x 16 tiles of the pupil grid the target sees, at the same screen / DM pixels, so
+// a block that owns one stripe of 16 pupil rows reads every phase pixel once and feeds both
+// paths: per tile 48 MFMAs (pruned spot DFT) if it is a valid sub-aperture + 16 MFMAs (PSF row
+// DFT).  The pupil mask comes as 16-bit rows and tiles outside the pupil are skipped: HBM traffic
+// per environment drops from (layers + stack array) planes x 2 passes to the lit part once.
+// Block = 4 waves; wave w owns tiles w, w+4, ... of the stripe; PSF partial rows are reduced
+// across the waves at the end.  Layout: NL layers, DMs = [stack array, tip-tilt].
+// =============================================================================================
+template <int NL>
+struct FrameRaw {
+  float L[NL][4];
+  float P[4], T[8];
+  unsigned mrow;      // 16-bit mask row of the tile (this lane's row)
+  float F;
+};
+
+template <int NL, bool NOISE, bool WRITE_CUBE>
+__global__ __launch_bounds__(256) void k_frame_fused(DevSys sys, DevState st, int env_begin,
+                                                     int do_cog, float *__restrict__ TR,
+                                                     float *__restrict__ TPART, int nblk) {
+  extern __shared__ float smem[];
+  // per wave: one WFS amplitude tile and one target amplitude tile (re, im).  Each wave only ever
+  // touches its own tiles, LDS operations of a wave complete in order, so a single buffer and
+  // wave-level barriers are enough; the cross-wave reduction buffer aliases the tiles.
+  typedef float Tile[16][17];
+  Tile *sW = reinterpret_cast<Tile *>(smem);                 // [4 waves][2 re/im]
+  Tile *sT = sW + 4 * 2;                                     // [4 waves][2 re/im]
+  float *red = smem;                                         // [4][2][256] (after the tile loop)
+  float2 *sTw = reinterpret_cast<float2 *>(smem + 4 * 2 * 2 * 16 * 17);   // [128] WFS twiddles
+  float2 *stw = sTw + 128;                                   // [npsf] PSF twiddles (if it fits)
+  const int pd = sys.pupdiam, np = sys.npsf, ntl = sys.ntiles;
+  const bool tw_lds = np <= 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, c = lane & 15;
+  const int e = env_begin + blockIdx.y;
+  const int r = blockIdx.x;                                  // stripe: pupil rows 16 r .. 16 r + 15
+  if (tid < 128) {
+    float sn, cs;
+    sincospif((float)tid * (1.0f / 64.0f), &sn, &cs);
+    sTw[tid] = make_float2(cs, sn);
+  }
+  const float2 *gtw = reinterpret_cast<const float2 *>(sys.psf_tw);
+  if (tw_lds)
+    for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
+  const float2 *tw = tw_lds ? stw : gtw;
+  __syncthreads();
+  float Cc[4], Ss[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const float2 w = sTw[((4 * q + s) * (2 * c + 1)) & 127];
+    Cc[s] = w.x; Ss[s] = w.y;
+  }
+  const int ty = lane >> 2, tx0 = (lane & 3) * 4;
+  const int y = 16 * r + ty;                                 // pupil row of this lane
+  // ---- per-environment constants (target-path offsets; the WFS sees the same pixels)
+  const float *lay[NL];
+  unsigned lpx[NL], lpy[NL], ldim[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const DevLayer &L = sys.layers[l];
+    lay[l] = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+    ldim[l] = (unsigned)L.dim;
+    int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
+    int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
+    lpx[l] = (unsigned)px; lpy[l] = (unsigned)py;
+  }
+  const DevDm &D0 = sys.dms[0], &D1 = sys.dms[1];
+  const float *pzt = st.dm_shape + (long long)e * sys.shape_stride + D0.shape_off;
+  const float *ttslot = st.dm_shape + (long long)e * sys.shape_stride + D1.shape_off;
+  const float c0 = ttslot[0], c1 = ttslot[1];
+  const int half = pd / 2;
+  // row offsets of this lane (the stripe row is fixed)
+  unsigned lrow[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    unsigned py = (unsigned)y + lpy[l]; py = min(py, py - ldim[l]);
+    lrow[l] = py * (ldim[l] + RING_PAD);
+  }
+  const unsigned prow = (unsigned)(y + D0.toy) * (unsigned)D0.dim + (unsigned)D0.tox;
+  const unsigned trow = 2u * ((unsigned)(y + D1.toy) * (unsigned)D1.dim + (unsigned)D1.tox);
+  const uint16_t *mrowp = sys.tile_mask + (long long)y * ntl;
+  // pivot of the variance sums: phase at the grid centre
+  float pivot;
+  {
+    float v = pzt[(half + D0.toy) * D0.dim + half + D0.tox];
+    const float2 f = reinterpret_cast<const float2 *>(D1.influ)[(half + D1.toy) * D1.dim + half + D1.tox];
+    v += c0 * f.x + c1 * f.y;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      unsigned py = (unsigned)half + lpy[l]; py = min(py, py - ldim[l]);
+      unsigned px = (unsigned)half + lpx[l]; px = min(px, px - ldim[l]);
+      v += lay[l][py * (ldim[l] + RING_PAD) + px];
+    }
+    pivot = v;
+  }
+  const int *tsub = sys.tile_sub + r * ntl;
+  const float wfs_il = sys.wfs_inv_lambda, tar_il = sys.tar_inv_lambda;
+  FrameRaw<NL> raw;
+  // tile_sub: >= 0 valid sub-aperture, -1 lit tile without sub-aperture, -2 tile outside the pupil
+  auto fetch = [&](int t, int sub) {
+    if (sub == -2) return;                                   // wave-uniform
+    const unsigned x = (unsigned)(16 * t + tx0);
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      unsigned px = x + lpx[l]; px = min(px, px - ldim[l]);
+      const f4u v4 = *reinterpret_cast<const f4u *>(lay[l] + (lrow[l] + px));
+#pragma unroll
+      for (int j = 0; j < 4; j++) raw.L[l][j] = v4.v[j];
+    }
+    const f4u p4 = *reinterpret_cast<const f4u *>(pzt + (prow + x));
+#pragma unroll
+    for (int j = 0; j < 4; j++) raw.P[j] = p4.v[j];
+    const f4u t0 = *reinterpret_cast<const f4u *>(D1.influ + (trow + 2u * x));
+    const f4u t1 = *reinterpret_cast<const f4u *>(D1.influ + (trow + 2u * x + 4u));
+#pragma unroll
+    for (int j = 0; j < 4; j++) { raw.T[j] = t0.v[j]; raw.T[4 + j] = t1.v[j]; }
+    raw.mrow = mrowp[t];
+    raw.F = sub >= 0 ? sys.flux[sub] : 0.f;
+  };
+  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  float sd = 0.f, sd2 = 0.f, sm = 0.f;
+  const int kxf = c - 8;
+  Tile &Wr = sW[wv * 2], &Wi = sW[wv * 2 + 1];
+  Tile &Ar = sT[wv * 2], &Ai = sT[wv * 2 + 1];
+  int sub = wv < ntl ? tsub[wv] : -2;
+  fetch(wv, sub);
+  for (int t = wv; t < ntl; t += 4) {
+    const int tn = t + 4;
+    const int subn = tn < ntl ? tsub[tn] : -2;
+    if (sub != -2) {
+      const float flux_i = raw.F;
+      // ---- phase of the 4 pixels, both complex amplitudes -> LDS
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float ph = raw.P[j] + (c0 * raw.T[2 * j] + c1 * raw.T[2 * j + 1]);
+#pragma unroll
+        for (int l = 0; l < NL; l++) ph += raw.L[l][j];
+        const bool m = (raw.mrow >> (tx0 + j)) & 1u;
+        float a_ = ph * wfs_il; a_ -= rintf(a_);
+        float b_ = ph * tar_il; b_ -= rintf(b_);
+        Wr[ty][tx0 + j] = m ? __builtin_amdgcn_cosf(a_) : 0.f;
+        Wi[ty][tx0 + j] = m ? __builtin_amdgcn_sinf(a_) : 0.f;
+        Ar[ty][tx0 + j] = m ? __builtin_amdgcn_cosf(b_) : 0.f;
+        Ai[ty][tx0 + j] = m ? __builtin_amdgcn_sinf(b_) : 0.f;
+        const float d = m ? ph - pivot : 0.f;
+        sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
+      }
+      fetch(tn, subn);                                       // next tile's loads fly during the MFMAs
+      __builtin_amdgcn_wave_barrier();
+      // ---- science path: R[y][kx] += sum_{x in tile} a(y, x) exp(-2 pi i kx x / Npsf)
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int xl = 4 * s + q;
+        const float ar = Ar[c][xl], ai = Ai[c][xl];
+        const float2 w = tw[(kxf * (16 * t + xl)) & (np - 1)];
+        Rr = mfma16(ar, w.x, Rr);
+        Ri = mfma16(ai, w.x, Ri);
+        Rr = mfma16(ai, w.y, Rr);
+        Ri = mfma16(ar, -w.y, Ri);
+      }
+      // ---- WFS path (valid sub-apertures only; wave-uniform branch)
+      if (sub >= 0)
+        spot_compute<NOISE, WRITE_CUBE>(sys, st, e, sub, lane, 0, Cc, Ss, &Wr, &Wi, do_cog, flux_i);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      fetch(tn, subn);
+    }
+    sub = subn;
+  }
+  __syncthreads();
+  // ---- cross-wave reduction of the PSF rows; acc reg j of lane (q, c): y = 4q + j, kx = c
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    red[(wv * 2 + 0) * 256 + (4 * q + j) * 16 + c] = Rr[j];
+    red[(wv * 2 + 1) * 256 + (4 * q + j) * 16 + c] = Ri[j];
+  }
+  __syncthreads();
+  {
+    const int yy = tid >> 4, kx = tid & 15;
+    float vr = 0.f, vi = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; w4++) { vr += red[(w4 * 2) * 256 + tid]; vi += red[(w4 * 2 + 1) * 256 + tid]; }
+    float *o = TR + (((long long)blockIdx.y * pd + (16 * r + yy)) * 16 + kx) * 2;
+    o[0] = vr; o[1] = vi;
+  }
+  __syncthreads();
+  red[tid] = sd; red[256 + tid] = sd2; red[512 + tid] = sm;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+      red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; red[512 + tid] += red[512 + tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float *pp = TPART + ((long long)blockIdx.y * nblk + blockIdx.x) * 4;
+    pp[0] = red[0]; pp[1] = red[256]; pp[2] = red[512]; pp[3] = 0.f;
   }
 }
 

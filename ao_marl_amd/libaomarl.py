@@ -97,6 +97,8 @@ SYMBOLS = [
     ("aomarl_get_dm_shape", _i, _range + [_i, _vp, _vp]),
     ("aomarl_set_option", _i, [_vp, C.c_char_p, _i]),
     ("aomarl_target_psf", _i, _range + [_vp]),
+    ("aomarl_frame_fused_available", _i, [_vp]),
+    ("aomarl_frame_fused", _i, _range + [_i, _vp]),
     ("aomarl_comp_strehl", _i, _range + [_vp]),
     ("aomarl_reset_strehl", _i, _range + [_vp]),
     ("aomarl_volts2modes", _i, [_vp, C.POINTER(State), _i, _vp, _i, _vp, _vp]),

@@ -311,6 +311,22 @@ class HipSim(object):
             self._need_phase()
         la.check(self.lib.aomarl_target_psf(self.ctx, C.byref(self.st), b, n, self._stream()))
 
+    def frame_fused_available(self):
+        return bool(self.lib.aomarl_frame_fused_available(self.ctx))
+
+    def frame_fused(self, noise=True, write_bincube=False, cog=True, env_begin=0, env_count=None):
+        """target_psf + comp_image from one pass over the phase (aomarl_frame_fused)."""
+        b, n = self._range(env_begin, env_count)
+        fl = 0
+        if noise:
+            fl |= la.IMG_NOISE
+        if write_bincube:
+            self._need_bincube()
+            fl |= la.IMG_WRITE_BINCUBE
+        if cog:
+            fl |= la.IMG_COG
+        la.check(self.lib.aomarl_frame_fused(self.ctx, C.byref(self.st), b, n, fl, self._stream()))
+
     def comp_strehl(self, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         la.check(self.lib.aomarl_comp_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))

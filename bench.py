@@ -49,7 +49,15 @@ def stage_models(s, nenv, nmodes, nact):
               work=nenv * (s.nactu * 4.0 + shape_px * 4.0))
     tgt = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                work=nenv * ((nl + len(s.dms)) * p2 * 4.0))
-    return {"wfs_spot_cog": spot, "dm_shape": dm, "target_psf": tgt}
+    # one-pass frame kernel: every lit 16x16 tile of the pupil grid is read once (layers + stack
+    # array) and feeds the spot DFT (valid sub-apertures) and the 16-column PSF row DFT (16 kx x
+    # 256 pixels x 8 flop); the tip-tilt planes and the mask are shared by all environments
+    lit = int((s.spupil.reshape(s.pupdiam // 16, 16, s.pupdiam // 16, 16).sum(axis=(1, 3)) > 0).sum()) \
+        if s.pupdiam % 16 == 0 else 0
+    fused = dict(bound="mfma", unit="TFLOP/s", peak=FP32_MFMA_PEAK_TF,
+                 work=nenv * (s.nvalid * float(fft_flops + 256 * 20) + lit * 256 * 16 * 8.0),
+                 bytes=nenv * (lit * (nl + 1) * 1024.0 + s.nvalid * 8.0 + s.pupdiam * 16 * 8.0))
+    return {"wfs_spot_cog": spot, "dm_shape": dm, "target_psf": tgt, "frame_fused": fused}
 
 
 class StageTimer(object):
@@ -121,6 +129,10 @@ def main():
     ap.add_argument("--envs", type=int, default=256, help="environments per GPU")
     ap.add_argument("--config", default=WORKLOAD)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="separate science / WFS passes instead of the one-pass frame kernel")
+    ap.add_argument("--pmc", default="r01d_pmc_counters_256env.json",
+                    help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,16 +171,22 @@ def main():
     env.supervisor.next_part_one_split = True
     orig_np1 = env.supervisor.next_part_one
 
+    fused = sim.frame_fused_available() and not args.unfused
+
     def split_part_one(move_atmos=True, do_control=True):
         sim.move_atmos()
-        sim.target_psf()
-        sim.comp_image(noise=True, cog=True)
+        if fused:
+            sim.frame_fused(noise=True, cog=True)
+        else:
+            sim.target_psf()
+            sim.comp_image(noise=True, cog=True)
         sim.do_control()
         env.supervisor.iter += 1
 
     env.supervisor.next_part_one = split_part_one
     for name, label in (("move_atmos", "move_atmos"), ("target_psf", "target_psf"),
-                        ("comp_image", "wfs_spot_cog"), ("do_control", "do_control"),
+                        ("comp_image", "wfs_spot_cog"), ("frame_fused", "frame_fused"),
+                        ("do_control", "do_control"),
                         ("rl_control", "rl_control"), ("apply_control", "dm_shape"),
                         ("comp_strehl", "strehl_commit")):
         timer.wrap(sim, name, label)
@@ -212,7 +230,7 @@ def main():
         # MI355X_MICROARCH.md), measured off-line at 256 envs and scaled to this batch
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_counters_256env.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", args.pmc)))
             if dom in pmc and args.config == WORKLOAD:
                 traffic = pmc[dom]["hbm_traffic_bytes_per_launch"] * args.envs / pmc["_envs"]
         except Exception:
@@ -220,8 +238,9 @@ def main():
         roof = {"kernel": dom, "bound": m["bound"], "achieved": achieved, "peak": m["peak"],
                 "unit": m["unit"], "frac": achieved / m["peak"], "traffic": traffic,
                 "avg_launch_ms": ms}
-        spot_ms = stage_ms["wfs_spot_cog"]
-        sp = models["wfs_spot_cog"]
+        img = "frame_fused" if "frame_fused" in stage_ms else "wfs_spot_cog"
+        spot_ms = stage_ms[img]
+        sp = models[img]
         out = {
             "metric": "env steps/sec (AO frames/sec)", "value": args.envs * world * args.steps / elapsed,
             "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,7 +251,7 @@ def main():
                        layout.state_shapes()[-1:], "action_dim": layout.action_dim,
                        "parallelism": "independent env shards x%d" % world},
             "roofline": roof,
-            "spot_kernel": {"avg_launch_ms": spot_ms,
+            "image_kernel": {"kernel": img, "avg_launch_ms": spot_ms,
                             "algorithmic_tflops": sp["work"] / (spot_ms * 1e-3) * 1e-12,
                             "frac_fp32_mfma_peak": sp["work"] / (spot_ms * 1e-3) * 1e-12 / FP32_MFMA_PEAK_TF,
                             "algorithmic_gbs": sp["bytes"] / (spot_ms * 1e-3) * 1e-9,

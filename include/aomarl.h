@@ -197,12 +197,25 @@ int aomarl_comp_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int e
 int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int k,
                         float *dst, void *stream);
 /* implementation switches for tests / A-B measurements: "force_generic_dm" (per-pixel gather
- * tables instead of the separable-lattice kernel), "force_valu_target" (VALU PSF rows kernel) */
+ * tables instead of the separable-lattice kernel), "force_valu_target" (VALU PSF rows kernel),
+ * "force_generic_spot" / "force_generic_target" (layout-agnostic kernels), "force_unfused_frame"
+ * (separate target and WFS passes in aomarl_next_part_one) */
 int aomarl_set_option(aomarl_ctx *ctx, const char *name, int value);
 /* fused target raytrace + PSF window + phase variance into a pending slot
  * (RlSupervisor.raytrace_target, rlSupervisor.py:845-855) */
 int aomarl_target_psf(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                       void *stream);
+/* aomarl_target_psf + aomarl_comp_image in ONE pass over the phase (the two halves of
+ * RlSupervisor.next_part_one between move_atmos and do_control, rlSupervisor.py:829-843): the
+ * sub-aperture tiles of the WFS are the 16 x 16 tiles of the pupil grid the target sees, so every
+ * screen / DM pixel is read once and feeds both paths.  Needs the geometry to line up (WFS grid =
+ * pupil grid + symmetric guard band, same integer offsets, binary pupil, DMs = [stack array,
+ * tip-tilt]): aomarl_frame_fused_available() says whether it does
+ * (and "force_unfused_frame" was not set).  flags as aomarl_comp_image minus FROM_PHASE_BUFFER /
+ * NO_ATMOS / NO_DMS.  aomarl_next_part_one uses it automatically when available. */
+int aomarl_frame_fused_available(aomarl_ctx *ctx);
+int aomarl_frame_fused(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int flags,
+                       void *stream);
 /* Target.comp_image + comp_strehl (targetCompass.py:193,205): publish the pending PSF */
 int aomarl_comp_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                        void *stream);

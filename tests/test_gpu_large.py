@@ -53,11 +53,15 @@ def _push(sim, oracles):
             sim.t["ext_count"][e, l] = o.ext_count[l]
 
 
-def test_large_frames_match_oracle(large):
+@pytest.mark.parametrize("unfused", [0, 1])
+def test_large_frames_match_oracle(large, unfused):
+    """unfused=0: one-pass frame kernel (science + WFS from the same tiles); 1: separate passes."""
     from ao_marl_amd.sim import HipSim
     _, s, cal = large
     seeds = [1234, 4321]
     sim = HipSim(s, nenv=2, keep_bincube=True)
+    assert sim.frame_fused_available()
+    sim.set_option("force_unfused_frame", unfused)
     sim.set_modal(cal.volts2modes, cal.modes2volts)
     sim.reset(seeds)                       # exercises the full 1296-round reset on the GPU
     assert sim.screen(0).std().item() > 0.05
@@ -97,7 +101,7 @@ def test_noisy_wfs_matches_oracle():
     the oracle; photon counts are integers, so all but a handful of pixels agree exactly."""
     from ao_marl_amd.sim import HipSim
     sysm = G.build_system(params.builtin("production_sh_40x40_8m_3layers_d0_noise"))
-    s = system.from_system(sysm)
+    s = system.from_system(sysm, strehl_halfwin=8)
     assert s.noise == 3.0 and s.delay == 0.0 and abs(float(s.nphot) - 241.141) < 1e-2
     s.cmat = np.zeros((s.nactu + 0, s.nslope), dtype=np.float32)
     # no calibration needed: compare the raw image formation on an un-filtered system
@@ -106,8 +110,12 @@ def test_noisy_wfs_matches_oracle():
     sim.reset([7, 8])
     sim.t["seeds"].copy_(torch.tensor([7, 8], dtype=torch.int32))
     _push(sim, oracles)
+    assert sim.frame_fused_available()
     for frame in range(2):
-        sim.comp_image(noise=True, write_bincube=True, cog=True)
+        if frame == 0:
+            sim.comp_image(noise=True, write_bincube=True, cog=True)
+        else:                                  # same noise streams through the one-pass kernel
+            sim.frame_fused(noise=True, write_bincube=True, cog=True)
         cube = sim.t["bincube"].cpu().numpy()
         sl = sim.slopes.cpu().numpy()
         for e, o in enumerate(oracles):

@@ -245,9 +245,54 @@ def test_target_psf_and_strehl_match_oracle(setup, valu):
     sim.set_option("force_generic_target", 0)
 
 
-def test_closed_loop_trace_matches_oracle(setup):
-    """40 frames of the integrator loop (next_part_two + next_part_one) from a common state."""
+def test_fused_frame_matches_oracle_and_unfused(setup):
+    """One-pass frame kernel (science PSF rows + WFS spots from the same phase tiles) vs the
+    oracle and vs the separate target / WFS kernels, with and without the bincube."""
     _, s, _, sim, oracles = setup
+    assert sim.frame_fused_available()
+    _push_oracle_state(sim, oracles)
+    rng = np.random.default_rng(11)
+    volts = rng.normal(0, 0.4, size=(len(oracles), s.nactu)).astype(np.float32)
+    volts[:, -2:] = rng.normal(0, 0.05, size=(len(oracles), 2))      # tip-tilt: analytic planes
+    sim.comp_dm_shape(torch.from_numpy(volts).cuda())
+    out = {}
+    for mode in ("unfused", "fused_cube", "fused"):
+        sim.reset_strehl()
+        if mode == "unfused":
+            sim.target_psf()
+            sim.comp_image(noise=False, write_bincube=True, cog=True)
+        else:
+            sim.t["bincube"].zero_()
+            sim.slopes.zero_()
+            sim.frame_fused(noise=False, write_bincube=(mode == "fused_cube"), cog=True)
+        sim.comp_strehl()
+        out[mode] = (sim.slopes.cpu().numpy().copy(), sim.strehl.cpu().numpy().copy(),
+                     sim.t["bincube"].cpu().numpy().copy())
+    for e, o in enumerate(oracles):
+        o.comp_shapes(volts[e])
+        o.reset_strehl()
+        o.raytrace_target()
+        want = o.comp_strehl()
+        o.raytrace_wfs(atm=True, dms=True, reset=True)
+        o.comp_image(noise=False)
+        o.do_centroids()
+        for mode in ("fused_cube", "fused"):
+            sl, st, cube = out[mode]
+            assert np.abs(sl[e] - o.slopes).max() < 2e-5, mode
+            assert np.abs(sl[e] - out["unfused"][0][e]).max() < 2e-5, mode
+            assert abs(st[e, 0] - want[0]) < 2e-5 * max(want[0], 1e-3) + 1e-7, mode
+            assert abs(st[e, 2] - want[2]) < 1e-4 * want[2] + 1e-9, mode
+        cube = out["fused_cube"][2]
+        assert np.abs(cube[e] - o.bincube).max() < 2e-5 * o.bincube.max()
+        assert np.array_equal(cube[e].argmax(axis=1), o.bincube.argmax(axis=1))
+
+
+@pytest.mark.parametrize("unfused", [0, 1])
+def test_closed_loop_trace_matches_oracle(setup, unfused):
+    """40 frames of the integrator loop (next_part_two + next_part_one) from a common state, with
+    the one-pass frame kernel (0) and with separate target / WFS passes (1)."""
+    _, s, _, sim, oracles = setup
+    sim.set_option("force_unfused_frame", unfused)
     sim.reset(SEEDS)
     for o, sd in zip(oracles, SEEDS):
         o.reset(sd)
@@ -270,6 +315,7 @@ def test_closed_loop_trace_matches_oracle(setup):
             assert np.abs(cm[e] - o.com).max() < 5e-5 * np.abs(o.com).max() + 1e-3, it
             assert abs(st[e, 0] - o.strehl_se) < 1e-4, it
             assert abs(st[e, 1] - o.strehl_le) < 1e-4, it
+    sim.set_option("force_unfused_frame", 0)
     assert sim.strehl[:, 0].min().item() > 0.3   # the loop closed
     print("worst slope deviation over the trace: %.3g arcsec" % worst)
 

@@ -22,25 +22,19 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-print("spot default     %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True)))
-for g in (4, 8, 16, 32, 64, 150, 300):
-    sim.set_option("spot_blocks_per_env", g)
-    print("spot gx=%-4d      %.3f ms" % (g, timeit(lambda: sim.comp_image(noise=False, cog=True))))
-sim.set_option("spot_blocks_per_env", 0)
-for pad in (0, 30000, 45000, 70000, 140000):
-    sim.set_option("spot_lds_pad", pad)
-    print("spot lds_pad=%-6d %.3f ms" % (pad, timeit(lambda: sim.comp_image(noise=False, cog=True))))
-sim.set_option("spot_lds_pad", 0)
-print("spot no_atmos     %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True, atm=False)))
-print("spot no_dms       %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True, dms=False)))
-print("spot none         %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True, atm=False, dms=False)))
+print("spot              %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True)))
+print("spot noise        %.3f ms" % timeit(lambda: sim.comp_image(noise=True, cog=True)))
 print("target_psf        %.3f ms" % timeit(lambda: sim.target_psf()))
+print("frame_fused       %.3f ms" % timeit(lambda: sim.frame_fused(noise=False, cog=True)))
+print("frame_fused noise %.3f ms" % timeit(lambda: sim.frame_fused(noise=True, cog=True)))
 print("dm_shape          %.3f ms" % timeit(lambda: sim.comp_dm_shape()))
 print("move_atmos        %.3f ms" % timeit(lambda: sim.move_atmos()))
 print("do_control        %.3f ms" % timeit(lambda: sim.do_control()))
 a = torch.zeros(nenv, nm, device="cuda")
 print("rl_control        %.3f ms" % timeit(lambda: sim.rl_control(a)))
 print("volts2modes       %.3f ms" % timeit(lambda: sim.volts2modes(sim.com)))
-
-print("target+wfs serial  %.3f ms" % timeit(lambda: (sim.target_psf(), sim.comp_image(noise=False, cog=True))))
-print("target||wfs        %.3f ms" % timeit(lambda: sim.target_and_wfs(noise=False)))
+print("part_one fused    %.3f ms" % timeit(lambda: sim.next_part_one()))
+sim.set_option("force_unfused_frame", 1)
+print("part_one unfused  %.3f ms" % timeit(lambda: sim.next_part_one()))
+sim.set_option("force_unfused_frame", 0)
+print("part_two          %.3f ms" % timeit(lambda: sim.next_part_two(None)))
