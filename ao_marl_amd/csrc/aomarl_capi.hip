@@ -51,6 +51,8 @@ struct aomarl_ctx {
   bool force_generic_dm = false, force_valu_target = false;
   int spot_blocks_per_env = 0, spot_lds_pad = 0;
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
+  bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
+  int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
   // controller matrices
   float *cmat = nullptr;           // [nactu][ld_s]
   int ld_cmat = 0;
@@ -331,7 +333,7 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
     bool ok = s.wfs_all_int && s.tar_all_int && d->ndm == 2 && d->dms[0].type == AOMARL_DM_PZT &&
               d->dms[1].type == AOMARL_DM_TT && (d->nlayers == 1 || d->nlayers == 3) &&
               d->strehl_halfwin == 8 && pd % 16 == 0 && pad >= 0 && d->n == pd + 2 * pad &&
-              (d->npsf & (d->npsf - 1)) == 0 && pd / 16 <= 256;
+              (d->npsf & (d->npsf - 1)) == 0 && d->npsf <= 4096 && pd / 16 <= 256;
     for (int l = 0; l < d->nlayers && ok; l++)
       ok = s.layers[l].wox + pad == s.layers[l].tox && s.layers[l].woy + pad == s.layers[l].toy;
     for (int k = 0; k < d->ndm && ok; k++)
@@ -368,6 +370,22 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
       UP(int32_t, tsub.data(), tsub.size(), s.tile_sub);
       UP(uint16_t, tmask.data(), tmask.size(), s.tile_mask);
       s.fused_ok = 1; s.ntiles = nt;
+      // stack-array DM evaluated from the command lattice inside the frame kernel
+      const DevDm &Z = s.dms[0];
+      s.otf_ok = 0;
+      if (Z.sep && Z.pitch > 0 && 16 % Z.pitch == 0) {
+        auto first = [&](int p0, int pmin) {
+          const int num = p0 - pmin - (Z.ss - 1);
+          return num >= 0 ? (num + Z.pitch - 1) / Z.pitch : -((-num) / Z.pitch);
+        };
+        s.otf_gx0 = first(Z.tox, Z.i1min); s.otf_gy0 = first(Z.toy, Z.j1min);
+        s.otf_xoff = Z.tox - (Z.i1min + Z.pitch * s.otf_gx0);
+        s.otf_yoff = Z.toy - (Z.j1min + Z.pitch * s.otf_gy0);
+        const int cnt = std::max((s.otf_xoff + 15) / Z.pitch + 1, (s.otf_yoff + 15) / Z.pitch + 1);
+        s.otf_nb = (cnt + 3) / 4; s.otf_tpn = 16 / Z.pitch;
+        s.otf_latw = (nt - 1) * s.otf_tpn + 4 * s.otf_nb;
+        s.otf_ok = (s.otf_nb >= 1 && s.otf_nb <= 2 && s.otf_xoff >= 0 && s.otf_yoff >= 0) ? 1 : 0;
+      }
     }
   }
 #undef UP
@@ -686,10 +704,10 @@ int aomarl_get_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, 
 }
 
 // ---------------------------------------------------------------- DMs
-int aomarl_comp_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *volts, void *stream) {
-  int rc = check_range(c, st, b, n);
-  if (rc) return rc;
-  if (n == 0) return 0;
+// skip_stack: leave the stack-array planes alone (their phase will be evaluated from st->voltage
+// inside the one-pass frame kernel); the tip-tilt slot (commands + pivot) is always refreshed
+static int dm_shape_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *volts,
+                         bool skip_stack, void *stream) {
   const float *v = volts ? volts : st->voltage + (size_t)b * st->ld_actu;
   const int ldv = volts ? c->sys.nactu : st->ld_actu;
   DevState ds = dev_state(st);
@@ -698,6 +716,8 @@ int aomarl_comp_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, const fl
     const int np = D.dim * D.dim;
     if (D.type == AOMARL_DM_TT)
       hipLaunchKernelGGL(k_dm_shape, dim3(1, n), dim3(64), 0, (hipStream_t)stream, c->sys, ds, b, k, v, ldv);
+    else if (skip_stack)
+      continue;
     else if (D.sep && !c->force_generic_dm)
       hipLaunchKernelGGL(k_dm_shape_sep, dim3((D.dim + DMS_TX - 1) / DMS_TX, (D.dim + DMS_TY - 1) / DMS_TY, n),
                          dim3(256), 0, (hipStream_t)stream, c->sys, ds, b, k, v, ldv);
@@ -706,6 +726,17 @@ int aomarl_comp_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, const fl
     LAUNCHCHK();
   }
   return 0;
+}
+
+int aomarl_comp_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *volts, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  return dm_shape_impl(c, st, b, n, volts, false, stream);
+}
+
+int aomarl_dm_from_voltage_available(aomarl_ctx *c) {
+  return c && c->sys.fused_ok && c->sys.otf_ok && !c->force_unfused_frame ? 1 : 0;
 }
 
 int aomarl_get_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, int k, float *dst, void *stream) {
@@ -724,6 +755,8 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
+  if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
+  if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
   if (!strcmp(name, "force_unfused_frame")) { c->force_unfused_frame = value != 0; return 0; }
   if (!strcmp(name, "force_generic_spot")) { c->force_generic_spot = value != 0; return 0; }
   if (!strcmp(name, "force_generic_target")) { c->force_generic_target = value != 0; return 0; }
@@ -901,9 +934,10 @@ int aomarl_apply_control(aomarl_ctx *c, aomarl_state *st, int b, int n, int comp
   float wa, wb, wc;
   if (d <= 1.f) { wa = 1.f - d; wb = d; wc = 0.f; } else { wa = 0.f; wb = 2.f - d; wc = d - 1.f; }
   const int na = c->sys.nactu;
-  hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, dev_state(st), na, st->ld_actu, wa, wb, wc, b, comp_voltage);
+  hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, dev_state(st), na, st->ld_actu, wa, wb, wc, b, comp_voltage & AOMARL_APPLY_COMP_VOLTAGE);
   LAUNCHCHK();
-  return aomarl_comp_dm_shape(c, st, b, n, nullptr, stream);
+  const bool defer = (comp_voltage & AOMARL_APPLY_DEFER_STACK_SHAPE) && aomarl_dm_from_voltage_available(c);
+  return dm_shape_impl(c, st, b, n, nullptr, defer, stream);
 }
 
 // ---------------------------------------------------------------- target
@@ -990,9 +1024,11 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     return fail("frame_fused: FROM_PHASE_BUFFER / NO_ATMOS / NO_DMS are not supported here");
   const bool noise = (flags & AOMARL_IMG_NOISE) && c->sys.noise >= 0.f;
   const bool cube = flags & AOMARL_IMG_WRITE_BINCUBE;
-  const int cog = (flags & AOMARL_IMG_COG) ? 1 : 0;
+  const bool otf = flags & AOMARL_IMG_DM_FROM_VOLTAGE;
+  const int cog = ((flags & AOMARL_IMG_COG) ? 1 : 0) | (c->fused_debug << 8);
+  if (otf && !c->sys.otf_ok) return fail("frame_fused: DM_FROM_VOLTAGE needs a separable stack-array lattice (see aomarl_dm_from_voltage_available)");
   if (cube && !st->bincube) return fail("frame_fused: WRITE_BINCUBE needs st->bincube");
-  if (!cube && !cog) return fail("frame_fused: nothing to produce (neither bincube nor slopes)");
+  if (!cube && !(cog & 1)) return fail("frame_fused: nothing to produce (neither bincube nor slopes)");
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   Work w = work_layout(c, st->nenv);
@@ -1002,18 +1038,26 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   float *PEND = st->work + w.PEND + (size_t)b * (W * W + 4);
   DevState ds = dev_state(st);
   if (w.nblk != c->sys.ntiles) return fail("frame_fused: internal stripe count mismatch");
-  const size_t smm = sizeof(float) * (4 * 2 * 2 * 16 * 17 + 2 * 128) +
-                     (c->sys.npsf <= 4096 ? sizeof(float) * 2 * c->sys.npsf : 0);
-  dim3 grid(c->sys.ntiles, n), blk(256);
-#define FUSED(NL, NZ, WC) hipLaunchKernelGGL((k_frame_fused<NL, NZ, WC>), grid, blk, smm, s, c->sys, ds, b, cog, TR, TP, w.nblk)
-  if (c->nlayers == 1) {
-    if (noise) { if (cube) FUSED(1, true, true); else FUSED(1, true, false); }
-    else { if (cube) FUSED(1, false, true); else FUSED(1, false, false); }
-  } else {
-    if (noise) { if (cube) FUSED(3, true, true); else FUSED(3, true, false); }
-    else { if (cube) FUSED(3, false, true); else FUSED(3, false, false); }
-  }
-#undef FUSED
+  const int nb = otf ? c->sys.otf_nb : 1;
+  const size_t smm = sizeof(float) * (2 * 128 + 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD +
+                                      (otf ? 4 * 4 * nb * c->sys.otf_latw : 0));
+  dim3 grid(c->sys.ntiles, (n + 3) / 4), blk(256);
+#define FW(NL, NB, OTF, NZ, WC) hipLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC>), grid, blk, smm, s, c->sys, ds, b, n, cog, TR, TP, w.nblk)
+#define FW_NC(NL, NB, OTF)                                                                     \
+  do {                                                                                          \
+    if (noise) { if (cube) FW(NL, NB, OTF, true, true); else FW(NL, NB, OTF, true, false); }     \
+    else { if (cube) FW(NL, NB, OTF, false, true); else FW(NL, NB, OTF, false, false); }         \
+  } while (0)
+#define FW_L(NL)                                                          \
+  do {                                                                    \
+    if (!otf) FW_NC(NL, 1, false);                                        \
+    else if (nb == 1) FW_NC(NL, 1, true);                                 \
+    else FW_NC(NL, 2, true);                                              \
+  } while (0)
+  if (c->nlayers == 1) FW_L(1); else FW_L(3);
+#undef FW_L
+#undef FW_NC
+#undef FW
   LAUNCHCHK();
   hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
   LAUNCHCHK();
@@ -1022,13 +1066,22 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   return 0;
 }
 
+/* refresh the stack-array planes of st->dm_shape from st->voltage (after deferred apply_control) */
+int aomarl_materialize_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  return dm_shape_impl(c, st, b, n, nullptr, false, stream);
+}
+
 int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
                          int image_flags, void *stream) {
   int rc = aomarl_move_atmos(c, st, b, n, accumx, accumy, stream);
   if (rc) return rc;
   int fl = (image_flags | AOMARL_IMG_COG | AOMARL_IMG_NOISE) & ~(AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS);
+  const bool defer = c->defer_dm_shape && aomarl_dm_from_voltage_available(c);
   if (aomarl_frame_fused_available(c) && !(fl & AOMARL_IMG_FROM_PHASE_BUFFER)) {
-    rc = aomarl_frame_fused(c, st, b, n, fl, stream);
+    rc = aomarl_frame_fused(c, st, b, n, fl | (defer ? AOMARL_IMG_DM_FROM_VOLTAGE : 0), stream);
     if (rc) return rc;
     return aomarl_do_control(c, st, b, n, stream);
   }
@@ -1050,7 +1103,7 @@ int aomarl_next_part_two(aomarl_ctx *c, aomarl_state *st, int b, int n, const fl
     rc = aomarl_rl_control(c, st, b, n, action, stream);
     if (rc) return rc;
   }
-  rc = aomarl_apply_control(c, st, b, n, 1, stream);
+  rc = aomarl_apply_control(c, st, b, n, AOMARL_APPLY_COMP_VOLTAGE | (c->defer_dm_shape ? AOMARL_APPLY_DEFER_STACK_SHAPE : 0), stream);
   if (rc) return rc;
   return aomarl_comp_strehl(c, st, b, n, stream);
 }

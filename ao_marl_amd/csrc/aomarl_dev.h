@@ -62,6 +62,12 @@ struct DevSys {
   int fused_ok, ntiles;          // ntiles = pupdiam / 16 tiles per axis
   const int32_t *tile_sub;       // [ntiles][ntiles] (stripe, tile) -> sub-aperture index or -1
   const uint16_t *tile_mask;     // [pupdiam][ntiles]: bit b = spupil[y][16 t + b] != 0
+  // stack-array DM phase from the command lattice inside the frame kernel (separable lattice whose
+  // pitch divides the tile size): nodes per axis that reach a tile <= 4 otf_nb
+  int otf_ok, otf_nb, otf_tpn;   // otf_tpn = lattice nodes per tile step (16 / pitch)
+  int otf_gx0, otf_gy0;          // first node column / row that reaches tile 0 / stripe 0
+  int otf_xoff, otf_yoff;        // DM pixel of the tile origin minus the position of that node
+  int otf_latw;                  // lattice columns a stripe can touch
 };
 
 struct DevState {

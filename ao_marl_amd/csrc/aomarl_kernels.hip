@@ -390,6 +390,20 @@ __global__ __launch_bounds__(256) void k_dm_shape(DevSys sys, DevState st, int e
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (D.type == AOMARL_DM_TT) {
     if (p < 2) shape[p] = com[p];
+    if (p == 2 && sys.fused_ok) {
+      // stack-array DM value at the centre of the pupil grid (pivot of the one-pass frame kernel's
+      // variance sums when the stack-array shape is evaluated from the commands on the fly)
+      const DevDm &Z = sys.dms[0];
+      const float *zc = volts + (long long)blockIdx.y * ldv + Z.com_off;
+      const int half = sys.pupdiam / 2, zp = (half + Z.toy) * Z.dim + half + Z.tox;
+      const int ss2 = Z.ss * Z.ss, s0 = Z.influstart[zp], cn = Z.ninflu[zp];
+      float acc = 0.f;
+      for (int t = 0; t < cn; t++) {
+        const int pos = Z.influpos[s0 + t];
+        acc += Z.influ[pos] * zc[pos / ss2];
+      }
+      shape[2] = acc;
+    }
     return;
   }
   if (p >= D.dim * D.dim) return;
@@ -590,12 +604,12 @@ __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
 // Accumulator layout of stage 1 (row y = 4q + reg, col k = c) is again exactly the B-operand
 // K-order stage 2 wants, and the twiddle registers serve as B operand (stage 1) and A operand
 // (stage 2) alike, so nothing moves between the stages.
+// operands: br[s] / bi[s] = complex amplitude of pixel (y = c, x = 4q + s) of the tile
 template <bool NOISE, bool WRITE_CUBE>
-__device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &st, int e, int i,
-                                             int lane, int wv, const float (&Cc)[4],
-                                             const float (&Ss)[4],
-                                             float (*sAr)[16][17], float (*sAi)[16][17], int do_cog,
-                                             float flux_i) {
+__device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st, int e, int i,
+                                          int lane, const float (&Cc)[4], const float (&Ss)[4],
+                                          const float (&br)[4], const float (&bi)[4], int do_cog,
+                                          float flux_i) {
   const int q = lane >> 4, c = lane & 15;
   const bool owner = (c & 1) == 0;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -603,11 +617,10 @@ __device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &
   f32x4 PCr = z4, PCi = z4, PSr = z4, PSi = z4;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    const float br = sAr[wv][c][4 * q + s], bi = sAi[wv][c][4 * q + s];
-    PCr = mfma16(br, Cc[s], PCr);
-    PCi = mfma16(bi, Cc[s], PCi);
-    PSr = mfma16(br, Ss[s], PSr);
-    PSi = mfma16(bi, Ss[s], PSi);
+    PCr = mfma16(br[s], Cc[s], PCr);
+    PCi = mfma16(bi[s], Cc[s], PCi);
+    PSr = mfma16(br[s], Ss[s], PSr);
+    PSi = mfma16(bi[s], Ss[s], PSi);
   }
   f32x4 Tr[2], Ti[2];                 // [0]: kx = +(k+1/2)   [1]: kx = -(k+1/2)
   Tr[0] = PCr + PSi; Ti[0] = PCi - PSr;
@@ -716,6 +729,19 @@ __device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &
       }
     }
   }
+}
+
+template <bool NOISE, bool WRITE_CUBE>
+__device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &st, int e, int i,
+                                             int lane, int wv, const float (&Cc)[4],
+                                             const float (&Ss)[4],
+                                             float (*sAr)[16][17], float (*sAi)[16][17], int do_cog,
+                                             float flux_i) {
+  const int q = lane >> 4, c = lane & 15;
+  float br[4], bi[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) { br[s] = sAr[wv][c][4 * q + s]; bi[s] = sAi[wv][c][4 * q + s]; }
+  spot_core<NOISE, WRITE_CUBE>(sys, st, e, i, lane, Cc, Ss, br, bi, do_cog, flux_i);
 }
 
 // phase (sum of all sources) and pupil mask of the 4 pixels this lane owns in sub-aperture i
@@ -1098,64 +1124,80 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
 }
 
 // =============================================================================================
-// FUSED FRAME KERNEL: WFS spot images + COG  and  science-path PSF rows from ONE pass over the
-// phase.  The sub-aperture tiles (16 x 16 phase pixels starting at 2 + 16 k of the WFS grid) are
+// ONE-PASS FRAME KERNEL: WFS spot images + COG  and  science-path PSF rows from ONE pass over the
+// phase.  The sub-aperture tiles (16 x 16 phase pixels starting at pad + 16 k of the WFS grid) are
 // exactly the 16 x 16 tiles of the pupil grid the target sees, at the same screen / DM pixels, so
-// a block that owns one stripe of 16 pupil rows reads every phase pixel once and feeds both
-// paths: per tile 48 MFMAs (pruned spot DFT) if it is a valid sub-aperture + 16 MFMAs (PSF row
-// DFT).  The pupil mask comes as 16-bit rows and tiles outside the pupil are skipped: HBM traffic
-// per environment drops from (layers + stack array) planes x 2 passes to the lit part once.
-// Block = 4 waves; wave w owns tiles w, w+4, ... of the stripe; PSF partial rows are reduced
-// across the waves at the end.  Layout: NL layers, DMs = [stack array, tip-tilt].
+// every phase pixel is read once and feeds both paths: per tile 48 MFMAs (pruned spot DFT) if it
+// is a valid sub-aperture + 16 MFMAs (PSF row DFT).
+//
+// Work split: ONE WAVE = ONE (environment, stripe of 16 pupil rows); it walks the tiles of the
+// stripe left to right, so its 16 PSF rows stay in its accumulators (no cross-wave reduction) and
+// its per-environment constants are scalars.  The 4 waves of a block work on the same stripe of
+// 4 consecutive environments: the data shared by all environments (tip-tilt planes, pupil mask
+// rows, PSF twiddles) is fetched at about the same time by the 4 waves and hits in the L1.
+// The pupil mask comes as 16-bit rows; tiles outside the pupil are skipped.
+//
+// Lane (q, c) owns the pixels (y = c, x = 4q .. 4q+3) of the tile -- the accumulator layout of a
+// 16x16x4 MFMA whose M index is x and N index is y, so the stack-array DM phase can be produced IN
+// PLACE on the matrix cores (OTF = true): with the separable influence profile u and the command
+// lattice C of the environment,
+//     S[x][y] = sum_j u(x - X_j) sum_i C[j][i] u(y - Y_i)
+// is two tiny GEMMs (lattice nodes that reach a tile: 4 .. 8 per axis): stage A over i (A operand
+// = lattice patch from LDS, B operand = profile column, a per-lane constant), stage B over j
+// (A operand = profile, B operand = the accumulator registers of stage A, whose row order
+// j(m) = (m >> 2) + 4 (m & 3) makes register s the K-slice of MFMA s).  2 MFMAs for <= 4 nodes
+// (NB = 1), 4 for <= 8 (NB = 2): the DM shape of the pupil never exists in memory.
+// LDS tiles are stored transposed ([x][y], row stride 20 floats): writes by (q, c) and the
+// operand reads (x = 4q + s, y = c) both touch 32 distinct banks per half wave.
 // =============================================================================================
-template <int NL>
+#define FW_LD 20
+template <int NL, bool OTF>
 struct FrameRaw {
   float L[NL][4];
-  float P[4], T[8];
+  float P[OTF ? 1 : 4], T[8];
   unsigned mrow;      // 16-bit mask row of the tile (this lane's row)
   float F;
 };
 
-template <int NL, bool NOISE, bool WRITE_CUBE>
-__global__ __launch_bounds__(256) void k_frame_fused(DevSys sys, DevState st, int env_begin,
-                                                     int do_cog, float *__restrict__ TR,
-                                                     float *__restrict__ TPART, int nblk) {
+template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE>
+__global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int env_begin,
+                                                    int env_count, int do_cog,
+                                                    float *__restrict__ TR,
+                                                    float *__restrict__ TPART, int nblk) {
   extern __shared__ float smem[];
-  // per wave: one WFS amplitude tile and one target amplitude tile (re, im).  Each wave only ever
-  // touches its own tiles, LDS operations of a wave complete in order, so a single buffer and
-  // wave-level barriers are enough; the cross-wave reduction buffer aliases the tiles.
-  typedef float Tile[16][17];
-  Tile *sW = reinterpret_cast<Tile *>(smem);                 // [4 waves][2 re/im]
-  Tile *sT = sW + 4 * 2;                                     // [4 waves][2 re/im]
-  float *red = smem;                                         // [4][2][256] (after the tile loop)
-  float2 *sTw = reinterpret_cast<float2 *>(smem + 4 * 2 * 2 * 16 * 17);   // [128] WFS twiddles
-  float2 *stw = sTw + 128;                                   // [npsf] PSF twiddles (if it fits)
   const int pd = sys.pupdiam, np = sys.npsf, ntl = sys.ntiles;
-  const bool tw_lds = np <= 4096;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, c = lane & 15;
-  const int e = env_begin + blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2 *sTw = reinterpret_cast<float2 *>(smem);            // [128] WFS twiddles
+  float2 *stw = sTw + 128;                                   // [npsf] PSF twiddles (npsf <= 4096)
+  float *tiles = reinterpret_cast<float *>(stw + np);        // [4 waves][4][16 * FW_LD]
+  float *lat_all = tiles + 4 * 4 * 16 * FW_LD;               // [4 waves][4 NB][latw]
+  const int dbg = do_cog >> 8;                               // development switches (kbench)
+  do_cog &= 1;
   const int r = blockIdx.x;                                  // stripe: pupil rows 16 r .. 16 r + 15
+  const int el = 4 * blockIdx.y + wv;                        // environment of this wave
   if (tid < 128) {
     float sn, cs;
     sincospif((float)tid * (1.0f / 64.0f), &sn, &cs);
     sTw[tid] = make_float2(cs, sn);
   }
   const float2 *gtw = reinterpret_cast<const float2 *>(sys.psf_tw);
-  if (tw_lds)
-    for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
-  const float2 *tw = tw_lds ? stw : gtw;
-  __syncthreads();
+  for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
+  __syncthreads();                                           // the only block-wide barrier
+  if (el >= env_count) return;
+  const int e = env_begin + el;
   float Cc[4], Ss[4];
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const float2 w = sTw[((4 * q + s) * (2 * c + 1)) & 127];
     Cc[s] = w.x; Ss[s] = w.y;
   }
-  const int ty = lane >> 2, tx0 = (lane & 3) * 4;
-  const int y = 16 * r + ty;                                 // pupil row of this lane
+  float *Twr = tiles + wv * 4 * 16 * FW_LD, *Twi = Twr + 16 * FW_LD;   // WFS amplitude [x][y]
+  float *Tar = Twi + 16 * FW_LD, *Tai = Tar + 16 * FW_LD;              // target amplitude [x][y]
+  const int y = 16 * r + c;                                  // pupil row of this lane
   // ---- per-environment constants (target-path offsets; the WFS sees the same pixels)
   const float *lay[NL];
-  unsigned lpx[NL], lpy[NL], ldim[NL];
+  unsigned lpx[NL], ldim[NL], lrow[NL];
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     const DevLayer &L = sys.layers[l];
@@ -1163,44 +1205,69 @@ __global__ __launch_bounds__(256) void k_frame_fused(DevSys sys, DevState st, in
     ldim[l] = (unsigned)L.dim;
     int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
     int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
-    lpx[l] = (unsigned)px; lpy[l] = (unsigned)py;
+    lpx[l] = (unsigned)px + 4u * (unsigned)q;
+    unsigned pr = (unsigned)y + (unsigned)py; pr = min(pr, pr - ldim[l]);
+    lrow[l] = pr * (ldim[l] + RING_PAD);
   }
   const DevDm &D0 = sys.dms[0], &D1 = sys.dms[1];
   const float *pzt = st.dm_shape + (long long)e * sys.shape_stride + D0.shape_off;
   const float *ttslot = st.dm_shape + (long long)e * sys.shape_stride + D1.shape_off;
   const float c0 = ttslot[0], c1 = ttslot[1];
   const int half = pd / 2;
-  // row offsets of this lane (the stripe row is fixed)
-  unsigned lrow[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    unsigned py = (unsigned)y + lpy[l]; py = min(py, py - ldim[l]);
-    lrow[l] = py * (ldim[l] + RING_PAD);
-  }
-  const unsigned prow = (unsigned)(y + D0.toy) * (unsigned)D0.dim + (unsigned)D0.tox;
-  const unsigned trow = 2u * ((unsigned)(y + D1.toy) * (unsigned)D1.dim + (unsigned)D1.tox);
+  const unsigned prow = (unsigned)(y + D0.toy) * (unsigned)D0.dim + (unsigned)D0.tox + 4u * (unsigned)q;
+  const unsigned trow = 2u * ((unsigned)(y + D1.toy) * (unsigned)D1.dim + (unsigned)D1.tox + 4u * (unsigned)q);
   const uint16_t *mrowp = sys.tile_mask + (long long)y * ntl;
-  // pivot of the variance sums: phase at the grid centre
+  // pivot of the variance sums: phase at the grid centre (ttslot[2]: stack-array value there)
   float pivot;
   {
-    float v = pzt[(half + D0.toy) * D0.dim + half + D0.tox];
+    float v = OTF ? ttslot[2] : pzt[(half + D0.toy) * D0.dim + half + D0.tox];
     const float2 f = reinterpret_cast<const float2 *>(D1.influ)[(half + D1.toy) * D1.dim + half + D1.tox];
     v += c0 * f.x + c1 * f.y;
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-      unsigned py = (unsigned)half + lpy[l]; py = min(py, py - ldim[l]);
-      unsigned px = (unsigned)half + lpx[l]; px = min(px, px - ldim[l]);
-      v += lay[l][py * (ldim[l] + RING_PAD) + px];
+      const DevLayer &L = sys.layers[l];
+      int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
+      int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
+      unsigned pyc = (unsigned)(half + py); pyc = min(pyc, pyc - ldim[l]);
+      unsigned pxc = (unsigned)(half + px); pxc = min(pxc, pxc - ldim[l]);
+      v += lay[l][pyc * (ldim[l] + RING_PAD) + pxc];
     }
     pivot = v;
   }
+  // ---- on-the-fly stack-array DM: profile operands + the lattice rows of this stripe in LDS
+  float Pxr[NB], Pyr[NB];
+  const int jm = (c >> 2) + 4 * (c & 3);
+  const bool jm_ok = jm < 4 * NB;
+  const int latw = sys.otf_latw, tpn = sys.otf_tpn;
+  float *lat = lat_all + wv * (4 * NB * latw);
+  if (OTF) {
+#pragma unroll
+    for (int s = 0; s < NB; s++) {
+      const int ax = sys.otf_xoff + c - D0.pitch * (q + 4 * s);
+      const int ay = sys.otf_yoff + c - D0.pitch * (q + 4 * s);
+      Pxr[s] = (ax >= 0 && ax < D0.ss) ? D0.prof[ax] : 0.f;
+      Pyr[s] = (ay >= 0 && ay < D0.ss) ? D0.prof[ay] : 0.f;
+    }
+    const float *volt = st.voltage + (long long)e * st.ld_actu + D0.com_off;
+    for (int idx = lane; idx < 4 * NB * latw; idx += 64) {
+      const int i = idx / latw, jj = idx - i * latw;
+      const int gy = sys.otf_gy0 + r * tpn + i, gx = sys.otf_gx0 + jj;
+      float v = 0.f;
+      if (gx >= 0 && gx < D0.gw && gy >= 0 && gy < D0.gh) {
+        const int a = D0.grid[gy * D0.gw + gx];
+        if (a >= 0) v = volt[a];
+      }
+      lat[idx] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   const int *tsub = sys.tile_sub + r * ntl;
   const float wfs_il = sys.wfs_inv_lambda, tar_il = sys.tar_inv_lambda;
-  FrameRaw<NL> raw;
+  FrameRaw<NL, OTF> raw;
   // tile_sub: >= 0 valid sub-aperture, -1 lit tile without sub-aperture, -2 tile outside the pupil
   auto fetch = [&](int t, int sub) {
-    if (sub == -2) return;                                   // wave-uniform
-    const unsigned x = (unsigned)(16 * t + tx0);
+    if (sub == -2 || (dbg & 4)) return;                      // wave-uniform
+    const unsigned x = (unsigned)(16 * t);
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       unsigned px = x + lpx[l]; px = min(px, px - ldim[l]);
@@ -1208,9 +1275,11 @@ __global__ __launch_bounds__(256) void k_frame_fused(DevSys sys, DevState st, in
 #pragma unroll
       for (int j = 0; j < 4; j++) raw.L[l][j] = v4.v[j];
     }
-    const f4u p4 = *reinterpret_cast<const f4u *>(pzt + (prow + x));
+    if (!OTF) {
+      const f4u p4 = *reinterpret_cast<const f4u *>(pzt + (prow + x));
 #pragma unroll
-    for (int j = 0; j < 4; j++) raw.P[j] = p4.v[j];
+      for (int j = 0; j < 4; j++) raw.P[OTF ? 0 : j] = p4.v[j];
+    }
     const f4u t0 = *reinterpret_cast<const f4u *>(D1.influ + (trow + 2u * x));
     const f4u t1 = *reinterpret_cast<const f4u *>(D1.influ + (trow + 2u * x + 4u));
 #pragma unroll
@@ -1221,81 +1290,80 @@ __global__ __launch_bounds__(256) void k_frame_fused(DevSys sys, DevState st, in
   f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int kxf = c - 8;
-  Tile &Wr = sW[wv * 2], &Wi = sW[wv * 2 + 1];
-  Tile &Ar = sT[wv * 2], &Ai = sT[wv * 2 + 1];
-  int sub = wv < ntl ? tsub[wv] : -2;
-  fetch(wv, sub);
-  for (int t = wv; t < ntl; t += 4) {
-    const int tn = t + 4;
-    const int subn = tn < ntl ? tsub[tn] : -2;
+  int sub = tsub[0];
+  fetch(0, sub);
+  for (int t = 0; t < ntl; t++) {
+    const int subn = t + 1 < ntl ? tsub[t + 1] : -2;
     if (sub != -2) {
+      // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
+      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+      if (OTF) {
+        f32x4 U = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NB; kb++) {
+          const float a = lat[(q + 4 * kb) * latw + t * tpn + (jm_ok ? jm : 0)];
+          U = mfma16(jm_ok ? a : 0.f, Pyr[kb], U);
+        }
+#pragma unroll
+        for (int s = 0; s < NB; s++) S = mfma16(Pxr[s], U[s], S);
+      }
       const float flux_i = raw.F;
       // ---- phase of the 4 pixels, both complex amplitudes -> LDS
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float ph = raw.P[j] + (c0 * raw.T[2 * j] + c1 * raw.T[2 * j + 1]);
+        float ph = (OTF ? S[j] : raw.P[OTF ? 0 : j]) + (c0 * raw.T[2 * j] + c1 * raw.T[2 * j + 1]);
 #pragma unroll
         for (int l = 0; l < NL; l++) ph += raw.L[l][j];
-        const bool m = (raw.mrow >> (tx0 + j)) & 1u;
+        const bool m = (raw.mrow >> (4 * q + j)) & 1u;
         float a_ = ph * wfs_il; a_ -= rintf(a_);
         float b_ = ph * tar_il; b_ -= rintf(b_);
-        Wr[ty][tx0 + j] = m ? __builtin_amdgcn_cosf(a_) : 0.f;
-        Wi[ty][tx0 + j] = m ? __builtin_amdgcn_sinf(a_) : 0.f;
-        Ar[ty][tx0 + j] = m ? __builtin_amdgcn_cosf(b_) : 0.f;
-        Ai[ty][tx0 + j] = m ? __builtin_amdgcn_sinf(b_) : 0.f;
+        const int o = (4 * q + j) * FW_LD + c;
+        Twr[o] = m ? __builtin_amdgcn_cosf(a_) : 0.f;
+        Twi[o] = m ? __builtin_amdgcn_sinf(a_) : 0.f;
+        Tar[o] = m ? __builtin_amdgcn_cosf(b_) : 0.f;
+        Tai[o] = m ? __builtin_amdgcn_sinf(b_) : 0.f;
         const float d = m ? ph - pivot : 0.f;
         sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
       }
-      fetch(tn, subn);                                       // next tile's loads fly during the MFMAs
+      fetch(t + 1, subn);                                    // next tile's loads fly during the MFMAs
       __builtin_amdgcn_wave_barrier();
       // ---- science path: R[y][kx] += sum_{x in tile} a(y, x) exp(-2 pi i kx x / Npsf)
+      if (!(dbg & 2)) {
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const int xl = 4 * s + q;
-        const float ar = Ar[c][xl], ai = Ai[c][xl];
-        const float2 w = tw[(kxf * (16 * t + xl)) & (np - 1)];
-        Rr = mfma16(ar, w.x, Rr);
-        Ri = mfma16(ai, w.x, Ri);
-        Rr = mfma16(ai, w.y, Rr);
-        Ri = mfma16(ar, -w.y, Ri);
+        for (int s = 0; s < 4; s++) {
+          const int xl = 4 * q + s;
+          const float ar = Tar[xl * FW_LD + c], ai = Tai[xl * FW_LD + c];
+          const int widx = (kxf * (16 * t + xl)) & (np - 1);
+          const float2 w = stw[widx];
+          Rr = mfma16(ar, w.x, Rr);
+          Ri = mfma16(ai, w.x, Ri);
+          Rr = mfma16(ai, w.y, Rr);
+          Ri = mfma16(ar, -w.y, Ri);
+        }
       }
       // ---- WFS path (valid sub-apertures only; wave-uniform branch)
-      if (sub >= 0)
-        spot_compute<NOISE, WRITE_CUBE>(sys, st, e, sub, lane, 0, Cc, Ss, &Wr, &Wi, do_cog, flux_i);
+      if (sub >= 0 && !(dbg & 1)) {
+        float br[4], bi[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { br[s] = Twr[(4 * q + s) * FW_LD + c]; bi[s] = Twi[(4 * q + s) * FW_LD + c]; }
+        spot_core<NOISE, WRITE_CUBE>(sys, st, e, sub, lane, Cc, Ss, br, bi, do_cog, flux_i);
+      }
       __builtin_amdgcn_wave_barrier();
     } else {
-      fetch(tn, subn);
+      fetch(t + 1, subn);
     }
     sub = subn;
   }
-  __syncthreads();
-  // ---- cross-wave reduction of the PSF rows; acc reg j of lane (q, c): y = 4q + j, kx = c
+  // ---- PSF rows of this stripe: acc reg j of lane (q, c): y = 4q + j, kx = c
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    red[(wv * 2 + 0) * 256 + (4 * q + j) * 16 + c] = Rr[j];
-    red[(wv * 2 + 1) * 256 + (4 * q + j) * 16 + c] = Ri[j];
+    float2 *o = reinterpret_cast<float2 *>(TR) + ((long long)el * pd + (16 * r + 4 * q + j)) * 16 + c;
+    *o = make_float2(Rr[j], Ri[j]);
   }
-  __syncthreads();
-  {
-    const int yy = tid >> 4, kx = tid & 15;
-    float vr = 0.f, vi = 0.f;
-#pragma unroll
-    for (int w4 = 0; w4 < 4; w4++) { vr += red[(w4 * 2) * 256 + tid]; vi += red[(w4 * 2 + 1) * 256 + tid]; }
-    float *o = TR + (((long long)blockIdx.y * pd + (16 * r + yy)) * 16 + kx) * 2;
-    o[0] = vr; o[1] = vi;
-  }
-  __syncthreads();
-  red[tid] = sd; red[256 + tid] = sd2; red[512 + tid] = sm;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (tid < o) {
-      red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; red[512 + tid] += red[512 + tid + o];
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    float *pp = TPART + ((long long)blockIdx.y * nblk + blockIdx.x) * 4;
-    pp[0] = red[0]; pp[1] = red[256]; pp[2] = red[512]; pp[3] = 0.f;
+  sd = wave_sum(sd); sd2 = wave_sum(sd2); sm = wave_sum(sm);
+  if (lane == 0) {
+    float *pp = TPART + ((long long)el * nblk + r) * 4;
+    pp[0] = sd; pp[1] = sd2; pp[2] = sm; pp[3] = 0.f;
   }
 }
 

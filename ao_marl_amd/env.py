@@ -145,7 +145,9 @@ class VecRlSupervisor(object):
         if not linear_control:
             self.rl_control(action)
         if apply_control:
-            self.sim.apply_control()
+            # the stack-array shapes are left to the one-pass frame kernel when it can evaluate
+            # them from the voltages (any other consumer materialises them on demand)
+            self.sim.apply_control(defer_shape=getattr(self.sim, "defer_shape", False))
         if compute_tar_psf:
             self.sim.comp_strehl()
 
@@ -156,8 +158,7 @@ class VecRlSupervisor(object):
             # the bincube never leaves the device (the reference copies it to the host and back)
             if move_atmos:
                 self.sim.move_atmos()
-            self.sim.target_psf()
-            self.sim.comp_image(noise=True, write_bincube=True, cog=False)
+            self._target_and_image(write_bincube=True, cog=False)
             self.autoencoder.denoise_bincube_(self.sim.t["bincube"])
             self.sim.do_centroids()
             if do_control:
@@ -167,11 +168,19 @@ class VecRlSupervisor(object):
         else:
             if move_atmos:
                 self.sim.move_atmos()
-            self.sim.target_psf()
-            self.sim.comp_image(noise=True, cog=True)
+            self._target_and_image(write_bincube=False, cog=True)
             if do_control:
                 self.sim.do_control()
         self.iter += 1
+
+    def _target_and_image(self, write_bincube, cog):
+        """raytrace_target + PSF, raytrace_wfs + comp_image (rlSupervisor.py:829-843)."""
+        sim = self.sim
+        if getattr(sim, "frame_fused_available", lambda: False)():
+            sim.frame_fused(noise=True, write_bincube=write_bincube, cog=cog)
+        else:
+            sim.target_psf()
+            sim.comp_image(noise=True, write_bincube=write_bincube, cog=cog)
 
     # ---------------------------------------------------------------- getters (device tensors)
     def get_command(self):

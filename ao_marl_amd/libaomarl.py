@@ -18,6 +18,8 @@ DM_PZT, DM_TT = 0, 1
 TRACE_ATMOS, TRACE_DMS, TRACE_RESET = 1, 2, 4
 IMG_FROM_PHASE_BUFFER, IMG_NOISE, IMG_WRITE_BINCUBE, IMG_COG, IMG_NO_ATMOS, IMG_NO_DMS = \
     1, 2, 4, 8, 16, 32
+IMG_DM_FROM_VOLTAGE = 64
+APPLY_COMP_VOLTAGE, APPLY_DEFER_STACK_SHAPE = 1, 2
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -98,6 +100,8 @@ SYMBOLS = [
     ("aomarl_set_option", _i, [_vp, C.c_char_p, _i]),
     ("aomarl_target_psf", _i, _range + [_vp]),
     ("aomarl_frame_fused_available", _i, [_vp]),
+    ("aomarl_dm_from_voltage_available", _i, [_vp]),
+    ("aomarl_materialize_dm_shape", _i, _range + [_vp]),
     ("aomarl_frame_fused", _i, _range + [_i, _vp]),
     ("aomarl_comp_strehl", _i, _range + [_vp]),
     ("aomarl_reset_strehl", _i, _range + [_vp]),

@@ -36,6 +36,12 @@ class HipSim(object):
         self.keep_bincube, self.keep_phase = keep_bincube, keep_phase
         self.overlap_target = False
         self._side = None
+        # stack-array DM phase straight from the commands inside the one-pass frame kernel when
+        # the library can (next_part_two then skips materialising the shapes; any other consumer
+        # of the shapes triggers _ensure_shape() first)
+        self.defer_shape = True
+        self._defer_on = False       # the ctx option as currently set
+        self._stale = False          # st.dm_shape's stack-array planes are older than st.voltage
         self.ctx = C.c_void_p()
         self._create_ctx()
         self._alloc()
@@ -50,6 +56,7 @@ class HipSim(object):
         if self.ctx:
             self.lib.aomarl_destroy(self.ctx)
         self.ctx = ctx
+        self._defer_on, self._stale = False, False
         del keep
 
     def _alloc(self):
@@ -131,6 +138,7 @@ class HipSim(object):
         """Shape of DM k, [env_count, dim, dim] (materialised on demand: tip-tilt mirrors are
         never stored, their consumers evaluate the two planes on the fly)."""
         b, n = self._range(env_begin, env_count)
+        self._ensure_shape()
         d = self.s.dms[k]
         out = torch.empty(n, d.dim, d.dim, dtype=torch.float32, device=self.device)
         la.check(self.lib.aomarl_get_dm_shape(self.ctx, C.byref(self.st), b, n, k,
@@ -139,6 +147,26 @@ class HipSim(object):
 
     def set_option(self, name, value):
         la.check(self.lib.aomarl_set_option(self.ctx, name.encode(), int(value)))
+        if name == "force_unfused_frame" and value:
+            self._set_defer(False)
+
+    def dm_from_voltage_available(self):
+        return bool(self.lib.aomarl_dm_from_voltage_available(self.ctx))
+
+    def _set_defer(self, on):
+        on = bool(on)
+        if on != self._defer_on:
+            la.check(self.lib.aomarl_set_option(self.ctx, b"defer_dm_shape", int(on)))
+            self._defer_on = on
+        if not on:
+            self._ensure_shape()
+
+    def _ensure_shape(self):
+        """Bring st.dm_shape's stack-array planes up to date with st.voltage."""
+        if self._stale:
+            la.check(self.lib.aomarl_materialize_dm_shape(self.ctx, C.byref(self.st), 0, self.nenv,
+                                                          self._stream()))
+            self._stale = False
 
     def screen(self, layer, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
@@ -196,6 +224,8 @@ class HipSim(object):
         la.check(self.lib.aomarl_reset(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
                                        la.fptr(self.accumx), la.fptr(self.accumy),
                                        self._stream()))
+        if (b, n) == (0, self.nenv):
+            self._stale = False             # commands, voltages and shapes are all zero again
 
     def move_atmos(self, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
@@ -227,6 +257,7 @@ class HipSim(object):
     def raytrace_wfs(self, atm=True, dms=True, reset=True, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         self._need_phase()
+        self._ensure_shape()
         fl = (la.TRACE_ATMOS if atm else 0) | (la.TRACE_DMS if dms else 0) | \
             (la.TRACE_RESET if reset else 0)
         la.check(self.lib.aomarl_raytrace_wfs(self.ctx, C.byref(self.st), b, n, fl,
@@ -235,6 +266,7 @@ class HipSim(object):
     def raytrace_target(self, atm=True, dms=True, reset=True, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         self._need_phase()
+        self._ensure_shape()
         fl = (la.TRACE_ATMOS if atm else 0) | (la.TRACE_DMS if dms else 0) | \
             (la.TRACE_RESET if reset else 0)
         la.check(self.lib.aomarl_raytrace_target(self.ctx, C.byref(self.st), b, n, fl,
@@ -258,6 +290,7 @@ class HipSim(object):
             fl |= la.IMG_NO_ATMOS
         if not dms:
             fl |= la.IMG_NO_DMS
+        self._ensure_shape()
         la.check(self.lib.aomarl_comp_image(self.ctx, C.byref(self.st), b, n, fl, self._stream()))
 
     def do_centroids(self, env_begin=0, env_count=None):
@@ -288,10 +321,19 @@ class HipSim(object):
         la.check(self.lib.aomarl_rl_control(self.ctx, C.byref(self.st), b, n, action.data_ptr(),
                                             self._stream()))
 
-    def apply_control(self, comp_voltage=True, env_begin=0, env_count=None):
+    def apply_control(self, comp_voltage=True, env_begin=0, env_count=None, defer_shape=False):
+        """defer_shape: leave the stack-array shapes to the one-pass frame kernel (which then
+        evaluates them from st.voltage); only honoured when the library supports it."""
         b, n = self._range(env_begin, env_count)
-        la.check(self.lib.aomarl_apply_control(self.ctx, C.byref(self.st), b, n,
-                                               1 if comp_voltage else 0, self._stream()))
+        fl = la.APPLY_COMP_VOLTAGE if comp_voltage else 0
+        defer = bool(defer_shape) and self.dm_from_voltage_available()
+        if defer:
+            fl |= la.APPLY_DEFER_STACK_SHAPE
+        elif (b, n) != (0, self.nenv):
+            self._ensure_shape()              # a partial refresh must not hide older stale rows
+        la.check(self.lib.aomarl_apply_control(self.ctx, C.byref(self.st), b, n, fl,
+                                               self._stream()))
+        self._stale = defer or (self._stale and (b, n) != (0, self.nenv))
 
     def comp_dm_shape(self, volts=None, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
@@ -301,23 +343,39 @@ class HipSim(object):
             if volts.shape != (n, self.s.nactu):
                 raise ValueError("volts must be [env_count, nactu]")
             ptr = volts.data_ptr()
+            # the shapes no longer follow st.voltage: the composites must read them from memory
+            self._set_defer(False)
+        if (b, n) != (0, self.nenv):
+            self._ensure_shape()
         la.check(self.lib.aomarl_comp_dm_shape(self.ctx, C.byref(self.st), b, n, ptr,
                                                self._stream()))
+        if (b, n) == (0, self.nenv):
+            self._stale = False
 
     def target_psf(self, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         if not all(float(o).is_integer() for t in (self.s.tar_atm_off + self.s.tar_dm_off)
                    for o in t):
             self._need_phase()
+        self._ensure_shape()
         la.check(self.lib.aomarl_target_psf(self.ctx, C.byref(self.st), b, n, self._stream()))
 
     def frame_fused_available(self):
         return bool(self.lib.aomarl_frame_fused_available(self.ctx))
 
-    def frame_fused(self, noise=True, write_bincube=False, cog=True, env_begin=0, env_count=None):
-        """target_psf + comp_image from one pass over the phase (aomarl_frame_fused)."""
+    def frame_fused(self, noise=True, write_bincube=False, cog=True, env_begin=0, env_count=None,
+                    dm_from_voltage=None):
+        """target_psf + comp_image from one pass over the phase (aomarl_frame_fused).
+        dm_from_voltage: evaluate the stack-array DM from st.voltage inside the kernel (default:
+        exactly when the stored shapes are stale, i.e. after a deferred apply_control)."""
         b, n = self._range(env_begin, env_count)
+        if dm_from_voltage is None:
+            dm_from_voltage = self._stale
         fl = 0
+        if dm_from_voltage:
+            fl |= la.IMG_DM_FROM_VOLTAGE
+        else:
+            self._ensure_shape()
         if noise:
             fl |= la.IMG_NOISE
         if write_bincube:
@@ -353,6 +411,8 @@ class HipSim(object):
         b, n = self._range(env_begin, env_count)
         if overlap is None:
             overlap = self.overlap_target
+        if not self._defer_on:
+            self._ensure_shape()
         if not overlap:
             fl = 0
             if write_bincube:
@@ -388,8 +448,12 @@ class HipSim(object):
             if action.shape != (n, self.nact):
                 raise ValueError("action must be [env_count, %d]" % self.nact)
             ptr = action.data_ptr()
+        self._set_defer(self.defer_shape and self.dm_from_voltage_available())
+        if not self._defer_on and (b, n) != (0, self.nenv):
+            self._ensure_shape()
         la.check(self.lib.aomarl_next_part_two(self.ctx, C.byref(self.st), b, n, ptr,
                                                self._stream()))
+        self._stale = self._defer_on or (self._stale and (b, n) != (0, self.nenv))
 
     def gemm_nt(self, A, B, alpha=1.0, beta=0.0, Cout=None):
         """C = alpha * A @ B.T + beta * C on the library's fp32 MFMA GEMM (tests)."""

@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="separate science / WFS passes instead of the one-pass frame kernel")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="materialise the stack-array DM shapes instead of evaluating them from the "
+                         "voltages inside the frame kernel")
     ap.add_argument("--pmc", default="r01d_pmc_counters_256env.json",
                     help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes")
     args = ap.parse_args()
@@ -172,6 +175,10 @@ def main():
     orig_np1 = env.supervisor.next_part_one
 
     fused = sim.frame_fused_available() and not args.unfused
+    if args.unfused:
+        sim.set_option("force_unfused_frame", 1)
+    if args.no_defer:
+        sim.defer_shape = False
 
     def split_part_one(move_atmos=True, do_control=True):
         sim.move_atmos()

@@ -39,7 +39,18 @@ enum {
   AOMARL_IMG_WRITE_BINCUBE = 4,     /* store the 16x16 spot images (st->bincube)              */
   AOMARL_IMG_COG = 8,               /* fused centre of gravity -> st->slopes                  */
   AOMARL_IMG_NO_ATMOS = 16,         /* fused raytrace: DMs only (interaction matrix)          */
-  AOMARL_IMG_NO_DMS = 32            /* fused raytrace: atmosphere only                        */
+  AOMARL_IMG_NO_DMS = 32,           /* fused raytrace: atmosphere only                        */
+  AOMARL_IMG_DM_FROM_VOLTAGE = 64   /* aomarl_frame_fused only: evaluate the stack-array DM phase
+                                       from st->voltage on the fly (st->dm_shape's stack-array
+                                       planes are not read; see aomarl_dm_from_voltage_available) */
+};
+/* bits of aomarl_apply_control's comp_voltage argument */
+enum {
+  AOMARL_APPLY_COMP_VOLTAGE = 1,     /* run the delay line (Rtc.apply_control's compVoltage)     */
+  AOMARL_APPLY_DEFER_STACK_SHAPE = 2 /* do not materialise the stack-array shapes now: the next
+                                        aomarl_frame_fused(DM_FROM_VOLTAGE) evaluates them from
+                                        st->voltage; ignored when that path is unavailable.
+                                        aomarl_materialize_dm_shape refreshes them on demand     */
 };
 
 typedef struct {
@@ -186,9 +197,16 @@ int aomarl_set_com(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_cou
  * action_dev [env_count][nact] device memory */
 int aomarl_rl_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                       const float *action_dev, void *stream);
-/* Rtc.apply_control (rtcCompass.py:582): delay line -> voltage -> Dm.comp_shape per DM */
+/* Rtc.apply_control (rtcCompass.py:582): delay line -> voltage -> Dm.comp_shape per DM;
+ * comp_voltage: AOMARL_APPLY_* bits (1 = the reference's compVoltage=True) */
 int aomarl_apply_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                          int comp_voltage, void *stream);
+/* 1 when the one-pass frame kernel can evaluate the stack-array DM from the command lattice
+ * (separable influence functions on a regular lattice whose pitch divides the 16-pixel tile) */
+int aomarl_dm_from_voltage_available(aomarl_ctx *ctx);
+/* Dm.comp_shape of every DM from st->voltage, also after AOMARL_APPLY_DEFER_STACK_SHAPE */
+int aomarl_materialize_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                                void *stream);
 /* Dm.set_com + comp_shape (dmCompass.py:64-146): volts_dev [env_count][nactu] or NULL=voltage */
 int aomarl_comp_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                          const float *volts_dev, void *stream);
@@ -199,7 +217,10 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
 /* implementation switches for tests / A-B measurements: "force_generic_dm" (per-pixel gather
  * tables instead of the separable-lattice kernel), "force_valu_target" (VALU PSF rows kernel),
  * "force_generic_spot" / "force_generic_target" (layout-agnostic kernels), "force_unfused_frame"
- * (separate target and WFS passes in aomarl_next_part_one) */
+ * (separate target and WFS passes in aomarl_next_part_one), "defer_dm_shape" (the composites
+ * aomarl_next_part_two / aomarl_next_part_one use AOMARL_APPLY_DEFER_STACK_SHAPE /
+ * AOMARL_IMG_DM_FROM_VOLTAGE when available: st->voltage is the DM state and the stack-array
+ * planes of st->dm_shape stay stale until aomarl_materialize_dm_shape) */
 int aomarl_set_option(aomarl_ctx *ctx, const char *name, int value);
 /* fused target raytrace + PSF window + phase variance into a pending slot
  * (RlSupervisor.raytrace_target, rlSupervisor.py:845-855) */

@@ -77,7 +77,7 @@ class OracleVecSim(object):
             m[self.amodes] += a[e] * self.freedom[self.amodes]       # :813
             o.set_com(self.m2v.dot(m))                               # :816, :733
 
-    def apply_control(self):
+    def apply_control(self, defer_shape=False):
         for o in self.sims:
             o.apply_control()
 

@@ -53,15 +53,17 @@ def _push(sim, oracles):
             sim.t["ext_count"][e, l] = o.ext_count[l]
 
 
-@pytest.mark.parametrize("unfused", [0, 1])
+@pytest.mark.parametrize("unfused", [0, 1, 2])
 def test_large_frames_match_oracle(large, unfused):
-    """unfused=0: one-pass frame kernel (science + WFS from the same tiles); 1: separate passes."""
+    """0: one-pass frame kernel (science + WFS from the same tiles, stack-array DM from the
+    commands); 1: separate passes; 2: one-pass kernel reading materialised DM shapes."""
     from ao_marl_amd.sim import HipSim
     _, s, cal = large
     seeds = [1234, 4321]
     sim = HipSim(s, nenv=2, keep_bincube=True)
     assert sim.frame_fused_available()
-    sim.set_option("force_unfused_frame", unfused)
+    sim.set_option("force_unfused_frame", 1 if unfused == 1 else 0)
+    sim.defer_shape = unfused == 0
     sim.set_modal(cal.volts2modes, cal.modes2volts)
     sim.reset(seeds)                       # exercises the full 1296-round reset on the GPU
     assert sim.screen(0).std().item() > 0.05

@@ -256,18 +256,30 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
     volts[:, -2:] = rng.normal(0, 0.05, size=(len(oracles), 2))      # tip-tilt: analytic planes
     sim.comp_dm_shape(torch.from_numpy(volts).cuda())
     out = {}
-    for mode in ("unfused", "fused_cube", "fused"):
+    for mode in ("unfused", "fused_cube", "fused", "otf_cube", "otf"):
         sim.reset_strehl()
+        if mode.startswith("otf"):
+            # stack-array DM evaluated from st.voltage inside the kernel: the stored planes are
+            # poisoned to prove they are not read
+            assert sim.dm_from_voltage_available()
+            sim.set_com(torch.from_numpy(volts).cuda())
+            sim.apply_control(comp_voltage=False, defer_shape=True)
+            nz = s.dms[0].dim ** 2
+            sim.t["dm_shape"][:, :nz] = 1e3
+            assert sim._stale
         if mode == "unfused":
             sim.target_psf()
             sim.comp_image(noise=False, write_bincube=True, cog=True)
         else:
             sim.t["bincube"].zero_()
             sim.slopes.zero_()
-            sim.frame_fused(noise=False, write_bincube=(mode == "fused_cube"), cog=True)
+            sim.frame_fused(noise=False, write_bincube=mode.endswith("cube"), cog=True)
         sim.comp_strehl()
         out[mode] = (sim.slopes.cpu().numpy().copy(), sim.strehl.cpu().numpy().copy(),
                      sim.t["bincube"].cpu().numpy().copy())
+    # materialising afterwards restores the stored planes from the same voltages
+    shp = sim.dm_shape(0).cpu().numpy()
+    assert not sim._stale
     for e, o in enumerate(oracles):
         o.comp_shapes(volts[e])
         o.reset_strehl()
@@ -276,23 +288,27 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
         o.raytrace_wfs(atm=True, dms=True, reset=True)
         o.comp_image(noise=False)
         o.do_centroids()
-        for mode in ("fused_cube", "fused"):
+        assert np.abs(shp[e].ravel() - o.dm_shapes[0].ravel()).max() < 2e-6 * max(1.0, np.abs(o.dm_shapes[0]).max())
+        for mode in ("fused_cube", "fused", "otf_cube", "otf"):
             sl, st, cube = out[mode]
             assert np.abs(sl[e] - o.slopes).max() < 2e-5, mode
             assert np.abs(sl[e] - out["unfused"][0][e]).max() < 2e-5, mode
             assert abs(st[e, 0] - want[0]) < 2e-5 * max(want[0], 1e-3) + 1e-7, mode
             assert abs(st[e, 2] - want[2]) < 1e-4 * want[2] + 1e-9, mode
-        cube = out["fused_cube"][2]
-        assert np.abs(cube[e] - o.bincube).max() < 2e-5 * o.bincube.max()
-        assert np.array_equal(cube[e].argmax(axis=1), o.bincube.argmax(axis=1))
+        for mode in ("fused_cube", "otf_cube"):
+            cube = out[mode][2]
+            assert np.abs(cube[e] - o.bincube).max() < 2e-5 * o.bincube.max(), mode
+            assert np.array_equal(cube[e].argmax(axis=1), o.bincube.argmax(axis=1)), mode
 
 
-@pytest.mark.parametrize("unfused", [0, 1])
+@pytest.mark.parametrize("unfused", [0, 1, 2])
 def test_closed_loop_trace_matches_oracle(setup, unfused):
-    """40 frames of the integrator loop (next_part_two + next_part_one) from a common state, with
-    the one-pass frame kernel (0) and with separate target / WFS passes (1)."""
+    """40 frames of the integrator loop (next_part_two + next_part_one) from a common state: the
+    one-pass frame kernel with the stack-array DM evaluated from the commands (0), separate
+    target / WFS passes (1), the one-pass kernel reading materialised DM shapes (2)."""
     _, s, _, sim, oracles = setup
-    sim.set_option("force_unfused_frame", unfused)
+    sim.set_option("force_unfused_frame", 1 if unfused == 1 else 0)
+    sim.defer_shape = unfused == 0
     sim.reset(SEEDS)
     for o, sd in zip(oracles, SEEDS):
         o.reset(sd)
@@ -316,6 +332,7 @@ def test_closed_loop_trace_matches_oracle(setup, unfused):
             assert abs(st[e, 0] - o.strehl_se) < 1e-4, it
             assert abs(st[e, 1] - o.strehl_le) < 1e-4, it
     sim.set_option("force_unfused_frame", 0)
+    sim.defer_shape = True
     assert sim.strehl[:, 0].min().item() > 0.3   # the loop closed
     print("worst slope deviation over the trace: %.3g arcsec" % worst)
 

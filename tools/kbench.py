@@ -25,7 +25,12 @@ def timeit(fn, reps=20):
 print("spot              %.3f ms" % timeit(lambda: sim.comp_image(noise=False, cog=True)))
 print("spot noise        %.3f ms" % timeit(lambda: sim.comp_image(noise=True, cog=True)))
 print("target_psf        %.3f ms" % timeit(lambda: sim.target_psf()))
-print("frame_fused       %.3f ms" % timeit(lambda: sim.frame_fused(noise=False, cog=True)))
+print("frame_fused       %.3f ms" % timeit(lambda: sim.frame_fused(noise=False, cog=True, dm_from_voltage=False)))
+print("frame_fused otf   %.3f ms" % timeit(lambda: sim.frame_fused(noise=False, cog=True, dm_from_voltage=True)))
+for d, what in ((1, "no spot"), (2, "no psf mfma"), (3, "loads+amplitudes only"), (4, "no loads"), (7, "amplitudes only")):
+    sim.set_option("fused_debug", d)
+    print("frame_fused otf dbg=%d (%s) %.3f ms" % (d, what, timeit(lambda: sim.frame_fused(noise=False, cog=True, dm_from_voltage=True))))
+sim.set_option("fused_debug", 0)
 print("frame_fused noise %.3f ms" % timeit(lambda: sim.frame_fused(noise=True, cog=True)))
 print("dm_shape          %.3f ms" % timeit(lambda: sim.comp_dm_shape()))
 print("move_atmos        %.3f ms" % timeit(lambda: sim.move_atmos()))
@@ -33,7 +38,9 @@ print("do_control        %.3f ms" % timeit(lambda: sim.do_control()))
 a = torch.zeros(nenv, nm, device="cuda")
 print("rl_control        %.3f ms" % timeit(lambda: sim.rl_control(a)))
 print("volts2modes       %.3f ms" % timeit(lambda: sim.volts2modes(sim.com)))
+print("part_two deferred %.3f ms" % timeit(lambda: sim.next_part_two(None)))
 print("part_one fused    %.3f ms" % timeit(lambda: sim.next_part_one()))
+sim.defer_shape = False
 sim.set_option("force_unfused_frame", 1)
 print("part_one unfused  %.3f ms" % timeit(lambda: sim.next_part_one()))
 sim.set_option("force_unfused_frame", 0)

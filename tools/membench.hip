@@ -1,0 +1,108 @@
+// Development aid: what does the frame kernel's access pattern cost on its own?
+// Reads 16x16 tiles (rows of 64 B at an arbitrary 4-byte alignment, row stride 5200 B) of NL planes
+// per environment exactly like k_frame_wave does and sums them; variants change the lane -> pixel
+// mapping, the prefetch depth and the number of resident waves.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/membench tools/membench.hip && /tmp/membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int DIM = 1296, LD = 1300, NT = 40, NL = 3;
+
+// MAP 0: lane -> (row = lane >> 2, col = 4 (lane & 3));  MAP 1: (row = lane & 15, col = 4 (lane >> 4))
+// block = 4 waves; MODE 0: wave = (env, stripe), walks 40 tiles;  MODE 1: waves of a block split a stripe
+template <int MAP, int DEPTH, int MODE>
+__global__ __launch_bounds__(256) void k_read(const float *__restrict__ scr, long long env_stride,
+                                              const int *__restrict__ org, float *__restrict__ out,
+                                              int nenv, int lds_pad) {
+  extern __shared__ float pad[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = blockIdx.x;
+  const int e = MODE == 0 ? 4 * blockIdx.y + wv : blockIdx.y;
+  if (e >= nenv) return;
+  const int row = MAP == 0 ? lane >> 2 : lane & 15, col = MAP == 0 ? 4 * (lane & 3) : 4 * (lane >> 4);
+  const float *lay[NL];
+  unsigned lpx[NL], lrow[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    lay[l] = scr + (long long)e * env_stride + (long long)l * DIM * LD;
+    unsigned px = org[(e * NL + l) * 2] + 330, py = org[(e * NL + l) * 2 + 1] + 330 + 16 * r + row;
+    px -= px >= DIM ? DIM : 0; py -= py >= DIM ? DIM : 0;
+    lpx[l] = px + col; lrow[l] = py * LD;
+  }
+  float raw[DEPTH][NL][4];
+  auto fetch = [&](int t, int slot) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      unsigned px = 16u * t + lpx[l]; px = min(px, px - DIM);
+      const f4u v = *reinterpret_cast<const f4u *>(lay[l] + (lrow[l] + px));
+#pragma unroll
+      for (int j = 0; j < 4; j++) raw[slot][l][j] = v.v[j];
+    }
+  };
+  const int t0 = MODE == 0 ? 0 : wv, dt = MODE == 0 ? 1 : 4;
+  const int ntw = MODE == 0 ? NT : (NT - wv + 3) / 4;       // tiles of this wave
+  float acc = 0.f;
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) if (d < ntw) fetch(t0 + d * dt, d);
+  for (int k = 0; k < ntw; k += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+      if (k + d < ntw) {
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc += raw[d][l][j];
+        if (k + d + DEPTH < ntw) fetch(t0 + (k + d + DEPTH) * dt, d);
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc + pad[lds_pad ? 0 : 0];
+}
+
+template <int MAP, int DEPTH, int MODE>
+float run(const float *scr, long long es, const int *org, float *out, int nenv, int lds) {
+  dim3 grid(NT, MODE == 0 ? (nenv + 3) / 4 : nenv), blk(256);
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_read<MAP, DEPTH, MODE>), grid, blk, lds, 0, scr, es, org, out, nenv, lds);
+  CK(hipEventRecord(a));
+  const int reps = 10;
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_read<MAP, DEPTH, MODE>), grid, blk, lds, 0, scr, es, org, out, nenv, lds);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main() {
+  const int nenv = 256;
+  const long long es = (long long)NL * DIM * LD;
+  float *scr, *out; int *org;
+  CK(hipMalloc(&scr, sizeof(float) * es * nenv));
+  CK(hipMemset(scr, 0, sizeof(float) * es * nenv));
+  CK(hipMalloc(&out, 64));
+  std::vector<int> h(nenv * NL * 2);
+  srand(1);
+  for (auto &v : h) v = rand() % DIM;
+  CK(hipMalloc(&org, sizeof(int) * h.size()));
+  CK(hipMemcpy(org, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+  const double bytes = (double)nenv * NT * NT * NL * 1024.0;
+  printf("algorithmic bytes per launch: %.3f GB (all 1600 tiles)\n", bytes * 1e-9);
+#define R(MAP, DEPTH, MODE, LDS)                                                              \
+  do {                                                                                        \
+    float ms = run<MAP, DEPTH, MODE>(scr, es, org, out, nenv, LDS);                            \
+    printf("map %d depth %d mode %d lds %6d : %.3f ms  %.2f TB/s\n", MAP, DEPTH, MODE, LDS, ms, \
+           bytes / ms * 1e-9);                                                                \
+  } while (0)
+  R(0, 1, 0, 0); R(0, 2, 0, 0); R(0, 4, 0, 0);
+  R(1, 1, 0, 0); R(1, 2, 0, 0); R(1, 4, 0, 0);
+  R(0, 1, 1, 0); R(0, 2, 1, 0); R(0, 4, 1, 0);
+  R(1, 1, 1, 0); R(1, 2, 1, 0);
+  R(0, 2, 0, 40000); R(0, 2, 0, 60000); R(1, 2, 0, 40000);
+  return 0;
+}
