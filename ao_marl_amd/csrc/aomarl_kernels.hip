@@ -187,6 +187,138 @@ __global__ __launch_bounds__(256) void k_gemm_nt_batched(int M, int N, int K,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant (operands 16-byte aligned, lda / ldb multiples of 4): block tile 64 x 64 x 32,
+// double-buffered LDS (one barrier per k-tile), the global loads of tile k+1 are issued before the
+// MFMAs of tile k.  K order inside a tile is permuted so that every lane reads its 16 k-values of
+// a row as four 128-bit LDS reads: MFMA number i of the tile uses k = 16 (lane >> 5) + i for both
+// operands (any order is fine as long as A and B agree).  Row stride 36 floats: the 16 lanes of
+// a 128-bit read pass hit 64 distinct banks.
+// ---------------------------------------------------------------------------------------------
+#define G2_LD 36
+__device__ __forceinline__ float4 g2_load4(const float *p, int k, int ke, bool row_ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row_ok) {
+    if (k + 3 < ke) v = *reinterpret_cast<const float4 *>(p + k);
+    else {
+      if (k < ke) v.x = p[k];
+      if (k + 1 < ke) v.y = p[k + 1];
+      if (k + 2 < ke) v.z = p[k + 2];
+    }
+  }
+  return v;
+}
+
+// acc += A[m0.., kb..ke) . B[n0.., kb..ke)^T for the 32 x 32 sub-tile (wm, wn) of this wave
+__device__ __forceinline__ void g2_mainloop(const float *__restrict__ A, int lda,
+                                            const float *__restrict__ B, int ldb, int M, int N,
+                                            int m0, int n0, int kb, int ke, float *As, float *Bs,
+                                            f32x16 &acc) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;
+  const float *pa0 = A + (long long)(m0 + lr) * lda, *pa1 = A + (long long)(m0 + lr + 32) * lda;
+  const float *pb0 = B + (long long)(n0 + lr) * ldb, *pb1 = B + (long long)(n0 + lr + 32) * ldb;
+  const bool a0 = m0 + lr < M, a1 = m0 + lr + 32 < M, b0 = n0 + lr < N, b1 = n0 + lr + 32 < N;
+  float4 ra0, ra1, rb0, rb1;
+  auto gload = [&](int k0) {
+    ra0 = g2_load4(pa0, k0 + lc, ke, a0); ra1 = g2_load4(pa1, k0 + lc, ke, a1);
+    rb0 = g2_load4(pb0, k0 + lc, ke, b0); rb1 = g2_load4(pb1, k0 + lc, ke, b1);
+  };
+  auto lstore = [&](int buf) {
+    float *as = As + buf * 64 * G2_LD, *bs = Bs + buf * 64 * G2_LD;
+    *reinterpret_cast<float4 *>(as + lr * G2_LD + lc) = ra0;
+    *reinterpret_cast<float4 *>(as + (lr + 32) * G2_LD + lc) = ra1;
+    *reinterpret_cast<float4 *>(bs + lr * G2_LD + lc) = rb0;
+    *reinterpret_cast<float4 *>(bs + (lr + 32) * G2_LD + lc) = rb1;
+  };
+  const int ro = (lane & 31) * G2_LD + 16 * (lane >> 5);
+  gload(kb);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += 32, buf ^= 1) {
+    const bool more = k0 + 32 < ke;
+    if (more) gload(k0 + 32);
+    const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
+    const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
+    float4 a4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      a4[j] = *reinterpret_cast<const float4 *>(as + 4 * j);
+      b4[j] = *reinterpret_cast<const float4 *>(bs + 4 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alpha,
+                                                  const float *__restrict__ A, int lda,
+                                                  const float *__restrict__ B, int ldb, float beta,
+                                                  float *__restrict__ C, int ldc, int kchunk,
+                                                  float *__restrict__ P) {
+  __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  g2_mainloop(A, lda, B, ldb, M, N, m0, n0, kb, ke, As, Bs, acc);
+  const int col = n0 + wn * 32 + (lane & 31);
+  const bool split = gridDim.z > 1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      if (split) {
+        P[((long long)blockIdx.z * M + row) * N + col] = acc[r];
+      } else {
+        float *c = C + (long long)row * ldc + col;
+        float v = alpha * acc[r];
+        if (beta != 0.f) v += beta * (*c);
+        *c = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
+                                                          const float *__restrict__ A, int lda, long long sA,
+                                                          const float *__restrict__ B, int ldb, long long sB,
+                                                          const float *__restrict__ bias, long long sBias,
+                                                          float *__restrict__ C, int ldc, long long sC,
+                                                          int relu) {
+  __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  g2_mainloop(A, lda, B, ldb, M, N, m0, n0, 0, K, As, Bs, acc);
+  const int col = n0 + wn * 32 + (lane & 31);
+  const float bv = (bias && col < N) ? bias[(long long)blockIdx.z * sBias + col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      float v = acc[r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      C[(long long)row * ldc + col] = v;
+    }
+  }
+}
+
 __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float *__restrict__ P,
                               float beta, float *__restrict__ C, int ldc) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,6 +332,9 @@ __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float
   *c = v;
 }
 
+static bool g_gemm_legacy = false;    // "gemm_legacy" option: the un-pipelined kernels (A/B tests)
+static int g_gemm_target_blocks = 512;
+
 // ws / ws_floats: optional split-K workspace (NULL: never split)
 void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
                     int ldb, float beta, float *C, int ldc, hipStream_t s, float *ws = nullptr,
@@ -208,16 +343,19 @@ void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   const int bx = (N + 63) / 64, by = (M + 63) / 64;
   int nsplit = 1;
   if (ws && bx * by < 384) {
-    nsplit = (512 + bx * by - 1) / (bx * by);
+    nsplit = (g_gemm_target_blocks + bx * by - 1) / (bx * by);
     if (nsplit > 8) nsplit = 8;
     while (nsplit > 1 && (K / nsplit < 128 || (size_t)nsplit * M * N > ws_floats)) nsplit--;
   }
-  int kchunk = ((K + nsplit - 1) / nsplit + 15) & ~15;
+  int kchunk = ((K + nsplit - 1) / nsplit + 31) & ~31;
   nsplit = (K + kchunk - 1) / kchunk;
   dim3 grid(bx, by, nsplit);
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
-  if (al)
+  if (al && !g_gemm_legacy)
+    hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
+                       ldc, kchunk, ws);
+  else if (al)
     hipLaunchKernelGGL(k_gemm_nt<true>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
                        C, ldc, kchunk, ws);
   else

@@ -41,7 +41,8 @@ def _push_oracle_state(sim, oracles):
 def test_gemm_nt_matches_torch(setup):
     sim = setup[3]
     g = torch.Generator(device="cpu").manual_seed(0)
-    for (M, N, K) in [(3, 90, 128), (64, 64, 16), (130, 257, 1957), (5, 7, 3), (256, 1286, 2400)]:
+    for (M, N, K) in [(3, 90, 128), (64, 64, 16), (130, 257, 1957), (5, 7, 3), (256, 1286, 2400),
+                      (70, 130, 100), (33, 65, 36), (64, 64, 4)]:
         A = torch.randn(M, K, generator=g).cuda()
         B = torch.randn(N, K, generator=g).cuda()
         Cm = sim.gemm_nt(A, B, alpha=-1.0)

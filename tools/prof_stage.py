@@ -1,4 +1,4 @@
-"""Run each hot stage a few times on a warm 256-env 40x40 system (target of rocprofv3 --pmc)."""
+"""Run the hot stages a few times on a warm 256-env 40x40 system (target of rocprofv3 --pmc)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,13 +12,13 @@ sim = HipSim(s, nenv=nenv)
 nm = cal.volts2modes.shape[0]
 sim.set_modal(cal.volts2modes, cal.modes2volts, np.full(nm, 0.01, np.float32), np.arange(nm))
 sim.reset(1234 + 16 * np.arange(nenv))
+a = torch.zeros(nenv, nm, device="cuda")
 for _ in range(5):
-    sim.next_part_two(None); sim.next_part_one()
+    sim.next_part_two(a); sim.next_part_one()
 torch.cuda.synchronize()
 for _ in range(reps):
-    sim.comp_image(noise=False, cog=True)
-    sim.target_psf()
-    sim.comp_dm_shape()
-    sim.do_control()
+    sim.next_part_two(a)          # rl_control GEMMs, delay line, (deferred) DM shapes, Strehl commit
+    sim.next_part_one()           # extrusion, one-pass frame kernel, command GEMM
+    sim.volts2modes(sim.com)
 torch.cuda.synchronize()
 print("done")
