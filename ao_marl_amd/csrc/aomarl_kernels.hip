@@ -712,6 +712,16 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// An all-zero accumulator the compiler cannot rematerialise: MFMAs that start a chain read it as
+// their C operand (dst != srcC form) instead of zero-filling a fresh accumulator with v_mov each
+// time (fp32 MFMAs and VALU instructions share the issue slots, so every v_mov counts).
+__device__ __forceinline__ f32x4 opaque_zero4() {
+  float z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  f32x4 r = {z, z, z, z};
+  return r;
+}
+
 __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
   if (!(lam > 0.f)) return 0.f;
   if (lam < 30.f) {
@@ -747,10 +757,9 @@ template <bool NOISE, bool WRITE_CUBE>
 __device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st, int e, int i,
                                           int lane, const float (&Cc)[4], const float (&Ss)[4],
                                           const float (&br)[4], const float (&bi)[4], int do_cog,
-                                          float flux_i) {
+                                          float flux_i, const f32x4 z4) {
   const int q = lane >> 4, c = lane & 15;
   const bool owner = (c & 1) == 0;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   // ---- stage 1 (y = c on M, x = 4q + s on K, k = c on N)
   f32x4 PCr = z4, PCi = z4, PSr = z4, PSi = z4;
 #pragma unroll
@@ -879,7 +888,8 @@ __device__ __forceinline__ void spot_compute(const DevSys &sys, const DevState &
   float br[4], bi[4];
 #pragma unroll
   for (int s = 0; s < 4; s++) { br[s] = sAr[wv][c][4 * q + s]; bi[s] = sAi[wv][c][4 * q + s]; }
-  spot_core<NOISE, WRITE_CUBE>(sys, st, e, i, lane, Cc, Ss, br, bi, do_cog, flux_i);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  spot_core<NOISE, WRITE_CUBE>(sys, st, e, i, lane, Cc, Ss, br, bi, do_cog, flux_i, z4);
 }
 
 // phase (sum of all sources) and pupil mask of the 4 pixels this lane owns in sub-aperture i
@@ -1426,6 +1436,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     raw.F = sub >= 0 ? sys.flux[sub] : 0.f;
   };
   f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 Z4 = opaque_zero4();
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int kxf = c - 8;
   int sub = tsub[0];
@@ -1434,9 +1445,9 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     const int subn = t + 1 < ntl ? tsub[t + 1] : -2;
     if (sub != -2) {
       // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
-      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+      f32x4 S = Z4;
       if (OTF) {
-        f32x4 U = {0.f, 0.f, 0.f, 0.f};
+        f32x4 U = Z4;
 #pragma unroll
         for (int kb = 0; kb < NB; kb++) {
           const float a = lat[(q + 4 * kb) * latw + t * tpn + (jm_ok ? jm : 0)];
@@ -1484,7 +1495,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
         float br[4], bi[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) { br[s] = Twr[(4 * q + s) * FW_LD + c]; bi[s] = Twi[(4 * q + s) * FW_LD + c]; }
-        spot_core<NOISE, WRITE_CUBE>(sys, st, e, sub, lane, Cc, Ss, br, bi, do_cog, flux_i);
+        spot_core<NOISE, WRITE_CUBE>(sys, st, e, sub, lane, Cc, Ss, br, bi, do_cog, flux_i, Z4);
       }
       __builtin_amdgcn_wave_barrier();
     } else {

@@ -1,5 +1,5 @@
 // Development aid: what does the frame kernel's access pattern cost on its own?
-// Reads 16x16 tiles (rows of 64 B at an arbitrary 4-byte alignment, row stride 5200 B) of NL planes
+// Reads 16x16 tiles (rows of 64 B at an arbitrary 4-byte alignment, row stride 2608 B) of NL planes
 // per environment exactly like k_frame_wave does and sums them; variants change the lane -> pixel
 // mapping, the prefetch depth and the number of resident waves.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/membench tools/membench.hip && /tmp/membench
@@ -11,7 +11,7 @@
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-constexpr int DIM = 1296, LD = 1300, NT = 40, NL = 3;
+constexpr int DIM = 648, LD = 652, NT = 40, NL = 3;   // the 40x40 configuration's screens
 
 // MAP 0: lane -> (row = lane >> 2, col = 4 (lane & 3));  MAP 1: (row = lane & 15, col = 4 (lane >> 4))
 // block = 4 waves; MODE 0: wave = (env, stripe), walks 40 tiles;  MODE 1: waves of a block split a stripe
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_read(const float *__restrict__ scr, lon
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     lay[l] = scr + (long long)e * env_stride + (long long)l * DIM * LD;
-    unsigned px = org[(e * NL + l) * 2] + 330, py = org[(e * NL + l) * 2 + 1] + 330 + 16 * r + row;
+    unsigned px = org[(e * NL + l) * 2] + 4, py = org[(e * NL + l) * 2 + 1] + 4 + 16 * r + row;
     px -= px >= DIM ? DIM : 0; py -= py >= DIM ? DIM : 0;
     lpx[l] = px + col; lrow[l] = py * LD;
   }
