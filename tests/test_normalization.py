@@ -1,0 +1,84 @@
+"""Normalisation / action-bound generator (reference recipe:
+preprocessing/normalization/obtain_normalization.py:139-243).
+
+CPU: the device accumulation and the frame ordering against a plain NumPy restatement of the
+reference loop over the oracle.  GPU: the recipe itself (seeds 1..20 x 1000 integrator frames) on the
+HIP path, compared with the statistics the reference recorded from real COMPASS
+(ao_marl_amd/data/norm_*.npz, imported by tools/import_norm_data.py) -- distributional parity, since
+COMPASS's cuRAND streams cannot be reproduced."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from ao_marl_amd import normalization as N  # noqa: E402
+from ao_marl_amd.env import load_norm  # noqa: E402
+
+
+def test_normalization_loop_matches_numpy_recipe_on_the_oracle():
+    from tests.oracle_vecsim import OracleVecSim
+    from oracle import aoref
+    from ao_marl_amd.env import VecRlSupervisor
+    frames, seeds = 12, (1, 2)
+    sup = VecRlSupervisor("production_sh_10x10_2m", dict(n_reverse_filtered_from_cmat=5), len(seeds),
+                          initial_seed=1, seed_stride=1, device="cpu", sim_factory=OracleVecSim)
+    norm, zn, sr = N.normalization_loop(sup, frames=frames)
+    # the reference loop, one episode after the other (obtain_normalization.py:160-197)
+    wfs, dm, res = [], [], []
+    v2m = sup.volts2modes
+    for sd in seeds:
+        o = aoref.OracleSim(sup.s, seed=sd)
+        for _ in range(frames):
+            o.next_part_one()
+            o.next_part_two(None)
+            wfs.append(o.slopes.copy()); dm.append(v2m.dot(o.com)); res.append(v2m.dot(o.err))
+    for key, lst in (("wfs", wfs), ("dm", dm), ("dm_residual", res)):
+        a = np.asarray(lst, dtype=np.float64)
+        scale = np.abs(a).max()
+        assert np.abs(norm[key]["mean"] - a.mean(axis=0)).max() < 1e-5 * scale
+        assert np.abs(norm[key]["std"] - a.std(axis=0)).max() < 1e-5 * scale
+        assert np.abs(norm[key]["max"] - a.max(axis=0)).max() < 1e-5 * scale
+        assert np.abs(norm[key]["min"] - a.min(axis=0)).max() < 1e-5 * scale
+    d = np.asarray(dm)
+    assert np.allclose(zn, (np.abs(d.max(axis=0)) + np.abs(d.min(axis=0))) / 2.0, rtol=1e-5, atol=1e-7)
+    assert sr.shape == (2,)
+
+
+def test_save_norm_round_trips_through_load_norm(tmp_path, monkeypatch):
+    rng = np.random.default_rng(0)
+    norm = {k: {st: rng.normal(size=7).astype(np.float32) for st in ("mean", "std", "max", "min")}
+            for k in N.KEYS}
+    zn = rng.random(7).astype(np.float32)
+    N.save_norm(str(tmp_path / "norm_demo.npz"), norm, zn)
+    import ao_marl_amd.env as E
+    monkeypatch.setattr(E, "DATA_DIR", str(tmp_path))
+    got, zn2 = load_norm("demo.py")
+    assert np.array_equal(zn, zn2)
+    for k in N.KEYS:
+        for st in ("mean", "std", "max", "min"):
+            assert np.array_equal(got[k][st], norm[k][st])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["production_sh_10x10_2m", "production_sh_40x40_8m_3layers"])
+def test_statistics_match_the_references_recorded_compass_runs(name):
+    """Acceptance of SURVEY section 8c: median ratio of the per-slope and per-mode standard
+    deviations within +-10 %, action bounds (extreme-value statistics) within +-20 %."""
+    ref, zn_ref = load_norm(name)
+    norm, zn, sr = N.obtain_normalization(name, modes_filtered=5, episodes=20, frames=1000)
+    assert norm["wfs"]["std"].shape == ref["wfs"]["std"].shape
+    assert norm["dm"]["std"].shape == ref["dm"]["std"].shape == zn.shape == zn_ref.shape
+    r_wfs = np.median(norm["wfs"]["std"] / ref["wfs"]["std"])
+    nm = zn.shape[0]
+    live = np.arange(nm) < nm - 5 - 2                      # filtered modes carry no command
+    live[-2:] = True
+    r_dm = np.median(norm["dm"]["std"][live] / ref["dm"]["std"][live])
+    r_res = np.median(norm["dm_residual"]["std"][live] / ref["dm_residual"]["std"][live])
+    r_zn = np.median(zn[live] / zn_ref[live])
+    print("%s: median std ratio  slopes %.3f  command modes %.3f  residual modes %.3f  zn_norm %.3f  "
+          "LE Strehl %.3f" % (name, r_wfs, r_dm, r_res, r_zn, sr.mean()))
+    assert abs(r_wfs - 1) < 0.10
+    assert abs(r_dm - 1) < 0.10
+    assert abs(r_res - 1) < 0.10
+    assert abs(r_zn - 1) < 0.20
+    assert np.abs(norm["wfs"]["mean"]).max() < 0.2 * norm["wfs"]["std"].max()
