@@ -1,0 +1,394 @@
+"""On-device replay memory + batched multi-agent SAC update + the training episode loop.
+
+The reference trains one SAC agent per OS process (torch RPC): the master pushes each agent's
+(s, a, r, s', mask) into a per-agent master memory during the episode, and at the end of the
+episode every agent runs `updates_per_episode_rpc` updates, trickling one master transition into
+its own `ReplayMemory` per update (train_rpc.py:734-780, 1086-1133; replay_memory_rpc.py:5-29).
+Here all agents are slices of stacked parameter tensors (same scheme as agents.py), the replay
+memory is one ring buffer in HBM holding the *global* state once per transition (every agent's
+state is an index gather of it), and one update step = one autograd pass over all agents: the
+total loss is the sum of the per-agent losses, the parameter sets are disjoint, and Adam is
+element-wise, so each agent receives exactly the update the reference computes for it.
+
+Restated reference logic (cited per method):
+  SAC.get_bellman_backup / update_critic / calculate_q_loss     train_rpc.py:985-1038
+  SAC.update_actor / calculate_policy_loss                       train_rpc.py:1044-1064
+  SAC.update_alpha, initialise_alpha                             train_rpc.py:1070-1084, 838-854
+  SAC.update_parameters_sac                                      train_rpc.py:1086-1133
+  GaussianPolicy.sample (log-prob with tanh correction)          algorithms_rpc/model_rpc.py:133-164
+  QNetwork                                                       algorithms_rpc/model_rpc.py:17-69
+  soft_update / hard_update                                      algorithms_rpc/utils.py:24-30
+  TrainerRPC.episode / manage_memory / save_model                train_rpc.py:503-547, 734-757, 1140-1161
+Pinned by tests/golden/host_sac_update.pt (tools/gen_golden_sac.py runs the reference's own update
+methods on the reference's modules).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from .agents import BatchedGaussianPolicy, LOG_SIG_MIN, _xavier_uniform
+
+EPSILON = 1e-5                         # model_rpc.py:8
+
+# defaults of config/parameters_sac.cfg + GlobalConfig.py:52-63
+DEFAULT_SAC = dict(alpha=0.2, automatic_entropy_tuning=True, batch_size=256, gamma=0.1,
+                   hidden_size_actor=256, hidden_size_critic=256, num_layers_actor=2,
+                   lr=3e-4, target_update_interval=1, tau=0.005, memory_size=1000000,
+                   gaussian_mu=0.0, gaussian_std=1.0, initialize_last_layer_0=True,
+                   LOG_SIG_MAX=2.0, updates_per_episode_rpc=1000)
+
+
+class BatchedReplay(object):
+    """All agents' ReplayMemory objects as one ring buffer of global transitions in HBM.
+
+    One row = (state [state_dim], action [action_dim], reward [n_agents], next_state, mask): the
+    per-agent tuples the reference stores (manage_memory, train_rpc.py:734-757) are index gathers
+    of it.  Sampling draws an independent index set per agent (each reference agent samples its
+    own memory); indices are drawn with replacement on the device (the reference uses
+    `random.sample`, without replacement: indistinguishable for batch 256 of >= 1e4 rows)."""
+
+    def __init__(self, state_dim, action_dim, n_agents, capacity, device, seed=0):
+        self.capacity, self.device = int(capacity), torch.device(device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.state = torch.zeros(self.capacity, state_dim, **f32)
+        self.next_state = torch.zeros(self.capacity, state_dim, **f32)
+        self.action = torch.zeros(self.capacity, action_dim, **f32)
+        self.reward = torch.zeros(self.capacity, n_agents, **f32)
+        self.mask = torch.zeros(self.capacity, 1, **f32)
+        self.position, self.size = 0, 0
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+
+    def __len__(self):
+        return self.size
+
+    def reset(self):
+        self.position, self.size = 0, 0
+
+    def push(self, state, action, reward, next_state, mask):
+        """Append n transitions ([n, ...] tensors; mask scalar or [n]); oldest rows are overwritten."""
+        n = state.shape[0]
+        if n > self.capacity:
+            state, action, reward, next_state = (t[-self.capacity:] for t in
+                                                 (state, action, reward, next_state))
+            n = self.capacity
+        idx = (self.position + torch.arange(n, device=self.device)) % self.capacity
+        self.state[idx], self.action[idx] = state, action
+        self.reward[idx], self.next_state[idx] = reward, next_state
+        if not torch.is_tensor(mask):
+            mask = torch.full((n, 1), float(mask), dtype=torch.float32, device=self.device)
+        elif mask.numel() == 1:
+            mask = mask.reshape(1, 1).expand(n, 1)
+        self.mask[idx] = mask.reshape(-1, 1)[-n:].to(torch.float32)
+        self.position = (self.position + n) % self.capacity
+        self.size = min(self.size + n, self.capacity)
+
+    def rows(self, begin, count):
+        """`count` rows starting at logical row `begin` (insertion order while not wrapped)."""
+        idx = (begin + torch.arange(count, device=self.device)) % self.capacity
+        return (self.state[idx], self.action[idx], self.reward[idx], self.next_state[idx],
+                self.mask[idx])
+
+    def sample_indices(self, n_agents, batch_size):
+        return torch.randint(0, self.size, (n_agents, batch_size), generator=self.gen,
+                             device=self.device)
+
+
+class BatchedSAC(object):
+    """Soft actor-critic for all agents of an AgentLayout at once."""
+
+    def __init__(self, layout, config=None, seed=1234, device="cuda:0", memory_size=None):
+        cfg = dict(DEFAULT_SAC)
+        cfg.update(config or {})
+        self.cfg, self.layout, self.device = cfg, layout, torch.device(device)
+        self.gamma, self.tau, self.lr = cfg["gamma"], cfg["tau"], cfg["lr"]
+        self.target_update_interval = cfg["target_update_interval"]
+        self.automatic_entropy_tuning = bool(cfg["automatic_entropy_tuning"])
+        A = layout.n_agents
+        self.A = A
+        self.policy = BatchedGaussianPolicy(
+                layout, hidden=cfg["hidden_size_actor"], num_layers=cfg["num_layers_actor"],
+                log_sig_max=cfg["LOG_SIG_MAX"], action_scale=cfg["gaussian_std"],
+                action_bias=cfg["gaussian_mu"], last_layer_zero=cfg["initialize_last_layer_0"],
+                seed=seed, device=device)
+        p = self.policy
+        self.in_max, self.act_max = p.in_max, p.act_max
+        ins, acts = layout.state_shapes(), layout.action_shapes()
+        self.ins, self.acts = ins, acts
+        dev = self.device
+        am = torch.zeros(A, 1, self.act_max, device=dev)
+        for i, na in enumerate(acts):
+            am[i, 0, :na] = 1.0
+        self.act_mask = am
+        # ---- critic: Linear(in+act, H) - ReLU - Linear(H, 1), twice (the reference passes
+        #      hidden_size_critic as a one-element list: no extra hidden layers, GlobalConfig.py:36)
+        H = cfg["hidden_size_critic"]
+        g = torch.Generator().manual_seed(seed + 7919)
+        self.critic = []
+        for _ in range(2):
+            Win = torch.zeros(A, self.in_max + self.act_max, H)
+            Wout = torch.zeros(A, H, 1)
+            for i in range(A):
+                w = _xavier_uniform(g, H, ins[i] + acts[i]).T
+                Win[i, :ins[i]] = w[:ins[i]]
+                Win[i, self.in_max:self.in_max + acts[i]] = w[ins[i]:]
+                Wout[i] = _xavier_uniform(g, 1, H).T
+            self.critic.append(dict(Win=Win.to(dev), bin=torch.zeros(A, 1, H, device=dev),
+                                    Wout=Wout.to(dev), bout=torch.zeros(A, 1, 1, device=dev)))
+        self.critic_target = [{k: v.clone() for k, v in q.items()} for q in self.critic]   # hard_update
+        # ---- entropy temperature (initialise_alpha)
+        self.target_entropy = -torch.tensor([float(a) for a in acts], device=dev).reshape(A, 1, 1)
+        self.log_alpha = torch.zeros(A, 1, 1, device=dev)
+        self.alpha = torch.full((A, 1, 1), float(cfg["alpha"]), device=dev)
+        # ---- optimisers (Adam is element-wise: one optimiser over stacked tensors == one per agent)
+        for t in self._policy_params() + self._critic_params() + [self.log_alpha]:
+            t.requires_grad_(True)
+        self.policy_optim = torch.optim.Adam(self._policy_params(), lr=self.lr)
+        self.critic_optim = torch.optim.Adam(self._critic_params(), lr=self.lr)
+        self.alpha_optim = torch.optim.Adam([self.log_alpha], lr=self.lr)
+        self.memory = BatchedReplay(layout.state_dim, layout.action_dim, A,
+                                    memory_size if memory_size is not None else cfg["memory_size"],
+                                    device, seed=seed)
+        self.gen = torch.Generator(device=dev).manual_seed(seed + 1)
+        self.total_update = 0
+        self.last_losses = None
+
+    # ------------------------------------------------------------------ parameters
+    def _policy_params(self):
+        p = self.policy
+        return [p.W1, p.b1] + list(p.Wh) + list(p.bh) + [p.Wm, p.bm, p.Ws, p.bs]
+
+    def _critic_params(self):
+        return [q[k] for q in self.critic for k in ("Win", "bin", "Wout", "bout")]
+
+    def load_reference_agent(self, i, policy_sd=None, critic_sd=None, critic_target_sd=None):
+        """Load reference state_dicts (train_rpc.py:1155-1161: actor 'model_state_dict', critic
+        `critic.state_dict()`) into agent slot i."""
+        if policy_sd is not None:
+            self.policy.load_agent(i, policy_sd)
+        ni, na = self.ins[i], self.acts[i]
+
+        def put(qs, sd):
+            with torch.no_grad():
+                for k, q in enumerate(qs):
+                    w = sd["Q%d_input.weight" % (k + 1)].to(self.device)       # [H, ni + na]
+                    q["Win"][i].zero_()
+                    q["Win"][i, :ni] = w[:, :ni].T
+                    q["Win"][i, self.in_max:self.in_max + na] = w[:, ni:].T
+                    q["bin"][i, 0] = sd["Q%d_input.bias" % (k + 1)].to(self.device)
+                    q["Wout"][i] = sd["Q%d_output.weight" % (k + 1)].to(self.device).T
+                    q["bout"][i, 0] = sd["Q%d_output.bias" % (k + 1)].to(self.device)
+        if critic_sd is not None:
+            put(self.critic, critic_sd)
+            put(self.critic_target, critic_target_sd if critic_target_sd is not None else critic_sd)
+
+    def export_agent(self, i, target=False):
+        """(actor state_dict, critic state_dict) of agent i in the reference's layout
+        (target=True: the target critic instead of the critic)."""
+        p, ni, na = self.policy, self.ins[i], self.acts[i]
+        actor = OrderedDict()
+        actor["linear1.weight"] = p.W1[i, :ni].detach().T.contiguous().cpu()
+        actor["linear1.bias"] = p.b1[i, 0].detach().cpu().clone()
+        for j, (W, b) in enumerate(zip(p.Wh, p.bh)):
+            actor["hidden.%d.weight" % j] = W[i].detach().T.contiguous().cpu()
+            actor["hidden.%d.bias" % j] = b[i, 0].detach().cpu().clone()
+        actor["mean_linear.weight"] = p.Wm[i, :, :na].detach().T.contiguous().cpu()
+        actor["mean_linear.bias"] = p.bm[i, 0, :na].detach().cpu().clone()
+        actor["log_std_linear.weight"] = p.Ws[i, :, :na].detach().T.contiguous().cpu()
+        actor["log_std_linear.bias"] = p.bs[i, 0, :na].detach().cpu().clone()
+        critic = OrderedDict()
+        for k, q in enumerate(self.critic_target if target else self.critic):
+            w = torch.cat([q["Win"][i, :ni], q["Win"][i, self.in_max:self.in_max + na]], dim=0)
+            critic["Q%d_input.weight" % (k + 1)] = w.detach().T.contiguous().cpu()
+            critic["Q%d_input.bias" % (k + 1)] = q["bin"][i, 0].detach().cpu().clone()
+            critic["Q%d_output.weight" % (k + 1)] = q["Wout"][i].detach().T.contiguous().cpu()
+            critic["Q%d_output.bias" % (k + 1)] = q["bout"][i, 0].detach().cpu().clone()
+        return actor, critic
+
+    def save_model(self, path_prefix, episode, experiment_name="aomarl"):
+        """One actor + one critic file per agent, the reference's container
+        (SAC.save_model, train_rpc.py:1140-1161)."""
+        paths = []
+        for i, (wid, modes) in enumerate(self.layout.agents.items()):
+            actor, critic = self.export_agent(i)
+            ap = "%s_worker_%d_sac_actor_%s_episode_%d" % (path_prefix, wid, experiment_name, episode)
+            cp = "%s_worker_%d_sac_critic_%s_episode_%d" % (path_prefix, wid, experiment_name, episode)
+            torch.save({"worker_id": wid, "models_controlled": list(modes),
+                        "model_state_dict": actor}, ap)
+            torch.save(critic, cp)
+            paths.append((ap, cp))
+        return paths
+
+    # ------------------------------------------------------------------ networks (autograd path)
+    def _policy_forward(self, x):
+        p = self.policy
+        h = torch.relu(torch.baddbmm(p.b1, x, p.W1))
+        for W, b in zip(p.Wh, p.bh):
+            h = torch.relu(torch.baddbmm(b, h, W))
+        mean = torch.baddbmm(p.bm, h, p.Wm)
+        log_std = torch.baddbmm(p.bs, h, p.Ws).clamp(LOG_SIG_MIN, p.log_sig_max)
+        return mean, log_std
+
+    def sample(self, x, eps=None):
+        """GaussianPolicy.sample for split states x [A, B, in_max] -> (action, log_prob, mean);
+        padded action columns are zero and carry no log-probability.  `eps`: the standard-normal
+        draws ([A, B, act_max]; default: from this object's generator)."""
+        p = self.policy
+        mean, log_std = self._policy_forward(x)
+        std = log_std.exp()
+        if eps is None:
+            eps = torch.randn(mean.shape, generator=self.gen, device=self.device)
+        x_t = mean + std * eps
+        y_t = torch.tanh(x_t)
+        action = (y_t * p.scale + p.bias) * self.act_mask
+        # Normal(mean, std).log_prob(x_t) - log(scale (1 - y^2) + eps)          model_rpc.py:153-158
+        log_prob = -0.5 * eps * eps - log_std - 0.5 * math.log(2.0 * math.pi)
+        log_prob = log_prob - torch.log(p.scale * (1.0 - y_t.pow(2).clamp(min=0, max=1)) + EPSILON)
+        log_prob = (log_prob * self.act_mask).sum(dim=2, keepdim=True)
+        mean_a = (torch.tanh(mean) * p.scale + p.bias) * self.act_mask
+        return action, log_prob, mean_a
+
+    @staticmethod
+    def _q(qs, x, a):
+        xa = torch.cat([x, a], dim=2)
+        out = []
+        for q in qs:
+            h = torch.relu(torch.baddbmm(q["bin"], xa, q["Win"]))
+            out.append(torch.baddbmm(q["bout"], h, q["Wout"]))
+        return out[0], out[1]
+
+    # ------------------------------------------------------------------ one update
+    def update(self, x, a, r, x2, mask, eps_next=None, eps_pi=None):
+        """update_critic -> update_actor -> update_alpha -> soft_update for every agent.
+        x, x2 [A, B, in_max]; a [A, B, act_max]; r, mask [A, B, 1].  Returns per-agent losses."""
+        # ---- critic                                                     train_rpc.py:985-1038
+        with torch.no_grad():
+            a2, logp2, _ = self.sample(x2, eps_next)
+            q1t, q2t = self._q(self.critic_target, x2, a2)
+            min_q = torch.min(q1t, q2t) - self.alpha * logp2
+            target = r + mask * self.gamma * min_q
+        q1, q2 = self._q(self.critic, x, a)
+        q1_loss = ((q1 - target) ** 2).mean(dim=(1, 2))                 # F.mse_loss per agent
+        q2_loss = ((q2 - target) ** 2).mean(dim=(1, 2))
+        self.critic_optim.zero_grad(set_to_none=True)
+        (q1_loss + q2_loss).sum().backward()
+        self.critic_optim.step()
+        # ---- actor                                                      train_rpc.py:1044-1064
+        pi, log_pi, _ = self.sample(x, eps_pi)
+        q1p, q2p = self._q(self.critic, x, pi)
+        policy_loss = (self.alpha * log_pi - torch.min(q1p, q2p)).mean(dim=(1, 2))
+        self.policy_optim.zero_grad(set_to_none=True)
+        policy_loss.sum().backward()
+        self.policy_optim.step()
+        self.policy._native = None                # inference copies of the weights are stale
+        # ---- temperature                                                train_rpc.py:1070-1084
+        if self.automatic_entropy_tuning:
+            alpha_loss = -(self.log_alpha * (log_pi + self.target_entropy).detach()).mean(dim=(1, 2))
+            self.alpha_optim.zero_grad(set_to_none=True)
+            alpha_loss.sum().backward()
+            self.alpha_optim.step()
+            self.alpha = self.log_alpha.detach().exp()
+        else:
+            alpha_loss = torch.zeros(self.A, device=self.device)
+        # ---- target network                                             train_rpc.py:1128-1129
+        self.total_update += 1
+        if self.total_update % self.target_update_interval == 0:
+            with torch.no_grad():
+                for qt, q in zip(self.critic_target, self.critic):
+                    for k in qt:
+                        qt[k].mul_(1.0 - self.tau).add_(q[k].detach(), alpha=self.tau)
+        self.last_losses = dict(q1=q1_loss.detach(), q2=q2_loss.detach(),
+                                policy=policy_loss.detach(), alpha=alpha_loss.detach(),
+                                alpha_value=self.alpha.reshape(-1).clone())
+        return self.last_losses
+
+    # ------------------------------------------------------------------ replay plumbing
+    def split_rewards(self, reward):
+        """[n, A] -> [A, n, 1]"""
+        return reward.T.unsqueeze(2).contiguous()
+
+    def batch_from_memory(self, batch_size):
+        """Independent index set per agent -> tensors in the layout `update` takes."""
+        m, p = self.memory, self.policy
+        idx = m.sample_indices(self.A, batch_size)                           # [A, B]
+        flat = idx.reshape(-1)
+
+        def gather_state(buf):
+            s = buf[flat].reshape(self.A, batch_size, -1)
+            s = torch.cat([s, s.new_zeros(self.A, batch_size, 1)], dim=2)    # zero pad column
+            return torch.gather(s, 2, p.gather.unsqueeze(1).expand(-1, batch_size, -1))
+
+        x, x2 = gather_state(m.state), gather_state(m.next_state)
+        act = m.action[flat].reshape(self.A, batch_size, -1)
+        a = torch.gather(act, 2, self._action_gather.unsqueeze(1).expand(-1, batch_size, -1)) \
+            * self.act_mask
+        r = m.reward[flat].reshape(self.A, batch_size, self.A)
+        r = torch.gather(r, 2, torch.arange(self.A, device=self.device).reshape(self.A, 1, 1)
+                         .expand(-1, batch_size, -1))
+        mask = m.mask[flat].reshape(self.A, batch_size, 1)
+        return x, a, r, x2, mask
+
+    @property
+    def _action_gather(self):
+        if not hasattr(self, "_ag"):
+            g = torch.zeros(self.A, self.act_max, dtype=torch.long, device=self.device)
+            for i, (w, (lo, hi)) in enumerate(self.layout.action_slices.items()):
+                g[i, :hi - lo] = torch.arange(lo, hi, device=self.device)
+            self._ag = g
+        return self._ag
+
+    def update_parameters(self, master, batch_size=None, n_updates=None):
+        """SAC.update_parameters_sac: n_updates updates; before each, the next slice of the
+        episode's master memory moves into the agents' memory (1 transition per update in the
+        reference, which steps one environment; len(master) / n_updates here)."""
+        batch_size = batch_size or self.cfg["batch_size"]
+        n_updates = n_updates or self.cfg["updates_per_episode_rpc"]
+        total, moved = len(master), 0
+        per = -(-total // n_updates) if total else 0
+        done = 0
+        for _ in range(n_updates):
+            if moved < total:
+                n = min(per, total - moved)
+                self.memory.push(*master.rows(moved, n))
+                moved += n
+            if len(self.memory) > batch_size:
+                self.update(*self.batch_from_memory(batch_size))
+                done += 1
+        return done
+
+
+def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_control=False,
+                master=None, n_updates=None, batch_size=None):
+    """TrainerRPC.episode (train=True) / test_episode (train=False), batched over env.nenv
+    environments (train_rpc.py:503-547, 549-603).  Returns a dict of device tensors:
+    r_total [nenv], r_per_agent [nenv, A], sr_le [nenv], sr_se_mean [nenv] (+ updates done)."""
+    from .env import DelayedMDP
+    cfg = env.config_rl
+    max_steps = max_steps or cfg["max_steps_per_episode"]
+    s = env.reset()
+    mdp = DelayedMDP(cfg["delayed_assignment"], cfg["modification_online"])
+    if train and master is None:
+        master = BatchedReplay(env.layout.state_dim, env.layout.action_dim, env.layout.n_agents,
+                               max_steps * env.nenv, env.device)
+    r_agents = torch.zeros(env.nenv, env.layout.n_agents, device=env.device)
+    sr_se = torch.zeros(env.nenv, device=env.device)
+    for _ in range(max_steps):
+        if linear_control:
+            a = None
+        else:
+            a, mu = sac.policy.select_action(s, eval_mode=eval_mode)
+        s_next, r, done, _ = env.step(a, linear_control=linear_control)
+        if train:
+            if mdp.check_update_possibility():                     # manage_memory
+                s0, a0, s2 = mdp.credit_assignment()
+                master.push(s0, a0, r, s2, float(not done))
+            mdp.save(s, a, s_next)                                 # manage_delayed_mdp
+        r_agents += r
+        sr_se += env.supervisor.get_strehl()[:, 0]
+        s = s_next
+    out = dict(r_total=r_agents.sum(dim=1), r_per_agent=r_agents,
+               sr_le=env.supervisor.get_strehl()[:, 1].clone(), sr_se_mean=sr_se / max_steps)
+    if train:
+        out["updates"] = sac.update_parameters(master, batch_size=batch_size, n_updates=n_updates)
+        master.reset()
+    return out

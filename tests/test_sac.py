@@ -1,0 +1,205 @@
+"""Batched SAC update + replay memory against the reference's own update code.
+
+tests/golden/host_sac_update.pt was produced by tools/gen_golden_sac.py, which runs
+`SAC.update_critic / update_actor / update_alpha` + `soft_update` of the reference
+(train_rpc.py:1016-1133) on the reference's GaussianPolicy / QNetwork for two agents of different
+sizes and three consecutive updates, recording the normal draws."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from ao_marl_amd.agents import AgentLayout  # noqa: E402
+from ao_marl_amd.sac import BatchedReplay, BatchedSAC  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_sac_update.pt")
+
+
+def _layout():
+    # 10x10 layout of BASELINE configs[1]: one 80-mode agent (state 4 x 80) + the tip-tilt agent
+    return AgentLayout(87, [0, 80], 1, include_tip_tilt=True, n_filtered=5)
+
+
+def _pad(t, width):
+    out = t.new_zeros(t.shape[0], width)
+    out[:, :t.shape[1]] = t
+    return out
+
+
+def test_batched_update_reproduces_the_references_sac_update():
+    g = torch.load(GOLD)
+    h = g["hyper"]
+    lay = _layout()
+    assert lay.state_shapes() == [a["nin"] for a in g["agents"]]
+    assert lay.action_shapes() == [a["nact"] for a in g["agents"]]
+    sac = BatchedSAC(lay, dict(hidden_size_actor=h["hidden"], hidden_size_critic=h["hidden"],
+                               lr=h["lr"], gamma=h["gamma"], tau=h["tau"], memory_size=64,
+                               initialize_last_layer_0=False), device="cpu")
+    for i, ag in enumerate(g["agents"]):
+        sac.load_reference_agent(i, ag["policy0"], ag["critic0"])
+    for u in range(h["updates"]):
+        ups = [ag["updates"][u] for ag in g["agents"]]
+        x = torch.stack([_pad(t["s"], sac.in_max) for t in ups])
+        x2 = torch.stack([_pad(t["s2"], sac.in_max) for t in ups])
+        a = torch.stack([_pad(t["a"], sac.act_max) for t in ups])
+        r = torch.stack([t["r"] for t in ups])
+        mask = torch.stack([t["mask"] for t in ups])
+        e1 = torch.stack([_pad(t["eps_next"], sac.act_max) for t in ups])
+        e2 = torch.stack([_pad(t["eps_pi"], sac.act_max) for t in ups])
+        losses = sac.update(x, a, r, x2, mask, eps_next=e1, eps_pi=e2)
+        for i, t in enumerate(ups):
+            assert abs(losses["q1"][i].item() - t["q1_loss"]) < 1e-5 * max(1, abs(t["q1_loss"])), (u, i)
+            assert abs(losses["q2"][i].item() - t["q2_loss"]) < 1e-5 * max(1, abs(t["q2_loss"])), (u, i)
+            assert abs(losses["policy"][i].item() - t["policy_loss"]) < 1e-5 * max(1, abs(t["policy_loss"]))
+            assert abs(losses["alpha"][i].item() - t["alpha_loss"]) < 1e-5 * max(1, abs(t["alpha_loss"]))
+            assert abs(sac.alpha[i].item() - t["alpha"]) < 1e-6
+            actor, critic = sac.export_agent(i)
+            _, target = sac.export_agent(i, target=True)
+            for name, ref in t["policy"].items():
+                assert torch.allclose(actor[name], ref, atol=2e-6, rtol=1e-5), (u, i, name)
+            for name, ref in t["critic"].items():
+                assert torch.allclose(critic[name], ref, atol=2e-6, rtol=1e-5), (u, i, name)
+            for name, ref in t["critic_target"].items():
+                assert torch.allclose(target[name], ref, atol=2e-6, rtol=1e-5), (u, i, name)
+    # padding never learns anything
+    assert sac.policy.W1[1, 8:].abs().max().item() == 0.0
+    assert sac.policy.Wm[1, :, 2:].abs().max().item() == 0.0
+    assert sac.critic[0]["Win"][1, 8:sac.in_max].abs().max().item() == 0.0
+
+
+def test_replay_ring_and_per_agent_batches():
+    lay = _layout()
+    sac = BatchedSAC(lay, dict(hidden_size_actor=16, hidden_size_critic=16, memory_size=50), device="cpu")
+    m = sac.memory
+    rng = torch.Generator().manual_seed(0)
+    rows = []
+    for step in range(9):                       # 9 x 8 = 72 rows into a ring of 50
+        s = torch.randn(8, lay.state_dim, generator=rng)
+        a = torch.rand(8, lay.action_dim, generator=rng)
+        r = -torch.rand(8, lay.n_agents, generator=rng)
+        s2 = torch.randn(8, lay.state_dim, generator=rng)
+        m.push(s, a, r, s2, 1.0)
+        rows += [(s[k], a[k], r[k], s2[k]) for k in range(8)]
+    assert len(m) == 50 and m.position == 72 % 50
+    # the ring holds the newest 50 rows
+    newest = torch.stack([t[0] for t in rows[-50:]])
+    held = torch.cat([m.state[m.position:], m.state[:m.position]])
+    assert torch.equal(held, newest)
+    x, a, r, x2, mask = sac.batch_from_memory(32)
+    assert x.shape == (2, 32, sac.in_max) and a.shape == (2, 32, sac.act_max)
+    assert r.shape == (2, 32, 1) and mask.shape == (2, 32, 1) and mask.min() == 1.0
+    # every sampled per-agent tuple is the split of ONE stored row (same row for s, a, r, s')
+    for i in range(2):
+        ni, na = lay.state_shapes()[i], lay.action_shapes()[i]
+        idx = torch.as_tensor(list(lay.modes_chosen.values())[i])
+        lo, hi = list(lay.action_slices.values())[i]
+        for b in range(0, 32, 7):
+            cand = (m.state[:, idx] == x[i, b, :ni]).all(dim=1).nonzero().reshape(-1)
+            assert cand.numel() >= 1
+            k = cand[0]
+            assert torch.equal(m.next_state[k, idx], x2[i, b, :ni])
+            assert torch.equal(m.action[k, lo:hi], a[i, b, :na])
+            assert m.reward[k, i] == r[i, b, 0]
+        assert x[i, :, ni:].abs().max() == 0 if ni < sac.in_max else True
+        assert a[i, :, na:].abs().max() == 0 if na < sac.act_max else True
+
+
+def test_update_parameters_trickles_the_episode_into_memory():
+    lay = _layout()
+    sac = BatchedSAC(lay, dict(hidden_size_actor=16, hidden_size_critic=16, memory_size=1000,
+                               batch_size=16), device="cpu")
+    master = BatchedReplay(lay.state_dim, lay.action_dim, lay.n_agents, 200, "cpu")
+    master.push(torch.randn(120, lay.state_dim), torch.rand(120, lay.action_dim),
+                -torch.rand(120, lay.n_agents), torch.randn(120, lay.state_dim), 1.0)
+    before = [t.detach().clone() for t in sac._policy_params()]
+    done = sac.update_parameters(master, n_updates=40)        # 3 rows per update
+    # updates start once the memory holds more than one batch: 16 / 3 -> from the 6th push on
+    assert done == 40 - 5 and len(sac.memory) == 120 and sac.total_update == done
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, sac._policy_params()))
+    assert torch.isfinite(sac.last_losses["q1"]).all()
+
+
+def test_training_episode_on_the_oracle_backed_env():
+    from tests.oracle_vecsim import OracleVecSim
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.sac import run_episode
+    env = VecAoEnv("production_sh_10x10_2m", 2, dict(n_zernike_start_end=[0, 80],
+                                                     n_reverse_filtered_from_cmat=5),
+                   n_agents_modal=1, device="cpu", sim_factory=OracleVecSim)
+    sac = BatchedSAC(env.layout, dict(hidden_size_actor=32, hidden_size_critic=32, batch_size=4,
+                                      memory_size=100), device="cpu")
+    out = run_episode(env, sac, max_steps=6, train=True, n_updates=5)
+    # delay 1, no modification: the first tuple is available at step 3 -> 4 steps x 2 envs stored
+    assert len(sac.memory) == 8 and out["updates"] >= 1
+    assert out["r_total"].shape == (2,) and out["r_per_agent"].shape == (2, 2)
+    assert (out["r_total"] <= 0).all() and torch.isfinite(out["sr_le"]).all()
+    ev = run_episode(env, sac, max_steps=3, train=False, eval_mode=True)
+    assert "updates" not in ev
+
+
+def test_checkpoints_use_the_references_container(tmp_path):
+    """SAC.save_model layout (train_rpc.py:1140-1161): {'worker_id', 'models_controlled',
+    'model_state_dict'} per actor, a bare state_dict per critic; both load back into any slot."""
+    lay = _layout()
+    a = BatchedSAC(lay, dict(hidden_size_actor=16, hidden_size_critic=16, memory_size=8,
+                             initialize_last_layer_0=False), seed=1, device="cpu")
+    b = BatchedSAC(lay, dict(hidden_size_actor=16, hidden_size_critic=16, memory_size=8), seed=2,
+                   device="cpu")
+    paths = a.save_model(str(tmp_path / "exp"), episode=800, experiment_name="demo")
+    assert len(paths) == lay.n_agents
+    for i, (ap, cp) in enumerate(paths):
+        ck = torch.load(ap)
+        assert set(ck) == {"worker_id", "models_controlled", "model_state_dict"}
+        assert ck["worker_id"] == i + 1 and ck["models_controlled"] == list(list(lay.agents.values())[i])
+        assert list(ck["model_state_dict"]) == ["linear1.weight", "linear1.bias", "hidden.0.weight",
+                                                "hidden.0.bias", "mean_linear.weight",
+                                                "mean_linear.bias", "log_std_linear.weight",
+                                                "log_std_linear.bias"]
+        b.load_reference_agent(i, ck["model_state_dict"], torch.load(cp))
+    s = torch.randn(5, lay.state_dim)
+    ma, la_ = a.policy.forward(s)
+    mb, lb = b.policy.forward(s)
+    assert torch.equal(ma, mb) and torch.equal(la_, lb)
+    x = a.policy.split_states(s)
+    act = torch.rand(lay.n_agents, 5, a.act_max) * a.act_mask
+    qa, qb = a._q(a.critic, x, act), b._q(b.critic, x, act)
+    assert torch.equal(qa[0], qb[0]) and torch.equal(qa[1], qb[1])
+
+
+@pytest.mark.gpu
+def test_training_episode_on_the_gpu_and_update_rate():
+    """End-to-end on the HIP path: rollout with the native batched GEMM actors, replay in HBM,
+    batched SAC updates through autograd; prints the production-size update rate."""
+    import time
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.sac import run_episode
+    env = VecAoEnv("production_sh_10x10_2m", 16, dict(n_zernike_start_end=[0, 80],
+                                                      n_reverse_filtered_from_cmat=5),
+                   n_agents_modal=1)
+    sac = BatchedSAC(env.layout, dict(memory_size=4096, batch_size=64))
+    w0 = sac.policy.W1.detach().clone()
+    out = run_episode(env, sac, max_steps=30, train=True, n_updates=20)
+    assert len(sac.memory) == 28 * 16 and out["updates"] == 20
+    assert not torch.equal(w0, sac.policy.W1.detach())
+    assert torch.isfinite(out["r_total"]).all() and (out["sr_le"] > 0).all()
+    # production layout: 14 agents (13 x 98 modes + TT, window 20), batch 256
+    lay = AgentLayout(1283, [0, 1274], 13, include_tip_tilt=True, window_n_zernike=20,
+                      include_tip_tilt_windowed=True, n_filtered=5)
+    big = BatchedSAC(lay, dict(memory_size=20000))
+    big.memory.push(torch.randn(20000, lay.state_dim, device="cuda"),
+                    torch.rand(20000, lay.action_dim, device="cuda") * 2 - 1,
+                    -torch.rand(20000, lay.n_agents, device="cuda"),
+                    torch.randn(20000, lay.state_dim, device="cuda"), 1.0)
+    for _ in range(3):
+        big.update(*big.batch_from_memory(256))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(20):
+        big.update(*big.batch_from_memory(256))
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 20
+    print("SAC update, 14 agents x batch 256: %.2f ms per update (%.0f agent-updates/s)" %
+          (dt * 1e3, 14 / dt))
+    assert torch.isfinite(big.last_losses["q1"]).all()
