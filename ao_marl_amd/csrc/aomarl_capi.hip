@@ -61,6 +61,13 @@ struct aomarl_ctx {
   int32_t *amodes = nullptr;
   uint32_t *seed_stage = nullptr;  // device staging for reset seeds
   int seed_stage_n = 0;
+  // geometric controller (aomarl_set_geo): host copies of the lattice tables it is built from,
+  // projection operands on the device
+  std::vector<int32_t> h_grid;     // [gh][gw] actuator index or -1 (stack-array DM 0)
+  std::vector<float> h_prof, h_spupil, h_tt;
+  float *geoW = nullptr, *geoUx = nullptr, *geoUy = nullptr, *geoPlanes = nullptr;
+  int32_t *geoMap = nullptr;       // stack-array actuator -> j * gh + i of the lattice product
+  int geo_ldw = 0, geo_gw = 0, geo_gh = 0, geo_npzt = 0, geo_ldr = 0;
 };
 
 const char *aomarl_last_error(void) { return g_err; }
@@ -106,6 +113,7 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
   s.n = d->n; s.pupdiam = d->pupdiam;
   UP(float, d->mpupil, (size_t)d->n * d->n, s.mpupil);
   UP(float, d->spupil, (size_t)d->pupdiam * d->pupdiam, s.spupil);
+  c->h_spupil.assign(d->spupil, d->spupil + (size_t)d->pupdiam * d->pupdiam);
   s.nvalid = d->nvalid; s.pdiam = d->pdiam; s.nfft = d->nfft; s.npix = d->npix;
   s.nrebin = d->nrebin; s.nxsub = d->nxsub;
   const int pd2 = d->pdiam * d->pdiam;
@@ -291,12 +299,14 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
             D.sep = 1; D.pitch = pitch; D.i1min = imin; D.j1min = jmin; D.gw = gw; D.gh = gh;
             UP(int32_t, grid.data(), grid.size(), D.grid);
             UP(float, prof.data(), prof.size(), D.prof);
+            if (k == 0) { c->h_grid = grid; c->h_prof = prof; }
           }
         }
       }
     } else if (M.type == AOMARL_DM_TT) {
       if (M.nact != 2) { aomarl_destroy(c); return fail("tip-tilt DM must have 2 actuators"); }
       UP(float, M.influ, (size_t)M.dim * M.dim * 2, D.influ);
+      if (k == 1) c->h_tt.assign(M.influ, M.influ + (size_t)M.dim * M.dim * 2);
     } else {
       aomarl_destroy(c);
       return fail("DM %d: unknown type %d", k, M.type);
@@ -1009,6 +1019,140 @@ int aomarl_comp_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stre
   hipLaunchKernelGGL(k_strehl_commit, dim3(n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, PEND);
   LAUNCHCHK();
   return 0;
+}
+
+// ---------------------------------------------------------------- geometric controller
+__global__ void k_geo_assemble(int nactu, int npzt, int ldr, int gwgh, const int32_t *__restrict__ map,
+                               const float *__restrict__ lat, const float *__restrict__ r3,
+                               float *__restrict__ r) {
+  const int e = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= ldr) return;
+  float v = 0.f;
+  if (a < npzt) v = lat[(long long)e * gwgh + map[a]];
+  else if (a <= nactu) v = r3[(long long)e * 4 + (a - npzt)];   // TT0, TT1, sum
+  r[(long long)e * ldr + a] = v;
+}
+
+int aomarl_set_geo(aomarl_ctx *c, const float *W) {
+  if (!c || !W) return fail("aomarl_set_geo: null argument");
+  const DevSys &s = c->sys;
+  if (!(s.ndm == 2 && s.dms[0].type == AOMARL_DM_PZT && s.dms[0].sep && s.dms[1].type == AOMARL_DM_TT &&
+        s.tar_all_int))
+    return fail("aomarl_set_geo: needs DMs = [separable stack array, tip-tilt] at integer target offsets");
+  const DevDm &Z = s.dms[0], &T = s.dms[1];
+  const int pd = s.pupdiam, na = s.nactu, npzt = Z.nact;
+  const int gw = Z.gw, gh = Z.gh;
+  // profile matrices over the pupil window: UxT[j][x] = u(x + tox - X_j), UyT[i][y] likewise
+  std::vector<float> ux((size_t)gw * pd, 0.f), uy((size_t)gh * pd, 0.f);
+  for (int j = 0; j < gw; j++)
+    for (int x = 0; x < pd; x++) {
+      const int a = x + Z.tox - (Z.i1min + Z.pitch * j);
+      if (a >= 0 && a < Z.ss) ux[(size_t)j * pd + x] = c->h_prof[a];
+    }
+  for (int i = 0; i < gh; i++)
+    for (int y = 0; y < pd; y++) {
+      const int a = y + Z.toy - (Z.j1min + Z.pitch * i);
+      if (a >= 0 && a < Z.ss) uy[(size_t)i * pd + y] = c->h_prof[a];
+    }
+  // planes: the two tip-tilt influence maps and the constant, over the pupil window (the phase
+  // handed in is already masked, so the planes need no mask)
+  std::vector<float> planes((size_t)3 * pd * pd);
+  for (int y = 0; y < pd; y++)
+    for (int x = 0; x < pd; x++) {
+      const size_t o = (size_t)(y + T.toy) * T.dim + x + T.tox, p = (size_t)y * pd + x;
+      planes[p] = c->h_tt[2 * o]; planes[(size_t)pd * pd + p] = c->h_tt[2 * o + 1];
+      planes[(size_t)2 * pd * pd + p] = 1.0f;
+    }
+  std::vector<int32_t> map(npzt, -1);
+  for (int i = 0; i < gh; i++)
+    for (int j = 0; j < gw; j++) {
+      const int a = c->h_grid[(size_t)i * gw + j];
+      if (a >= 0) { if (a >= npzt) return fail("aomarl_set_geo: lattice table out of range"); map[a] = j * gh + i; }
+    }
+  for (int a = 0; a < npzt; a++) if (map[a] < 0) return fail("aomarl_set_geo: actuator %d is not on the lattice", a);
+  c->geo_ldw = (na + 1 + 3) & ~3;
+  std::vector<float> w((size_t)na * c->geo_ldw, 0.f);
+  for (int r = 0; r < na; r++) memcpy(&w[(size_t)r * c->geo_ldw], W + (size_t)r * (na + 1), sizeof(float) * (na + 1));
+  int rc = replace_dev(c, &c->geoW, w);
+  if (!rc) rc = replace_dev(c, &c->geoUx, ux);
+  if (!rc) rc = replace_dev(c, &c->geoUy, uy);
+  if (!rc) rc = replace_dev(c, &c->geoPlanes, planes);
+  if (rc) return rc;
+  if (c->geoMap) {
+    for (size_t i = 0; i < c->owned.size(); i++)
+      if (c->owned[i] == c->geoMap) { c->owned.erase(c->owned.begin() + i); break; }
+    (void)hipFree(c->geoMap);
+    c->geoMap = nullptr;
+  }
+  rc = upload<int32_t>(c, map.data(), map.size(), &c->geoMap);
+  if (rc) return rc;
+  c->geo_gw = gw; c->geo_gh = gh; c->geo_npzt = npzt; c->geo_ldr = c->geo_ldw;
+  return 0;
+}
+
+// floats of scratch aomarl_geo_control needs: row products [n][gw][pd], lattice products
+// [n][gw][gh], plane products [n][4], right-hand sides [n][ldr], split-K workspace
+struct GeoWork { size_t T, LAT, R3, R, GEMM, gemm_floats, total; };
+static GeoWork geo_layout(aomarl_ctx *c, int n) {
+  GeoWork g; size_t o = 0;
+  auto take = [&](size_t k) { size_t at = o; o += (k + 63) & ~(size_t)63; return at; };
+  g.T = take((size_t)n * c->geo_gw * c->sys.pupdiam);
+  g.LAT = take((size_t)n * c->geo_gw * c->geo_gh);
+  g.R3 = take((size_t)n * 4);
+  g.R = take((size_t)n * c->geo_ldr);
+  g.gemm_floats = (size_t)8 * n * std::max(c->sys.nactu, 4);
+  g.GEMM = take(g.gemm_floats);
+  g.total = o;
+  return g;
+}
+
+size_t aomarl_geo_workspace_floats(aomarl_ctx *c, int nenv) {
+  if (!c || !c->geoW || nenv <= 0) return 0;
+  return geo_layout(c, nenv).total;
+}
+
+int aomarl_geo_control(aomarl_ctx *c, aomarl_state *st, int b, int n, float *work, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!c->geoW) return fail("geo_control: no projector (aomarl_set_geo)");
+  if (!st->tar_phase) return fail("geo_control needs st->tar_phase (masked atmosphere phase of the target)");
+  if (!work) return fail("geo_control: null workspace");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int pd = c->sys.pupdiam, gw = c->geo_gw, gh = c->geo_gh, na = c->sys.nactu;
+  GeoWork g = geo_layout(c, n);
+  const float *phi = st->tar_phase + (size_t)b * pd * pd;
+  float *T = work + g.T, *LAT = work + g.LAT, *R3 = work + g.R3, *R = work + g.R;
+  // T[e][j][y] = sum_x UxT[j][x] phi[e][y][x]
+  hipLaunchKernelGGL(k_gemm_nt_batched2, dim3((pd + 63) / 64, (gw + 63) / 64, n), dim3(256), 0, s, gw, pd, pd,
+                     c->geoUx, pd, (long long)0, phi, pd, (long long)pd * pd, (const float *)nullptr,
+                     (long long)0, T, pd, (long long)gw * pd, 0);
+  LAUNCHCHK();
+  // LAT[e][j][i] = sum_y T[e][j][y] UyT[i][y]
+  hipLaunchKernelGGL(k_gemm_nt_batched2, dim3((gh + 63) / 64, (gw + 63) / 64, n), dim3(256), 0, s, gw, gh, pd,
+                     T, pd, (long long)gw * pd, c->geoUy, pd, (long long)0, (const float *)nullptr,
+                     (long long)0, LAT, gh, (long long)gw * gh, 0);
+  LAUNCHCHK();
+  // R3[e][k] = sum_p phi[e][p] planes[k][p]   (TT0, TT1, 1)
+  launch_gemm_nt(n, 3, pd * pd, 1.0f, phi, pd * pd, c->geoPlanes, pd * pd, 0.0f, R3, 4, s, work + g.GEMM,
+                 g.gemm_floats);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_geo_assemble, dim3((c->geo_ldr + 255) / 256, n), dim3(256), 0, s, na, c->geo_npzt,
+                     c->geo_ldr, gw * gh, c->geoMap, LAT, R3, R);
+  LAUNCHCHK();
+  // com[e] = W . r[e]
+  launch_gemm_nt(n, na, na + 1, 1.0f, R, c->geo_ldr, c->geoW, c->geo_ldw, 0.0f,
+                 st->com + (size_t)b * st->ld_actu, st->ld_actu, s, work + g.GEMM, g.gemm_floats);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_target_psf_buffer(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!st->tar_phase) return fail("target_psf_buffer needs st->tar_phase");
+  if (n == 0) return 0;
+  return target_psf_impl(c, st, b, n, true, stream);
 }
 
 // ---------------------------------------------------------------- composites

@@ -693,6 +693,7 @@ __global__ __launch_bounds__(256) void k_raytrace(DevSys sys, DevState st, int e
       }
     }
   }
+  if (flags & AOMARL_TRACE_MASK) v *= (TARGET ? sys.spupil : sys.mpupil)[p];
   out[p] = v;
 }
 

@@ -56,7 +56,7 @@ class VecRlSupervisor(object):
 
     def __init__(self, config, config_rl, nenv, *, initial_seed=1234, seed_stride=16,
                  device="cuda:0", strehl_halfwin=8, keep_bincube=False, sim_factory=None,
-                 autoencoder=None):
+                 autoencoder=None, geo=False):
         # autoencoder: a denoiser.SubapDenoiser (rlSupervisor.py:147, :977-978) or None
         self.autoencoder = autoencoder
         self.config = config if not isinstance(config, str) else params.builtin(config)
@@ -87,6 +87,10 @@ class VecRlSupervisor(object):
         self.sim = make(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
         self.freedom_vector = None
         self._push_modal()
+        # controller 1 of the non-noise parameter files: the geometric reference controller with
+        # its own DM pair and target (rlSupervisor.py:989-1013); off by default -- it changes
+        # nothing controller 0 sees and is only read by evaluation episodes
+        self.geo = self.sim.geo_twin(self.cal.IF) if geo else None
         self.initial_seed, self.seed_stride = int(initial_seed), int(seed_stride)
         self.current_seed = int(initial_seed)
         self.iter = 0
@@ -127,6 +131,8 @@ class VecRlSupervisor(object):
     def reset(self):
         """rlSupervisor.py:236-246 for every environment (seed e: current_seed + stride*e)."""
         self.sim.reset(self.env_seeds())
+        if self.geo is not None:
+            self.geo.reset()
         self.iter = 0
 
     def rl_control(self, action):
@@ -150,6 +156,8 @@ class VecRlSupervisor(object):
             self.sim.apply_control(defer_shape=getattr(self.sim, "defer_shape", False))
         if compute_tar_psf:
             self.sim.comp_strehl()
+            if self.geo is not None:
+                self.geo.comp_strehl()              # tar_trace covers every target (:943-946)
 
     def next_part_one(self, move_atmos=True, do_control=True):
         """rlSupervisor.py:1015-1051 -> next_part_one_integrator :954-987"""
@@ -163,7 +171,7 @@ class VecRlSupervisor(object):
             self.sim.do_centroids()
             if do_control:
                 self.sim.do_control()
-        elif move_atmos and do_control:
+        elif move_atmos and do_control and self.geo is None:
             self.sim.next_part_one()
         else:
             if move_atmos:
@@ -171,6 +179,8 @@ class VecRlSupervisor(object):
             self._target_and_image(write_bincube=False, cog=True)
             if do_control:
                 self.sim.do_control()
+        if self.geo is not None and do_control:
+            self.geo.next_part_one_geo()            # next_part_one_geo, after controller 0 (:1038-1049)
         self.iter += 1
 
     def _target_and_image(self, write_bincube, cog):
@@ -183,7 +193,14 @@ class VecRlSupervisor(object):
             sim.comp_image(noise=True, write_bincube=write_bincube, cog=cog)
 
     # ---------------------------------------------------------------- getters (device tensors)
-    def get_command(self):
+    def get_command(self, ncontrol=0):
+        if ncontrol == 1:
+            if self.geo is None:
+                raise RuntimeError("no geometric controller (VecRlSupervisor(..., geo=True))")
+            return self.geo.com
+        return self._get_command0()
+
+    def _get_command0(self):
         return self.sim.com
 
     def get_slopes(self):
@@ -195,7 +212,11 @@ class VecRlSupervisor(object):
     def get_voltages(self):
         return self.sim.voltage
 
-    def get_strehl(self):
+    def get_strehl(self, tar_index=0):
+        if tar_index == 1:
+            if self.geo is None:
+                raise RuntimeError("no geometric controller (VecRlSupervisor(..., geo=True))")
+            return self.geo.strehl
         return self.sim.strehl
 
 
@@ -205,7 +226,8 @@ class VecAoEnv(object):
 
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
-                 strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None):
+                 strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None,
+                 geo=False):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -219,7 +241,7 @@ class VecAoEnv(object):
         self.supervisor = VecRlSupervisor(config, cfg, nenv, initial_seed=initial_seed,
                                           seed_stride=seed_stride, device=device,
                                           strehl_halfwin=strehl_halfwin, sim_factory=sim_factory,
-                                          autoencoder=autoencoder)
+                                          autoencoder=autoencoder, geo=geo)
         sup = self.supervisor
         self.nenv, self.device = nenv, sup.device
         self.nmodes = sup.nmodes

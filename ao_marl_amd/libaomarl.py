@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libaomarl_hip.so")
 MAX_LAYERS, MAX_DMS, ABI_VERSION = 8, 4, 1
 
 DM_PZT, DM_TT = 0, 1
-TRACE_ATMOS, TRACE_DMS, TRACE_RESET = 1, 2, 4
+TRACE_ATMOS, TRACE_DMS, TRACE_RESET, TRACE_MASK = 1, 2, 4, 8
 IMG_FROM_PHASE_BUFFER, IMG_NOISE, IMG_WRITE_BINCUBE, IMG_COG, IMG_NO_ATMOS, IMG_NO_DMS = \
     1, 2, 4, 8, 16, 32
 IMG_DM_FROM_VOLTAGE = 64
@@ -99,6 +99,10 @@ SYMBOLS = [
     ("aomarl_get_dm_shape", _i, _range + [_i, _vp, _vp]),
     ("aomarl_set_option", _i, [_vp, C.c_char_p, _i]),
     ("aomarl_target_psf", _i, _range + [_vp]),
+    ("aomarl_target_psf_buffer", _i, _range + [_vp]),
+    ("aomarl_set_geo", _i, [_vp, _fp]),
+    ("aomarl_geo_workspace_floats", C.c_size_t, [_vp, _i]),
+    ("aomarl_geo_control", _i, _range + [_vp, _vp]),
     ("aomarl_frame_fused_available", _i, [_vp]),
     ("aomarl_dm_from_voltage_available", _i, [_vp]),
     ("aomarl_materialize_dm_shape", _i, _range + [_vp]),

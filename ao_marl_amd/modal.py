@@ -156,6 +156,50 @@ def cmat_with_btt(D, Btt, nfilt):
     return (Bf @ Dmp).astype(np.float32)
 
 
+def geo_projector(IF):
+    """Projection matrix of the geometric ("GEO") controller, COMPASS's sutra_controller_geo as the
+    reference configures it (rtc_init.py:418-448: influence functions of the controller's DMs on
+    the pupil pixels; rlSupervisor.py:989-1013: do_control(sources=target)).  The native source is
+    not in the reference tree; restated from the published algorithm: the pupil phase minus its
+    mean is projected on the tip-tilt mirror first, the stack array then fits what is left,
+    both by least squares (inverse of IF^T IF), and the command is minus the fit.
+
+    IF [Npup, nactu] sparse, stack-array columns first, the 2 tip-tilt columns last.
+    Returns W [nactu, nactu + 1] (float64) such that
+        com = W . [ IFp^T phi | TT^T phi | sum(phi) ]          (phi on the lit pupil pixels)."""
+    IF = sp.csc_matrix(IF, dtype=np.float64)
+    npix, na = IF.shape
+    npz = na - 2
+    P, T = IF[:, :npz], IF[:, npz:].toarray()
+    one = np.ones(npix)
+    Gp = (P.T @ P).toarray()
+    Gpi = np.linalg.inv(Gp)
+    Gti = np.linalg.inv(T.T @ T)
+    bp1, bpT, t1 = P.T @ one, P.T @ T, T.T @ one
+    # r = [rP (npz) | rT (2) | r1 (1)]
+    A_tt = np.zeros((2, na + 1))
+    A_tt[:, npz:npz + 2] = Gti
+    A_tt[:, na] = -Gti @ t1 / npix
+    A_p = np.zeros((npz, na + 1))
+    A_p[:, :npz] = Gpi
+    A_p[:, na] = -Gpi @ bp1 / npix
+    A_p -= Gpi @ bpT @ A_tt
+    return -np.vstack([A_p, A_tt])
+
+
+def geo_command(IF, phi_lit):
+    """The same projection written out step by step (used by the oracle and by the tests)."""
+    IF = sp.csc_matrix(IF, dtype=np.float64)
+    na = IF.shape[1]
+    P, T = IF[:, :na - 2], IF[:, na - 2:].toarray()
+    d = np.asarray(phi_lit, dtype=np.float64)
+    d = d - d.mean()
+    ctt = np.linalg.solve(T.T @ T, T.T @ d)
+    d = d - T @ ctt
+    cp = np.linalg.solve((P.T @ P).toarray(), P.T @ d)
+    return -np.concatenate([cp, ctt])
+
+
 class Calibration(object):
     pass
 

@@ -372,6 +372,8 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
                                max_steps * env.nenv, env.device)
     r_agents = torch.zeros(env.nenv, env.layout.n_agents, device=env.device)
     sr_se = torch.zeros(env.nenv, device=env.device)
+    geo = getattr(env.supervisor, "geo", None) if not train else None
+    geo_prev, geo_sq = None, None
     for _ in range(max_steps):
         if linear_control:
             a = None
@@ -385,9 +387,21 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
             mdp.save(s, a, s_next)                                 # manage_delayed_mdp
         r_agents += r
         sr_se += env.supervisor.get_strehl()[:, 0]
+        if geo is not None:                 # test_episode: v2m . rtc.get_command(1) per step
+            gm = env.supervisor.sim.volts2modes(env.supervisor.get_command(1))
+            if geo_prev is not None:
+                d = gm - geo_prev
+                geo_sq = d * d if geo_sq is None else geo_sq + d * d
+            geo_prev = gm
         s = s_next
     out = dict(r_total=r_agents.sum(dim=1), r_per_agent=r_agents,
                sr_le=env.supervisor.get_strehl()[:, 1].clone(), sr_se_mean=sr_se / max_steps)
+    if geo is not None and geo_sq is not None:
+        # divide_rewards_for_agents_geometric (train_rpc.py:381-400): squared frame-to-frame
+        # increments of the geometric command's modes, summed over the episode
+        out["r_geo_per_agent"] = geo_sq @ env._reward_mat
+        out["r_geo_total"] = out["r_geo_per_agent"].sum(dim=1)
+        out["sr_le_geo"] = env.supervisor.get_strehl(1)[:, 1].clone()
     if train:
         out["updates"] = sac.update_parameters(master, batch_size=batch_size, n_updates=n_updates)
         master.reset()

@@ -411,8 +411,14 @@ class HipSim(object):
         b, n = self._range(env_begin, env_count)
         if overlap is None:
             overlap = self.overlap_target
-        if not self._defer_on:
-            self._ensure_shape()
+        # stack-array shapes left to the frame kernel by a deferred apply_control: let the
+        # composite evaluate them from the voltages; otherwise it reads them from memory
+        if self._stale and self.defer_shape and self.dm_from_voltage_available():
+            if not self._defer_on:
+                la.check(self.lib.aomarl_set_option(self.ctx, b"defer_dm_shape", 1))
+                self._defer_on = True
+        else:
+            self._set_defer(False)
         if not overlap:
             fl = 0
             if write_bincube:
@@ -467,6 +473,11 @@ class HipSim(object):
                                          self._stream()))
         return Cout
 
+    # ------------------------------------------------------------------ geometric controller
+    def geo_twin(self, IF):
+        """A GEO twin of this simulator (see HipGeoTwin)."""
+        return HipGeoTwin(self, IF)
+
     # ------------------------------------------------------------------ calibration backend
     def dm_response(self, commands, geometric):
         """slopes [K, nslope] for commands [K, nactu], atmosphere off (modal.calibrate backend)."""
@@ -485,3 +496,75 @@ class HipSim(object):
                                 env_count=n)
             out[k0:k0 + n] = self.slopes[:n].cpu().numpy()
         return out
+
+
+class HipGeoTwin(object):
+    """The geometric ("GEO") reference controller next to a HipSim: controller 1 / DMs 1, 3 /
+    target 1 of the reference's non-noise parameter files (rlSupervisor.py:989-1013,
+    rtc_init.py:418-448).  Same geometry as the main loop's mirrors and target (the parameter
+    files duplicate them), same atmosphere: a second aomarl_state that SHARES the main state's
+    screens and owns its commands, DM shapes, science phase and Strehl accumulators."""
+
+    def __init__(self, sim, IF):
+        from . import modal
+        self.sim, self.lib, self.ctx = sim, sim.lib, sim.ctx
+        s, n, dev = sim.s, sim.nenv, sim.device
+        self.s, self.nenv, self.device = s, n, dev
+        W = np.ascontiguousarray(modal.geo_projector(IF), dtype=np.float32)
+        if W.shape != (s.nactu, s.nactu + 1):
+            raise ValueError("influence matrix does not match the system's actuators")
+        la.check(self.lib.aomarl_set_geo(self.ctx, la.fptr(W)))
+        f32 = dict(dtype=torch.float32, device=dev)
+        Wn = 2 * s.strehl_halfwin
+        t = {}
+        for k in ("com", "com1", "com2", "err", "voltage"):
+            t[k] = torch.zeros(n, sim.ld_actu, **f32)
+        t["slopes"] = torch.zeros(n, s.nslope, **f32)
+        t["dm_shape"] = torch.zeros(n, sim.shape_stride, **f32)
+        t["tar_phase"] = torch.zeros(n, s.pupdiam, s.pupdiam, **f32)
+        t["strehl"] = torch.zeros(n, 8, **f32)
+        t["le_img"] = torch.zeros(n, Wn * Wn, **f32)
+        t["frame"] = torch.zeros(n, dtype=torch.int32, device=dev)
+        t["work"] = torch.zeros(int(self.lib.aomarl_workspace_floats(self.ctx, n)), **f32)
+        self.t = t
+        self.gwork = torch.zeros(int(self.lib.aomarl_geo_workspace_floats(self.ctx, n)), **f32)
+        st = la.State()
+        st.nenv, st.ld_actu = n, sim.ld_actu
+        for k in ("screens", "origin", "seeds", "ext_count"):          # shared atmosphere
+            setattr(st, k, sim.t[k].data_ptr())
+        for k, v in t.items():
+            setattr(st, k, v.data_ptr())
+        self.st = st
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def com(self):
+        return self.t["com"][:, :self.s.nactu]
+
+    @property
+    def strehl(self):
+        s = self.t["strehl"]
+        avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
+        return torch.stack([s[:, 0], s[:, 1], s[:, 2], avg], dim=1)
+
+    def reset(self):
+        for k in ("com", "com1", "com2", "err", "voltage", "dm_shape", "strehl", "le_img"):
+            self.t[k].zero_()
+
+    def next_part_one_geo(self, env_begin=0, env_count=None):
+        """target.raytrace(atmosphere) -> do_control(sources=target) -> apply_control (delay 0)
+        -> target.raytrace(dms, reset=False) -> pending PSF  (rlSupervisor.py:989-1013)."""
+        b, n = self.sim._range(env_begin, env_count)
+        L, st, sm = self.lib, C.byref(self.st), self._stream()
+        la.check(L.aomarl_raytrace_target(self.ctx, st, b, n,
+                                          la.TRACE_ATMOS | la.TRACE_RESET | la.TRACE_MASK, sm))
+        la.check(L.aomarl_geo_control(self.ctx, st, b, n, self.gwork.data_ptr(), sm))
+        la.check(L.aomarl_apply_control(self.ctx, st, b, n, 0, sm))       # voltage = com, shapes
+        la.check(L.aomarl_raytrace_target(self.ctx, st, b, n, la.TRACE_DMS, sm))
+        la.check(L.aomarl_target_psf_buffer(self.ctx, st, b, n, sm))
+
+    def comp_strehl(self, env_begin=0, env_count=None):
+        b, n = self.sim._range(env_begin, env_count)
+        la.check(self.lib.aomarl_comp_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))

@@ -1,0 +1,124 @@
+"""Geometric ("GEO") reference controller (rlSupervisor.py:989-1013,
+rtc_init.py:418-448).  The native code is not in the reference tree: the projection is restated
+from the published algorithm (ao_marl_amd.modal.geo_projector, unpinned).  CPU: the precombined
+matrix against the step-by-step projection and its defining properties.  GPU: the HIP path
+(separable-lattice GEMMs + precombined matrix) against the oracle twin (explicit sparse influence
+matrix), commands and Strehl."""
+import numpy as np
+import pytest
+
+from ao_marl_amd import modal
+from tests import helpers
+
+NAME = "production_sh_10x10_2m"
+
+
+def test_projector_matrix_equals_stepwise_projection_and_is_a_projection():
+    sysm, s, cal = helpers.calibrated(NAME)
+    IF = cal.IF
+    W = modal.geo_projector(IF)
+    assert W.shape == (s.nactu, s.nactu + 1)
+    rng = np.random.default_rng(0)
+    phi = rng.normal(size=IF.shape[0]) + 3.0
+    r = np.concatenate([IF[:, :-2].T @ phi, IF[:, -2:].toarray().T @ phi, [phi.sum()]])
+    com = modal.geo_command(IF, phi)
+    assert np.abs(W @ r - com).max() < 1e-8 * np.abs(com).max()
+    # piston is ignored; a phase the mirrors can make exactly is cancelled exactly
+    assert np.abs(modal.geo_command(IF, phi + 5.0) - com).max() < 1e-8 * np.abs(com).max()
+    # a pure tip-tilt phase is taken out by the tip-tilt mirror alone (tip-tilt is fitted first)
+    ctt = np.array([0.3, -0.2])
+    back = modal.geo_command(IF, IF[:, -2:].toarray() @ ctt)
+    assert np.abs(back[-2:] + ctt).max() < 1e-4        # (the planes are not exactly piston-free)
+    # the stack array then fits what is left in the least-squares sense: its residual is
+    # orthogonal to every stack-array influence function
+    res = (phi - phi.mean()) + IF @ com
+    assert np.abs(IF[:, :-2].T @ res).max() < 1e-7 * np.abs(IF[:, :-2].T @ phi).max()
+
+
+def test_oracle_geo_twin_flattens_the_wavefront():
+    from oracle import aoref
+    sysm, s, cal = helpers.calibrated(NAME)
+    o = aoref.OracleSim(s, seed=3)
+    g = aoref.OracleGeo(o, cal.IF)
+    o.move_atmos()
+    o.raytrace_target(atm=True, dms=False, reset=True)
+    lit = s.spupil.reshape(-1) > 0
+    before = o.tar_phase.reshape(-1)[lit].std()
+    g.next_part_one_geo()
+    sr = g.comp_strehl()
+    after = g.twin.tar_phase.reshape(-1)[lit].std()
+    assert after < 0.25 * before and sr[0] > 0.5            # fitting error only
+    assert np.abs(g.com).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [NAME, "production_sh_40x40_8m_3layers"])
+def test_hip_geo_twin_matches_oracle(name):
+    import torch
+    from oracle import aoref
+    from ao_marl_amd.sim import HipSim
+    if name == NAME:
+        sysm, s, cal = helpers.calibrated(name)
+    else:
+        from ao_marl_amd import geometry as G, params, system
+        sysm = G.build_system(params.builtin(name))
+        s = system.from_system(sysm, strehl_halfwin=8)
+        cal = modal.calibrate(s, sysm, HipSim(s, nenv=512, keep_phase=True), nfilt=5)
+    seeds = [5, 6]
+    sim = HipSim(s, nenv=2)
+    sim.reset(seeds)
+    twin = sim.geo_twin(cal.IF)
+    oracles = [aoref.OracleSim(s, seed=sd) for sd in seeds]
+    if name != NAME:                       # cheap screens for the big system: copy the HIP ones
+        for o in oracles:
+            o.accumx[:] = 0; o.accumy[:] = 0
+    geos = [aoref.OracleGeo(o, cal.IF) for o in oracles]
+    for l in range(s.nscreens):
+        scr = sim.screen(l).cpu().numpy()
+        for e, o in enumerate(oracles):
+            o.screens[l] = scr[e].copy()
+    for frame in range(2):
+        twin.next_part_one_geo()
+        twin.comp_strehl()
+        com = twin.com.cpu().numpy()
+        st = twin.strehl.cpu().numpy()
+        for e, g in enumerate(geos):
+            g.next_part_one_geo()
+            want = g.comp_strehl()
+            scale = np.abs(g.com).max()
+            print("%s frame %d env %d: |dcom|/max|com| = %.2e  SR %.4f vs %.4f" %
+                  (name, frame, e, np.abs(com[e] - g.com).max() / scale, st[e, 0], want[0]))
+            assert np.abs(com[e] - g.com).max() < 2e-3 * scale, (frame, e)
+            assert abs(st[e, 0] - want[0]) < 2e-3, (frame, e)
+            assert abs(st[e, 2] - want[2]) < 2e-2 * want[2] + 1e-7
+        assert st[:, 0].min() > 0.5
+        # same screens on both sides for the next frame: integer moves only
+        sim.move_atmos()
+        for l in range(s.nscreens):
+            scr = sim.screen(l).cpu().numpy()
+            for e, o in enumerate(oracles):
+                o.screens[l] = scr[e].copy()
+
+
+@pytest.mark.gpu
+def test_env_with_the_geometric_twin():
+    """VecAoEnv(geo=True): controller 1 runs after controller 0 every frame, leaves controller 0
+    untouched, and the evaluation episode reports the reference's geometric metrics."""
+    import torch
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.sac import BatchedSAC, run_episode
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    env = VecAoEnv(NAME, 4, rl, n_agents_modal=1, geo=True)
+    ref = VecAoEnv(NAME, 4, rl, n_agents_modal=1)
+    sac = BatchedSAC(env.layout, dict(memory_size=16))
+    out = run_episode(env, sac, max_steps=40, train=False, linear_control=True)
+    base = run_episode(ref, sac, max_steps=40, train=False, linear_control=True)
+    assert torch.allclose(out["r_total"], base["r_total"], rtol=1e-5)
+    assert torch.allclose(out["sr_le"], base["sr_le"], rtol=1e-5)
+    assert "r_geo_per_agent" not in base
+    assert out["r_geo_per_agent"].shape == (4, 2) and (out["r_geo_total"] < 0).all()
+    # the geometric controller sees the phase without delay or measurement error
+    assert (out["sr_le_geo"] > out["sr_le"]).all() and (out["sr_le_geo"] > 0.8).all()
+    assert env.supervisor.get_command(1).shape == env.supervisor.get_command(0).shape
+    with pytest.raises(RuntimeError):
+        ref.supervisor.get_strehl(1)
