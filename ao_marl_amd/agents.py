@@ -190,6 +190,9 @@ class BatchedGaussianPolicy(object):
             lo[a:b] = torch.arange(b - a)
         self.sc_agent, self.sc_local = ag.to(dev), lo.to(dev)
         self.gen = torch.Generator(device=dev).manual_seed(seed)
+        self.gather_i32 = self.gather.to(torch.int32).contiguous()
+        self.sc_agent_i32, self.sc_local_i32 = self.sc_agent.to(torch.int32), self.sc_local.to(torch.int32)
+        self.seed, self._draws = int(seed), 0
         self._native = None          # stacked nn.Linear-layout copies for the HIP batched GEMM
         self.use_native = self.device.type == "cuda"
 
@@ -223,23 +226,31 @@ class BatchedGaussianPolicy(object):
 
     def split_states(self, state):
         """[nenv, state_dim] -> [A, nenv, in_max] (TrainerRPC.divide_states_for_agents)."""
+        if self.use_native and not state.requires_grad:
+            from . import libaomarl as la
+            return la.split_states(state.to(torch.float32), self.gather_i32)
         padded = torch.cat([state, state.new_zeros(state.shape[0], 1)], dim=1)
         return padded[:, self.gather].permute(1, 0, 2).contiguous()
 
-    def forward(self, state):
+    def _native_head(self, state):
+        """[A, nenv, 2 * act_max] = mean | log_std (unclamped), all layers on the HIP batched GEMM."""
+        from . import libaomarl as la
+        if self._native is None:
+            self._refresh_native()
+        n = self._native
         x = self.split_states(state.to(torch.float32))
+        x = la.linear_batched(x, n["W1"], n["b1"], relu=True)
+        for W, b in zip(n["Wh"], n["bh"]):
+            x = la.linear_batched(x, W, b, relu=True)
+        return la.linear_batched(x, n["Whead"], n["bhead"], relu=False)
+
+    def forward(self, state):
         if self.use_native:
-            from . import libaomarl as la
-            if self._native is None:
-                self._refresh_native()
-            n = self._native
-            x = la.linear_batched(x, n["W1"], n["b1"], relu=True)
-            for W, b in zip(n["Wh"], n["bh"]):
-                x = la.linear_batched(x, W, b, relu=True)
-            head = la.linear_batched(x, n["Whead"], n["bhead"], relu=False)
+            head = self._native_head(state)
             mean = head[:, :, :self.act_max]
             log_std = head[:, :, self.act_max:].clamp(LOG_SIG_MIN, self.log_sig_max)
             return mean, log_std
+        x = self.split_states(state.to(torch.float32))
         x = torch.relu(torch.baddbmm(self.b1, x, self.W1))
         for W, b in zip(self.Wh, self.bh):
             x = torch.relu(torch.baddbmm(b, x, W))
@@ -252,12 +263,27 @@ class BatchedGaussianPolicy(object):
         return per_agent[self.sc_agent, :, self.sc_local].T.contiguous()
 
     @torch.no_grad()
-    def select_action(self, state, eval_mode=False):
+    def select_action(self, state, eval_mode=False, eps=None):
         """(action, mean), both [nenv, action_dim] in [-1, 1]*scale+bias.  A normal sample is
-        always drawn, like the reference does even in eval mode (model_rpc.py:137-144)."""
+        always drawn, like the reference does even in eval mode (model_rpc.py:137-144).
+        On the GPU the whole tail (clamp, exp, sample, tanh, scale, scatter into the global action
+        vector) is one kernel with its own counter-based normals (Philox keyed by this policy's
+        seed and draw count); `eps` [nenv, action_dim] overrides the draws."""
+        if self.use_native:
+            from . import libaomarl as la
+            head = self._native_head(state)
+            self._draws += 1
+            a, m = la.policy_sample(head, self.act_max, self.sc_agent_i32, self.sc_local_i32,
+                                    LOG_SIG_MIN, self.log_sig_max, self.scale, self.bias, self.seed,
+                                    self._draws, eps=eps)
+            return (m if eval_mode else a), m
         mean, log_std = self.forward(state)
-        eps = torch.randn(mean.shape, generator=self.gen, device=self.device)
-        x_t = mean + log_std.exp() * eps
+        if eps is None:
+            e = torch.randn(mean.shape, generator=self.gen, device=self.device)
+        else:       # [nenv, action_dim] -> per-agent layout
+            e = torch.zeros_like(mean)
+            e[self.sc_agent, :, self.sc_local] = eps.T
+        x_t = mean + log_std.exp() * e
         action = torch.tanh(x_t) * self.scale + self.bias
         mu = torch.tanh(mean) * self.scale + self.bias
         a, m = self._assemble(action), self._assemble(mu)

@@ -500,7 +500,7 @@ static Work work_layout(const aomarl_ctx *c, int nenv) {
   w.PEND = take((size_t)nenv * (W * W + 4));
   {
     size_t mn = std::max(ncol * (size_t)w.ldn, (size_t)nenv * (size_t)w.ldm);
-    w.gemm_floats = 8 * mn;
+    w.gemm_floats = 8 * mn + 4096;     // + split-K ticket counters
     w.GEMM = take(w.gemm_floats);
   }
   w.total = o;
@@ -766,6 +766,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
   if (!strcmp(name, "gemm_legacy")) { g_gemm_legacy = value != 0; return 0; }
+  if (!strcmp(name, "gemm_inkernel_reduce")) { g_gemm_inkernel_reduce = value != 0; return 0; }
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
   if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
@@ -1021,6 +1022,125 @@ int aomarl_comp_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stre
   return 0;
 }
 
+// ---------------------------------------------------------------- agent-side glue (A12 - A15)
+// The reference does these in NumPy / torch on the host, a handful of tiny operations per agent
+// per step; on the device each of them would be its own ~5 us launch, so the chains are fused.
+__global__ void k_split_states(int nenv, int state_dim, int in_max, const int32_t *__restrict__ gather,
+                               const float *__restrict__ state, float *__restrict__ out) {
+  // out[a][e][k] = state[e][gather[a][k]]  (gather == state_dim -> 0: padding)
+  const int a = blockIdx.z, e = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= in_max) return;
+  const int g = gather[a * in_max + k];
+  out[((long long)a * nenv + e) * in_max + k] = g < state_dim ? state[(long long)e * state_dim + g] : 0.f;
+}
+
+__global__ void k_policy_sample(int nenv, int act_max, int action_dim, const float *__restrict__ head,
+                                float ls_min, float ls_max, float scale, float bias,
+                                const int32_t *__restrict__ sc_agent, const int32_t *__restrict__ sc_local,
+                                const float *__restrict__ eps_in, uint32_t seed, uint32_t counter,
+                                float *__restrict__ action, float *__restrict__ mean) {
+  const int e = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= action_dim) return;
+  const int a = sc_agent[g], l = sc_local[g];
+  const float *h = head + ((long long)a * nenv + e) * (2 * act_max);
+  const float m = h[l];
+  const float ls = fminf(fmaxf(h[act_max + l], ls_min), ls_max);
+  const float eps = eps_in ? eps_in[(long long)e * action_dim + g]
+                           : philox_normal(seed, 7u, counter, (uint32_t)e, (uint32_t)g);
+  const float x = m + expf(ls) * eps;
+  action[(long long)e * action_dim + g] = tanhf(x) * scale + bias;
+  mean[(long long)e * action_dim + g] = tanhf(m) * scale + bias;
+}
+
+struct StateBlocks {
+  const float *src[8], *mean[8], *std[8];
+  int ld[8], dim[8], off[8];
+  int nblocks, total;
+};
+
+__global__ void k_assemble_state(int nenv, StateBlocks sb, float *__restrict__ out) {
+  const int e = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= sb.total) return;
+  int b = 0;
+#pragma unroll
+  for (int k = 1; k < 8; k++) if (k < sb.nblocks && j >= sb.off[k]) b = k;
+  const int i = j - sb.off[b];
+  float v = sb.src[b][(long long)e * sb.ld[b] + i];
+  if (sb.mean[b]) v = (v - sb.mean[b][i]) / sb.std[b][i];
+  out[(long long)e * sb.total + j] = v;
+}
+
+__global__ void k_agent_rewards(int nenv, int nmodes, int n_agents, const float *__restrict__ res, int ld,
+                                const int32_t *__restrict__ lohi, float factor, float *__restrict__ out) {
+  // out[e][a] = -factor * mean(res[e][lo:hi]^2); one wave per (env, agent)
+  const int e = blockIdx.y, a = blockIdx.x, lane = threadIdx.x;
+  const int lo = lohi[2 * a], hi = lohi[2 * a + 1];
+  float s = 0.f;
+  for (int m = lo + lane; m < hi; m += 64) { const float v = res[(long long)e * ld + m]; s += v * v; }
+  s = wave_sum(s);
+  if (lane == 0) out[(long long)e * n_agents + a] = -factor * s / (float)(hi - lo);
+}
+
+int aomarl_split_states(int nenv, int state_dim, int n_agents, int in_max, const int32_t *gather,
+                        const float *state, float *out, void *stream) {
+  if (!gather || !state || !out) return fail("split_states: null pointer");
+  if (nenv <= 0 || n_agents <= 0 || in_max <= 0) return 0;
+  hipLaunchKernelGGL(k_split_states, dim3((in_max + 255) / 256, nenv, n_agents), dim3(256), 0,
+                     (hipStream_t)stream, nenv, state_dim, in_max, gather, state, out);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_policy_sample(int nenv, int act_max, int action_dim, const float *head, float log_sig_min,
+                         float log_sig_max, float scale, float bias, const int32_t *sc_agent,
+                         const int32_t *sc_local, const float *eps, uint32_t seed, uint32_t counter,
+                         float *action, float *mean, void *stream) {
+  if (!head || !sc_agent || !sc_local || !action || !mean) return fail("policy_sample: null pointer");
+  if (nenv <= 0 || action_dim <= 0) return 0;
+  hipLaunchKernelGGL(k_policy_sample, dim3((action_dim + 255) / 256, nenv), dim3(256), 0,
+                     (hipStream_t)stream, nenv, act_max, action_dim, head, log_sig_min, log_sig_max, scale,
+                     bias, sc_agent, sc_local, eps, seed, counter, action, mean);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_assemble_state(int nenv, int nblocks, const float *const *src, const int32_t *ld,
+                          const int32_t *dim, const float *const *mean, const float *const *std_,
+                          float *out, void *stream) {
+  if (!src || !ld || !dim || !out) return fail("assemble_state: null pointer");
+  if (nblocks < 1 || nblocks > 8) return fail("assemble_state: 1..8 blocks");
+  StateBlocks sb;
+  int off = 0;
+  for (int k = 0; k < 8; k++) {
+    const bool on = k < nblocks;
+    sb.src[k] = on ? src[k] : nullptr; sb.ld[k] = on ? ld[k] : 0; sb.dim[k] = on ? dim[k] : 0;
+    sb.mean[k] = (on && mean) ? mean[k] : nullptr; sb.std[k] = (on && std_) ? std_[k] : nullptr;
+    sb.off[k] = off;
+    if (on) {
+      if (!src[k] || dim[k] <= 0 || ld[k] < dim[k]) return fail("assemble_state: bad block %d", k);
+      if ((sb.mean[k] == nullptr) != (sb.std[k] == nullptr)) return fail("assemble_state: mean/std must come together");
+      off += dim[k];
+    }
+  }
+  sb.nblocks = nblocks; sb.total = off;
+  if (nenv <= 0) return 0;
+  hipLaunchKernelGGL(k_assemble_state, dim3((off + 255) / 256, nenv), dim3(256), 0, (hipStream_t)stream,
+                     nenv, sb, out);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_modes, int ld,
+                         const int32_t *lohi, float factor, float *out, void *stream) {
+  if (!res_modes || !lohi || !out) return fail("agent_rewards: null pointer");
+  if (ld < nmodes) return fail("agent_rewards: ld < nmodes");
+  if (nenv <= 0 || n_agents <= 0) return 0;
+  hipLaunchKernelGGL(k_agent_rewards, dim3(n_agents, nenv), dim3(64), 0, (hipStream_t)stream, nenv, nmodes,
+                     n_agents, res_modes, ld, lohi, factor, out);
+  LAUNCHCHK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- geometric controller
 __global__ void k_geo_assemble(int nactu, int npzt, int ldr, int gwgh, const int32_t *__restrict__ map,
                                const float *__restrict__ lat, const float *__restrict__ r3,
@@ -1100,7 +1220,7 @@ static GeoWork geo_layout(aomarl_ctx *c, int n) {
   g.LAT = take((size_t)n * c->geo_gw * c->geo_gh);
   g.R3 = take((size_t)n * 4);
   g.R = take((size_t)n * c->geo_ldr);
-  g.gemm_floats = (size_t)8 * n * std::max(c->sys.nactu, 4);
+  g.gemm_floats = (size_t)8 * n * std::max(c->sys.nactu, 4) + 4096;
   g.GEMM = take(g.gemm_floats);
   g.total = o;
   return g;

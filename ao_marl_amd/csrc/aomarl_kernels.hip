@@ -209,20 +209,28 @@ __device__ __forceinline__ float4 g2_load4(const float *p, int k, int ke, bool r
   return v;
 }
 
-// acc += A[m0.., kb..ke) . B[n0.., kb..ke)^T for the 32 x 32 sub-tile (wm, wn) of this wave
+// acc += A[m0.., kb..ke) . B[n0.., kb..ke)^T for the 32 x 32 sub-tile (wm, wn) of this wave.
+// Rows past M / N are clamped to the last valid row (their products land in output rows the
+// epilogue drops), so only the K tail needs guarded, zero-filling loads: every full k-tile is
+// four unconditional 128-bit loads per thread.
 __device__ __forceinline__ void g2_mainloop(const float *__restrict__ A, int lda,
                                             const float *__restrict__ B, int ldb, int M, int N,
                                             int m0, int n0, int kb, int ke, float *As, float *Bs,
                                             f32x16 &acc) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const float *pa0 = A + (long long)(m0 + lr) * lda, *pa1 = A + (long long)(m0 + lr + 32) * lda;
-  const float *pb0 = B + (long long)(n0 + lr) * ldb, *pb1 = B + (long long)(n0 + lr + 32) * ldb;
-  const bool a0 = m0 + lr < M, a1 = m0 + lr + 32 < M, b0 = n0 + lr < N, b1 = n0 + lr + 32 < N;
+  const float *pa0 = A + (long long)min(m0 + lr, M - 1) * lda + lc;
+  const float *pa1 = A + (long long)min(m0 + lr + 32, M - 1) * lda + lc;
+  const float *pb0 = B + (long long)min(n0 + lr, N - 1) * ldb + lc;
+  const float *pb1 = B + (long long)min(n0 + lr + 32, N - 1) * ldb + lc;
   float4 ra0, ra1, rb0, rb1;
-  auto gload = [&](int k0) {
-    ra0 = g2_load4(pa0, k0 + lc, ke, a0); ra1 = g2_load4(pa1, k0 + lc, ke, a1);
-    rb0 = g2_load4(pb0, k0 + lc, ke, b0); rb1 = g2_load4(pb1, k0 + lc, ke, b1);
+  auto gload_full = [&](int k0) {
+    ra0 = *reinterpret_cast<const float4 *>(pa0 + k0); ra1 = *reinterpret_cast<const float4 *>(pa1 + k0);
+    rb0 = *reinterpret_cast<const float4 *>(pb0 + k0); rb1 = *reinterpret_cast<const float4 *>(pb1 + k0);
+  };
+  auto gload_tail = [&](int k0) {
+    ra0 = g2_load4(pa0 - lc, k0 + lc, ke, true); ra1 = g2_load4(pa1 - lc, k0 + lc, ke, true);
+    rb0 = g2_load4(pb0 - lc, k0 + lc, ke, true); rb1 = g2_load4(pb1 - lc, k0 + lc, ke, true);
   };
   auto lstore = [&](int buf) {
     float *as = As + buf * 64 * G2_LD, *bs = Bs + buf * 64 * G2_LD;
@@ -232,13 +240,14 @@ __device__ __forceinline__ void g2_mainloop(const float *__restrict__ A, int lda
     *reinterpret_cast<float4 *>(bs + (lr + 32) * G2_LD + lc) = rb1;
   };
   const int ro = (lane & 31) * G2_LD + 16 * (lane >> 5);
-  gload(kb);
+  if (kb + 32 <= ke) gload_full(kb); else gload_tail(kb);
   lstore(0);
   __syncthreads();
   int buf = 0;
   for (int k0 = kb; k0 < ke; k0 += 32, buf ^= 1) {
-    const bool more = k0 + 32 < ke;
-    if (more) gload(k0 + 32);
+    const int kn = k0 + 32;
+    if (kn + 32 <= ke) gload_full(kn);            // wave-uniform branches
+    else if (kn < ke) gload_tail(kn);
     const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
     const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
     float4 a4[4], b4[4];
@@ -254,7 +263,7 @@ __device__ __forceinline__ void g2_mainloop(const float *__restrict__ A, int lda
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
     }
-    if (more) lstore(buf ^ 1);
+    if (kn < ke) lstore(buf ^ 1);
     __syncthreads();
   }
 }
@@ -263,9 +272,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alp
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb, float beta,
                                                   float *__restrict__ C, int ldc, int kchunk,
-                                                  float *__restrict__ P) {
+                                                  float *__restrict__ P, unsigned *counters) {
   __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
@@ -289,6 +299,32 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alp
       }
     }
   }
+  if (!split || !counters) return;
+  // ---- split-K epilogue without a second launch: the block that arrives last at this tile sums
+  // the partial tiles in z order (deterministic) and writes C; the ticket counter resets itself
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(&counters[blockIdx.y * gridDim.x + blockIdx.x], 1u);
+    s_last = (t == gridDim.z - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const volatile float *Pv = P;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      float v = 0.f;
+      for (int z = 0; z < (int)gridDim.z; z++) v += Pv[((long long)z * M + row) * N + col];
+      float *c = C + (long long)row * ldc + col;
+      v *= alpha;
+      if (beta != 0.f) v += beta * (*c);
+      *c = v;
+    }
+  }
+  if (threadIdx.x == 0) counters[blockIdx.y * gridDim.x + blockIdx.x] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
@@ -334,6 +370,8 @@ __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float
 
 static bool g_gemm_legacy = false;    // "gemm_legacy" option: the un-pipelined kernels (A/B tests)
 static int g_gemm_target_blocks = 512;
+static bool g_gemm_inkernel_reduce = false;  // "gemm_inkernel_reduce": measured 4x SLOWER (per-block L2 write-back of __threadfence)
+#define G_COUNTERS 4096
 
 // ws / ws_floats: optional split-K workspace (NULL: never split)
 void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
@@ -352,9 +390,17 @@ void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   dim3 grid(bx, by, nsplit);
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
-  if (al && !g_gemm_legacy)
+  // in-kernel split-K reduction: ticket counters live in the last G_COUNTERS floats of the (zero
+  // initialised, self-resetting) workspace
+  unsigned *counters = nullptr;
+  if (al && !g_gemm_legacy && nsplit > 1 && g_gemm_inkernel_reduce && bx * by <= G_COUNTERS &&
+      (size_t)nsplit * M * N + G_COUNTERS <= ws_floats)
+    counters = reinterpret_cast<unsigned *>(ws + ws_floats - G_COUNTERS);
+  if (al && !g_gemm_legacy) {
     hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                       ldc, kchunk, ws);
+                       ldc, kchunk, ws, counters);
+    if (counters) return;
+  }
   else if (al)
     hipLaunchKernelGGL(k_gemm_nt<true>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
                        C, ldc, kchunk, ws);

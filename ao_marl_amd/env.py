@@ -291,6 +291,12 @@ class VecAoEnv(object):
             self.set_agents(n_agents_modal)
         self._hist_dm, self._hist_wfs, self._hist_res = [], [], []
         self._last_res_modes = None
+        # fused glue kernels of the library (GPU + the HIP simulator only)
+        self._native_glue = self.device.type == "cuda" and hasattr(sup.sim, "lib")
+        self._default_state_layout = (
+            list(self.state_keys) == ["dm_history_%d" % i for i in
+                                      range(cfg["number_of_previous_dm"], 0, -1)] +
+            ["dm_before_linear", "dm_residual"] and cfg["number_of_previous_dm"] > 0)
 
     # ------------------------------------------------------------------ agents
     def set_agents(self, n_agents_modal):
@@ -308,6 +314,9 @@ class VecAoEnv(object):
         for j, (w, (a, b)) in enumerate(self.layout.agents.items()):
             M[a:b, j] = -factor / (b - a)                      # -factor * mean(reward[a:b])
         self._reward_mat = M
+        self._reward_factor = factor
+        self._lohi_i32 = torch.tensor([list(v) for v in self.layout.agents.values()],
+                                      dtype=torch.int32, device=self.device)
         return self.layout
 
     # ------------------------------------------------------------------ helpers
@@ -338,6 +347,8 @@ class VecAoEnv(object):
     def linear_step(self, return_dict=False):
         """ao_env.py:871-909"""
         cfg, sup = self.config_rl, self.supervisor
+        if self._native_glue and not return_dict and self._default_state_layout:
+            return self._linear_step_fused()
         s_dm_before = self.transform_state_to_zernike(sup.get_command())
         sup.next_part_one()
         s_dm_after = self.transform_state_to_zernike(sup.get_command()) \
@@ -377,6 +388,24 @@ class VecAoEnv(object):
             return out
         return torch.cat(list(out.values()), dim=1)
 
+    def _linear_step_fused(self):
+        """linear_step for the default state layout on the GPU: the four blocks are standardised
+        and concatenated by one kernel (aomarl_assemble_state) instead of ~10 tensor operations."""
+        from . import libaomarl as la
+        cfg, sup = self.config_rl, self.supervisor
+        s_dm_before = self.transform_state_to_zernike(sup.get_command())
+        sup.next_part_one()
+        res_full = sup.sim.volts2modes(sup.get_err())
+        self._last_res_modes = res_full
+        s_res = res_full if (self.windowed or self._sel is None) else res_full[:, self._sel]
+        blocks = list(self._hist_dm) + [s_dm_before, s_res]
+        norms = None
+        if self.normalization_bool:
+            norms = [self.norm["dm"]] * (len(self._hist_dm) + 1) + [self.norm["dm_residual"]]
+        state = la.assemble_state(blocks, norms)
+        self._hist_dm = self._hist_dm[1:] + [s_dm_before]
+        return state
+
     def calculate_reward(self):
         """ao_env.py:585-860, the branches the shipped configurations use."""
         st = self.supervisor.get_strehl()
@@ -410,6 +439,9 @@ class VecAoEnv(object):
         if self.layout is None:
             raise RuntimeError("no agent layout (set_agents)")
         r = self._last_res_modes
+        if self._native_glue:
+            from . import libaomarl as la
+            return la.agent_rewards(r, self._lohi_i32, self._reward_factor)
         return (r * r) @ self._reward_mat
 
     def step(self, action, linear_control=False):

@@ -99,6 +99,12 @@ SYMBOLS = [
     ("aomarl_get_dm_shape", _i, _range + [_i, _vp, _vp]),
     ("aomarl_set_option", _i, [_vp, C.c_char_p, _i]),
     ("aomarl_target_psf", _i, _range + [_vp]),
+    ("aomarl_split_states", _i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("aomarl_policy_sample", _i, [_i, _i, _i, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp,
+                                  _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    ("aomarl_assemble_state", _i, [_i, _i, C.POINTER(C.c_void_p), _ip, _ip, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_void_p), _vp, _vp]),
+    ("aomarl_agent_rewards", _i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _vp]),
     ("aomarl_target_psf_buffer", _i, _range + [_vp]),
     ("aomarl_set_geo", _i, [_vp, _fp]),
     ("aomarl_geo_workspace_floats", C.c_size_t, [_vp, _i]),
@@ -255,4 +261,77 @@ def linear_batched(x, weight, bias=None, relu=False, out=None):
             weight.stride(0), bias.data_ptr() if bias is not None else None,
             bias.stride(0) if bias is not None else 0, out.data_ptr(), out.stride(1), out.stride(0),
             1 if relu else 0, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out
+
+
+def _stream_of(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def split_states(state, gather_i32, out=None):
+    """[nenv, state_dim] -> [A, nenv, in_max] (aomarl_split_states)."""
+    import torch
+    nenv, sd = state.shape
+    A, in_max = gather_i32.shape
+    state = state.contiguous()
+    if out is None:
+        out = torch.empty(A, nenv, in_max, dtype=torch.float32, device=state.device)
+    check(load().aomarl_split_states(nenv, sd, A, in_max, gather_i32.data_ptr(), state.data_ptr(),
+                                     out.data_ptr(), _stream_of(state)))
+    return out
+
+
+def policy_sample(head, act_max, sc_agent_i32, sc_local_i32, log_sig_min, log_sig_max, scale, bias,
+                  seed, counter, eps=None):
+    """head [A, nenv, 2*act_max] -> (action, mean) [nenv, action_dim] (aomarl_policy_sample)."""
+    import torch
+    A, nenv, _ = head.shape
+    ad = sc_agent_i32.numel()
+    head = head.contiguous()
+    action = torch.empty(nenv, ad, dtype=torch.float32, device=head.device)
+    mean = torch.empty_like(action)
+    if eps is not None:
+        eps = eps.contiguous()
+    check(load().aomarl_policy_sample(nenv, act_max, ad, head.data_ptr(), log_sig_min, log_sig_max,
+                                      scale, bias, sc_agent_i32.data_ptr(), sc_local_i32.data_ptr(),
+                                      eps.data_ptr() if eps is not None else None,
+                                      int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF,
+                                      action.data_ptr(), mean.data_ptr(), _stream_of(head)))
+    return action, mean
+
+
+def assemble_state(blocks, norms=None, out=None):
+    """blocks: list of [nenv, d_k] tensors (row stride free, unit column stride); norms: list of
+    (mean, std) tensors or None per block -> [nenv, sum d_k] (aomarl_assemble_state)."""
+    import torch
+    n = len(blocks)
+    nenv = blocks[0].shape[0]
+    for b in blocks:
+        assert b.stride(1) == 1 and b.shape[0] == nenv and b.dtype == torch.float32
+    src = (C.c_void_p * n)(*[b.data_ptr() for b in blocks])
+    ld = (C.c_int32 * n)(*[b.stride(0) for b in blocks])
+    dim = (C.c_int32 * n)(*[b.shape[1] for b in blocks])
+    mean = std = None
+    if norms is not None:
+        mean = (C.c_void_p * n)(*[(m[0].data_ptr() if m is not None else None) for m in norms])
+        std = (C.c_void_p * n)(*[(m[1].data_ptr() if m is not None else None) for m in norms])
+    total = sum(b.shape[1] for b in blocks)
+    if out is None:
+        out = torch.empty(nenv, total, dtype=torch.float32, device=blocks[0].device)
+    check(load().aomarl_assemble_state(nenv, n, src, ld, dim, mean, std, out.data_ptr(),
+                                       _stream_of(blocks[0])))
+    return out
+
+
+def agent_rewards(res_modes, lohi_i32, factor):
+    """[nenv, nmodes] -> [nenv, A]: -factor * mean(res[:, lo:hi]**2) (aomarl_agent_rewards)."""
+    import torch
+    assert res_modes.stride(1) == 1
+    nenv, nm = res_modes.shape
+    A = lohi_i32.shape[0]
+    out = torch.empty(nenv, A, dtype=torch.float32, device=res_modes.device)
+    check(load().aomarl_agent_rewards(nenv, nm, A, res_modes.data_ptr(), res_modes.stride(0),
+                                      lohi_i32.data_ptr(), float(factor), out.data_ptr(),
+                                      _stream_of(res_modes)))
     return out

@@ -238,6 +238,30 @@ int aomarl_target_psf(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_
 int aomarl_frame_fused_available(aomarl_ctx *ctx);
 int aomarl_frame_fused(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int flags,
                        void *stream);
+/* ---- agent-side glue, all device pointers, no context (fused chains of the tiny host operations
+ * the reference does per agent per step):
+ * aomarl_split_states   TrainerRPC.divide_states_for_agents (train_rpc.py:418-427):
+ *                       out[a][e][k] = state[e][gather[a][k]], gather == state_dim -> 0 (padding)
+ * aomarl_policy_sample  GaussianPolicy.sample(only_choosing_action) on the head outputs
+ *                       (model_rpc.py:137-144): head [A][nenv][2*act_max] = mean | log_std ->
+ *                       action, mean [nenv][action_dim]; eps: standard normals [nenv][action_dim]
+ *                       or NULL (Philox4x32-10 keyed by seed, counter = step, env, action index)
+ * aomarl_assemble_state AoEnv.linear_step's concatenation + standardise (ao_env.py:470-480,
+ *                       871-909): out[e] = concat_k (src_k[e] - mean_k) / std_k  (mean/std NULL:
+ *                       raw); src / mean / std_ are HOST arrays of device pointers
+ * aomarl_agent_rewards  helper_rewards.get_separated_rewards (helper_rewards.py:14-22):
+ *                       out[e][a] = -factor * mean(res[e][lo_a:hi_a]^2), lohi [A][2] on the device */
+int aomarl_split_states(int nenv, int state_dim, int n_agents, int in_max, const int32_t *gather,
+                        const float *state, float *out, void *stream);
+int aomarl_policy_sample(int nenv, int act_max, int action_dim, const float *head, float log_sig_min,
+                         float log_sig_max, float scale, float bias, const int32_t *sc_agent,
+                         const int32_t *sc_local, const float *eps, uint32_t seed, uint32_t counter,
+                         float *action, float *mean, void *stream);
+int aomarl_assemble_state(int nenv, int nblocks, const float *const *src, const int32_t *ld,
+                          const int32_t *dim, const float *const *mean, const float *const *std_,
+                          float *out, void *stream);
+int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_modes, int ld,
+                         const int32_t *lohi, float factor, float *out, void *stream);
 /* PSF window + phase variance of st->tar_phase as it stands (pending, like aomarl_target_psf) */
 int aomarl_target_psf_buffer(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                              void *stream);

@@ -1,0 +1,90 @@
+"""Fused agent-side kernels of the library (state split, policy tail, state assembly, per-agent
+rewards) against the tensor-operation paths they replace (which the CPU tests pin to the
+reference's host code)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from ao_marl_amd.agents import AgentLayout, BatchedGaussianPolicy  # noqa: E402
+
+
+def _layout():
+    return AgentLayout(1283, [0, 1274], 13, include_tip_tilt=True, window_n_zernike=20,
+                       include_tip_tilt_windowed=True, n_filtered=5)
+
+
+def test_split_states_and_policy_tail_match_tensor_ops():
+    lay = _layout()
+    pol = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=5, device="cuda:0")
+    with torch.no_grad():
+        pol.bm.normal_(0, 0.3); pol.bs.normal_(0, 0.3)
+    st = torch.randn(33, lay.state_dim, device="cuda:0")
+    pol.use_native = True
+    x1 = pol.split_states(st)
+    pol.use_native = False
+    x0 = pol.split_states(st)
+    assert torch.equal(x0, x1)
+    eps = torch.randn(33, lay.action_dim, device="cuda:0")
+    a0, m0 = pol.select_action(st, eps=eps)
+    pol.use_native = True
+    a1, m1 = pol.select_action(st, eps=eps)
+    assert torch.allclose(a0, a1, atol=5e-5, rtol=1e-4) and torch.allclose(m0, m1, atol=5e-5, rtol=1e-4)
+    # own counter-based normals: reproducible per (seed, draw), fresh per draw, N(0, 1)
+    big = torch.randn(512, lay.state_dim, device="cuda:0")
+    pol._draws = 0
+    b1, mu = pol.select_action(big)
+    b2, _ = pol.select_action(big)
+    pol._draws = 0
+    b3, _ = pol.select_action(big)
+    assert torch.equal(b1, b3) and not torch.equal(b1, b2)
+    # with a zero last layer the action is tanh(eps): recover the normals
+    flat = BatchedGaussianPolicy(lay, last_layer_zero=True, seed=9, device="cuda:0")
+    act, mu0 = flat.select_action(big)
+    assert mu0.abs().max().item() == 0.0
+    z = torch.atanh(act.clamp(-0.9999999, 0.9999999))
+    assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1.0) < 0.01
+    assert abs((z ** 4).mean().item() - 3.0) < 0.1                  # Gaussian kurtosis
+    c = torch.corrcoef(torch.stack([z[:, 0], z[:, 1], z[0, :512], z[1, :512]]))
+    assert (c - torch.eye(4, device=c.device)).abs().max().item() < 0.2
+
+
+def test_state_assembly_and_rewards_match_tensor_ops():
+    from ao_marl_amd import libaomarl as la
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    nenv, nm = 19, 1283
+    blocks = [torch.randn(nenv, nm, device="cuda:0", generator=g) for _ in range(3)]
+    padded = torch.randn(nenv, 1288, device="cuda:0", generator=g)
+    blocks.append(padded[:, :nm])                                   # a strided view
+    norms = [(torch.randn(nm, device="cuda:0", generator=g),
+              torch.rand(nm, device="cuda:0", generator=g) + 0.5) for _ in range(2)]
+    nl = [norms[0], norms[0], norms[0], norms[1]]
+    got = la.assemble_state(blocks, nl)
+    want = torch.cat([(b - m) / s for b, (m, s) in zip(blocks, nl)], dim=1)
+    assert torch.allclose(got, want, atol=1e-6, rtol=1e-6)
+    raw = la.assemble_state(blocks, None)
+    assert torch.equal(raw, torch.cat(blocks, dim=1))
+    lay = _layout()
+    lohi = torch.tensor([list(v) for v in lay.agents.values()], dtype=torch.int32, device="cuda:0")
+    r = la.agent_rewards(blocks[3], lohi, 1000.0)
+    want = torch.stack([-1000.0 * (blocks[3][:, a:b] ** 2).mean(dim=1) for a, b in lay.agents.values()], dim=1)
+    assert torch.allclose(r, want, rtol=1e-5, atol=1e-6)
+
+
+def test_env_step_with_fused_glue_equals_tensor_op_path():
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    assert a._native_glue and a._default_state_layout
+    b._native_glue = False
+    sa, sb = a.reset(), b.reset()
+    assert torch.allclose(sa, sb, rtol=1e-5, atol=1e-5 * sb.abs().max().item())
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    for _ in range(4):
+        act = torch.rand(3, a.layout.action_dim, device="cuda:0", generator=g) * 2 - 1
+        sa, ra, _, _ = a.step(act)
+        sb, rb, _, _ = b.step(act)
+        assert torch.allclose(sa, sb, rtol=1e-4, atol=1e-5 * sb.abs().max().item())
+        assert torch.allclose(ra, rb, rtol=1e-4, atol=1e-6)
