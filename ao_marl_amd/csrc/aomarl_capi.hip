@@ -568,11 +568,8 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
     launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
                    0.0f, NEWL, w.ldn, s, st->work + w.GEMM, w.gemm_floats);
     LAUNCHCHK();
-    hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol, (dimc + 255) / 256), dim3(256), 0, s, c->sys,
-                       ds, b, ops, NEWL, w.ldn, ZREF);
-    LAUNCHCHK();
-    hipLaunchKernelGGL(k_extrude_commit, dim3((ncol + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
-                       ncol, ops);
+    hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
+                       ZREF);
     LAUNCHCHK();
   }
   return 0;
@@ -972,7 +969,7 @@ static int target_psf_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, bool f
     else
       hipLaunchKernelGGL(k_target_rows_fast<3>, dim3(w.nblk, n), dim3(256), smm, s, c->sys, ds, b, TR, TP, w.nblk);
     LAUNCHCHK();
-    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
+    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND, (uint32_t *)nullptr);
     LAUNCHCHK();
     return 0;
   }
@@ -983,7 +980,7 @@ static int target_psf_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, bool f
     else
       hipLaunchKernelGGL(k_target_rows_mfma<false>, dim3(w.nblk, n), dim3(256), smm, s, c->sys, ds, b, TR, TP, w.nblk);
     LAUNCHCHK();
-    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
+    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND, (uint32_t *)nullptr);
     LAUNCHCHK();
     return 0;
   }
@@ -1325,9 +1322,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
 #undef FW_NC
 #undef FW
   LAUNCHCHK();
-  hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND);
-  LAUNCHCHK();
-  hipLaunchKernelGGL(k_inc_u32, dim3((n + 255) / 256), dim3(256), 0, s, st->frame + b, n);
+  hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
   LAUNCHCHK();
   return 0;
 }

@@ -449,6 +449,8 @@ __global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st,
   if (j == 0) ZREF[col] = zref;
 }
 
+// new line -> ring (+ mirror columns), then the ring origin / extrusion counter of this
+// (environment, layer) advance: one block per column, so nobody else reads that origin
 __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st, int env_begin,
                                                          RoundOps ops,
                                                          const float *__restrict__ NEWL, int ldn,
@@ -459,41 +461,37 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
   const DevLayer &L = sys.layers[li];
   const int n = L.dim;
   float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-  const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
-  const int r = blockIdx.y * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  const float v = NEWL[(long long)col * ldn + r] + ZREF[col];
-  int px, py;
-  if (dir == 1) {
-    px = ox;
-    py = r + oy; py -= (py >= n) ? n : 0;
-  } else if (dir == -1) {
-    px = ox - 1; px += (px < 0) ? n : 0;
-    py = n - 1 - r + oy; py -= (py >= n) ? n : 0;
-  } else if (dir == 2) {
-    py = oy;
-    px = r + ox; px -= (px >= n) ? n : 0;
-  } else {
-    py = oy - 1; py += (py < 0) ? n : 0;
-    px = n - 1 - r + ox; px -= (px >= n) ? n : 0;
-  }
-  const int stride = n + RING_PAD;
-  base[py * stride + px] = v;
-  if (px < RING_PAD) base[py * stride + n + px] = v;     // mirror columns
-}
-
-__global__ void k_extrude_commit(DevSys sys, DevState st, int env_begin, int ncol, RoundOps ops) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ncol) return;
-  const int e = env_begin + col / ops.nops, op = col % ops.nops;
-  const int li = ops.layer[op], dir = ops.dir[op];
-  const int n = sys.layers[li].dim;
   int *o = st.origin + (e * sys.nlayers + li) * 2;
-  if (dir == 1) o[0] = (o[0] + 1 >= n) ? 0 : o[0] + 1;
-  else if (dir == -1) o[0] = (o[0] - 1 < 0) ? n - 1 : o[0] - 1;
-  else if (dir == 2) o[1] = (o[1] + 1 >= n) ? 0 : o[1] + 1;
-  else o[1] = (o[1] - 1 < 0) ? n - 1 : o[1] - 1;
-  st.ext_count[e * sys.nlayers + li] += 1u;
+  const int ox = o[0], oy = o[1];
+  const float zref = ZREF[col];
+  const int stride = n + RING_PAD;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    const float v = NEWL[(long long)col * ldn + r] + zref;
+    int px, py;
+    if (dir == 1) {
+      px = ox;
+      py = r + oy; py -= (py >= n) ? n : 0;
+    } else if (dir == -1) {
+      px = ox - 1; px += (px < 0) ? n : 0;
+      py = n - 1 - r + oy; py -= (py >= n) ? n : 0;
+    } else if (dir == 2) {
+      py = oy;
+      px = r + ox; px -= (px >= n) ? n : 0;
+    } else {
+      py = oy - 1; py += (py < 0) ? n : 0;
+      px = n - 1 - r + ox; px -= (px >= n) ? n : 0;
+    }
+    base[py * stride + px] = v;
+    if (px < RING_PAD) base[py * stride + n + px] = v;     // mirror columns
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (dir == 1) o[0] = (ox + 1 >= n) ? 0 : ox + 1;
+    else if (dir == -1) o[0] = (ox - 1 < 0) ? n - 1 : ox - 1;
+    else if (dir == 2) o[1] = (oy + 1 >= n) ? 0 : oy + 1;
+    else o[1] = (oy - 1 < 0) ? n - 1 : oy - 1;
+    st.ext_count[e * sys.nlayers + li] += 1u;
+  }
 }
 
 __global__ void k_fill_f32(float *p, long long n, float v) {
@@ -2121,8 +2119,10 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
 // stage 2 on MFMA: G[ky][kx] = sum_y E[ky][y] R[y][kx]; 4 waves split y, one block per env
 __global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const float *__restrict__ TR,
                                                             const float *__restrict__ TPART, int nblk,
-                                                            float *__restrict__ PEND) {
+                                                            float *__restrict__ PEND,
+                                                            uint32_t *__restrict__ frame) {
   __shared__ float red[4 * 2 * 256];
+  __shared__ double dred[3][64];
   const int pd = sys.pupdiam, np = sys.npsf;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, c = lane & 15;
@@ -2133,22 +2133,38 @@ __global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const fl
   f32x4 Gr = {0.f, 0.f, 0.f, 0.f}, Gi = {0.f, 0.f, 0.f, 0.f};
   const int per = ((pd + 15) / 16) * 4;              // rows per wave, multiple of 4
   const int yb = wv * per, ye = min(pd, yb + per);
-  for (int yy = yb; yy < ye; yy += 4) {
-    const int y = yy + q;
-    float2 r = make_float2(0.f, 0.f), w = make_float2(0.f, 0.f);
-    if (y < ye) {
-      r = R[y * 16 + c];                               // B operand: R[y = yy + q][kx = c]
-      w = tw[(kyf * y) & (np - 1)];                    // A operand: E[ky = c - 8][y = yy + q]
+  // 8 steps (32 rows) of operands are fetched before their MFMAs: the loop is latency-bound
+  for (int y0 = yb; y0 < ye; y0 += 32) {
+    float2 r[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int y = y0 + 4 * u + q;
+      r[u] = make_float2(0.f, 0.f); w[u] = make_float2(0.f, 0.f);
+      if (y < ye) {
+        r[u] = R[y * 16 + c];                          // B operand: R[y][kx = c]
+        w[u] = tw[(kyf * y) & (np - 1)];               // A operand: E[ky = c - 8][y]
+      }
     }
-    Gr = mfma16(w.x, r.x, Gr);
-    Gi = mfma16(w.x, r.y, Gi);
-    Gr = mfma16(w.y, r.y, Gr);
-    Gi = mfma16(-w.y, r.x, Gi);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      Gr = mfma16(w[u].x, r[u].x, Gr);
+      Gi = mfma16(w[u].x, r[u].y, Gi);
+      Gr = mfma16(w[u].y, r[u].y, Gr);
+      Gi = mfma16(-w[u].y, r[u].x, Gi);
+    }
   }
 #pragma unroll
   for (int r4 = 0; r4 < 4; r4++) {
     red[(wv * 2 + 0) * 256 + (4 * q + r4) * 16 + c] = Gr[r4];
     red[(wv * 2 + 1) * 256 + (4 * q + r4) * 16 + c] = Gi[r4];
+  }
+  if (tid < 64) {
+    double sd = 0., sd2 = 0., sm = 0.;
+    for (int k = tid; k < nblk; k += 64) {
+      const float *pp = TPART + ((long long)b * nblk + k) * 4;
+      sd += pp[0]; sd2 += pp[1]; sm += pp[2];
+    }
+    dred[0][tid] = sd; dred[1][tid] = sd2; dred[2][tid] = sm;
   }
   __syncthreads();
   {
@@ -2159,13 +2175,11 @@ __global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const fl
   }
   if (tid == 0) {
     double sd = 0., sd2 = 0., sm = 0.;
-    for (int k = 0; k < nblk; k++) {
-      const float *pp = TPART + ((long long)b * nblk + k) * 4;
-      sd += pp[0]; sd2 += pp[1]; sm += pp[2];
-    }
+    for (int k = 0; k < 64; k++) { sd += dred[0][k]; sd2 += dred[1][k]; sm += dred[2][k]; }
     double var = 0.;
     if (sm > 0.) { double mean = sd / sm; var = sd2 / sm - mean * mean; }
     pend[256] = (float)var;
+    if (frame) frame[b] += 1u;                         // WFS noise frame counter (one-pass path)
   }
 }
 
