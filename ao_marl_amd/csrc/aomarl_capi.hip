@@ -342,7 +342,7 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
     const int pd = d->pupdiam, pad = (d->n - pd) / 2;
     bool ok = s.wfs_all_int && s.tar_all_int && d->ndm == 2 && d->dms[0].type == AOMARL_DM_PZT &&
               d->dms[1].type == AOMARL_DM_TT && (d->nlayers == 1 || d->nlayers == 3) &&
-              d->strehl_halfwin == 8 && pd % 16 == 0 && pad >= 0 && d->n == pd + 2 * pad &&
+              d->strehl_halfwin == 8 && pd % 16 == 0 && pad >= 0 && d->n == pd + 2 * pad && d->nvalid <= 0xFFFF &&
               (d->npsf & (d->npsf - 1)) == 0 && d->npsf <= 4096 && pd / 16 <= 256;
     for (int l = 0; l < d->nlayers && ok; l++)
       ok = s.layers[l].wox + pad == s.layers[l].tox && s.layers[l].woy + pad == s.layers[l].toy;
@@ -377,7 +377,20 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
       }
     }
     if (ok) {
-      UP(int32_t, tsub.data(), tsub.size(), s.tile_sub);
+      // tile_info: [15:0] sub-aperture, bit 16 lit, 17 every pixel lit, 18 valid sub-aperture
+      std::vector<int32_t> tinfo(tsub.size(), 0);
+      for (int r = 0; r < nt; r++)
+        for (int t = 0; t < nt; t++) {
+          const int32_t sb = tsub[(size_t)r * nt + t];
+          bool full = true;
+          for (int yy = 0; yy < 16; yy++) full = full && tmask[(size_t)(16 * r + yy) * nt + t] == 0xFFFF;
+          int32_t v = 0;
+          if (sb != -2) v |= 0x10000;
+          if (full) v |= 0x20000;
+          if (sb >= 0) { v |= 0x40000 | sb; v |= 0x10000; }     // an unlit tile with a sub-aperture is still imaged
+          tinfo[(size_t)r * nt + t] = v;
+        }
+      UP(int32_t, tinfo.data(), tinfo.size(), s.tile_info);
       UP(uint16_t, tmask.data(), tmask.size(), s.tile_mask);
       s.fused_ok = 1; s.ntiles = nt;
       // stack-array DM evaluated from the command lattice inside the frame kernel

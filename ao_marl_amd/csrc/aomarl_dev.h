@@ -60,7 +60,7 @@ struct DevSys {
   // ---- fused frame kernel (WFS + science path share every phase pixel: the 16x16 sub-aperture
   // tiles ARE the tiles of the pupil grid): available when the geometry lines up (see create)
   int fused_ok, ntiles;          // ntiles = pupdiam / 16 tiles per axis
-  const int32_t *tile_sub;       // [ntiles][ntiles] (stripe, tile) -> sub-aperture index or -1
+  const int32_t *tile_info;      // [ntiles][ntiles] (stripe, tile): sub-aperture | lit / full / has-sub bits
   const uint16_t *tile_mask;     // [pupdiam][ntiles]: bit b = spupil[y][16 t + b] != 0
   // stack-array DM phase from the command lattice inside the frame kernel (separable lattice whose
   // pitch divides the tile size): nodes per axis that reach a tile <= 4 otf_nb
@@ -122,10 +122,12 @@ __device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, 
 }
 
 // ring-buffered screen: logical (x, y) -> physical float index.  Physical rows are
-// n + RING_PAD floats long: columns [n, n + RING_PAD) mirror columns [0, RING_PAD), so any 4
-// consecutive logical pixels starting at a physical column < n are 4 consecutive floats (no wrap
-// branch in the consumers); the extrusion scatter keeps the mirror up to date.
-#define RING_PAD 4
+// n + RING_PAD floats long: columns [n, n + RING_PAD) mirror columns [0, RING_PAD), so up to
+// RING_PAD consecutive logical pixels starting at a physical column < n are consecutive floats:
+// a 16-pixel tile row whose first pixel is in range needs no wrap test per lane (the one-pass
+// frame kernel wraps once per tile, on the scalar unit); the extrusion scatter keeps the mirror
+// up to date.
+#define RING_PAD 16
 __device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
   int px = x + ox;
   px -= (px >= n) ? n : 0;

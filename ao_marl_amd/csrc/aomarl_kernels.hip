@@ -23,6 +23,18 @@ __device__ __forceinline__ float wave_sum(float v) {
           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
 }
 
+// sum over the 64 lanes, valid in LANE 63 ONLY: 6 DPP adds, no v_readlane (row_bcast:15 / :31 carry
+// the row sums across the four 16-lane rows)
+__device__ __forceinline__ float wave_sum_last(float v) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror -> every lane holds its 16-lane row sum
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31
+  return v;
+}
+
 // 4 consecutive floats at a dword-aligned (not necessarily 16-byte aligned) address: one
 // global_load_dwordx4 (gfx950 supports unaligned vector access; the compiler emits it for this type)
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
@@ -864,14 +876,15 @@ __device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st,
           sx_ += v[sy][sx][h] * (float)(sx ? Xm : Xp);
           sy_ += v[sy][sx][h] * (float)Y;
         }
-    tot = wave_sum(owner ? tot : 0.f);
-    sx_ = wave_sum(owner ? sx_ : 0.f);
-    sy_ = wave_sum(owner ? sy_ : 0.f);
-    if (do_cog && lane == 0) {
+    tot = wave_sum_last(owner ? tot : 0.f);
+    sx_ = wave_sum_last(owner ? sx_ : 0.f);
+    sy_ = wave_sum_last(owner ? sy_ : 0.f);
+    if (do_cog && lane == 63) {
       float *sl = st.slopes + (long long)e * sys.nslope;
       if (tot > 0.f) {
-        sl[i] = (sx_ / tot - sys.cog_offset) * sys.cog_scale;
-        sl[sys.nvalid + i] = (sy_ / tot - sys.cog_offset) * sys.cog_scale;
+        const float inv = __builtin_amdgcn_rcpf(tot);       // 1 ulp; slopes are compared at 1e-4"
+        sl[i] = (sx_ * inv - sys.cog_offset) * sys.cog_scale;
+        sl[sys.nvalid + i] = (sy_ * inv - sys.cog_offset) * sys.cog_scale;
       } else {
         sl[i] = 0.f;
         sl[sys.nvalid + i] = 0.f;
@@ -1344,6 +1357,10 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
 // operand reads (x = 4q + s, y = c) both touch 32 distinct banks per half wave.
 // =============================================================================================
 #define FW_LD 20
+// tile_info bits: [15:0] sub-aperture index, 16 lit, 17 every pixel lit, 18 has a valid sub-aperture
+#define FW_LIT 0x10000
+#define FW_FULL 0x20000
+#define FW_SUB 0x40000
 template <int NL, bool OTF>
 struct FrameRaw {
   float L[NL][4];
@@ -1388,28 +1405,34 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   float *Twr = tiles + wv * 4 * 16 * FW_LD, *Twi = Twr + 16 * FW_LD;   // WFS amplitude [x][y]
   float *Tar = Twi + 16 * FW_LD, *Tai = Tar + 16 * FW_LD;              // target amplitude [x][y]
   const int y = 16 * r + c;                                  // pupil row of this lane
-  // ---- per-environment constants (target-path offsets; the WFS sees the same pixels)
-  const float *lay[NL];
-  unsigned lpx[NL], ldim[NL], lrow[NL];
+  // ---- per-environment constants (target-path offsets; the WFS sees the same pixels).
+  // Every load address is  scalar base (advances with the tile)  +  per-lane byte offset (fixed
+  // for the stripe): rows carry RING_PAD = 16 mirror columns, so the 16-byte load of a lane may
+  // start up to 12 floats past the scalar wrap point without wrapping itself.
+  const char *layb[NL];
+  unsigned lpxs[NL], ldim[NL], lvo[NL];
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     const DevLayer &L = sys.layers[l];
-    lay[l] = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+    layb[l] = reinterpret_cast<const char *>(st.screens + (long long)e * sys.screen_stride + L.screen_off);
     ldim[l] = (unsigned)L.dim;
     int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
     int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
-    lpx[l] = (unsigned)px + 4u * (unsigned)q;
+    lpxs[l] = (unsigned)px;
     unsigned pr = (unsigned)y + (unsigned)py; pr = min(pr, pr - ldim[l]);
-    lrow[l] = pr * (ldim[l] + RING_PAD);
+    lvo[l] = 4u * (pr * (ldim[l] + RING_PAD) + 4u * (unsigned)q);
   }
   const DevDm &D0 = sys.dms[0], &D1 = sys.dms[1];
   const float *pzt = st.dm_shape + (long long)e * sys.shape_stride + D0.shape_off;
   const float *ttslot = st.dm_shape + (long long)e * sys.shape_stride + D1.shape_off;
   const float c0 = ttslot[0], c1 = ttslot[1];
   const int half = pd / 2;
-  const unsigned prow = (unsigned)(y + D0.toy) * (unsigned)D0.dim + (unsigned)D0.tox + 4u * (unsigned)q;
-  const unsigned trow = 2u * ((unsigned)(y + D1.toy) * (unsigned)D1.dim + (unsigned)D1.tox + 4u * (unsigned)q);
-  const uint16_t *mrowp = sys.tile_mask + (long long)y * ntl;
+  const unsigned pvo = 4u * ((unsigned)(y + D0.toy) * (unsigned)D0.dim + (unsigned)D0.tox + 4u * (unsigned)q);
+  const unsigned tvo = 8u * ((unsigned)(y + D1.toy) * (unsigned)D1.dim + (unsigned)D1.tox + 4u * (unsigned)q);
+  const unsigned mvo = 2u * (unsigned)y * (unsigned)ntl;
+  const char *pztb = reinterpret_cast<const char *>(pzt);
+  const char *ttb = reinterpret_cast<const char *>(D1.influ);
+  const char *mkb = reinterpret_cast<const char *>(sys.tile_mask);
   // pivot of the variance sums: phase at the grid centre (ttslot[2]: stack-array value there)
   float pivot;
   {
@@ -1419,11 +1442,10 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       const DevLayer &L = sys.layers[l];
-      int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
       int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
       unsigned pyc = (unsigned)(half + py); pyc = min(pyc, pyc - ldim[l]);
-      unsigned pxc = (unsigned)(half + px); pxc = min(pxc, pxc - ldim[l]);
-      v += lay[l][pyc * (ldim[l] + RING_PAD) + pxc];
+      unsigned pxc = (unsigned)half + lpxs[l]; pxc = min(pxc, pxc - ldim[l]);
+      v += reinterpret_cast<const float *>(layb[l])[pyc * (ldim[l] + RING_PAD) + pxc];
     }
     pivot = v;
   }
@@ -1454,61 +1476,78 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     }
     __builtin_amdgcn_wave_barrier();
   }
-  const int *tsub = sys.tile_sub + r * ntl;
+  const float *latq = lat + (jm_ok ? jm : 0);
+  const int *tinfo = sys.tile_info + r * ntl;
   const float wfs_il = sys.wfs_inv_lambda, tar_il = sys.tar_inv_lambda;
-  FrameRaw<NL, OTF> raw;
-  // tile_sub: >= 0 valid sub-aperture, -1 lit tile without sub-aperture, -2 tile outside the pupil
-  auto fetch = [&](int t, int sub) {
-    if (sub == -2 || (dbg & 4)) return;                      // wave-uniform
-    const unsigned x = (unsigned)(16 * t);
+  const f32x4 Z4 = opaque_zero4();
+  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  float sd = 0.f, sd2 = 0.f, sm = 0.f;
+  const int kxf = c - 8;
+
+  auto fetch = [&](int t, int info, FrameRaw<NL, OTF> &raw) {
+    if (!(info & FW_LIT) || (dbg & 4)) return;               // wave-uniform
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-      unsigned px = x + lpx[l]; px = min(px, px - ldim[l]);
-      const f4u v4 = *reinterpret_cast<const f4u *>(lay[l] + (lrow[l] + px));
+      unsigned sx = 16u * (unsigned)t + lpxs[l]; sx -= (sx >= ldim[l]) ? ldim[l] : 0u;   // scalar
+      const f4u v4 = *reinterpret_cast<const f4u *>(layb[l] + 4u * sx + lvo[l]);
 #pragma unroll
       for (int j = 0; j < 4; j++) raw.L[l][j] = v4.v[j];
     }
     if (!OTF) {
-      const f4u p4 = *reinterpret_cast<const f4u *>(pzt + (prow + x));
+      const f4u p4 = *reinterpret_cast<const f4u *>(pztb + 64u * (unsigned)t + pvo);
 #pragma unroll
       for (int j = 0; j < 4; j++) raw.P[OTF ? 0 : j] = p4.v[j];
     }
-    const f4u t0 = *reinterpret_cast<const f4u *>(D1.influ + (trow + 2u * x));
-    const f4u t1 = *reinterpret_cast<const f4u *>(D1.influ + (trow + 2u * x + 4u));
+    const char *tb = ttb + 128u * (unsigned)t;
+    const f4u t0 = *reinterpret_cast<const f4u *>(tb + tvo);
+    const f4u t1 = *reinterpret_cast<const f4u *>(tb + 16 + tvo);
 #pragma unroll
     for (int j = 0; j < 4; j++) { raw.T[j] = t0.v[j]; raw.T[4 + j] = t1.v[j]; }
-    raw.mrow = mrowp[t];
-    raw.F = sub >= 0 ? sys.flux[sub] : 0.f;
+    raw.mrow = (info & FW_FULL) ? 0xFFFFu : *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)t + mvo);
+    raw.F = (info & FW_SUB) ? sys.flux[info & 0xFFFF] : 0.f;
   };
-  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 Z4 = opaque_zero4();
-  float sd = 0.f, sd2 = 0.f, sm = 0.f;
-  const int kxf = c - 8;
-  int sub = tsub[0];
-  fetch(0, sub);
-  for (int t = 0; t < ntl; t++) {
-    const int subn = t + 1 < ntl ? tsub[t + 1] : -2;
-    if (sub != -2) {
-      // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
-      f32x4 S = Z4;
-      if (OTF) {
-        f32x4 U = Z4;
+
+  // one tile: consume `cur`, prefetch tile t + 1 into `nxt`
+  auto tile = [&](int t, int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt) {
+    if (!(info & FW_LIT)) { fetch(t + 1, infon, nxt); return; }
+    // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
+    f32x4 S = Z4;
+    if (OTF) {
+      f32x4 U = Z4;
 #pragma unroll
-        for (int kb = 0; kb < NB; kb++) {
-          const float a = lat[(q + 4 * kb) * latw + t * tpn + (jm_ok ? jm : 0)];
-          U = mfma16(jm_ok ? a : 0.f, Pyr[kb], U);
-        }
-#pragma unroll
-        for (int s = 0; s < NB; s++) S = mfma16(Pxr[s], U[s], S);
+      for (int kb = 0; kb < NB; kb++) {
+        const float a = latq[(q + 4 * kb) * latw + t * tpn];
+        U = mfma16(jm_ok ? a : 0.f, Pyr[kb], U);
       }
-      const float flux_i = raw.F;
-      // ---- phase of the 4 pixels, both complex amplitudes -> LDS
+#pragma unroll
+      for (int s = 0; s < NB; s++) S = mfma16(Pxr[s], U[s], S);
+    }
+    const float flux_i = cur.F;
+    // ---- phase of the 4 pixels, both complex amplitudes -> LDS
+    if (info & FW_FULL) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float ph = (OTF ? S[j] : raw.P[OTF ? 0 : j]) + (c0 * raw.T[2 * j] + c1 * raw.T[2 * j + 1]);
+        float ph = (OTF ? S[j] : cur.P[OTF ? 0 : j]) + (c0 * cur.T[2 * j] + c1 * cur.T[2 * j + 1]);
 #pragma unroll
-        for (int l = 0; l < NL; l++) ph += raw.L[l][j];
-        const bool m = (raw.mrow >> (4 * q + j)) & 1u;
+        for (int l = 0; l < NL; l++) ph += cur.L[l][j];
+        float a_ = ph * wfs_il; a_ -= rintf(a_);
+        float b_ = ph * tar_il; b_ -= rintf(b_);
+        const int o = (4 * q + j) * FW_LD + c;
+        Twr[o] = __builtin_amdgcn_cosf(a_);
+        Twi[o] = __builtin_amdgcn_sinf(a_);
+        Tar[o] = __builtin_amdgcn_cosf(b_);
+        Tai[o] = __builtin_amdgcn_sinf(b_);
+        const float d = ph - pivot;
+        sd += d; sd2 += d * d;
+      }
+      sm += 4.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float ph = (OTF ? S[j] : cur.P[OTF ? 0 : j]) + (c0 * cur.T[2 * j] + c1 * cur.T[2 * j + 1]);
+#pragma unroll
+        for (int l = 0; l < NL; l++) ph += cur.L[l][j];
+        const bool m = (cur.mrow >> (4 * q + j)) & 1u;
         float a_ = ph * wfs_il; a_ -= rintf(a_);
         float b_ = ph * tar_il; b_ -= rintf(b_);
         const int o = (4 * q + j) * FW_LD + c;
@@ -1519,34 +1558,39 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
         const float d = m ? ph - pivot : 0.f;
         sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
       }
-      fetch(t + 1, subn);                                    // next tile's loads fly during the MFMAs
-      __builtin_amdgcn_wave_barrier();
-      // ---- science path: R[y][kx] += sum_{x in tile} a(y, x) exp(-2 pi i kx x / Npsf)
-      if (!(dbg & 2)) {
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int xl = 4 * q + s;
-          const float ar = Tar[xl * FW_LD + c], ai = Tai[xl * FW_LD + c];
-          const int widx = (kxf * (16 * t + xl)) & (np - 1);
-          const float2 w = stw[widx];
-          Rr = mfma16(ar, w.x, Rr);
-          Ri = mfma16(ai, w.x, Ri);
-          Rr = mfma16(ai, w.y, Rr);
-          Ri = mfma16(ar, -w.y, Ri);
-        }
-      }
-      // ---- WFS path (valid sub-apertures only; wave-uniform branch)
-      if (sub >= 0 && !(dbg & 1)) {
-        float br[4], bi[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) { br[s] = Twr[(4 * q + s) * FW_LD + c]; bi[s] = Twi[(4 * q + s) * FW_LD + c]; }
-        spot_core<NOISE, WRITE_CUBE>(sys, st, e, sub, lane, Cc, Ss, br, bi, do_cog, flux_i, Z4);
-      }
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      fetch(t + 1, subn);
     }
-    sub = subn;
+    fetch(t + 1, infon, nxt);                                // next tile's loads fly during the MFMAs
+    __builtin_amdgcn_wave_barrier();
+    // ---- science path: R[y][kx] += sum_{x in tile} a(y, x) exp(-2 pi i kx x / Npsf)
+    if (!(dbg & 2)) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int xl = 4 * q + s;
+        const float ar = Tar[xl * FW_LD + c], ai = Tai[xl * FW_LD + c];
+        const float2 w = stw[(kxf * (16 * t + xl)) & (np - 1)];
+        Rr = mfma16(ar, w.x, Rr);
+        Ri = mfma16(ai, w.x, Ri);
+        Rr = mfma16(ai, w.y, Rr);
+        Ri = mfma16(ar, -w.y, Ri);
+      }
+    }
+    // ---- WFS path (valid sub-apertures only; wave-uniform branch)
+    if ((info & FW_SUB) && !(dbg & 1)) {
+      float br[4], bi[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) { br[s] = Twr[(4 * q + s) * FW_LD + c]; bi[s] = Twi[(4 * q + s) * FW_LD + c]; }
+      spot_core<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Cc, Ss, br, bi, do_cog, flux_i, Z4);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  FrameRaw<NL, OTF> raw;
+  int info = tinfo[0];
+  fetch(0, info, raw);
+  for (int t = 0; t < ntl; t++) {
+    const int infon = t + 1 < ntl ? tinfo[t + 1] : 0;
+    tile(t, info, infon, raw, raw);
+    info = infon;
   }
   // ---- PSF rows of this stripe: acc reg j of lane (q, c): y = 4q + j, kx = c
 #pragma unroll
