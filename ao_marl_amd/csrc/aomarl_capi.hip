@@ -1151,6 +1151,9 @@ int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_mo
   return 0;
 }
 
+// ---------------------------------------------------------------- WFS-image denoiser (A17)
+#include "aomarl_denoise.hip"
+
 // ---------------------------------------------------------------- geometric controller
 __global__ void k_geo_assemble(int nactu, int npzt, int ldr, int gwgh, const int32_t *__restrict__ map,
                                const float *__restrict__ lat, const float *__restrict__ r3,

@@ -1,0 +1,379 @@
+// aomarl_denoise.hip -- the WFS-image denoiser as ONE fused gfx950 kernel.
+//
+// Network (reference: DenoisingAutoencoderCNN2DSingleSubapeture, src/autoencoder/
+// autoencoder_models.py:130-197), per 16x16 spot image:
+//   conv3x3(1->16)+ReLU+pool2 -> conv3x3(16->32)+ReLU+pool2 -> conv3x3(32->64)+ReLU ->
+//   convT4x4s2(64->32)+ReLU -> convT4x4s2(32->16)+ReLU -> convT3x3s1(16->1)
+// 1 712 128 MAC per image, 1200 images per environment per frame.
+//
+// One block (2 waves) = one image at a time, persistent over the images.  Every layer is a small
+// GEMM on v_mfma_f32_16x16x4_f32 with M = 16 spatial positions, N = 16 output channels,
+// K = (tap, 4 input channels):
+//  * activations live in LDS, channel-last, zero-padded by one pixel (no border tests: every tap is
+//    a compile-time immediate offset) with the channel stride padded by 4 floats (conflict-free
+//    128-bit operand reads); two regions ping-pong between the layers;
+//  * the K order inside a group of 16 channels is permuted so lane group q reads channels
+//    4q..4q+3 with ONE ds_read_b128 and feeds four MFMAs; the weights are pre-arranged on the host
+//    in exactly that order, one float4 per lane per (tap, channel group, channel tile), streamed
+//    from L2 (they are shared by every image) and reused across the M tiles;
+//  * pooling layers map the four pixels of a 2x2 window to the four accumulator registers of a
+//    lane (m = 4 * window + r), so ReLU + max-pool is a max over registers;
+//  * the transposed convolutions are split into their 4 output-parity classes, each a 2x2-tap
+//    convolution of the input (no zero-stuffing);
+//  * the last layer (16 -> 1) runs on the VALU.
+// The network sees the image transposed ([x][y], the reference feeds COMPASS's first-index-fastest
+// arrays); the transpose happens on the way into and out of LDS.
+#include "aomarl_dev.h"
+
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+
+struct DenoiseW {
+  const float *w1;        // [3][64]                 L1: tap 4i+q, channel c
+  const float4 *w2;       // [9][1][2][64]           L2
+  const float4 *w3;       // [9][2][4][64]           L3
+  const float4 *w4;       // [4][4][4][2][64]        D1: class, tap, group, tile
+  const float4 *w5;       // [4][4][2][1][64]        D2
+  const float *w6;        // [9][16]                 D3 (taps as a plain correlation)
+  const float *b1, *b2, *b3, *b4, *b5;
+  float b6;
+};
+
+#define DN_X 5184          // floats of region X (A1 2000, A3 2448, A5 5184)
+#define DN_Y 3600          // floats of region Y (IN 324, A2 1296, A4 3600)
+#define DN_S16 20          // padded channel strides
+#define DN_S32 36
+#define DN_S64 68
+
+__device__ __forceinline__ f32x4d dn_mfma(float a, float b, f32x4d c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dn_zero(float *p, int n, int tid) {
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid * 4; i < n; i += 128 * 4) *reinterpret_cast<float4 *>(p + i) = z;
+}
+
+// four MFMAs: A = 4 consecutive channels of this lane's position, B = the matching weights
+__device__ __forceinline__ f32x4d dn_quad(const float4 a, const float4 b, f32x4d acc) {
+  acc = dn_mfma(a.x, b.x, acc);
+  acc = dn_mfma(a.y, b.y, acc);
+  acc = dn_mfma(a.z, b.z, acc);
+  acc = dn_mfma(a.w, b.w, acc);
+  return acc;
+}
+
+__global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__ cube, int nimg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 144; i += 128) W6[i] = w.w6[i];
+  // ---- per-lane constants
+  // L1: B operand (3 k-steps), A-operand tap offsets (tap 4i+q of the 3x3 stencil; taps >= 9 unused)
+  float b1w[3];
+  int t1off[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    b1w[i] = w.w1[i * 64 + lane];
+    const int tap = 4 * i + q;
+    t1off[i] = tap < 9 ? (tap / 3 - 1) * 18 + (tap % 3 - 1) : 0;
+  }
+  const float bias1 = w.b1[c], bias2 = w.b2[16 * wv + c], bias4 = w.b4[16 * wv + c], bias5 = w.b5[c];
+  const float bias3a = w.b3[32 * wv + c], bias3b = w.b3[32 * wv + 16 + c];
+  const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+    float *tile = cube + (long long)img * 256;
+    // ================= input (transposed) -> IN = Y[18][18]
+    dn_zero(Y, 324, tid);
+    __syncthreads();
+    for (int p = tid; p < 256; p += 128) {
+      const int ty = p >> 4, tx = p & 15;                    // tile[ty][tx] -> net row tx, col ty
+      Y[(tx + 1) * 18 + (ty + 1)] = tile[p];
+    }
+    dn_zero(X, 2000, tid);                                   // A1 [10][10][20]
+    __syncthreads();
+    // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X
+    {
+      // A operand: lane (q, c): m = c -> window 4*mt + (c >> 2), pixel r = c & 3 of the window
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int mt = 8 * wv + k;
+        const int win = 4 * mt + (c >> 2), r = c & 3;
+        const int py = 2 * (win >> 3) + (r >> 1), px = 2 * (win & 7) + (r & 1);
+        const float *in = Y + (py + 1) * 18 + (px + 1);
+        f32x4d acc = Z;
+#pragma unroll
+        for (int i = 0; i < 3; i++) acc = dn_mfma(in[t1off[i]], b1w[i], acc);
+        // D: lane (q, c): window 4*mt + q, channel c, the 4 registers = the 2x2 window
+        const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
+        const int wo = 4 * mt + q;
+        X[(((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DN_S16 + c] = v;
+      }
+    }
+    __syncthreads();                                         // every wave is done reading IN
+    dn_zero(Y, 1296, tid);                                   // A2 [6][6][36]
+    __syncthreads();
+    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y ; wave = channel tile
+    {
+      f32x4d acc[4] = {Z, Z, Z, Z};
+      int abase[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+        const int win = 4 * mt + (c >> 2), r = c & 3;
+        const int py = 2 * (win >> 2) + (r >> 1), px = 2 * (win & 3) + (r & 1);
+        abase[mt] = ((py + 1) * 10 + (px + 1)) * DN_S16 + 4 * q;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const float4 b = w.w2[(tap * 2 + wv) * 64 + lane];
+        const int toff = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * DN_S16;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+          const float4 a = *reinterpret_cast<const float4 *>(X + abase[mt] + toff);
+          acc[mt] = dn_quad(a, b, acc[mt]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+        const float v = fmaxf(fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3])) + bias2, 0.f);
+        const int wo = 4 * mt + q;                           // window in the 4x4 pooled grid
+        Y[(((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DN_S32 + 16 * wv + c] = v;
+      }
+    }
+    __syncthreads();
+    dn_zero(X, 2448, tid);                                   // A3 [6][6][68]
+    __syncthreads();
+    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X ; wave = channel tiles 2wv, 2wv+1
+    {
+      f32x4d acc0 = Z, acc1 = Z;
+      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DN_S32 + 4 * q;
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int toff = ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DN_S32;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          const float4 a = *reinterpret_cast<const float4 *>(Y + abase + toff + 16 * g);
+          const float4 b0 = w.w3[((tap * 2 + g) * 4 + 2 * wv) * 64 + lane];
+          const float4 b1 = w.w3[((tap * 2 + g) * 4 + 2 * wv + 1) * 64 + lane];
+          acc0 = dn_quad(a, b0, acc0);
+          acc1 = dn_quad(a, b1, acc1);
+        }
+      }
+      // D: m = 4q + r -> pixel (q, r)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float *o = X + ((q + 1) * 6 + r + 1) * DN_S64 + 32 * wv + c;
+        o[0] = fmaxf(acc0[r] + bias3a, 0.f);
+        o[16] = fmaxf(acc1[r] + bias3b, 0.f);
+      }
+    }
+    __syncthreads();
+    dn_zero(Y, 3600, tid);                                   // A4 [10][10][36]
+    __syncthreads();
+    // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y ; wave = channel tile
+    {
+      const int a0 = c >> 2, b0 = c & 3;                     // A operand: m = c -> input pixel (a0, b0)
+      const int abase = ((a0 + 1) * 6 + b0 + 1) * DN_S64 + 4 * q;
+#pragma unroll
+      for (int cls = 0; cls < 4; cls++) {
+        const int py = cls >> 1, px = cls & 1;
+        f32x4d acc = Z;
+#pragma unroll
+        for (int tap = 0; tap < 4; tap++) {
+          const int ty = tap >> 1, tx = tap & 1;
+          const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
+          const int toff = (dy * 6 + dx) * DN_S64;
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const float4 a = *reinterpret_cast<const float4 *>(X + abase + toff + 16 * g);
+            const float4 b = w.w4[(((cls * 4 + tap) * 4 + g) * 2 + wv) * 64 + lane];
+            acc = dn_quad(a, b, acc);
+          }
+        }
+        // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          Y[((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32 + 16 * wv + c] = fmaxf(acc[r] + bias4, 0.f);
+      }
+    }
+    __syncthreads();
+    dn_zero(X, 5184, tid);                                   // A5 [18][18][16]
+    __syncthreads();
+    // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X ; wave = output row parity
+    {
+      int abase[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+        abase[mt] = ((2 * mt + (c >> 3) + 1) * 10 + (c & 7) + 1) * DN_S32 + 4 * q;
+      const int py = wv;
+#pragma unroll
+      for (int px = 0; px < 2; px++) {
+        const int cls = 2 * py + px;
+        f32x4d acc[4] = {Z, Z, Z, Z};
+#pragma unroll
+        for (int tap = 0; tap < 4; tap++) {
+          const int ty = tap >> 1, tx = tap & 1;
+          const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
+          const int toff = (dy * 10 + dx) * DN_S32;
+#pragma unroll
+          for (int g = 0; g < 2; g++) {
+            const float4 b = w.w5[((cls * 4 + tap) * 2 + g) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+              const float4 a = *reinterpret_cast<const float4 *>(Y + abase[mt] + toff + 16 * g);
+              acc[mt] = dn_quad(a, b, acc[mt]);
+            }
+          }
+        }
+        // D: m = 4q + r -> input pixel (2 mt + (q >> 1), 4 (q & 1) + r)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int a = 2 * mt + (q >> 1), b = 4 * (q & 1) + r;
+            X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r] + bias5, 0.f);
+          }
+      }
+    }
+    __syncthreads();
+    // ================= D3: 3x3 correlation 16 -> 1 on the VALU, write back transposed
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int p = tid + 128 * k;                           // net pixel (row p >> 4, col p & 15)
+      const int ry = p >> 4, rx = p & 15;
+      float s0 = w.b6, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const float *in = X + ((ry + tap / 3) * 18 + rx + tap % 3) * 16;
+        const float *wt = W6 + tap * 16;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const float4 a = *reinterpret_cast<const float4 *>(in + 4 * g);
+          const float4 ww = *reinterpret_cast<const float4 *>(wt + 4 * g);
+          s0 += a.x * ww.x; s1 += a.y * ww.y; s2 += a.z * ww.z; s3 += a.w * ww.w;
+        }
+      }
+      tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ host side
+struct aomarl_denoiser {
+  DenoiseW w;
+  std::vector<void *> owned;
+};
+
+template <typename T>
+static int dn_upload(aomarl_denoiser *d, const std::vector<T> &h, const T **dev) {
+  void *p = nullptr;
+  if (hipMalloc(&p, h.size() * sizeof(T)) != hipSuccess) return fail("denoiser: hipMalloc failed");
+  d->owned.push_back(p);
+  if (hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    return fail("denoiser: hipMemcpy failed");
+  *dev = reinterpret_cast<const T *>(p);
+  return 0;
+}
+
+int aomarl_denoiser_destroy(aomarl_denoiser *d) {
+  if (!d) return 0;
+  for (void *p : d->owned) (void)hipFree(p);
+  delete d;
+  return 0;
+}
+
+// weights / biases: 6 host arrays each, PyTorch layouts of the reference checkpoint
+// (encoder1..3: Conv2d [Cout][Cin][3][3]; decoder1, 2: ConvTranspose2d [Cin][Cout][4][4];
+//  decoder3: ConvTranspose2d [16][1][3][3])
+int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomarl_denoiser **out) {
+  if (!wt || !bs || !out) return fail("denoiser_create: null argument");
+  for (int i = 0; i < 6; i++) if (!wt[i] || !bs[i]) return fail("denoiser_create: null layer %d", i);
+  aomarl_denoiser *d = new aomarl_denoiser();
+  int rc = 0;
+  // value for lane (q, c), slot j of a (tap, group, tile) quad: input channel 16 g + 4 q + j,
+  // output channel 16 nt + c
+  auto lane_q = [](int lane) { return lane >> 4; };
+  auto lane_c = [](int lane) { return lane & 15; };
+  {  // L1: [3][64]: tap 4 i + q, output channel c
+    std::vector<float> h(3 * 64, 0.f);
+    for (int i = 0; i < 3; i++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int tap = 4 * i + lane_q(lane), co = lane_c(lane);
+        if (tap < 9) h[i * 64 + lane] = wt[0][(co * 1 + 0) * 9 + tap];
+      }
+    rc = dn_upload<float>(d, h, &d->w.w1);
+  }
+  auto conv_pack = [&](const float *W, int Cout, int Cin, std::vector<float4> &h) {
+    const int G = Cin / 16, NT = Cout / 16;
+    h.assign((size_t)9 * G * NT * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int tap = 0; tap < 9; tap++)
+      for (int g = 0; g < G; g++)
+        for (int nt = 0; nt < NT; nt++)
+          for (int lane = 0; lane < 64; lane++) {
+            float v[4];
+            for (int j = 0; j < 4; j++) {
+              const int ci = 16 * g + 4 * lane_q(lane) + j, co = 16 * nt + lane_c(lane);
+              v[j] = W[((size_t)co * Cin + ci) * 9 + tap];
+            }
+            h[((size_t)(tap * G + g) * NT + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+  };
+  auto convT_pack = [&](const float *W, int Cin, int Cout, std::vector<float4> &h) {
+    const int G = Cin / 16, NT = Cout / 16;
+    h.assign((size_t)16 * G * NT * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int cls = 0; cls < 4; cls++)
+      for (int tap = 0; tap < 4; tap++) {
+        const int py = cls >> 1, px = cls & 1, ty = tap >> 1, tx = tap & 1;
+        // oy = 2 iy - 1 + ky: even rows take ky = 1 (same input row) / 3 (row above),
+        // odd rows ky = 2 (same) / 0 (row below); columns alike
+        const int ky = py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
+        const int kx = px == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
+        for (int g = 0; g < G; g++)
+          for (int nt = 0; nt < NT; nt++)
+            for (int lane = 0; lane < 64; lane++) {
+              float v[4];
+              for (int j = 0; j < 4; j++) {
+                const int ci = 16 * g + 4 * lane_q(lane) + j, co = 16 * nt + lane_c(lane);
+                v[j] = W[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+              }
+              h[((size_t)((cls * 4 + tap) * G + g) * NT + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+      }
+  };
+  std::vector<float4> h4;
+  if (!rc) { conv_pack(wt[1], 32, 16, h4); rc = dn_upload<float4>(d, h4, &d->w.w2); }
+  if (!rc) { conv_pack(wt[2], 64, 32, h4); rc = dn_upload<float4>(d, h4, &d->w.w3); }
+  if (!rc) { convT_pack(wt[3], 64, 32, h4); rc = dn_upload<float4>(d, h4, &d->w.w4); }
+  if (!rc) { convT_pack(wt[4], 32, 16, h4); rc = dn_upload<float4>(d, h4, &d->w.w5); }
+  if (!rc) {  // D3: out[oy][ox] = sum in[oy + 1 - ky][ox + 1 - kx] w[ci][0][ky][kx]: tap (ty, tx) = (2 - ky, 2 - kx)
+    std::vector<float> h(9 * 16);
+    for (int ty = 0; ty < 3; ty++)
+      for (int tx = 0; tx < 3; tx++)
+        for (int ci = 0; ci < 16; ci++) h[(ty * 3 + tx) * 16 + ci] = wt[5][(ci * 9) + (2 - ty) * 3 + (2 - tx)];
+    rc = dn_upload<float>(d, h, &d->w.w6);
+  }
+  const int nb[5] = {16, 32, 64, 32, 16};
+  const float **bdev[5] = {&d->w.b1, &d->w.b2, &d->w.b3, &d->w.b4, &d->w.b5};
+  for (int i = 0; i < 5 && !rc; i++) {
+    std::vector<float> h(bs[i], bs[i] + nb[i]);
+    rc = dn_upload<float>(d, h, bdev[i]);
+  }
+  d->w.b6 = bs[5][0];
+  if (rc) { aomarl_denoiser_destroy(d); return rc; }
+  *out = d;
+  return 0;
+}
+
+int aomarl_denoiser_apply(aomarl_denoiser *d, float *cube, long long nimg, void *stream) {
+  if (!d || !cube) return fail("denoiser_apply: null argument");
+  if (nimg <= 0) return 0;
+  if (nimg > 0x7fffffffLL) return fail("denoiser_apply: too many images");
+  const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
+  const int blocks = (int)std::min<long long>(nimg, 256 * 4 * 4);
+  hipLaunchKernelGGL(k_denoise, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+  LAUNCHCHK();
+  return 0;
+}

@@ -11,9 +11,13 @@ Orientation: the reference feeds the network `np.moveaxis(np.array(d_bincube), -
 [subap][x][y] (COMPASS arrays are first-index-fastest), the transpose of this repo's [y][x] tiles;
 the trained weights expect that, so tiles are transposed on the way in and out.
 
-PyTorch-ROCm (MIOpen convolutions, channels_last) is the engine here, as SURVEY section 7 step 8
-plans for the first version; 1 712 128 MAC per 16x16 image.
+On the GPU the whole network is one fused MFMA kernel of the library (aomarl_denoiser_apply,
+ao_marl_amd/csrc/aomarl_denoise.hip); the tensor-library path (`forward`, MIOpen convolutions) is
+kept as the definition it is tested against and for CPU runs.  1 712 128 MAC per 16x16 image.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -35,6 +39,30 @@ class SubapDenoiser(object):
                 "decoder1": (64, 32, 4, 4), "decoder2": (32, 16, 4, 4), "decoder3": (16, 1, 3, 3)}
         if shapes != want:
             raise ValueError("unexpected autoencoder layout %r" % (shapes,))
+        self._handle = None
+        self.use_native = self.device.type == "cuda" and dtype == torch.float32
+        self._host = {k: state_dict[k].detach().to("cpu", torch.float32).contiguous().numpy()
+                      for k in ["%s.%s" % (a, b) for a in KEYS for b in ("weight", "bias")]}
+
+    def _native(self):
+        if self._handle is None:
+            from . import libaomarl as la
+            fp = C.POINTER(C.c_float)
+            wt = (fp * 6)(*[self._host[k + ".weight"].ctypes.data_as(fp) for k in KEYS])
+            bs = (fp * 6)(*[self._host[k + ".bias"].ctypes.data_as(fp) for k in KEYS])
+            h = C.c_void_p()
+            la.check(la.load().aomarl_denoiser_create(wt, bs, C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                from . import libaomarl as la
+                la.load().aomarl_denoiser_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
 
     @classmethod
     def load(cls, path, **kw):
@@ -62,6 +90,12 @@ class SubapDenoiser(object):
     def denoise_bincube_(self, bincube):
         """In place on a [nenv, nvalid, 256] bincube of [y][x] tiles."""
         n, nv, np2 = bincube.shape
+        if self.use_native and bincube.is_contiguous() and bincube.dtype == torch.float32:
+            from . import libaomarl as la
+            la.check(la.load().aomarl_denoiser_apply(
+                    self._native(), bincube.data_ptr(), n * nv,
+                    C.c_void_p(torch.cuda.current_stream(bincube.device).cuda_stream)))
+            return bincube
         flat = bincube.view(n * nv, 16, 16)
         for i0 in range(0, n * nv, self.chunk):
             t = flat[i0:i0 + self.chunk]

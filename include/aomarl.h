@@ -262,6 +262,18 @@ int aomarl_assemble_state(int nenv, int nblocks, const float *const *src, const 
                           float *out, void *stream);
 int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_modes, int ld,
                          const int32_t *lohi, float factor, float *out, void *stream);
+/* WFS-image denoiser in the loop (RlSupervisor.autoencoder_denoising, rlSupervisor.py:876-891;
+ * DenoisingAutoencoderCNN2DSingleSubapeture.forward, src/autoencoder/autoencoder_models.py:130-197):
+ * every 16 x 16 spot image of a bincube goes through the conv autoencoder, in place, in one fused
+ * kernel.  weights / biases: 6 HOST arrays each in the reference checkpoint's layouts (encoder1..3
+ * Conv2d [Cout][Cin][3][3]; decoder1, 2 ConvTranspose2d [Cin][Cout][4][4]; decoder3
+ * ConvTranspose2d [16][1][3][3]).  cube: device [nimg][256], tiles [y][x] as aomarl_comp_image
+ * writes them (the network sees them transposed, like the reference feeds them). */
+typedef struct aomarl_denoiser aomarl_denoiser;
+int aomarl_denoiser_create(const float *const *weights, const float *const *biases,
+                           aomarl_denoiser **out);
+int aomarl_denoiser_apply(aomarl_denoiser *dn, float *cube, long long nimg, void *stream);
+int aomarl_denoiser_destroy(aomarl_denoiser *dn);
 /* PSF window + phase variance of st->tar_phase as it stands (pending, like aomarl_target_psf) */
 int aomarl_target_psf_buffer(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                              void *stream);

@@ -67,3 +67,26 @@ def test_denoised_wfs_path_matches_oracle(blob):
         o.do_centroids()
         good = np.abs(sl[e] - o.slopes) < 2e-3
         assert good.mean() > 0.995, good.mean()
+
+
+@pytest.mark.gpu
+def test_fused_mfma_denoiser_matches_the_tensor_library_path(golden_dir):
+    """aomarl_denoiser_apply (one fused MFMA kernel) vs the functional forward that the CPU tests
+    pin to the reference module, on the shipped weights: fixture images + random spot-like images."""
+    from ao_marl_amd.denoiser import SubapDenoiser
+    g = torch.load(os.path.join(golden_dir, "host_denoiser.pt"), weights_only=True)
+    dn = SubapDenoiser(g["state_dict"], device="cuda:0")
+    assert dn.use_native
+    gen = torch.Generator().manual_seed(3)
+    cube = (torch.rand(3, 50, 256, generator=gen) * 40.0).cuda()
+    cube[0, :8] = g["x"].reshape(8, 16, 16).transpose(1, 2).reshape(8, 256).cuda()   # [y][x] tiles
+    want = cube.clone()
+    dn.use_native = False
+    dn.denoise_bincube_(want)
+    dn.use_native = True
+    got = cube.clone()
+    dn.denoise_bincube_(got)
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-5 * scale
+    ref = g["y"].reshape(8, 16, 16).transpose(1, 2).reshape(8, 256).cuda()
+    assert (got[0, :8] - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
