@@ -43,6 +43,7 @@ struct DenoiseW {
 #define DN_S16 20          // padded channel strides
 #define DN_S32 36
 #define DN_S64 68
+#define DN_PF 6           // weight prefetch distance (steps) of the streamed layers
 
 __device__ __forceinline__ f32x4d dn_mfma(float a, float b, f32x4d c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -85,6 +86,10 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
 
   for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
     float *tile = cube + (long long)img * 256;
+    // the weight pointers are laundered once per image: otherwise every one of the ~130 streamed
+    // loads gets its loop-invariant 64-bit address hoisted out of this loop into registers
+    const float4 *w2p = w.w2, *w3p = w.w3, *w4p = w.w4, *w5p = w.w5;
+    asm volatile("" : "+s"(w2p), "+s"(w3p), "+s"(w4p), "+s"(w5p));
     // ================= input (transposed) -> IN = Y[18][18]
     dn_zero(Y, 324, tid);
     __syncthreads();
@@ -127,13 +132,14 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
       }
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
-        const float4 b = w.w2[(tap * 2 + wv) * 64 + lane];
+        const float4 b = w2p[(tap * 2 + wv) * 64 + lane];
         const int toff = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * DN_S16;
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
           const float4 a = *reinterpret_cast<const float4 *>(X + abase[mt] + toff);
           acc[mt] = dn_quad(a, b, acc[mt]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int mt = 0; mt < 4; mt++) {
@@ -149,17 +155,22 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
     {
       f32x4d acc0 = Z, acc1 = Z;
       const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DN_S32 + 4 * q;
+      // weights stream from L2 through a ring of DN_PF steps (2 float4 per step), issued that
+      // many steps ahead; the scheduling barriers keep the compiler from hoisting all 36 loads
+      const float4 *wp = w3p + 2 * wv * 64 + lane;          // step s = tap * 2 + g: + s * 4 * 64
+      float4 rb0[DN_PF], rb1[DN_PF];
 #pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
+      for (int s = 0; s < DN_PF; s++) { rb0[s] = wp[s * 256]; rb1[s] = wp[s * 256 + 64]; }
+#pragma unroll
+      for (int s = 0; s < 18; s++) {
+        const int tap = s >> 1, g = s & 1;
         const int toff = ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DN_S32;
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-          const float4 a = *reinterpret_cast<const float4 *>(Y + abase + toff + 16 * g);
-          const float4 b0 = w.w3[((tap * 2 + g) * 4 + 2 * wv) * 64 + lane];
-          const float4 b1 = w.w3[((tap * 2 + g) * 4 + 2 * wv + 1) * 64 + lane];
-          acc0 = dn_quad(a, b0, acc0);
-          acc1 = dn_quad(a, b1, acc1);
-        }
+        const float4 a = *reinterpret_cast<const float4 *>(Y + abase + toff + 16 * g);
+        const float4 b0 = rb0[s % DN_PF], b1 = rb1[s % DN_PF];
+        if (s + DN_PF < 18) { rb0[s % DN_PF] = wp[(s + DN_PF) * 256]; rb1[s % DN_PF] = wp[(s + DN_PF) * 256 + 64]; }
+        acc0 = dn_quad(a, b0, acc0);
+        acc1 = dn_quad(a, b1, acc1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // D: m = 4q + r -> pixel (q, r)
 #pragma unroll
@@ -176,26 +187,30 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
     {
       const int a0 = c >> 2, b0 = c & 3;                     // A operand: m = c -> input pixel (a0, b0)
       const int abase = ((a0 + 1) * 6 + b0 + 1) * DN_S64 + 4 * q;
+      const float4 *wp = w4p + wv * 64 + lane;              // step s = (cls * 4 + tap) * 4 + g: + s * 2 * 64
+      float4 rb[DN_PF];
 #pragma unroll
-      for (int cls = 0; cls < 4; cls++) {
+      for (int s = 0; s < DN_PF; s++) rb[s] = wp[s * 128];
+      f32x4d acc = Z;
+#pragma unroll
+      for (int s = 0; s < 64; s++) {
+        const int cls = s >> 4, tap = (s >> 2) & 3, g = s & 3;
         const int py = cls >> 1, px = cls & 1;
-        f32x4d acc = Z;
+        const int ty = tap >> 1, tx = tap & 1;
+        const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
+        const int toff = (dy * 6 + dx) * DN_S64;
+        const float4 a = *reinterpret_cast<const float4 *>(X + abase + toff + 16 * g);
+        const float4 b = rb[s % DN_PF];
+        if (s + DN_PF < 64) rb[s % DN_PF] = wp[(s + DN_PF) * 128];
+        acc = dn_quad(a, b, acc);
+        if ((s & 15) == 15) {
+          // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
 #pragma unroll
-        for (int tap = 0; tap < 4; tap++) {
-          const int ty = tap >> 1, tx = tap & 1;
-          const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
-          const int toff = (dy * 6 + dx) * DN_S64;
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const float4 a = *reinterpret_cast<const float4 *>(X + abase + toff + 16 * g);
-            const float4 b = w.w4[(((cls * 4 + tap) * 4 + g) * 2 + wv) * 64 + lane];
-            acc = dn_quad(a, b, acc);
-          }
+          for (int r = 0; r < 4; r++)
+            Y[((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32 + 16 * wv + c] = fmaxf(acc[r] + bias4, 0.f);
+          acc = Z;
         }
-        // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          Y[((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32 + 16 * wv + c] = fmaxf(acc[r] + bias4, 0.f);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
@@ -219,12 +234,13 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
           const int toff = (dy * 10 + dx) * DN_S32;
 #pragma unroll
           for (int g = 0; g < 2; g++) {
-            const float4 b = w.w5[((cls * 4 + tap) * 2 + g) * 64 + lane];
+            const float4 b = w5p[((cls * 4 + tap) * 2 + g) * 64 + lane];
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) {
               const float4 a = *reinterpret_cast<const float4 *>(Y + abase[mt] + toff + 16 * g);
               acc[mt] = dn_quad(a, b, acc[mt]);
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
         // D: m = 4q + r -> input pixel (2 mt + (q >> 1), 4 (q & 1) + r)
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
           const float4 ww = *reinterpret_cast<const float4 *>(wt + 4 * g);
           s0 += a.x * ww.x; s1 += a.y * ww.y; s2 += a.z * ww.z; s3 += a.w * ww.w;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
     }
