@@ -51,6 +51,7 @@ struct aomarl_ctx {
   bool force_generic_dm = false, force_valu_target = false;
   int spot_blocks_per_env = 0, spot_lds_pad = 0;
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
+  bool force_f32_dft = false;          // frame kernel: fp32 MFMAs through LDS tiles instead of split-fp16
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
   int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
   // controller matrices
@@ -391,6 +392,27 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
           tinfo[(size_t)r * nt + t] = v;
         }
       UP(int32_t, tinfo.data(), tinfo.size(), s.tile_info);
+      // split-fp16 PSF twiddles for lane (q, c) of tile t: x = 16 t + 4 q + j, kx = c - 8;
+      // [hi(j = 0..3) | lo(j = 0..3)] of cos, sin, -sin (2 pi kx x / npsf)
+      {
+        std::vector<_Float16> tw((size_t)nt * 3 * 64 * 8);
+        for (int t = 0; t < nt; t++)
+          for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 4; j++) {
+              const int x = 16 * t + 4 * (lane >> 4) + j, kx = (lane & 15) - 8;
+              const double th = 2.0 * M_PI * (double)(((long long)kx * x) % d->npsf) / (double)d->npsf;
+              const float v[3] = {(float)cos(th), (float)sin(th), (float)-sin(th)};
+              for (int u = 0; u < 3; u++) {
+                const _Float16 hi = (_Float16)v[u];
+                const _Float16 lo = (_Float16)(v[u] - (float)hi);
+                _Float16 *o = &tw[(((size_t)t * 3 + u) * 64 + lane) * 8];
+                o[j] = hi; o[4 + j] = lo;
+              }
+            }
+        const _Float16 *dev = nullptr;
+        UP(_Float16, tw.data(), tw.size(), dev);
+        s.psf_tw_h = dev;
+      }
       UP(uint16_t, tmask.data(), tmask.size(), s.tile_mask);
       s.fused_ok = 1; s.ntiles = nt;
       // stack-array DM evaluated from the command lattice inside the frame kernel
@@ -780,6 +802,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
   if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
+  if (!strcmp(name, "force_f32_dft")) { c->force_f32_dft = value != 0; return 0; }
   if (!strcmp(name, "force_unfused_frame")) { c->force_unfused_frame = value != 0; return 0; }
   if (!strcmp(name, "force_generic_spot")) { c->force_generic_spot = value != 0; return 0; }
   if (!strcmp(name, "force_generic_target")) { c->force_generic_target = value != 0; return 0; }
@@ -1318,14 +1341,16 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   DevState ds = dev_state(st);
   if (w.nblk != c->sys.ntiles) return fail("frame_fused: internal stripe count mismatch");
   const int nb = otf ? c->sys.otf_nb : 1;
-  const size_t smm = sizeof(float) * (2 * 128 + 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD +
+  const bool hp = !c->force_f32_dft;
+  const size_t smm = sizeof(float) * (2 * 128 + (hp ? 0 : 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD) +
                                       (otf ? 4 * 4 * nb * c->sys.otf_latw : 0));
   dim3 grid(c->sys.ntiles, (n + 3) / 4), blk(256);
-#define FW(NL, NB, OTF, NZ, WC) hipLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC>), grid, blk, smm, s, c->sys, ds, b, n, cog, TR, TP, w.nblk)
+#define FW(NL, NB, OTF, NZ, WC, HP) hipLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm, s, c->sys, ds, b, n, cog, TR, TP, w.nblk)
+#define FW_H(NL, NB, OTF, NZ, WC) do { if (hp) FW(NL, NB, OTF, NZ, WC, true); else FW(NL, NB, OTF, NZ, WC, false); } while (0)
 #define FW_NC(NL, NB, OTF)                                                                     \
   do {                                                                                          \
-    if (noise) { if (cube) FW(NL, NB, OTF, true, true); else FW(NL, NB, OTF, true, false); }     \
-    else { if (cube) FW(NL, NB, OTF, false, true); else FW(NL, NB, OTF, false, false); }         \
+    if (noise) { if (cube) FW_H(NL, NB, OTF, true, true); else FW_H(NL, NB, OTF, true, false); }     \
+    else { if (cube) FW_H(NL, NB, OTF, false, true); else FW_H(NL, NB, OTF, false, false); }         \
   } while (0)
 #define FW_L(NL)                                                          \
   do {                                                                    \
@@ -1336,6 +1361,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   if (c->nlayers == 1) FW_L(1); else FW_L(3);
 #undef FW_L
 #undef FW_NC
+#undef FW_H
 #undef FW
   LAUNCHCHK();
   hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND, st->frame + b);

@@ -809,14 +809,53 @@ __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
 // Accumulator layout of stage 1 (row y = 4q + reg, col k = c) is again exactly the B-operand
 // K-order stage 2 wants, and the twiddle registers serve as B operand (stage 1) and A operand
 // (stage 2) alike, so nothing moves between the stages.
-// operands: br[s] / bi[s] = complex amplitude of pixel (y = c, x = 4q + s) of the tile
-template <bool NOISE, bool WRITE_CUBE>
-__device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st, int e, int i,
-                                          int lane, const float (&Cc)[4], const float (&Ss)[4],
-                                          const float (&br)[4], const float (&bi)[4], int do_cog,
-                                          float flux_i, const f32x4 z4) {
-  const int q = lane >> 4, c = lane & 15;
-  const bool owner = (c & 1) == 0;
+// ---------------------------------------------------------------------------------------------
+// Split-fp16 operands for the real matrix cores.  v_mfma_f32_16x16x32_f16 costs 16 cycles against
+// the 4 x 32 of the four fp32 MFMAs it replaces (fp32 MFMAs run at the vector rate).
+// A value v is carried as hi = f16(v), lo = f16(v - hi): 22 mantissa bits.  The K = 32 slots of
+// one instruction hold the 16 real terms twice, so
+//     mfma(pack(a), dup_hi(b)) + mfma(pack(a), dup_lo(b))     with pack(a) = [a_hi | a_lo]
+// is the full (a_hi + a_lo)(b_hi + b_lo) product, accumulated in fp32.  Lane (q, c) owns the 4
+// values (row c, k = 4q .. 4q+3) of an operand -- for the amplitude tile those are exactly the 4
+// pixels the lane computed, and for stage 2 exactly its 4 accumulator registers of stage 1: no LDS.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ hx2 cvt_h2(float a, float b) {
+  return __builtin_bit_cast(hx2, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// [hi(a0..a3) | lo(a0..a3)]
+__device__ __forceinline__ hx8 pack_hl(float a0, float a1, float a2, float a3) {
+  const hx2 h01 = cvt_h2(a0, a1), h23 = cvt_h2(a2, a3);
+  const hx2 l01 = cvt_h2(a0 - (float)h01[0], a1 - (float)h01[1]);
+  const hx2 l23 = cvt_h2(a2 - (float)h23[0], a3 - (float)h23[1]);
+  return hx8{h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+}
+// [hi | hi] and [lo | lo]
+__device__ __forceinline__ void dup_hl(float a0, float a1, float a2, float a3, hx8 &H, hx8 &L) {
+  const hx2 h01 = cvt_h2(a0, a1), h23 = cvt_h2(a2, a3);
+  const hx2 l01 = cvt_h2(a0 - (float)h01[0], a1 - (float)h01[1]);
+  const hx2 l23 = cvt_h2(a2 - (float)h23[0], a3 - (float)h23[1]);
+  H = hx8{h01[0], h01[1], h23[0], h23[1], h01[0], h01[1], h23[0], h23[1]};
+  L = hx8{l01[0], l01[1], l23[0], l23[1], l01[0], l01[1], l23[0], l23[1]};
+}
+__device__ __forceinline__ f32x4 mfma_h(hx8 a, hx8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// twiddle operands of the spot DFT in split-fp16 form (constant per lane)
+struct SpotTwH { hx8 CH, CL, SH, SL; };
+__device__ __forceinline__ SpotTwH spot_tw_h(const float (&Cc)[4], const float (&Ss)[4]) {
+  SpotTwH t;
+  dup_hl(Cc[0], Cc[1], Cc[2], Cc[3], t.CH, t.CL);
+  dup_hl(Ss[0], Ss[1], Ss[2], Ss[3], t.SH, t.SL);
+  return t;
+}
+
+// the two DFT stages on fp32 MFMAs: br[s] / bi[s] = complex amplitude of pixel (y = c, x = 4q + s)
+__device__ __forceinline__ void spot_dft_f32(const float (&Cc)[4], const float (&Ss)[4],
+                                             const float (&br)[4], const float (&bi)[4],
+                                             const f32x4 z4, f32x4 (&Xr)[2][2], f32x4 (&Xi)[2][2]) {
   // ---- stage 1 (y = c on M, x = 4q + s on K, k = c on N)
   f32x4 PCr = z4, PCi = z4, PSr = z4, PSi = z4;
 #pragma unroll
@@ -830,7 +869,6 @@ __device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st,
   Tr[0] = PCr + PSi; Ti[0] = PCi - PSr;
   Tr[1] = PCr - PSi; Ti[1] = PCi + PSr;
   // ---- stage 2 (ky' = c on M, y = 4q + s on K = accumulator reg s, kx' on N)
-  f32x4 Xr[2][2], Xi[2][2];           // [sy][sx], 0: +, 1: -
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     f32x4 QCr = z4, QCi = z4, QSr = z4, QSi = z4;
@@ -844,6 +882,40 @@ __device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st,
     Xr[0][m] = QCr + QSi; Xi[0][m] = QCi - QSr;
     Xr[1][m] = QCr - QSi; Xi[1][m] = QCi + QSr;
   }
+}
+
+// the same two stages on split-fp16 MFMAs (24 instructions)
+__device__ __forceinline__ void spot_dft_h(const SpotTwH &tw, const float (&br)[4],
+                                           const float (&bi)[4], const f32x4 z4,
+                                           f32x4 (&Xr)[2][2], f32x4 (&Xi)[2][2]) {
+  const hx8 ar = pack_hl(br[0], br[1], br[2], br[3]), ai = pack_hl(bi[0], bi[1], bi[2], bi[3]);
+  f32x4 PCr = mfma_h(ar, tw.CL, mfma_h(ar, tw.CH, z4));
+  f32x4 PCi = mfma_h(ai, tw.CL, mfma_h(ai, tw.CH, z4));
+  f32x4 PSr = mfma_h(ar, tw.SL, mfma_h(ar, tw.SH, z4));
+  f32x4 PSi = mfma_h(ai, tw.SL, mfma_h(ai, tw.SH, z4));
+  f32x4 Tr[2], Ti[2];
+  Tr[0] = PCr + PSi; Ti[0] = PCi - PSr;
+  Tr[1] = PCr - PSi; Ti[1] = PCi + PSr;
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const hx8 tr = pack_hl(Tr[m][0], Tr[m][1], Tr[m][2], Tr[m][3]);
+    const hx8 ti = pack_hl(Ti[m][0], Ti[m][1], Ti[m][2], Ti[m][3]);
+    const f32x4 QCr = mfma_h(tw.CL, tr, mfma_h(tw.CH, tr, z4));
+    const f32x4 QCi = mfma_h(tw.CL, ti, mfma_h(tw.CH, ti, z4));
+    const f32x4 QSr = mfma_h(tw.SL, tr, mfma_h(tw.SH, tr, z4));
+    const f32x4 QSi = mfma_h(tw.SL, ti, mfma_h(tw.SH, ti, z4));
+    Xr[0][m] = QCr + QSi; Xi[0][m] = QCi - QSr;
+    Xr[1][m] = QCr - QSi; Xi[1][m] = QCi + QSr;
+  }
+}
+
+// |X|^2, 2x2 binning, flux normalisation (+noise), COG on the accumulators of the DFT
+template <bool NOISE, bool WRITE_CUBE>
+__device__ __forceinline__ void spot_finish(const DevSys &sys, const DevState &st, int e, int i,
+                                            int lane, const f32x4 (&Xr)[2][2],
+                                            const f32x4 (&Xi)[2][2], int do_cog, float flux_i) {
+  const int q = lane >> 4, c = lane & 15;
+  const bool owner = (c & 1) == 0;
   // ---- |X|^2 and 2x2 binning.  Tile [sy][sx], reg r, lane (q, c): ky' = 4q + r, kx' = c;
   //      + tiles: k = k' -> LR index 8 + (k' >> 1);  - tiles: k = -(k'+1) -> LR index 7 - (k' >> 1)
   float v[2][2][2];
@@ -934,6 +1006,17 @@ __device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st,
       }
     }
   }
+}
+
+// operands: br[s] / bi[s] = complex amplitude of pixel (y = c, x = 4q + s) of the tile
+template <bool NOISE, bool WRITE_CUBE>
+__device__ __forceinline__ void spot_core(const DevSys &sys, const DevState &st, int e, int i,
+                                          int lane, const float (&Cc)[4], const float (&Ss)[4],
+                                          const float (&br)[4], const float (&bi)[4], int do_cog,
+                                          float flux_i, const f32x4 z4) {
+  f32x4 Xr[2][2], Xi[2][2];           // [sy][sx], 0: +, 1: -
+  spot_dft_f32(Cc, Ss, br, bi, z4, Xr, Xi);
+  spot_finish<NOISE, WRITE_CUBE>(sys, st, e, i, lane, Xr, Xi, do_cog, flux_i);
 }
 
 template <bool NOISE, bool WRITE_CUBE>
@@ -1361,7 +1444,7 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
 #define FW_LIT 0x10000
 #define FW_FULL 0x20000
 #define FW_SUB 0x40000
-template <int NL, bool OTF>
+template <int NL, bool OTF, bool HP>
 struct FrameRaw {
   float L[NL][4];
   float P[OTF ? 1 : 4], T[8];
@@ -1369,7 +1452,9 @@ struct FrameRaw {
   float F;
 };
 
-template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE>
+// HP = true: both DFTs (spot, PSF rows) on split-fp16 MFMAs fed straight from registers (no LDS
+// amplitude tiles); HP = false: fp32 MFMAs through transposed LDS tiles.
+template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     int env_count, int do_cog,
                                                     float *__restrict__ TR,
@@ -1380,8 +1465,8 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2 *sTw = reinterpret_cast<float2 *>(smem);            // [128] WFS twiddles
   float2 *stw = sTw + 128;                                   // [npsf] PSF twiddles (npsf <= 4096)
-  float *tiles = reinterpret_cast<float *>(stw + np);        // [4 waves][4][16 * FW_LD]
-  float *lat_all = tiles + 4 * 4 * 16 * FW_LD;               // [4 waves][4 NB][latw]
+  float *tiles = reinterpret_cast<float *>(stw + (HP ? 0 : np));       // [4 waves][4][16 * FW_LD]
+  float *lat_all = tiles + (HP ? 0 : 4 * 4 * 16 * FW_LD);    // [4 waves][4 NB][latw]
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
   const int r = blockIdx.x;                                  // stripe: pupil rows 16 r .. 16 r + 15
@@ -1392,7 +1477,8 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     sTw[tid] = make_float2(cs, sn);
   }
   const float2 *gtw = reinterpret_cast<const float2 *>(sys.psf_tw);
-  for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
+  if (!HP)
+    for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
   __syncthreads();                                           // the only block-wide barrier
   if (el >= env_count) return;
   const int e = env_begin + el;
@@ -1402,6 +1488,9 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     const float2 w = sTw[((4 * q + s) * (2 * c + 1)) & 127];
     Cc[s] = w.x; Ss[s] = w.y;
   }
+  SpotTwH twh;
+  if (HP) twh = spot_tw_h(Cc, Ss);
+  const char *twhb = reinterpret_cast<const char *>(sys.psf_tw_h) + 16u * (unsigned)lane;
   float *Twr = tiles + wv * 4 * 16 * FW_LD, *Twi = Twr + 16 * FW_LD;   // WFS amplitude [x][y]
   float *Tar = Twi + 16 * FW_LD, *Tai = Tar + 16 * FW_LD;              // target amplitude [x][y]
   const int y = 16 * r + c;                                  // pupil row of this lane
@@ -1484,7 +1573,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int kxf = c - 8;
 
-  auto fetch = [&](int t, int info, FrameRaw<NL, OTF> &raw) {
+  auto fetch = [&](int t, int info, FrameRaw<NL, OTF, HP> &raw) {
     if (!(info & FW_LIT) || (dbg & 4)) return;               // wave-uniform
 #pragma unroll
     for (int l = 0; l < NL; l++) {
@@ -1508,7 +1597,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   };
 
   // one tile: consume `cur`, prefetch tile t + 1 into `nxt`
-  auto tile = [&](int t, int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt) {
+  auto tile = [&](int t, int info, int infon, FrameRaw<NL, OTF, HP> &cur, FrameRaw<NL, OTF, HP> &nxt) {
     if (!(info & FW_LIT)) { fetch(t + 1, infon, nxt); return; }
     // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
     f32x4 S = Z4;
@@ -1523,7 +1612,17 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
       for (int s = 0; s < NB; s++) S = mfma16(Pxr[s], U[s], S);
     }
     const float flux_i = cur.F;
-    // ---- phase of the 4 pixels, both complex amplitudes -> LDS
+    // PSF twiddles of this tile in split-fp16 form (cos, sin, -sin as [hi | lo]; shared by all
+    // environments: L2 hits) -- issued here, consumed after the amplitude stage
+    hx8 cosP, sinP, nsinP;
+    if (HP) {
+      const char *wb = twhb + 3072u * (unsigned)t;           // [t][3][64] x 16 bytes
+      cosP = *reinterpret_cast<const hx8 *>(wb);
+      sinP = *reinterpret_cast<const hx8 *>(wb + 1024);
+      nsinP = *reinterpret_cast<const hx8 *>(wb + 2048);
+    }
+    // ---- phase of the 4 pixels, both complex amplitudes (registers; LDS tiles for the fp32 path)
+    float wr[4], wi[4], ar[4], ai[4];
     if (info & FW_FULL) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -1532,11 +1631,8 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
         for (int l = 0; l < NL; l++) ph += cur.L[l][j];
         float a_ = ph * wfs_il; a_ -= rintf(a_);
         float b_ = ph * tar_il; b_ -= rintf(b_);
-        const int o = (4 * q + j) * FW_LD + c;
-        Twr[o] = __builtin_amdgcn_cosf(a_);
-        Twi[o] = __builtin_amdgcn_sinf(a_);
-        Tar[o] = __builtin_amdgcn_cosf(b_);
-        Tai[o] = __builtin_amdgcn_sinf(b_);
+        wr[j] = __builtin_amdgcn_cosf(a_); wi[j] = __builtin_amdgcn_sinf(a_);
+        ar[j] = __builtin_amdgcn_cosf(b_); ai[j] = __builtin_amdgcn_sinf(b_);
         const float d = ph - pivot;
         sd += d; sd2 += d * d;
       }
@@ -1550,14 +1646,36 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
         const bool m = (cur.mrow >> (4 * q + j)) & 1u;
         float a_ = ph * wfs_il; a_ -= rintf(a_);
         float b_ = ph * tar_il; b_ -= rintf(b_);
-        const int o = (4 * q + j) * FW_LD + c;
-        Twr[o] = m ? __builtin_amdgcn_cosf(a_) : 0.f;
-        Twi[o] = m ? __builtin_amdgcn_sinf(a_) : 0.f;
-        Tar[o] = m ? __builtin_amdgcn_cosf(b_) : 0.f;
-        Tai[o] = m ? __builtin_amdgcn_sinf(b_) : 0.f;
+        wr[j] = m ? __builtin_amdgcn_cosf(a_) : 0.f; wi[j] = m ? __builtin_amdgcn_sinf(a_) : 0.f;
+        ar[j] = m ? __builtin_amdgcn_cosf(b_) : 0.f; ai[j] = m ? __builtin_amdgcn_sinf(b_) : 0.f;
         const float d = m ? ph - pivot : 0.f;
         sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
       }
+    }
+    if (HP) {
+      fetch(t + 1, infon, nxt);                              // next tile's loads fly during the MFMAs
+      // ---- science path: R[y][kx] += sum_x a(y, x) exp(-2 pi i kx x / Npsf), split-fp16
+      if (!(dbg & 2)) {
+        hx8 arH, arL, aiH, aiL;
+        dup_hl(ar[0], ar[1], ar[2], ar[3], arH, arL);
+        dup_hl(ai[0], ai[1], ai[2], ai[3], aiH, aiL);
+        Rr = mfma_h(arH, cosP, Rr); Rr = mfma_h(arL, cosP, Rr);
+        Rr = mfma_h(aiH, sinP, Rr); Rr = mfma_h(aiL, sinP, Rr);
+        Ri = mfma_h(aiH, cosP, Ri); Ri = mfma_h(aiL, cosP, Ri);
+        Ri = mfma_h(arH, nsinP, Ri); Ri = mfma_h(arL, nsinP, Ri);
+      }
+      // ---- WFS path (valid sub-apertures only; wave-uniform branch)
+      if ((info & FW_SUB) && !(dbg & 1)) {
+        f32x4 Xr[2][2], Xi[2][2];
+        spot_dft_h(twh, wr, wi, Z4, Xr, Xi);
+        spot_finish<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Xr, Xi, do_cog, flux_i);
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int o = (4 * q + j) * FW_LD + c;
+      Twr[o] = wr[j]; Twi[o] = wi[j]; Tar[o] = ar[j]; Tai[o] = ai[j];
     }
     fetch(t + 1, infon, nxt);                                // next tile's loads fly during the MFMAs
     __builtin_amdgcn_wave_barrier();
@@ -1584,7 +1702,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     __builtin_amdgcn_wave_barrier();
   };
 
-  FrameRaw<NL, OTF> raw;
+  FrameRaw<NL, OTF, HP> raw;
   int info = tinfo[0];
   fetch(0, info, raw);
   for (int t = 0; t < ntl; t++) {
