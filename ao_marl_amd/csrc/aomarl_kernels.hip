@@ -825,18 +825,31 @@ typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ hx2 cvt_h2(float a, float b) {
   return __builtin_bit_cast(hx2, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
+// a - f32(h.lo) and a - f32(h.hi) as single mixed-precision FMAs (v_fma_mix_f32 reads the f16 half
+// directly; the compiler will not form it from a - (float)h).  Operands always come out of ordinary
+// VALU instructions (v_cvt_pkrtz of the same value sits in between any producer and this read).
+__device__ __forceinline__ float sub_lo(hx2 h, float a) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float sub_hi(hx2 h, float a) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+  return r;
+}
 // [hi(a0..a3) | lo(a0..a3)]
 __device__ __forceinline__ hx8 pack_hl(float a0, float a1, float a2, float a3) {
   const hx2 h01 = cvt_h2(a0, a1), h23 = cvt_h2(a2, a3);
-  const hx2 l01 = cvt_h2(a0 - (float)h01[0], a1 - (float)h01[1]);
-  const hx2 l23 = cvt_h2(a2 - (float)h23[0], a3 - (float)h23[1]);
+  const hx2 l01 = cvt_h2(sub_lo(h01, a0), sub_hi(h01, a1));
+  const hx2 l23 = cvt_h2(sub_lo(h23, a2), sub_hi(h23, a3));
   return hx8{h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
 }
 // [hi | hi] and [lo | lo]
 __device__ __forceinline__ void dup_hl(float a0, float a1, float a2, float a3, hx8 &H, hx8 &L) {
   const hx2 h01 = cvt_h2(a0, a1), h23 = cvt_h2(a2, a3);
-  const hx2 l01 = cvt_h2(a0 - (float)h01[0], a1 - (float)h01[1]);
-  const hx2 l23 = cvt_h2(a2 - (float)h23[0], a3 - (float)h23[1]);
+  const hx2 l01 = cvt_h2(sub_lo(h01, a0), sub_hi(h01, a1));
+  const hx2 l23 = cvt_h2(sub_lo(h23, a2), sub_hi(h23, a3));
   H = hx8{h01[0], h01[1], h23[0], h23[1], h01[0], h01[1], h23[0], h23[1]};
   L = hx8{l01[0], l01[1], l23[0], l23[1], l01[0], l01[1], l23[0], l23[1]};
 }
