@@ -393,19 +393,19 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
         }
       UP(int32_t, tinfo.data(), tinfo.size(), s.tile_info);
       // split-fp16 PSF twiddles for lane (q, c) of tile t: x = 16 t + 4 q + j, kx = c - 8;
-      // [hi(j = 0..3) | lo(j = 0..3)] of cos, sin, -sin (2 pi kx x / npsf)
+      // [hi(j = 0..3) | lo(j = 0..3)] of cos, sin (2 pi kx x / npsf)
       {
-        std::vector<_Float16> tw((size_t)nt * 3 * 64 * 8);
+        std::vector<_Float16> tw((size_t)nt * 2 * 64 * 8);
         for (int t = 0; t < nt; t++)
           for (int lane = 0; lane < 64; lane++)
             for (int j = 0; j < 4; j++) {
               const int x = 16 * t + 4 * (lane >> 4) + j, kx = (lane & 15) - 8;
               const double th = 2.0 * M_PI * (double)(((long long)kx * x) % d->npsf) / (double)d->npsf;
-              const float v[3] = {(float)cos(th), (float)sin(th), (float)-sin(th)};
-              for (int u = 0; u < 3; u++) {
+              const float v[2] = {(float)cos(th), (float)sin(th)};
+              for (int u = 0; u < 2; u++) {
                 const _Float16 hi = (_Float16)v[u];
                 const _Float16 lo = (_Float16)(v[u] - (float)hi);
-                _Float16 *o = &tw[(((size_t)t * 3 + u) * 64 + lane) * 8];
+                _Float16 *o = &tw[(((size_t)t * 2 + u) * 64 + lane) * 8];
                 o[j] = hi; o[4 + j] = lo;
               }
             }
@@ -1343,7 +1343,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   const int nb = otf ? c->sys.otf_nb : 1;
   const bool hp = !c->force_f32_dft;
   const size_t smm = sizeof(float) * (2 * 128 + (hp ? 0 : 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD) +
-                                      (otf ? 4 * 4 * nb * c->sys.otf_latw : 0));
+                                      (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + (hp ? 8192 + 16 : 0);
   dim3 grid(c->sys.ntiles, (n + 3) / 4), blk(256);
 #define FW(NL, NB, OTF, NZ, WC, HP) hipLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm, s, c->sys, ds, b, n, cog, TR, TP, w.nblk)
 #define FW_H(NL, NB, OTF, NZ, WC) do { if (hp) FW(NL, NB, OTF, NZ, WC, true); else FW(NL, NB, OTF, NZ, WC, false); } while (0)

@@ -68,7 +68,7 @@ struct DevSys {
   int otf_gx0, otf_gy0;          // first node column / row that reaches tile 0 / stripe 0
   int otf_xoff, otf_yoff;        // DM pixel of the tile origin minus the position of that node
   int otf_latw;                  // lattice columns a stripe can touch
-  const void *psf_tw_h;          // [ntiles][3][64] x 16 B: split-fp16 PSF twiddles (cos, sin, -sin)
+  const void *psf_tw_h;          // [ntiles][2][64] x 16 B: split-fp16 PSF twiddles (cos, sin)
 };
 
 struct DevState {

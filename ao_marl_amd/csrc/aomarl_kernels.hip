@@ -1463,10 +1463,14 @@ struct FrameRaw {
   float P[OTF ? 1 : 4], T[8];
   unsigned mrow;      // 16-bit mask row of the tile (this lane's row)
   float F;
+  f4u SH;             // HP: this wave's quarter of the tile's environment-independent data
 };
 
 // HP = true: both DFTs (spot, PSF rows) on split-fp16 MFMAs fed straight from registers (no LDS
-// amplitude tiles); HP = false: fp32 MFMAs through transposed LDS tiles.
+// amplitude tiles); the data of a tile that does not depend on the environment (tip-tilt planes,
+// PSF twiddles: 4 x 16 bytes per lane) is fetched once per block -- each of the 4 waves loads one
+// quarter a tile ahead, parks it in a double-buffered LDS slot, one barrier per lit tile -- instead
+// of once per wave from L2.  HP = false: fp32 MFMAs through transposed LDS tiles.
 template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     int env_count, int do_cog,
@@ -1480,6 +1484,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   float2 *stw = sTw + 128;                                   // [npsf] PSF twiddles (npsf <= 4096)
   float *tiles = reinterpret_cast<float *>(stw + (HP ? 0 : np));       // [4 waves][4][16 * FW_LD]
   float *lat_all = tiles + (HP ? 0 : 4 * 4 * 16 * FW_LD);    // [4 waves][4 NB][latw]
+  float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // HP: [2][4][64]
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
   const int r = blockIdx.x;                                  // stripe: pupil rows 16 r .. 16 r + 15
@@ -1493,8 +1498,9 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   if (!HP)
     for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
   __syncthreads();                                           // the only block-wide barrier
-  if (el >= env_count) return;
-  const int e = env_begin + el;
+  const bool active = el < env_count;          // HP: idle waves still serve the block's shared loads
+  if (!HP && !active) return;
+  const int e = env_begin + (active ? el : env_count - 1);
   float Cc[4], Ss[4];
 #pragma unroll
   for (int s = 0; s < 4; s++) {
@@ -1503,7 +1509,10 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   }
   SpotTwH twh;
   if (HP) twh = spot_tw_h(Cc, Ss);
-  const char *twhb = reinterpret_cast<const char *>(sys.psf_tw_h) + 16u * (unsigned)lane;
+  // shared loads: wave 0 / 1: the two 16-byte halves of the lane's tip-tilt pairs, wave 2 / 3: the
+  // split-fp16 PSF cos / sin vectors [t][2][64] x 16 B
+  const char *shsrc;
+  unsigned shstep;
   float *Twr = tiles + wv * 4 * 16 * FW_LD, *Twi = Twr + 16 * FW_LD;   // WFS amplitude [x][y]
   float *Tar = Twi + 16 * FW_LD, *Tai = Tar + 16 * FW_LD;              // target amplitude [x][y]
   const int y = 16 * r + c;                                  // pupil row of this lane
@@ -1535,6 +1544,8 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   const char *pztb = reinterpret_cast<const char *>(pzt);
   const char *ttb = reinterpret_cast<const char *>(D1.influ);
   const char *mkb = reinterpret_cast<const char *>(sys.tile_mask);
+  if (wv < 2) { shsrc = ttb + tvo + 16u * (unsigned)wv; shstep = 128u; }
+  else { shsrc = reinterpret_cast<const char *>(sys.psf_tw_h) + 16u * (unsigned)lane + 1024u * (unsigned)(wv - 2); shstep = 2048u; }
   // pivot of the variance sums: phase at the grid centre (ttslot[2]: stack-array value there)
   float pivot;
   {
@@ -1582,9 +1593,10 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   const int *tinfo = sys.tile_info + r * ntl;
   const float wfs_il = sys.wfs_inv_lambda, tar_il = sys.tar_inv_lambda;
   const f32x4 Z4 = opaque_zero4();
-  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f}, Ri2 = {0.f, 0.f, 0.f, 0.f};
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int kxf = c - 8;
+  int nlit = 0;
 
   auto fetch = [&](int t, int info, FrameRaw<NL, OTF, HP> &raw) {
     if (!(info & FW_LIT) || (dbg & 4)) return;               // wave-uniform
@@ -1600,11 +1612,15 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
 #pragma unroll
       for (int j = 0; j < 4; j++) raw.P[OTF ? 0 : j] = p4.v[j];
     }
-    const char *tb = ttb + 128u * (unsigned)t;
-    const f4u t0 = *reinterpret_cast<const f4u *>(tb + tvo);
-    const f4u t1 = *reinterpret_cast<const f4u *>(tb + 16 + tvo);
+    if (HP) {
+      raw.SH = *reinterpret_cast<const f4u *>(shsrc + shstep * (unsigned)t);
+    } else {
+      const char *tb = ttb + 128u * (unsigned)t;
+      const f4u t0 = *reinterpret_cast<const f4u *>(tb + tvo);
+      const f4u t1 = *reinterpret_cast<const f4u *>(tb + 16 + tvo);
 #pragma unroll
-    for (int j = 0; j < 4; j++) { raw.T[j] = t0.v[j]; raw.T[4 + j] = t1.v[j]; }
+      for (int j = 0; j < 4; j++) { raw.T[j] = t0.v[j]; raw.T[4 + j] = t1.v[j]; }
+    }
     raw.mrow = (info & FW_FULL) ? 0xFFFFu : *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)t + mvo);
     raw.F = (info & FW_SUB) ? sys.flux[info & 0xFFFF] : 0.f;
   };
@@ -1625,14 +1641,19 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
       for (int s = 0; s < NB; s++) S = mfma16(Pxr[s], U[s], S);
     }
     const float flux_i = cur.F;
-    // PSF twiddles of this tile in split-fp16 form (cos, sin, -sin as [hi | lo]; shared by all
-    // environments: L2 hits) -- issued here, consumed after the amplitude stage
-    hx8 cosP, sinP, nsinP;
+    // environment-independent data of the tile through the block's LDS slot
+    hx8 cosP, sinP;
     if (HP) {
-      const char *wb = twhb + 3072u * (unsigned)t;           // [t][3][64] x 16 bytes
-      cosP = *reinterpret_cast<const hx8 *>(wb);
-      sinP = *reinterpret_cast<const hx8 *>(wb + 1024);
-      nsinP = *reinterpret_cast<const hx8 *>(wb + 2048);
+      float4 *slot = shb + (nlit & 1) * 256;
+      nlit++;
+      slot[wv * 64 + lane] = make_float4(cur.SH.v[0], cur.SH.v[1], cur.SH.v[2], cur.SH.v[3]);
+      __syncthreads();
+      const float4 t0 = slot[lane], t1 = slot[64 + lane];
+      cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
+      cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
+      cosP = __builtin_bit_cast(hx8, slot[128 + lane]);
+      sinP = __builtin_bit_cast(hx8, slot[192 + lane]);
+      if (!active) { fetch(t + 1, infon, nxt); return; }
     }
     // ---- phase of the 4 pixels, both complex amplitudes (registers; LDS tiles for the fp32 path)
     float wr[4], wi[4], ar[4], ai[4];
@@ -1675,7 +1696,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
         Rr = mfma_h(arH, cosP, Rr); Rr = mfma_h(arL, cosP, Rr);
         Rr = mfma_h(aiH, sinP, Rr); Rr = mfma_h(aiL, sinP, Rr);
         Ri = mfma_h(aiH, cosP, Ri); Ri = mfma_h(aiL, cosP, Ri);
-        Ri = mfma_h(arH, nsinP, Ri); Ri = mfma_h(arL, nsinP, Ri);
+        Ri2 = mfma_h(arH, sinP, Ri2); Ri2 = mfma_h(arL, sinP, Ri2);     // R_i = Ri - Ri2 at the end
       }
       // ---- WFS path (valid sub-apertures only; wave-uniform branch)
       if ((info & FW_SUB) && !(dbg & 1)) {
@@ -1723,6 +1744,8 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     tile(t, info, infon, raw, raw);
     info = infon;
   }
+  if (HP && !active) return;
+  if (HP) Ri = Ri - Ri2;
   // ---- PSF rows of this stripe: acc reg j of lane (q, c): y = 4q + j, kx = c
 #pragma unroll
   for (int j = 0; j < 4; j++) {
