@@ -218,7 +218,10 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
 /* implementation switches for tests / A-B measurements: "force_generic_dm" (per-pixel gather
  * tables instead of the separable-lattice kernel), "force_valu_target" (VALU PSF rows kernel),
  * "force_generic_spot" / "force_generic_target" (layout-agnostic kernels), "force_unfused_frame"
- * (separate target and WFS passes in aomarl_next_part_one), "defer_dm_shape" (the composites
+ * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
+ * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
+ * "gemm_legacy" / "gemm_target_blocks" / "gemm_inkernel_reduce" (GEMM variants),
+ * "defer_dm_shape" (the composites
  * aomarl_next_part_two / aomarl_next_part_one use AOMARL_APPLY_DEFER_STACK_SHAPE /
  * AOMARL_IMG_DM_FROM_VOLTAGE when available: st->voltage is the DM state and the stack-array
  * planes of st->dm_shape stay stale until aomarl_materialize_dm_shape) */

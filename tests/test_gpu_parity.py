@@ -257,8 +257,9 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
     volts[:, -2:] = rng.normal(0, 0.05, size=(len(oracles), 2))      # tip-tilt: analytic planes
     sim.comp_dm_shape(torch.from_numpy(volts).cuda())
     out = {}
-    for mode in ("unfused", "fused_cube", "fused", "otf_cube", "otf"):
+    for mode in ("unfused", "fused_cube", "fused", "otf_cube", "otf", "otf_f32"):
         sim.reset_strehl()
+        sim.set_option("force_f32_dft", 1 if mode == "otf_f32" else 0)
         if mode.startswith("otf"):
             # stack-array DM evaluated from st.voltage inside the kernel: the stored planes are
             # poisoned to prove they are not read
@@ -278,6 +279,7 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
         sim.comp_strehl()
         out[mode] = (sim.slopes.cpu().numpy().copy(), sim.strehl.cpu().numpy().copy(),
                      sim.t["bincube"].cpu().numpy().copy())
+    sim.set_option("force_f32_dft", 0)
     # materialising afterwards restores the stored planes from the same voltages
     shp = sim.dm_shape(0).cpu().numpy()
     assert not sim._stale
@@ -290,7 +292,7 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
         o.comp_image(noise=False)
         o.do_centroids()
         assert np.abs(shp[e].ravel() - o.dm_shapes[0].ravel()).max() < 2e-6 * max(1.0, np.abs(o.dm_shapes[0]).max())
-        for mode in ("fused_cube", "fused", "otf_cube", "otf"):
+        for mode in ("fused_cube", "fused", "otf_cube", "otf", "otf_f32"):
             sl, st, cube = out[mode]
             assert np.abs(sl[e] - o.slopes).max() < 2e-5, mode
             assert np.abs(sl[e] - out["unfused"][0][e]).max() < 2e-5, mode
@@ -302,14 +304,16 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
             assert np.array_equal(cube[e].argmax(axis=1), o.bincube.argmax(axis=1)), mode
 
 
-@pytest.mark.parametrize("unfused", [0, 1, 2])
+@pytest.mark.parametrize("unfused", [0, 1, 2, 3])
 def test_closed_loop_trace_matches_oracle(setup, unfused):
     """40 frames of the integrator loop (next_part_two + next_part_one) from a common state: the
-    one-pass frame kernel with the stack-array DM evaluated from the commands (0), separate
-    target / WFS passes (1), the one-pass kernel reading materialised DM shapes (2)."""
+    one-pass frame kernel with the stack-array DM evaluated from the commands and the DFTs on
+    split-fp16 MFMAs (0), separate target / WFS passes (1), the one-pass kernel reading
+    materialised DM shapes (2), the one-pass kernel with fp32 MFMAs through LDS tiles (3)."""
     _, s, _, sim, oracles = setup
     sim.set_option("force_unfused_frame", 1 if unfused == 1 else 0)
-    sim.defer_shape = unfused == 0
+    sim.set_option("force_f32_dft", 1 if unfused == 3 else 0)
+    sim.defer_shape = unfused in (0, 3)
     sim.reset(SEEDS)
     for o, sd in zip(oracles, SEEDS):
         o.reset(sd)
@@ -333,6 +337,7 @@ def test_closed_loop_trace_matches_oracle(setup, unfused):
             assert abs(st[e, 0] - o.strehl_se) < 1e-4, it
             assert abs(st[e, 1] - o.strehl_le) < 1e-4, it
     sim.set_option("force_unfused_frame", 0)
+    sim.set_option("force_f32_dft", 0)
     sim.defer_shape = True
     assert sim.strehl[:, 0].min().item() > 0.3   # the loop closed
     print("worst slope deviation over the trace: %.3g arcsec" % worst)
