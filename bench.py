@@ -151,13 +151,21 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
+    # one rank per GPU over RCCL (backend "nccl").  AOMARL_DIST_BACKEND=gloo lets the multi-rank path
+    # be rehearsed on a box with fewer GPUs than ranks (ranks then share devices round-robin).
+    backend = os.environ.get("AOMARL_DIST_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    device = "cuda:%d" % dev_index
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    device = "cuda:%d" % local_rank
-    torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ao_marl_amd.agents import BatchedGaussianPolicy
     from ao_marl_amd.env import VecAoEnv
@@ -248,7 +256,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
