@@ -59,7 +59,7 @@ struct aomarl_ctx {
   int ld_cmat = 0;
   int nmodes = 0, nact = 0, ld_v2m = 0, ld_m2v = 0;
   float *v2m = nullptr, *m2v = nullptr, *freedom = nullptr;
-  int32_t *amodes = nullptr;
+  int32_t *amodes = nullptr, *amode_inv = nullptr;   // action modes and their inverse map [nmodes]
   uint32_t *seed_stage = nullptr;  // device staging for reset seeds
   int seed_stage_n = 0;
   // geometric controller (aomarl_set_geo): host copies of the lattice tables it is built from,
@@ -504,6 +504,19 @@ int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m
     }
     rc = upload<int32_t>(c, amodes, nact, &c->amodes);
     if (rc) return rc;
+    if (c->amode_inv) {
+      for (size_t i = 0; i < c->owned.size(); i++)
+        if (c->owned[i] == c->amode_inv) { c->owned.erase(c->owned.begin() + i); break; }
+      (void)hipFree(c->amode_inv);
+      c->amode_inv = nullptr;
+    }
+    std::vector<int32_t> inv(nmodes, -1);
+    for (int j = 0; j < nact; j++) {
+      if (inv[amodes[j]] != -1) return fail("action mode %d listed twice", amodes[j]);
+      inv[amodes[j]] = j;
+    }
+    rc = upload<int32_t>(c, inv.data(), inv.size(), &c->amode_inv);
+    if (rc) return rc;
     c->nact = nact;
   }
   return 0;
@@ -600,11 +613,12 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
     hipLaunchKernelGGL(k_extrude_gather, dim3(ncol, (K + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
                        ops, Z, w.ldz, ZREF);
     LAUNCHCHK();
+    int nsp = 0;
     launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
-                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM, w.gemm_floats);
+                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM, w.gemm_floats, nullptr, &nsp);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
-                       ZREF);
+                       ZREF, st->work + w.GEMM, nsp, ncol, dimc);
     LAUNCHCHK();
   }
   return 0;
@@ -917,11 +931,16 @@ int aomarl_do_control(aomarl_ctx *c, aomarl_state *st, int b, int n, void *strea
   const int na = c->sys.nactu, nsl = c->sys.nslope;
   // err[env][a] = - sum_s slopes[env][s] cmat[a][s]
   Work w = work_layout(c, st->nenv);
-  launch_gemm_nt(n, na, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->cmat, c->ld_cmat, 0.0f,
-                 st->err + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats);
+  GemmEpi ep = {};
+  ep.mode = 1; ep.com = st->com + (size_t)b * st->ld_actu; ep.ldcom = st->ld_actu; ep.gain = c->gain;
+  const bool fused = launch_gemm_nt(n, na, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->cmat, c->ld_cmat, 0.0f,
+                                    st->err + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM,
+                                    w.gemm_floats, &ep);
   LAUNCHCHK();
-  hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b);
-  LAUNCHCHK();
+  if (!fused) {
+    hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b);
+    LAUNCHCHK();
+  }
   return 0;
 }
 
@@ -963,10 +982,15 @@ int aomarl_rl_control(aomarl_ctx *c, aomarl_state *st, int b, int n, const float
   float *modes = st->work + w.MODES;
   const int na = c->sys.nactu, nm = c->nmodes;
   float *com = st->com + (size_t)b * st->ld_actu;
-  launch_gemm_nt(n, nm, na, 1.0f, com, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, modes, w.ldm, s, st->work + w.GEMM, w.gemm_floats);
+  GemmEpi ep = {};
+  ep.mode = 2; ep.action = action; ep.nact = c->nact; ep.amode_inv = c->amode_inv; ep.freedom = c->freedom;
+  const bool fused = launch_gemm_nt(n, nm, na, 1.0f, com, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, modes, w.ldm, s,
+                                    st->work + w.GEMM, w.gemm_floats, &ep);
   LAUNCHCHK();
-  hipLaunchKernelGGL(k_modal_add, dim3((c->nact + 255) / 256, n), dim3(256), 0, s, modes, w.ldm, action, c->nact, c->amodes, c->freedom);
-  LAUNCHCHK();
+  if (!fused) {
+    hipLaunchKernelGGL(k_modal_add, dim3((c->nact + 255) / 256, n), dim3(256), 0, s, modes, w.ldm, action, c->nact, c->amodes, c->freedom);
+    LAUNCHCHK();
+  }
   launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, com, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats);
   LAUNCHCHK();
   return 0;

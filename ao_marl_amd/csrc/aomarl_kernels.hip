@@ -380,16 +380,49 @@ __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float
   *c = v;
 }
 
+// split-K reduce with the consumer's element-wise step folded in (saves that launch):
+//   mode 1: C = err, com += gain * err                                (Rtc.do_control)
+//   mode 2: C = modes, modes[m] += action[j] * freedom[m] for the action modes  (rl_control)
+struct GemmEpi {
+  int mode;
+  float *com; int ldcom; float gain;
+  const float *action; int nact; const int32_t *amode_inv; const float *freedom;
+};
+
+__global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const float *__restrict__ P,
+                                  float beta, float *__restrict__ C, int ldc, GemmEpi ep) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * N) return;
+  const int row = (int)(i / N), col = (int)(i - (long long)row * N);
+  float s = 0.f;
+  for (int z = 0; z < nsplit; z++) s += P[(long long)z * M * N + i];
+  float *c = C + (long long)row * ldc + col;
+  float v = alpha * s;
+  if (beta != 0.f) v += beta * (*c);
+  if (ep.mode == 1) {
+    ep.com[(long long)row * ep.ldcom + col] += ep.gain * v;
+  } else if (ep.mode == 2) {
+    const int j = ep.amode_inv[col];
+    if (j >= 0) v += ep.action[(long long)row * ep.nact + j] * ep.freedom[col];
+  }
+  *c = v;
+}
+
 static bool g_gemm_legacy = false;    // "gemm_legacy" option: the un-pipelined kernels (A/B tests)
 static int g_gemm_target_blocks = 512;
 static bool g_gemm_inkernel_reduce = false;  // "gemm_inkernel_reduce": measured 4x SLOWER (per-block L2 write-back of __threadfence)
 #define G_COUNTERS 4096
 
 // ws / ws_floats: optional split-K workspace (NULL: never split)
-void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
+// epi: applied by the split-K reduce when there is one (returns true), else left to the caller
+//      (returns false).  nsplit_out: when non-null and the GEMM was split, NO reduce is launched and
+//      the caller's next kernel sums the partial tiles ws[z][M][N] itself (*nsplit_out = count,
+//      0 = C is final).
+bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
                     int ldb, float beta, float *C, int ldc, hipStream_t s, float *ws = nullptr,
-                    size_t ws_floats = 0) {
-  if (M <= 0 || N <= 0) return;
+                    size_t ws_floats = 0, const GemmEpi *epi = nullptr, int *nsplit_out = nullptr) {
+  if (nsplit_out) *nsplit_out = 0;
+  if (M <= 0 || N <= 0) return false;
   const int bx = (N + 63) / 64, by = (M + 63) / 64;
   int nsplit = 1;
   if (ws && bx * by < 384) {
@@ -411,7 +444,7 @@ void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   if (al && !g_gemm_legacy) {
     hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
                        ldc, kchunk, ws, counters);
-    if (counters) return;
+    if (counters) return false;
   }
   else if (al)
     hipLaunchKernelGGL(k_gemm_nt<true>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
@@ -421,9 +454,16 @@ void launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
                        beta, C, ldc, kchunk, ws);
   if (nsplit > 1) {
     const long long tot = (long long)M * N;
+    if (nsplit_out) { *nsplit_out = nsplit; return false; }
+    if (epi) {
+      hipLaunchKernelGGL(k_gemm_reduce_epi, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, M, N,
+                         nsplit, alpha, ws, beta, C, ldc, *epi);
+      return true;
+    }
     hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, M, N,
                        nsplit, alpha, ws, beta, C, ldc);
   }
+  return false;
 }
 
 // =============================================================================================
@@ -466,7 +506,10 @@ __global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st,
 __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st, int env_begin,
                                                          RoundOps ops,
                                                          const float *__restrict__ NEWL, int ldn,
-                                                         const float *__restrict__ ZREF) {
+                                                         const float *__restrict__ ZREF,
+                                                         const float *__restrict__ P, int nsplit,
+                                                         int ncol, int pn) {
+  // nsplit > 0: the new lines are still split-K partial tiles P[z][ncol][pn] of the extrusion GEMM
   const int col = blockIdx.x;
   const int e = env_begin + col / ops.nops, op = col % ops.nops;
   const int li = ops.layer[op], dir = ops.dir[op];
@@ -478,7 +521,14 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
   const float zref = ZREF[col];
   const int stride = n + RING_PAD;
   for (int r = threadIdx.x; r < n; r += blockDim.x) {
-    const float v = NEWL[(long long)col * ldn + r] + zref;
+    float v = zref;
+    if (nsplit > 0) {
+      float acc = 0.f;
+      for (int z = 0; z < nsplit; z++) acc += P[((long long)z * ncol + col) * pn + r];
+      v += acc;
+    } else {
+      v += NEWL[(long long)col * ldn + r];
+    }
     int px, py;
     if (dir == 1) {
       px = ox;
