@@ -972,30 +972,55 @@ __device__ __forceinline__ void spot_dft_h(const SpotTwH &tw, const float (&br)[
   }
 }
 
-// |X|^2, 2x2 binning, flux normalisation (+noise), COG on the accumulators of the DFT
+// |X|^2 and 2x2 binning of one quadrant tile.  Reg r, lane (q, c): ky' = 4q + r, kx' = c;
+// + tiles: k = k' -> LR index 8 + (k' >> 1);  - tiles: k = -(k'+1) -> LR index 7 - (k' >> 1)
+__device__ __forceinline__ void spot_bin(const f32x4 Xr, const f32x4 Xi, float (&v)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float a0 = Xr[2 * h], b0 = Xi[2 * h], a1 = Xr[2 * h + 1], b1 = Xi[2 * h + 1];
+    v[h] = add_xor1((a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1));
+  }
+}
+
+// the split-fp16 DFT with the binning folded in per kx-sign half: only 2 of the 4 quadrant tiles
+// are ever live (32 accumulator registers instead of 64)
+__device__ __forceinline__ void spot_dft_h_v(const SpotTwH &tw, const float (&br)[4],
+                                             const float (&bi)[4], const f32x4 z4,
+                                             float (&v)[2][2][2]) {
+  const hx8 ar = pack_hl(br[0], br[1], br[2], br[3]), ai = pack_hl(bi[0], bi[1], bi[2], bi[3]);
+  f32x4 PCr = mfma_h(ar, tw.CL, mfma_h(ar, tw.CH, z4));
+  f32x4 PCi = mfma_h(ai, tw.CL, mfma_h(ai, tw.CH, z4));
+  f32x4 PSr = mfma_h(ar, tw.SL, mfma_h(ar, tw.SH, z4));
+  f32x4 PSi = mfma_h(ai, tw.SL, mfma_h(ai, tw.SH, z4));
+#pragma unroll
+  for (int m = 0; m < 2; m++) {                // [0]: kx = +(k+1/2)   [1]: kx = -(k+1/2)
+    const f32x4 Tr = m == 0 ? PCr + PSi : PCr - PSi;
+    const f32x4 Ti = m == 0 ? PCi - PSr : PCi + PSr;
+    const hx8 tr = pack_hl(Tr[0], Tr[1], Tr[2], Tr[3]);
+    const hx8 ti = pack_hl(Ti[0], Ti[1], Ti[2], Ti[3]);
+    const f32x4 QCr = mfma_h(tw.CL, tr, mfma_h(tw.CH, tr, z4));
+    const f32x4 QCi = mfma_h(tw.CL, ti, mfma_h(tw.CH, ti, z4));
+    const f32x4 QSr = mfma_h(tw.SL, tr, mfma_h(tw.SH, tr, z4));
+    const f32x4 QSi = mfma_h(tw.SL, ti, mfma_h(tw.SH, ti, z4));
+    spot_bin(QCr + QSi, QCi - QSr, v[0][m]);
+    spot_bin(QCr - QSi, QCi + QSr, v[1][m]);
+  }
+}
+
+// flux normalisation (+noise), COG on the binned quadrant values v[sy][sx][h]
 template <bool NOISE, bool WRITE_CUBE>
-__device__ __forceinline__ void spot_finish(const DevSys &sys, const DevState &st, int e, int i,
-                                            int lane, const f32x4 (&Xr)[2][2],
-                                            const f32x4 (&Xi)[2][2], int do_cog, float flux_i) {
+__device__ __forceinline__ void spot_finish_v(const DevSys &sys, const DevState &st, int e, int i,
+                                              int lane, const float (&v)[2][2][2], int do_cog,
+                                              float flux_i) {
   const int q = lane >> 4, c = lane & 15;
   const bool owner = (c & 1) == 0;
-  // ---- |X|^2 and 2x2 binning.  Tile [sy][sx], reg r, lane (q, c): ky' = 4q + r, kx' = c;
-  //      + tiles: k = k' -> LR index 8 + (k' >> 1);  - tiles: k = -(k'+1) -> LR index 7 - (k' >> 1)
-  float v[2][2][2];
   float tot = 0.f;
 #pragma unroll
   for (int sy = 0; sy < 2; sy++)
 #pragma unroll
     for (int sx = 0; sx < 2; sx++)
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        float a0 = Xr[sy][sx][2 * h], b0 = Xi[sy][sx][2 * h];
-        float a1 = Xr[sy][sx][2 * h + 1], b1 = Xi[sy][sx][2 * h + 1];
-        float t = (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1);
-        t = add_xor1(t);
-        v[sy][sx][h] = t;
-        tot += t;
-      }
+      for (int h = 0; h < 2; h++) tot += v[sy][sx][h];
   const int Xp = 8 + (c >> 1), Xm = 7 - (c >> 1);
   if (!NOISE && !WRITE_CUBE) {
     // only the slopes are wanted and nothing depends on the normalised pixel values: the COG is
@@ -1069,6 +1094,18 @@ __device__ __forceinline__ void spot_finish(const DevSys &sys, const DevState &s
       }
     }
   }
+}
+
+template <bool NOISE, bool WRITE_CUBE>
+__device__ __forceinline__ void spot_finish(const DevSys &sys, const DevState &st, int e, int i,
+                                            int lane, const f32x4 (&Xr)[2][2],
+                                            const f32x4 (&Xi)[2][2], int do_cog, float flux_i) {
+  float v[2][2][2];
+#pragma unroll
+  for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+    for (int sx = 0; sx < 2; sx++) spot_bin(Xr[sy][sx], Xi[sy][sx], v[sy][sx]);
+  spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, i, lane, v, do_cog, flux_i);
 }
 
 // operands: br[s] / bi[s] = complex amplitude of pixel (y = c, x = 4q + s) of the tile
@@ -1750,9 +1787,9 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
       }
       // ---- WFS path (valid sub-apertures only; wave-uniform branch)
       if ((info & FW_SUB) && !(dbg & 1)) {
-        f32x4 Xr[2][2], Xi[2][2];
-        spot_dft_h(twh, wr, wi, Z4, Xr, Xi);
-        spot_finish<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Xr, Xi, do_cog, flux_i);
+        float v[2][2][2];
+        spot_dft_h_v(twh, wr, wi, Z4, v);
+        spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, v, do_cog, flux_i);
       }
       return;
     }
