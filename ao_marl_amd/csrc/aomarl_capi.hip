@@ -392,6 +392,18 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
           tinfo[(size_t)r * nt + t] = v;
         }
       UP(int32_t, tinfo.data(), tinfo.size(), s.tile_info);
+      {
+        std::vector<int32_t> order(nt), work(nt, 0);
+        for (int r = 0; r < nt; r++) {
+          order[r] = r;
+          for (int t = 0; t < nt; t++) {
+            const int32_t v = tinfo[(size_t)r * nt + t];
+            work[r] += (v & 0x10000) ? ((v & 0x40000) ? 4 : 1) : 0;   // a sub-aperture tile costs ~4x a bare one
+          }
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[a] > work[b]; });
+        UP(int32_t, order.data(), order.size(), s.stripe_order);
+      }
       // split-fp16 PSF twiddles for lane (q, c) of tile t: x = 16 t + 4 q + j, kx = c - 8;
       // [hi(j = 0..3) | lo(j = 0..3)] of cos, sin (2 pi kx x / npsf)
       {
@@ -1368,7 +1380,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   const bool hp = !c->force_f32_dft;
   const size_t smm = sizeof(float) * (2 * 128 + (hp ? 0 : 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD) +
                                       (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + (hp ? 8192 + 16 : 0);
-  dim3 grid(c->sys.ntiles, (n + 3) / 4), blk(256);
+  dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
 #define FW(NL, NB, OTF, NZ, WC, HP) hipLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm, s, c->sys, ds, b, n, cog, TR, TP, w.nblk)
 #define FW_H(NL, NB, OTF, NZ, WC) do { if (hp) FW(NL, NB, OTF, NZ, WC, true); else FW(NL, NB, OTF, NZ, WC, false); } while (0)
 #define FW_NC(NL, NB, OTF)                                                                     \

@@ -60,6 +60,7 @@ struct DevSys {
   // ---- fused frame kernel (WFS + science path share every phase pixel: the 16x16 sub-aperture
   // tiles ARE the tiles of the pupil grid): available when the geometry lines up (see create)
   int fused_ok, ntiles;          // ntiles = pupdiam / 16 tiles per axis
+  const int32_t *stripe_order;   // [ntiles] stripes by decreasing number of lit tiles
   const int32_t *tile_info;      // [ntiles][ntiles] (stripe, tile): sub-aperture | lit / full / has-sub bits
   const uint16_t *tile_mask;     // [pupdiam][ntiles]: bit b = spupil[y][16 t + b] != 0
   // stack-array DM phase from the command lattice inside the frame kernel (separable lattice whose

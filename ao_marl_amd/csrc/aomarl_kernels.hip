@@ -1574,8 +1574,11 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // HP: [2][4][64]
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
-  const int r = blockIdx.x;                                  // stripe: pupil rows 16 r .. 16 r + 15
-  const int el = 4 * blockIdx.y + wv;                        // environment of this wave
+  // blocks are dispatched x-fastest: x = group of 4 environments, y = rank of the stripe by
+  // decreasing number of lit tiles -- the longest stripes start first and the launch ends on the
+  // shortest ones (longest-processing-time order: smaller tail)
+  const int r = sys.stripe_order[blockIdx.y];                // stripe: pupil rows 16 r .. 16 r + 15
+  const int el = 4 * blockIdx.x + wv;                        // environment of this wave
   if (tid < 128) {
     float sn, cs;
     sincospif((float)tid * (1.0f / 64.0f), &sn, &cs);
