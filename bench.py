@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--no-defer", action="store_true",
                     help="materialise the stack-array DM shapes instead of evaluating them from the "
                          "voltages inside the frame kernel")
-    ap.add_argument("--pmc", default="r01f_pmc_counters_256env.json",
+    ap.add_argument("--pmc", default="r01g_pmc_counters_256env.json",
                     help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes")
     args = ap.parse_args()
 
