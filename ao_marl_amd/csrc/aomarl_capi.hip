@@ -622,7 +622,7 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
     const int dimc = c->dim[ref], nsc = c->ns[ref], K = dimc + nsc;
     const int ncol = n * ops.nops;
     float *Z = st->work + w.Z, *NEWL = st->work + w.NEWL, *ZREF = st->work + w.ZREF;
-    hipLaunchKernelGGL(k_extrude_gather, dim3(ncol, (K + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
+    hipLaunchKernelGGL(k_extrude_gather, dim3(ncol, (nsc + (dimc + 3) / 4 + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
                        ops, Z, w.ldz, ZREF);
     LAUNCHCHK();
     int nsp = 0;

@@ -104,6 +104,22 @@ __device__ __forceinline__ float u01(uint32_t x) {
   return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
 
+// elements 4 j .. 4 j + 3 of the normal stream (seed, stream, counter): the four of them come out of
+// one Philox block and two Box-Muller pairs (same values as philox_normal element by element)
+__device__ __forceinline__ void philox_normal4(uint32_t seed, uint32_t stream, uint32_t cnt_lo,
+                                               uint32_t cnt_hi, uint32_t j, float out[4]) {
+  uint32_t x[4];
+  philox4x32_10(j, cnt_lo, cnt_hi, stream, seed, 0x414F4D52u, x);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float u0 = u01(x[2 * h]), u1 = u01(x[2 * h + 1]);
+    const float r = sqrtf(-2.0f * logf(u0));
+    const float a = 6.28318530717958647692f * u1;
+    out[2 * h] = r * cosf(a);
+    out[2 * h + 1] = r * sinf(a);
+  }
+}
+
 // element `idx` of the normal stream (seed, stream, counter)
 __device__ __forceinline__ float philox_normal(uint32_t seed, uint32_t stream, uint32_t cnt_lo,
                                                uint32_t cnt_hi, uint32_t idx) {

@@ -491,12 +491,18 @@ __global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st,
   const uint32_t *ist = (dir == 1 || dir == -1) ? L.istx : L.isty;
   const uint32_t seed = st.seeds[e] + (uint32_t)li;
   const uint32_t cnt = st.ext_count[e * sys.nlayers + li];
+  // threads [0, ns): stencil values; threads [ns, ns + ceil(n / 4)): 4 normals each (one Philox block)
   const int j = blockIdx.y * blockDim.x + threadIdx.x;
   if (j < ns) {
     uint32_t xy = ist[j];
     Z[(long long)col * ldz + j] = base[ring_idx(xy & 0xFFFF, xy >> 16, ox, oy, n)] - zref;
-  } else if (j < ns + n) {
-    Z[(long long)col * ldz + j] = L.amp * philox_normal(seed, 0u, cnt, 0u, (uint32_t)(j - ns));
+  } else if (j < ns + (n + 3) / 4) {
+    const int g = j - ns;
+    float z4[4];
+    philox_normal4(seed, 0u, cnt, 0u, (uint32_t)g, z4);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (4 * g + u < n) Z[(long long)col * ldz + ns + 4 * g + u] = L.amp * z4[u];
   }
   if (j == 0) ZREF[col] = zref;
 }
