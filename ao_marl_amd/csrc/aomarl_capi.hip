@@ -1008,6 +1008,45 @@ int aomarl_rl_control(aomarl_ctx *c, aomarl_state *st, int b, int n, const float
   return 0;
 }
 
+// modes = m0 + g * m1 (+ action on the action modes), written to the GEMM operand and to modes_out
+__global__ void k_modal_compose(int nm, const float *__restrict__ m0, const float *__restrict__ m1,
+                                float g, const float *__restrict__ action, int nact,
+                                const int32_t *__restrict__ amode_inv,
+                                const float *__restrict__ freedom, float *__restrict__ modes, int ldm,
+                                float *__restrict__ modes_out) {
+  const int r = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nm) return;
+  float v = m0[(long long)r * nm + m] + g * m1[(long long)r * nm + m];
+  if (action) {
+    const int j = amode_inv[m];
+    if (j >= 0) v += action[(long long)r * nact + j] * freedom[m];
+  }
+  modes[(long long)r * ldm + m] = v;
+  if (modes_out) modes_out[(long long)r * nm + m] = v;
+}
+
+int aomarl_rl_control_modes(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *m0,
+                            const float *m1, float g, const float *action, float *modes_out,
+                            void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!c->v2m || !c->m2v) return fail("rl_control_modes: no modal basis (aomarl_set_modal)");
+  if (!m0 || !m1) return fail("rl_control_modes: null modal vectors");
+  if (action && c->nact <= 0) return fail("rl_control_modes: no action modes set");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  Work w = work_layout(c, st->nenv);
+  float *modes = st->work + w.MODES;
+  const int na = c->sys.nactu, nm = c->nmodes;
+  hipLaunchKernelGGL(k_modal_compose, dim3((nm + 255) / 256, n), dim3(256), 0, s, nm, m0, m1, g, action,
+                     c->nact, c->amode_inv, c->freedom, modes, w.ldm, modes_out);
+  LAUNCHCHK();
+  launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f,
+                 st->com + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats);
+  LAUNCHCHK();
+  return 0;
+}
+
 int aomarl_apply_control(aomarl_ctx *c, aomarl_state *st, int b, int n, int comp_voltage, void *stream) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;

@@ -86,6 +86,8 @@ class VecRlSupervisor(object):
         self.include_tip_tilt = bool(self.config_rl["include_tip_tilt"])
         self.sim = make(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
         self.freedom_vector = None
+        self.gain = float(self.s.gain)
+        self.last_modes = None
         self._push_modal()
         # controller 1 of the non-noise parameter files: the geometric reference controller with
         # its own DM pair and target (rlSupervisor.py:989-1013); off by default -- it changes
@@ -145,10 +147,27 @@ class VecRlSupervisor(object):
             raise RuntimeError("freedom vector not loaded (load_freedom_vector)")
         self.sim.rl_control(action)
 
+    def set_gain(self, gain):
+        """rtc._rtc.d_control[0].set_gain (ao_env.py:950-958)"""
+        self.gain = float(gain)
+        self.sim.set_gain(self.gain)
+
     def next_part_two(self, action, linear_control=False, apply_control=True,
-                      compute_tar_psf=True):
-        """rlSupervisor.py:900-947"""
-        if not linear_control:
+                      compute_tar_psf=True, modes_pair=None):
+        """rlSupervisor.py:900-947.  modes_pair = (v2m . com_before, v2m . err) of the last
+        integrator frame: the Btt coordinates of the current command follow by linearity
+        (aomarl_rl_control_modes) and the coordinates after the action come back in
+        `self.last_modes`."""
+        self.last_modes = None
+        if not linear_control and modes_pair is not None and hasattr(self.sim, "rl_control_modes"):
+            std = self.config_rl["normalization_std_inside_environment"]
+            mean = self.config_rl["normalization_mean_inside_environment"]
+            if std != 1.0 or mean != 0.0:
+                action = action * std + mean
+            if self.freedom_vector is None:
+                raise RuntimeError("freedom vector not loaded (load_freedom_vector)")
+            self.last_modes = self.sim.rl_control_modes(modes_pair[0], modes_pair[1], self.gain, action)
+        elif not linear_control:
             self.rl_control(action)
         if apply_control:
             # the stack-array shapes are left to the one-pass frame kernel when it can evaluate
@@ -293,6 +312,10 @@ class VecAoEnv(object):
         self._last_res_modes = None
         # fused glue kernels of the library (GPU + the HIP simulator only)
         self._native_glue = self.device.type == "cuda" and hasattr(sup.sim, "lib")
+        # Btt coordinates of the command carried from frame to frame by linearity instead of two
+        # v2m GEMMs per step (aomarl_rl_control_modes); fp32 round-off apart, the same numbers
+        self.modal_shortcut = True
+        self._m_before_full, self._m_next, self._modal_valid = None, None, False
         self._default_state_layout = (
             list(self.state_keys) == ["dm_history_%d" % i for i in
                                       range(cfg["number_of_previous_dm"], 0, -1)] +
@@ -338,6 +361,7 @@ class VecAoEnv(object):
         """ao_env.py:316-359"""
         cfg = self.config_rl
         self.supervisor.reset()
+        self._m_next, self._modal_valid = None, False
         z = lambda d: torch.zeros(self.nenv, d, device=self.device)  # noqa: E731
         self._hist_dm = [z(self.dm_dim) for _ in range(cfg["number_of_previous_dm"])]
         self._hist_wfs = [z(self.wfs_dim) for _ in range(cfg["number_of_previous_wfs"])]
@@ -393,10 +417,15 @@ class VecAoEnv(object):
         and concatenated by one kernel (aomarl_assemble_state) instead of ~10 tensor operations."""
         from . import libaomarl as la
         cfg, sup = self.config_rl, self.supervisor
-        s_dm_before = self.transform_state_to_zernike(sup.get_command())
+        if self._m_next is not None:            # v2m . com came back from rl_control_modes
+            m_full, self._m_next = self._m_next, None
+        else:
+            m_full = sup.sim.volts2modes(sup.get_command())
+        s_dm_before = m_full if (self.windowed or self._sel is None) else m_full[:, self._sel]
         sup.next_part_one()
         res_full = sup.sim.volts2modes(sup.get_err())
         self._last_res_modes = res_full
+        self._m_before_full, self._modal_valid = m_full, True
         s_res = res_full if (self.windowed or self._sel is None) else res_full[:, self._sel]
         blocks = list(self._hist_dm) + [s_dm_before, s_res]
         norms = None
@@ -426,9 +455,15 @@ class VecAoEnv(object):
                 compute_env_reward=False):
         """ao_env.py:911-939. The reference computes the env-level reward and the trainer throws
         it away (train_rpc.py:641); it is only evaluated here on request."""
+        pair = None
+        if (self.modal_shortcut and self._native_glue and self._default_state_layout and
+                self._modal_valid and not linear_control):
+            pair = (self._m_before_full, self._last_res_modes)
         self.supervisor.next_part_two(action, linear_control=linear_control,
                                       apply_control=apply_control,
-                                      compute_tar_psf=compute_tar_psf)
+                                      compute_tar_psf=compute_tar_psf, modes_pair=pair)
+        self._m_next = self.supervisor.last_modes
+        self._modal_valid = False               # re-established by the next linear_step
         r = self.calculate_reward() if compute_env_reward else None
         return r, False, ""
 

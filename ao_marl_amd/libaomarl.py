@@ -94,6 +94,7 @@ SYMBOLS = [
     ("aomarl_do_control", _i, _range + [_vp]),
     ("aomarl_set_com", _i, _range + [_vp, _vp]),
     ("aomarl_rl_control", _i, _range + [_vp, _vp]),
+    ("aomarl_rl_control_modes", _i, _range + [_vp, _vp, C.c_float, _vp, _vp, _vp]),
     ("aomarl_apply_control", _i, _range + [_i, _vp]),
     ("aomarl_comp_dm_shape", _i, _range + [_vp, _vp]),
     ("aomarl_get_dm_shape", _i, _range + [_i, _vp, _vp]),

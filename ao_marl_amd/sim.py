@@ -321,6 +321,25 @@ class HipSim(object):
         la.check(self.lib.aomarl_rl_control(self.ctx, C.byref(self.st), b, n, action.data_ptr(),
                                             self._stream()))
 
+    def rl_control_modes(self, m0, m1, g, action=None, env_begin=0, env_count=None):
+        """rl_control from known Btt coordinates: modes = m0 + g m1 (+ action); com = m2v . modes.
+        Returns the modes ([env_count, nmodes]) -- they are v2m . com of the new command."""
+        b, n = self._range(env_begin, env_count)
+        m0, m1 = m0.contiguous(), m1.contiguous()
+        if m0.shape != (n, self.nmodes) or m1.shape != (n, self.nmodes):
+            raise ValueError("modal vectors must be [env_count, %d]" % self.nmodes)
+        ptr = None
+        if action is not None:
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device).contiguous()
+            if action.shape != (n, self.nact):
+                raise ValueError("action must be [env_count, %d]" % self.nact)
+            ptr = action.data_ptr()
+        out = torch.empty(n, self.nmodes, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_rl_control_modes(self.ctx, C.byref(self.st), b, n, m0.data_ptr(),
+                                                  m1.data_ptr(), float(g), ptr, out.data_ptr(),
+                                                  self._stream()))
+        return out
+
     def apply_control(self, comp_voltage=True, env_begin=0, env_count=None, defer_shape=False):
         """defer_shape: leave the stack-array shapes to the one-pass frame kernel (which then
         evaluates them from st.voltage); only honoured when the library supports it."""

@@ -198,6 +198,18 @@ int aomarl_set_com(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_cou
  * action_dev [env_count][nact] device memory */
 int aomarl_rl_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                       const float *action_dev, void *stream);
+/* aomarl_rl_control when the Btt coordinates of the current command are already known:
+ *     modes = m0 + g * m1 (+ action * freedom on the action modes) ; com = m2v . modes
+ * (m0, m1, modes_out: device [env_count][nmodes], modes_out may be NULL; action may be NULL).
+ * The commands never leave span(Btt) (cmat = Btt . D+, rl_control projects on it) and v2m . m2v = I,
+ * so v2m . com of the command the integrator left, com_before + g * err, is v2m . com_before +
+ * g * v2m . err by linearity -- two vectors the environment has just computed for its state
+ * (AoEnv.linear_step, ao_env.py:871-909): the v2m GEMM of rl_control and the one of the next
+ * state are saved.  ao_marl_amd/env.py uses it inside step(); results differ from aomarl_rl_control
+ * by fp32 round-off only. */
+int aomarl_rl_control_modes(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                            const float *m0_dev, const float *m1_dev, float g,
+                            const float *action_dev, float *modes_out_dev, void *stream);
 /* Rtc.apply_control (rtcCompass.py:582): delay line -> voltage -> Dm.comp_shape per DM;
  * comp_voltage: AOMARL_APPLY_* bits (1 = the reference's compVoltage=True) */
 int aomarl_apply_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,

@@ -88,3 +88,32 @@ def test_env_step_with_fused_glue_equals_tensor_op_path():
         sb, rb, _, _ = b.step(act)
         assert torch.allclose(sa, sb, rtol=1e-4, atol=1e-5 * sb.abs().max().item())
         assert torch.allclose(ra, rb, rtol=1e-4, atol=1e-6)
+
+
+def test_modal_shortcut_equals_full_projection_path():
+    """Carrying the Btt coordinates of the command by linearity (aomarl_rl_control_modes: no v2m
+    GEMM in rl_control, none for the next state) gives the states / rewards of the path that
+    projects the command explicitly, to fp32 round-off, over a closed-loop rollout."""
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    b.modal_shortcut = False
+    sa, sb = a.reset(), b.reset()
+    assert torch.equal(sa, sb)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    used = 0
+    for it in range(12):
+        act = torch.rand(3, a.layout.action_dim, device="cuda:0", generator=g) * 2 - 1
+        lin = it in (4, 5)                       # integrator-only steps in between
+        sa, ra, _, _ = a.step(act, linear_control=lin)
+        sb, rb, _, _ = b.step(act, linear_control=lin)
+        used += a.supervisor.last_modes is not None
+        # states are standardised with tiny std for some modes: compare in modal units
+        std = torch.cat([a.norm["dm"][1]] * 3 + [a.norm["dm_residual"][1]])
+        scale = (sb * std).abs().max().item()
+        assert ((sa - sb) * std).abs().max().item() < 2e-5 * scale, it
+        assert torch.allclose(ra, rb, rtol=2e-4, atol=1e-6), it
+        cb = b.supervisor.get_command()
+        assert (a.supervisor.get_command() - cb).abs().max().item() < 2e-5 * cb.abs().max().item()
+    assert used == 10
