@@ -1515,3 +1515,35 @@ int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int l
   LAUNCHCHK();
   return 0;
 }
+
+static int gemm_batched_launch(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
+                               long long strideA, const float *B, int ldb, long long strideB,
+                               const float *bias, long long strideBias, float *C, int ldc, long long strideC,
+                               int relu, int accumulate, const float *mask, int ldm, long long strideM,
+                               hipStream_t s) {
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  // 128-bit loads only where every row of every matrix of the batch starts on a 16-byte boundary
+  const int vecA = !((uintptr_t)A & 15) && !(strideA & 3) && !(lda & 3);
+  const int vecB = !((uintptr_t)B & 15) && !(strideB & 3) && !(ldb & 3);
+  dim3 grid((N + 63) / 64, (M + 63) / 64, batch), blk(256);
+#define GG(TA, TB) hipLaunchKernelGGL((k_gemm_batched_gen<TA, TB>), grid, blk, 0, s, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc, strideC, relu, accumulate, vecA, vecB, mask, ldm, strideM)
+  if (transA) { if (transB) GG(true, true); else GG(true, false); }
+  else { if (transB) GG(false, true); else GG(false, false); }
+#undef GG
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_gemm_batched(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
+                        long long strideA, const float *B, int ldb, long long strideB, const float *bias,
+                        long long strideBias, float *C, int ldc, long long strideC, int relu,
+                        int accumulate, void *stream) {
+  if (!A || !B || !C) return fail("gemm_batched: null pointer");
+  if (batch < 0 || M < 0 || N < 0 || K < 0 || ldc < N) return fail("gemm_batched: bad sizes");
+  if (lda < (transA ? M : K) || ldb < (transB ? N : K)) return fail("gemm_batched: leading dimension too small");
+  return gemm_batched_launch(batch, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias,
+                             C, ldc, strideC, relu, accumulate, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- multi-agent SAC update (section 8f)
+#include "aomarl_sac.hip"

@@ -367,6 +367,142 @@ __global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// General batched GEMM for the SAC networks' forward AND backward passes:
+//     C[b] = act( opA(A[b]) . opB(B[b]) + bias[b] ) (+ C[b] when accumulate)
+// opA(A) is M x K, opB(B) is K x N.  TA = false: A stored [M][K] (K contiguous); TA = true: A stored
+// [K][M].  TB = false: B stored [N][K] (the "NT" form above); TB = true: B stored [K][N].
+// The three products of a linear layer y = x W (W stored [in][out]) are
+//     forward  y  = x . W        TA = 0, TB = 1        backward dx = dy . W^T     TA = 0, TB = 0
+//     weights  dW = x^T . dy     TA = 1, TB = 1
+// Same tile / LDS image / MFMA loop as k_gemm_nt2; a k-strided operand is read with 128-bit loads
+// along its contiguous (row) direction and transposed on the way into LDS.
+// ---------------------------------------------------------------------------------------------
+template <bool T>
+__device__ __forceinline__ void gg_load(const float *__restrict__ P, int ld, int rows, int r0, int k0,
+                                        int ke, int tid, float (&v)[8], bool vec) {
+  // this thread's 8 elements of the 64 (rows) x 32 (k) tile starting at (r0, k0)
+  if (!T) {
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int r = min(r0 + lr + 32 * h, rows - 1);
+      const float *p = P + (long long)r * ld;
+      const int k = k0 + lc;
+      if (k + 3 < ke && vec) {
+        const float4 t = *reinterpret_cast<const float4 *>(p + k);
+        v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[4 * h + j] = (k + j < ke) ? p[k + j] : 0.f;
+      }
+    }
+  } else {
+    const int kk = tid >> 4, r4 = (tid & 15) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int k = k0 + kk + 16 * h;
+      const float *p = P + (long long)k * ld;
+      if (k < ke) {
+        if (r0 + r4 + 3 < rows && vec) {
+          const float4 t = *reinterpret_cast<const float4 *>(p + r0 + r4);
+          v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[4 * h + j] = p[min(r0 + r4 + j, rows - 1)];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[4 * h + j] = 0.f;
+      }
+    }
+  }
+}
+
+template <bool T>
+__device__ __forceinline__ void gg_store(float *S, int tid, const float (&v)[8]) {
+  if (!T) {
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      *reinterpret_cast<float4 *>(S + (lr + 32 * h) * G2_LD + lc) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+  } else {
+    const int kk = tid >> 4, r4 = (tid & 15) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) S[(r4 + j) * G2_LD + kk + 16 * h] = v[4 * h + j];
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm_batched_gen(int M, int N, int K,
+                                                          const float *__restrict__ A, int lda, long long sA,
+                                                          const float *__restrict__ B, int ldb, long long sB,
+                                                          const float *__restrict__ bias, long long sBias,
+                                                          float *__restrict__ C, int ldc, long long sC,
+                                                          int relu, int accumulate, int vecA, int vecB,
+                                                          const float *__restrict__ mask, int ldm, long long sM) {
+  // mask (the layer's forward output, for the ReLU backward): C = acc where mask > 0, else 0
+  __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  float va[8], vb[8];
+  gg_load<TA>(A, lda, M, m0, 0, K, tid, va, vecA);
+  gg_load<TB>(B, ldb, N, n0, 0, K, tid, vb, vecB);
+  gg_store<TA>(As, tid, va);
+  gg_store<TB>(Bs, tid, vb);
+  __syncthreads();
+  const int ro = (lane & 31) * G2_LD + 16 * (lane >> 5);
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += 32, buf ^= 1) {
+    const bool more = k0 + 32 < K;
+    if (more) {
+      gg_load<TA>(A, lda, M, m0, k0 + 32, K, tid, va, vecA);
+      gg_load<TB>(B, ldb, N, n0, k0 + 32, K, tid, vb, vecB);
+    }
+    const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
+    const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
+    float4 a4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      a4[j] = *reinterpret_cast<const float4 *>(as + 4 * j);
+      b4[j] = *reinterpret_cast<const float4 *>(bs + 4 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+    }
+    if (more) {
+      gg_store<TA>(As + (buf ^ 1) * 64 * G2_LD, tid, va);
+      gg_store<TB>(Bs + (buf ^ 1) * 64 * G2_LD, tid, vb);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+  const float bv = (bias && col < N) ? bias[(long long)blockIdx.z * sBias + col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      float *c = C + (long long)row * ldc + col;
+      float v = acc[r] + bv;
+      if (accumulate) v += *c;
+      if (relu) v = fmaxf(v, 0.f);
+      if (mask && !(mask[(long long)blockIdx.z * sM + (long long)row * ldm + col] > 0.f)) v = 0.f;
+      *c = v;
+    }
+  }
+}
+
 __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float *__restrict__ P,
                               float beta, float *__restrict__ C, int ldc) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

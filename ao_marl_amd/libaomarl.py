@@ -100,6 +100,13 @@ SYMBOLS = [
     ("aomarl_get_dm_shape", _i, _range + [_i, _vp, _vp]),
     ("aomarl_set_option", _i, [_vp, C.c_char_p, _i]),
     ("aomarl_target_psf", _i, _range + [_vp]),
+    ("aomarl_gemm_batched", _i, [_i, _i, _i, _i, _i, _i, _vp, _i, C.c_longlong, _vp, _i, C.c_longlong, _vp,
+                                 C.c_longlong, _vp, _i, C.c_longlong, _i, _i, _vp]),
+    ("aomarl_sac_layout", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("aomarl_sac_create", _i, [_vp, C.POINTER(C.c_void_p)]),
+    ("aomarl_sac_destroy", _i, [_vp]),
+    ("aomarl_sac_update", _i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, C.c_uint32,
+                               C.c_uint32, _i, _i, _vp, _vp]),
     ("aomarl_split_states", _i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("aomarl_policy_sample", _i, [_i, _i, _i, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp,
                                   _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
@@ -128,6 +135,21 @@ SYMBOLS = [
 ]
 
 _lib = None
+
+
+class SacDesc(C.Structure):
+    """aomarl_sac_desc (include/aomarl.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("n_agents", "batch", "in_max", "act_max", "hidden", "hidden_critic",
+                                         "n_hidden",
+                                         "state_dim", "action_dim")] + \
+               [("state_gather", C.c_void_p), ("action_gather", C.c_void_p), ("n_act", C.c_void_p),
+                ("target_entropy", C.c_void_p)] + \
+               [(n, C.c_float) for n in ("gamma", "tau", "lr", "beta1", "beta2", "adam_eps", "log_sig_min",
+                                         "log_sig_max", "action_scale", "action_bias")] + \
+               [(n, C.c_void_p) for n in ("policy", "policy_m", "policy_v", "policy_grad", "critic",
+                                          "critic_m", "critic_v", "critic_grad", "critic_target",
+                                          "log_alpha", "log_alpha_m", "log_alpha_v", "log_alpha_grad",
+                                          "alpha")]
 
 
 class AomarlError(RuntimeError):
@@ -338,4 +360,23 @@ def agent_rewards(res_modes, lohi_i32, factor):
     check(load().aomarl_agent_rewards(nenv, nm, A, res_modes.data_ptr(), res_modes.stride(0),
                                       lohi_i32.data_ptr(), float(factor), out.data_ptr(),
                                       _stream_of(res_modes)))
+    return out
+
+
+def gemm_batched(A, B, transA=False, transB=False, bias=None, relu=False, out=None, accumulate=False):
+    """act(opA(A) @ opB(B) + bias) for stacked matrices (aomarl_gemm_batched).  A: [b, M, K] or
+    [b, K, M] (transA); B: [b, N, K] or [b, K, N] (transB); bias [b, N]; returns [b, M, N]."""
+    import torch
+    assert A.stride(2) == 1 and B.stride(2) == 1
+    b = A.shape[0]
+    M, K = (A.shape[2], A.shape[1]) if transA else (A.shape[1], A.shape[2])
+    N = B.shape[2] if transB else B.shape[1]
+    assert (B.shape[1] if transB else B.shape[2]) == K and B.shape[0] == b
+    if out is None:
+        out = torch.empty(b, M, N, dtype=torch.float32, device=A.device)
+    check(load().aomarl_gemm_batched(
+            b, int(transA), int(transB), M, N, K, A.data_ptr(), A.stride(1), A.stride(0), B.data_ptr(),
+            B.stride(1), B.stride(0), bias.data_ptr() if bias is not None else None,
+            bias.stride(0) if bias is not None else 0, out.data_ptr(), out.stride(1), out.stride(0),
+            1 if relu else 0, 1 if accumulate else 0, _stream_of(A)))
     return out

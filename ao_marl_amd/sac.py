@@ -94,10 +94,151 @@ class BatchedReplay(object):
                              device=self.device)
 
 
-class BatchedSAC(object):
-    """Soft actor-critic for all agents of an AgentLayout at once."""
+class _StackedLinearHip(torch.autograd.Function):
+    """act(x W + b) for all agents at once on the library's batched GEMM (aomarl_gemm_batched):
+    x [A, B, in], W [A, in, out], b [A, 1, out].  Backward: dx = dy W^T, dW = x^T dy, db = sum dy,
+    the same three products autograd derives for torch.baddbmm."""
 
-    def __init__(self, layout, config=None, seed=1234, device="cuda:0", memory_size=None):
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        from . import libaomarl as L
+        x, W = x.contiguous(), W.contiguous()
+        y = L.gemm_batched(x, W, False, True, bias=b.reshape(b.shape[0], -1), relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, W, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import libaomarl as L
+        x, W, y = ctx.saved_tensors
+        dy = dy * (y > 0) if ctx.relu else dy.contiguous()
+        dx = L.gemm_batched(dy, W, False, False) if ctx.needs_input_grad[0] else None
+        dW = L.gemm_batched(x, dy, True, True) if ctx.needs_input_grad[1] else None
+        db = dy.sum(dim=1, keepdim=True) if ctx.needs_input_grad[2] else None
+        return dx, dW, db, None
+
+
+def stacked_linear(x, W, b, relu):
+    """One layer of every agent's network.  On the GPU: the HIP batched GEMM (rocBLAS / hipBLASLt
+    pick a 256x256 macro-tile for these 14-matrix batches and run them on 14 CUs); on the CPU (the
+    golden tests of the update rule) plain torch."""
+    if x.is_cuda:
+        return _StackedLinearHip.apply(x, W, b, relu)
+    y = torch.baddbmm(b, x, W)
+    return torch.relu(y) if relu else y
+
+
+def flat_layout(A, I, Na, H, Hc, L):
+    """Offsets (floats) of the stacked tensors inside the flat policy / critic buffers -- the
+    layout aomarl_sac_layout (include/aomarl.h) prescribes: every tensor starts on a multiple of 4
+    floats.  Returns (policy_off [2L + 2], policy_len, critic_off [4], critic_len)."""
+    def lay(sizes):
+        off, o = [], 0
+        for n in sizes:
+            off.append(o)
+            o = (o + n + 3) // 4 * 4
+        return off, o
+    po, plen = lay([A * I * H, A * H] + [A * H * H, A * H] * (L - 1) + [A * H * 2 * Na, A * 2 * Na])
+    co, clen = lay([A * (I + Na) * 2 * Hc, A * 2 * Hc, A * 2 * Hc, A * 2])
+    return po, plen, co, clen
+
+
+class NativeUpdater(object):
+    """Handle on the library's SAC update (aomarl_sac_create / aomarl_sac_update) for one batch
+    size, working in place on a BatchedSAC's flat parameter buffers.  Adam moments and the
+    gradients of the last update are tensors of this object (policy_grad, critic_grad, la_grad)."""
+
+    def __init__(self, sac, batch):
+        import ctypes as C
+        import numpy as np
+        from . import libaomarl as L
+        self.L, self.sac, self.batch = L, sac, int(batch)
+        lib = L.load()
+        p, lay = sac.policy, sac.layout
+        A, dev = sac.A, sac.device
+        sg = p.gather.cpu().numpy().astype(np.int32)
+        sg[sg >= lay.state_dim] = -1
+        ag = np.full((A, sac.act_max), -1, dtype=np.int32)
+        for i, (w, (lo, hi)) in enumerate(lay.action_slices.items()):
+            ag[i, :hi - lo] = np.arange(lo, hi)
+        nact = np.asarray(sac.acts, dtype=np.int32)
+        te = sac.target_entropy.reshape(-1).cpu().numpy().astype(np.float32)
+        self._keep = (sg, ag, nact, te)
+
+        def z(n):
+            return torch.zeros(n, dtype=torch.float32, device=dev)
+        np_, nc = sac._pflat.numel(), sac._cflat.numel()
+        self.policy_m, self.policy_v, self.policy_grad = z(np_), z(np_), z(np_)
+        self.critic_m, self.critic_v, self.critic_grad = z(nc), z(nc), z(nc)
+        self.la_m, self.la_v, self.la_grad = z(A), z(A), z(A)
+        d = L.SacDesc()
+        d.n_agents, d.batch, d.in_max, d.act_max = A, self.batch, sac.in_max, sac.act_max
+        d.hidden, d.hidden_critic, d.n_hidden = p.H, sac.Hc, p.L
+        d.state_dim, d.action_dim = lay.state_dim, lay.action_dim
+        d.state_gather, d.action_gather = sg.ctypes.data, ag.ctypes.data
+        d.n_act, d.target_entropy = nact.ctypes.data, te.ctypes.data
+        d.gamma, d.tau, d.lr = sac.gamma, sac.tau, sac.lr
+        d.beta1, d.beta2, d.adam_eps = 0.9, 0.999, 1e-8              # torch.optim.Adam defaults
+        d.log_sig_min, d.log_sig_max = LOG_SIG_MIN, p.log_sig_max
+        d.action_scale, d.action_bias = p.scale, p.bias
+        d.policy, d.policy_m, d.policy_v, d.policy_grad = [t.data_ptr() for t in (
+                sac._pflat, self.policy_m, self.policy_v, self.policy_grad)]
+        d.critic, d.critic_m, d.critic_v, d.critic_grad = [t.data_ptr() for t in (
+                sac._cflat, self.critic_m, self.critic_v, self.critic_grad)]
+        d.critic_target = sac._ctflat.data_ptr()
+        d.log_alpha, d.log_alpha_m, d.log_alpha_v, d.log_alpha_grad = [t.data_ptr() for t in (
+                sac.log_alpha, self.la_m, self.la_v, self.la_grad)]
+        d.alpha = sac.alpha.data_ptr()
+        po = (C.c_longlong * (2 * p.L + 2))()
+        co = (C.c_longlong * 4)()
+        pl, cl = C.c_longlong(), C.c_longlong()
+        L.check(lib.aomarl_sac_layout(C.byref(d), po, co, C.byref(pl), C.byref(cl)))
+        if (list(po), pl.value, list(co), cl.value) != (sac._poff, np_, sac._coff, nc):
+            raise L.AomarlError("flat parameter layout of the binding differs from the library's")
+        h = C.c_void_p()
+        L.check(lib.aomarl_sac_create(C.byref(d), C.byref(h)))
+        self.handle, self.lib = h, lib
+        self.losses = torch.zeros(5, A, dtype=torch.float32, device=dev)
+
+    def update(self, idx=None, eps_next=None, eps_pi=None):
+        """One update of every agent on rows of sac.memory (idx [A, B] int64, default: drawn in the
+        kernel); returns the [5, A] loss log (q1, q2, policy, alpha, alpha value)."""
+        sac, m = self.sac, self.sac.memory
+        step = sac.total_update + 1
+        flags = (1 if step % sac.target_update_interval == 0 else 0) | \
+                (2 if sac.automatic_entropy_tuning else 0)
+        for t in (idx, eps_next, eps_pi):
+            assert t is None or (t.is_contiguous() and t.is_cuda)
+        assert idx is None or (idx.dtype == torch.int64 and tuple(idx.shape) == (sac.A, self.batch))
+
+        def ptr(t):
+            return t.data_ptr() if t is not None else None
+        self.L.check(self.lib.aomarl_sac_update(
+                self.handle, m.state.data_ptr(), m.next_state.data_ptr(), m.action.data_ptr(),
+                m.reward.data_ptr(), m.mask.data_ptr(), len(m), ptr(idx), ptr(eps_next), ptr(eps_pi),
+                sac.seed & 0xFFFFFFFF, step & 0xFFFFFFFF, step, flags, self.losses.data_ptr(),
+                self.L._stream_of(m.state)))
+        return self.losses
+
+    def __del__(self):
+        try:
+            self.lib.aomarl_sac_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class BatchedSAC(object):
+    """Soft actor-critic for all agents of an AgentLayout at once.
+
+    Parameters live in two flat buffers (policy, critic; plus the target critic) laid out as
+    aomarl_sac_layout prescribes; the per-tensor attributes (policy.W1 ... , critic[k]["Win"] ...)
+    are views of them.  On the GPU `update_from_memory` runs the library's hand-written update
+    (NativeUpdater); `update` is the torch-autograd statement of the same rule (the CPU golden
+    tests against the reference's update run on it, and the GPU tests check the two against each
+    other)."""
+
+    def __init__(self, layout, config=None, seed=1234, device="cuda:0", memory_size=None, native=None):
         cfg = dict(DEFAULT_SAC)
         cfg.update(config or {})
         self.cfg, self.layout, self.device = cfg, layout, torch.device(device)
@@ -135,11 +276,14 @@ class BatchedSAC(object):
                 Wout[i] = _xavier_uniform(g, 1, H).T
             self.critic.append(dict(Win=Win.to(dev), bin=torch.zeros(A, 1, H, device=dev),
                                     Wout=Wout.to(dev), bout=torch.zeros(A, 1, 1, device=dev)))
-        self.critic_target = [{k: v.clone() for k, v in q.items()} for q in self.critic]   # hard_update
+        self.Hc, self.seed = H, int(seed)
+        self._flatten_parameters()
         # ---- entropy temperature (initialise_alpha)
         self.target_entropy = -torch.tensor([float(a) for a in acts], device=dev).reshape(A, 1, 1)
         self.log_alpha = torch.zeros(A, 1, 1, device=dev)
         self.alpha = torch.full((A, 1, 1), float(cfg["alpha"]), device=dev)
+        self.native = (dev.type == "cuda") if native is None else bool(native)
+        self._updaters = {}
         # ---- optimisers (Adam is element-wise: one optimiser over stacked tensors == one per agent)
         for t in self._policy_params() + self._critic_params() + [self.log_alpha]:
             t.requires_grad_(True)
@@ -152,8 +296,80 @@ class BatchedSAC(object):
         self.gen = torch.Generator(device=dev).manual_seed(seed + 1)
         self.total_update = 0
         self.last_losses = None
+        self._started_torch = False
+        self.keep_grads, self.grad_log = False, None    # tests: gradients of the torch update
 
     # ------------------------------------------------------------------ parameters
+    def _flatten_parameters(self):
+        """Move the freshly initialised tensors into the flat buffers and replace them by views."""
+        p, A, dev = self.policy, self.A, self.device
+        I, Na, H, Hc, L = self.in_max, self.act_max, p.H, self.Hc, p.L
+        po, plen, co, clen = flat_layout(A, I, Na, H, Hc, L)
+        self._poff, self._coff = po, co
+        pf = torch.zeros(plen, dtype=torch.float32, device=dev)
+
+        def view(flat, off, *shape):
+            n = 1
+            for k in shape:
+                n *= k
+            return flat[off:off + n].view(*shape)
+
+        def adopt(dst, src):
+            dst.copy_(src)
+            return dst
+        p.W1 = adopt(view(pf, po[0], A, I, H), p.W1)
+        p.b1 = adopt(view(pf, po[1], A, 1, H), p.b1)
+        p.Wh = [adopt(view(pf, po[2 * l], A, H, H), p.Wh[l - 1]) for l in range(1, L)]
+        p.bh = [adopt(view(pf, po[2 * l + 1], A, 1, H), p.bh[l - 1]) for l in range(1, L)]
+        whead, bhead = view(pf, po[2 * L], A, H, 2 * Na), view(pf, po[2 * L + 1], A, 1, 2 * Na)
+        p.Wm, p.Ws = adopt(whead[:, :, :Na], p.Wm), adopt(whead[:, :, Na:], p.Ws)
+        p.bm, p.bs = adopt(bhead[:, :, :Na], p.bm), adopt(bhead[:, :, Na:], p.bs)
+        p._native = None
+        cf = torch.zeros(clen, dtype=torch.float32, device=dev)
+
+        def critic_views(flat):
+            win, bin_ = view(flat, co[0], A, I + Na, 2 * Hc), view(flat, co[1], A, 1, 2 * Hc)
+            wout, bout = view(flat, co[2], A, 2, Hc), view(flat, co[3], A, 2)
+            return [dict(Win=win[:, :, k * Hc:(k + 1) * Hc], bin=bin_[:, :, k * Hc:(k + 1) * Hc],
+                         Wout=wout[:, k, :].unsqueeze(2), bout=bout[:, k].reshape(A, 1, 1))
+                    for k in range(2)]
+        new = critic_views(cf)
+        for qn, q in zip(new, self.critic):
+            for k in qn:
+                qn[k].copy_(q[k])
+        self.critic = new
+        ctf = cf.clone()                                                    # hard_update
+        self.critic_target = critic_views(ctf)
+        self._pflat, self._cflat, self._ctflat = pf, cf, ctf
+
+    def updater(self, batch_size):
+        """The native update for this batch size (created on first use)."""
+        if not self.native:
+            raise RuntimeError("this BatchedSAC was built with native=False")
+        if self._started_torch:
+            raise RuntimeError("the torch-autograd update already ran on this object: its Adam "
+                               "state and the library's are separate")
+        u = self._updaters.get(int(batch_size))
+        if u is None:
+            u = self._updaters[int(batch_size)] = NativeUpdater(self, batch_size)
+            if len(self._updaters) > 1:
+                raise RuntimeError("one batch size per BatchedSAC on the native path (the Adam "
+                                   "moments belong to the updater)")
+        return u
+
+    def update_from_memory(self, batch_size=None, idx=None, eps_next=None, eps_pi=None):
+        """One update of every agent on a batch drawn from self.memory: the library's update on the
+        GPU, the torch statement of it otherwise."""
+        batch_size = batch_size or self.cfg["batch_size"]
+        if self.native:
+            u = self.updater(batch_size)
+            lo = u.update(idx, eps_next, eps_pi)
+            self.total_update += 1
+            self.policy._native = None            # inference copies of the weights are stale
+            self.last_losses = dict(q1=lo[0], q2=lo[1], policy=lo[2], alpha=lo[3], alpha_value=lo[4])
+            return self.last_losses
+        return self.update(*self.batch_from_memory(batch_size, idx), eps_next=eps_next, eps_pi=eps_pi)
+
     def _policy_params(self):
         p = self.policy
         return [p.W1, p.b1] + list(p.Wh) + list(p.bh) + [p.Wm, p.bm, p.Ws, p.bs]
@@ -222,11 +438,11 @@ class BatchedSAC(object):
     # ------------------------------------------------------------------ networks (autograd path)
     def _policy_forward(self, x):
         p = self.policy
-        h = torch.relu(torch.baddbmm(p.b1, x, p.W1))
+        h = stacked_linear(x, p.W1, p.b1, True)
         for W, b in zip(p.Wh, p.bh):
-            h = torch.relu(torch.baddbmm(b, h, W))
-        mean = torch.baddbmm(p.bm, h, p.Wm)
-        log_std = torch.baddbmm(p.bs, h, p.Ws).clamp(LOG_SIG_MIN, p.log_sig_max)
+            h = stacked_linear(h, W, b, True)
+        mean = stacked_linear(h, p.Wm, p.bm, False)
+        log_std = stacked_linear(h, p.Ws, p.bs, False).clamp(LOG_SIG_MIN, p.log_sig_max)
         return mean, log_std
 
     def sample(self, x, eps=None):
@@ -253,14 +469,18 @@ class BatchedSAC(object):
         xa = torch.cat([x, a], dim=2)
         out = []
         for q in qs:
-            h = torch.relu(torch.baddbmm(q["bin"], xa, q["Win"]))
-            out.append(torch.baddbmm(q["bout"], h, q["Wout"]))
+            h = stacked_linear(xa, q["Win"], q["bin"], True)
+            out.append(stacked_linear(h, q["Wout"], q["bout"], False))
         return out[0], out[1]
 
     # ------------------------------------------------------------------ one update
     def update(self, x, a, r, x2, mask, eps_next=None, eps_pi=None):
         """update_critic -> update_actor -> update_alpha -> soft_update for every agent.
         x, x2 [A, B, in_max]; a [A, B, act_max]; r, mask [A, B, 1].  Returns per-agent losses."""
+        if self._updaters:
+            raise RuntimeError("the native update already ran on this object: its Adam state and "
+                               "torch's are separate")
+        self._started_torch = True
         # ---- critic                                                     train_rpc.py:985-1038
         with torch.no_grad():
             a2, logp2, _ = self.sample(x2, eps_next)
@@ -272,6 +492,9 @@ class BatchedSAC(object):
         q2_loss = ((q2 - target) ** 2).mean(dim=(1, 2))
         self.critic_optim.zero_grad(set_to_none=True)
         (q1_loss + q2_loss).sum().backward()
+        if self.keep_grads:
+            self.grad_log = dict(critic={k: [q[k].grad.clone() for q in self.critic]
+                                         for k in ("Win", "bin", "Wout", "bout")})
         self.critic_optim.step()
         # ---- actor                                                      train_rpc.py:1044-1064
         pi, log_pi, _ = self.sample(x, eps_pi)
@@ -279,6 +502,8 @@ class BatchedSAC(object):
         policy_loss = (self.alpha * log_pi - torch.min(q1p, q2p)).mean(dim=(1, 2))
         self.policy_optim.zero_grad(set_to_none=True)
         policy_loss.sum().backward()
+        if self.keep_grads:
+            self.grad_log["policy"] = [t.grad.clone() for t in self._policy_params()]
         self.policy_optim.step()
         self.policy._native = None                # inference copies of the weights are stale
         # ---- temperature                                                train_rpc.py:1070-1084
@@ -286,8 +511,10 @@ class BatchedSAC(object):
             alpha_loss = -(self.log_alpha * (log_pi + self.target_entropy).detach()).mean(dim=(1, 2))
             self.alpha_optim.zero_grad(set_to_none=True)
             alpha_loss.sum().backward()
+            if self.keep_grads:
+                self.grad_log["log_alpha"] = self.log_alpha.grad.clone()
             self.alpha_optim.step()
-            self.alpha = self.log_alpha.detach().exp()
+            self.alpha.copy_(self.log_alpha.detach().exp())
         else:
             alpha_loss = torch.zeros(self.A, device=self.device)
         # ---- target network                                             train_rpc.py:1128-1129
@@ -307,10 +534,11 @@ class BatchedSAC(object):
         """[n, A] -> [A, n, 1]"""
         return reward.T.unsqueeze(2).contiguous()
 
-    def batch_from_memory(self, batch_size):
+    def batch_from_memory(self, batch_size, idx=None):
         """Independent index set per agent -> tensors in the layout `update` takes."""
         m, p = self.memory, self.policy
-        idx = m.sample_indices(self.A, batch_size)                           # [A, B]
+        if idx is None:
+            idx = m.sample_indices(self.A, batch_size)                       # [A, B]
         flat = idx.reshape(-1)
 
         def gather_state(buf):
@@ -352,7 +580,7 @@ class BatchedSAC(object):
                 self.memory.push(*master.rows(moved, n))
                 moved += n
             if len(self.memory) > batch_size:
-                self.update(*self.batch_from_memory(batch_size))
+                self.update_from_memory(batch_size)
                 done += 1
         return done
 

@@ -253,6 +253,61 @@ int aomarl_target_psf(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_
 int aomarl_frame_fused_available(aomarl_ctx *ctx);
 int aomarl_frame_fused(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int flags,
                        void *stream);
+/* General batched fp32 GEMM (forward and backward passes of the stacked SAC networks):
+ * C[b] = act(opA(A[b]) . opB(B[b]) + bias[b]) (+ C[b] if accumulate); opA(A) is M x K (stored [M][K],
+ * or [K][M] when transA), opB(B) is K x N (stored [N][K], or [K][N] when transB).
+ * y = x W, dx = dy W^T, dW = x^T dy of a layer with W stored [in][out] are (0,1), (0,0), (1,1). */
+int aomarl_gemm_batched(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
+                        long long strideA, const float *B, int ldb, long long strideB, const float *bias,
+                        long long strideBias, float *C, int ldc, long long strideC, int relu,
+                        int accumulate, void *stream);
+/* ---- multi-agent soft actor-critic update (the learner side of the path) --------
+ * One call = update_critic -> update_actor -> update_alpha -> soft_update of EVERY agent on one
+ * replay batch per agent (reference: SAC.update_critic / update_actor / update_alpha / soft_update,
+ * src/reinforcement_learning/rpc_training/train_rpc.py:985-1038, 1044-1064, 1070-1084, 1128-1129,
+ * networks src/reinforcement_learning/rpc_training/model_rpc.py:60-160), forward AND hand-derived
+ * backward passes on the batched MFMA GEMM, Adam (torch.optim.Adam defaults) and the target update
+ * fused into one kernel per parameter set.
+ *
+ * Parameters live in caller-owned flat device buffers (zero-padded per agent, fp32):
+ *   policy : W1 [A][in_max][H], b1 [A][H], (Wh [A][H][H], bh [A][H]) x (n_hidden - 1),
+ *            Whead [A][H][2 act_max] (mean | log_std columns), bhead [A][2 act_max]
+ *   critic : Win [A][in_max + act_max][2 Hc] (Q1 | Q2 columns; rows: state then action),
+ *            bin [A][2 Hc], Wout [A][2][Hc], bout [A][2]
+ * each tensor starting on a multiple of 4 floats (aomarl_sac_layout returns the offsets). */
+typedef struct {
+  int32_t n_agents, batch, in_max, act_max, hidden, hidden_critic, n_hidden;
+  int32_t state_dim, action_dim;         /* row lengths of the replay ring */
+  const int32_t *state_gather;           /* host [A][in_max]: column of the state row, < 0 = zero pad */
+  const int32_t *action_gather;          /* host [A][act_max]: column of the action row, < 0 = pad */
+  const int32_t *n_act;                  /* host [A]: live action columns of each agent */
+  const float *target_entropy;           /* host [A] */
+  float gamma, tau, lr, beta1, beta2, adam_eps;
+  float log_sig_min, log_sig_max, action_scale, action_bias;
+  /* device buffers, caller-owned: parameters, Adam moments (m, v: zero before the first update) and
+   * the gradients of the last update (written by every call, laid out like the parameters) */
+  float *policy, *policy_m, *policy_v, *policy_grad;                  /* policy_len floats each */
+  float *critic, *critic_m, *critic_v, *critic_grad, *critic_target;  /* critic_len floats each */
+  float *log_alpha, *log_alpha_m, *log_alpha_v, *log_alpha_grad, *alpha;   /* [A] each */
+} aomarl_sac_desc;
+typedef struct aomarl_sac aomarl_sac;
+#define AOMARL_SAC_SOFT_UPDATE 1      /* target <- (1 - tau) target + tau critic after the critic step */
+#define AOMARL_SAC_TUNE_ALPHA 2       /* automatic entropy tuning */
+/* offsets (floats) of the tensors inside the flat buffers; policy_off [2 n_hidden + 2] in the order
+ * above, critic_off [4]; returns the two lengths. */
+int aomarl_sac_layout(const aomarl_sac_desc *d, long long *policy_off, long long *critic_off,
+                      long long *policy_len, long long *critic_len);
+int aomarl_sac_create(const aomarl_sac_desc *d, aomarl_sac **out);
+int aomarl_sac_destroy(aomarl_sac *s);
+/* replay ring: state / next_state [rows][state_dim], action [rows][action_dim], reward [rows][A],
+ * mask [rows].  idx: device [A][batch] row numbers (int64), or NULL: drawn uniformly in
+ * [0, replay_rows) from Philox (seed, counter).  eps_next / eps_pi: device [A][batch][act_max]
+ * standard-normal draws, or NULL: Philox (seed, counter).  adam_step: 1-based update count.
+ * losses: device [5][A] (q1, q2, policy, alpha losses, alpha value) or NULL. */
+int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state, const float *action,
+                      const float *reward, const float *mask, long long replay_rows, const int64_t *idx,
+                      const float *eps_next, const float *eps_pi, uint32_t seed, uint32_t counter,
+                      int adam_step, int flags, float *losses, void *stream);
 /* ---- agent-side glue, all device pointers, no context (fused chains of the tiny host operations
  * the reference does per agent per step):
  * aomarl_split_states   TrainerRPC.divide_states_for_agents (train_rpc.py:418-427):

@@ -203,3 +203,136 @@ def test_training_episode_on_the_gpu_and_update_rate():
     print("SAC update, 14 agents x batch 256: %.2f ms per update (%.0f agent-updates/s)" %
           (dt * 1e3, 14 / dt))
     assert torch.isfinite(big.last_losses["q1"]).all()
+
+
+def _twin_sacs(lay, cfg, rows, seed=3):
+    """A native and a torch-autograd BatchedSAC with identical parameters and replay contents."""
+    import torch
+    from ao_marl_amd.sac import BatchedSAC
+    cfg = dict(dict(memory_size=rows, initialize_last_layer_0=False), **cfg)
+    nat = BatchedSAC(lay, cfg, seed=seed, device="cuda:0", native=True)
+    ref = BatchedSAC(lay, cfg, seed=seed, device="cuda:0", native=False)
+    assert torch.equal(nat._pflat, ref._pflat) and torch.equal(nat._cflat, ref._cflat)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():               # biases and the twin critics away from their symmetric start
+        for s in (nat, ref):
+            s._pflat.add_(0.02 * torch.randn(s._pflat.shape, generator=torch.Generator(device="cuda").manual_seed(9), device="cuda") * (s._pflat != 0))
+        nat_b = 0.05 * torch.randn(nat._pflat.shape, generator=g, device="cuda")
+        for s in (nat, ref):
+            for b in [s.policy.b1] + s.policy.bh:
+                b.copy_(nat_b[:b.numel()].view(b.shape))
+            s.policy.bm.copy_((0.1 * nat_b[:s.policy.bm.numel()].view(s.policy.bm.shape)) * s.act_mask)
+            s.policy.bs.copy_((0.1 * nat_b[7:7 + s.policy.bs.numel()].view(s.policy.bs.shape) - 1.0) * s.act_mask)
+            for k, q in enumerate(s.critic):
+                q["bin"].copy_(nat_b[11 + k:11 + k + q["bin"].numel()].view(q["bin"].shape))
+                q["bout"].fill_(0.1 * (k + 1))
+            s._ctflat.copy_(s._cflat * 0.9)
+    data = (torch.randn(rows, lay.state_dim, generator=g, device="cuda"),
+            torch.rand(rows, lay.action_dim, generator=g, device="cuda") * 2 - 1,
+            -torch.rand(rows, lay.n_agents, generator=g, device="cuda"),
+            torch.randn(rows, lay.state_dim, generator=g, device="cuda"),
+            (torch.rand(rows, generator=g, device="cuda") > 0.1).float())
+    for s in (nat, ref):
+        s.memory.push(*data)
+    return nat, ref, g
+
+
+def _grad_views(sac, u):
+    """The updater's flat gradient buffers cut into the tensors of the torch path."""
+    p, A = sac.policy, sac.A
+    I, Na, H, Hc, L = sac.in_max, sac.act_max, p.H, sac.Hc, p.L
+    po, co = sac._poff, sac._coff
+
+    def v(flat, off, *shape):
+        n = 1
+        for k in shape:
+            n *= k
+        return flat[off:off + n].view(*shape)
+    gp = u.policy_grad
+    head, bhead = v(gp, po[2 * L], A, H, 2 * Na), v(gp, po[2 * L + 1], A, 1, 2 * Na)
+    pol = [v(gp, po[0], A, I, H), v(gp, po[1], A, 1, H)] + \
+          [v(gp, po[2 * l], A, H, H) for l in range(1, L)] + \
+          [v(gp, po[2 * l + 1], A, 1, H) for l in range(1, L)] + \
+          [head[:, :, :Na], bhead[:, :, :Na], head[:, :, Na:], bhead[:, :, Na:]]
+    gc = u.critic_grad
+    win, bin_ = v(gc, co[0], A, I + Na, 2 * Hc), v(gc, co[1], A, 1, 2 * Hc)
+    wout, bout = v(gc, co[2], A, 2, Hc), v(gc, co[3], A, 2)
+    cri = dict(Win=[win[:, :, k * Hc:(k + 1) * Hc] for k in range(2)],
+               bin=[bin_[:, :, k * Hc:(k + 1) * Hc] for k in range(2)],
+               Wout=[wout[:, k, :].unsqueeze(2) for k in range(2)],
+               bout=[bout[:, k].reshape(A, 1, 1) for k in range(2)])
+    return pol, cri
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["two_layer", "one_layer_wide_critic", "three_layer_fixed_alpha", "production"])
+def test_native_update_matches_the_autograd_update(case):
+    """aomarl_sac_update (hand-written forward + backward + Adam + soft update) against the torch
+    autograd statement of the update on the same replay rows and the same normal draws: gradients of
+    the first update, then parameters, temperature and losses over several updates."""
+    import torch
+    cfg, B, n_upd = {}, 64, 4
+    lay = _layout()
+    if case == "one_layer_wide_critic":
+        cfg = dict(num_layers_actor=1, hidden_size_actor=64, hidden_size_critic=192, gamma=0.5)
+        B = 37
+    elif case == "three_layer_fixed_alpha":
+        cfg = dict(num_layers_actor=3, hidden_size_actor=128, hidden_size_critic=64,
+                   automatic_entropy_tuning=False, target_update_interval=2, alpha=0.3)
+    elif case == "production":
+        lay = AgentLayout(1283, [0, 1274], 13, include_tip_tilt=True, window_n_zernike=20,
+                          include_tip_tilt_windowed=True, n_filtered=5)
+        B, n_upd = 256, 2
+    nat, ref, g = _twin_sacs(lay, cfg, rows=700)
+    ref.keep_grads = True
+    A, Na = nat.A, nat.act_max
+    for it in range(n_upd):
+        idx = torch.randint(0, 700, (A, B), generator=g, device="cuda")
+        e2 = torch.randn(A, B, Na, generator=g, device="cuda")
+        e1 = torch.randn(A, B, Na, generator=g, device="cuda")
+        ln = nat.update_from_memory(B, idx, e2, e1)
+        lr = ref.update(*ref.batch_from_memory(B, idx), eps_next=e2, eps_pi=e1)
+        if it == 0:
+            u = nat.updater(B)
+            pol, cri = _grad_views(nat, u)
+            for name in cri:
+                for k in range(2):
+                    want = ref.grad_log["critic"][name][k]
+                    err = (cri[name][k] - want).abs().max().item()
+                    assert err < 2e-4 * want.abs().max().item() + 1e-7, (name, k, err)
+            for i, (got, want) in enumerate(zip(pol, ref.grad_log["policy"])):
+                err = (got - want).abs().max().item()
+                assert err < 5e-4 * want.abs().max().item() + 1e-8, (i, err)
+            if ref.automatic_entropy_tuning:
+                assert torch.allclose(u.la_grad, ref.grad_log["log_alpha"].reshape(-1), rtol=1e-4, atol=1e-6)
+        for k in ("q1", "q2", "policy", "alpha", "alpha_value"):
+            assert torch.allclose(ln[k].reshape(-1), lr[k].reshape(-1), rtol=2e-3, atol=2e-4), (it, k)
+    # Adam's first steps are ~ lr * sign(g): a few lr is the resolution of a parameter comparison
+    tol = 3 * nat.lr
+    assert (nat._pflat - ref._pflat).abs().max().item() < tol
+    assert (nat._cflat - ref._cflat).abs().max().item() < tol
+    assert (nat._ctflat - ref._ctflat).abs().max().item() < tol
+    assert (nat._pflat - ref._pflat).abs().mean().item() < 0.02 * nat.lr
+    assert (nat._cflat - ref._cflat).abs().mean().item() < 0.02 * nat.lr
+    assert torch.allclose(nat.alpha, ref.alpha, rtol=1e-4)
+    assert nat.total_update == ref.total_update == n_upd
+
+
+@pytest.mark.gpu
+def test_native_update_draws_its_own_rows_and_noise():
+    """Without idx / eps the kernels draw rows and normals from Philox (seed, update count):
+    reproducible bit for bit, different from one update to the next, finite."""
+    import torch
+    a1, _, _ = _twin_sacs(_layout(), {}, rows=500, seed=5)
+    a2, _, _ = _twin_sacs(_layout(), {}, rows=500, seed=5)
+    p0 = a1._pflat.clone()
+    for _ in range(3):
+        l1 = a1.update_from_memory(128)
+        l2 = a2.update_from_memory(128)
+    assert torch.equal(a1._pflat, a2._pflat) and torch.equal(a1._cflat, a2._cflat)
+    assert all(torch.equal(l1[k], l2[k]) for k in l1)
+    assert all(torch.isfinite(v).all() for v in l1.values())
+    assert (a1._pflat - p0).abs().max().item() > 1e-5
+    first = a1.update_from_memory(128)["q1"].clone()
+    second = a1.update_from_memory(128)["q1"].clone()
+    assert not torch.equal(first, second)
