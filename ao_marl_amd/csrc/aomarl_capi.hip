@@ -818,7 +818,13 @@ int aomarl_get_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, int k, fl
 }
 
 int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
-  if (!c || !name) return fail("set_option: null argument");
+  if (!name) return fail("set_option: null argument");
+  if (!strcmp(name, "gemm_kgroups")) {          // process-wide, no context needed
+    if (value != 0 && value != 1 && value != 2 && value != 4) return fail("gemm_kgroups: 0, 1, 2 or 4");
+    g_gemm_kgroups = value;
+    return 0;
+  }
+  if (!c) return fail("set_option: null context");
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
@@ -1516,6 +1522,28 @@ int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int l
   return 0;
 }
 
+
+template <bool TA, bool TB, int G>
+static int gemm_batched_launch_g(dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
+                                 long long strideA, const float *B, int ldb, long long strideB,
+                                 const float *bias, long long strideBias, float *C, int ldc, long long strideC,
+                                 int relu, int accumulate, int vecA, int vecB, const float *mask, int ldm,
+                                 long long strideM) {
+  static bool attr_done = false;
+  const size_t smem = (size_t)G * 4 * 64 * G2_LD * sizeof(float);
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_gemm_batched_gen<TA, TB, G>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  const int ntile = (int)(grid.x * grid.y * grid.z);
+  hipLaunchKernelGGL((k_gemm_batched_gen<TA, TB, G>), dim3((ntile + 7) / 8 * 8), dim3(256 * G), smem, s, M, N, K, A,
+                     lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc, strideC, relu, accumulate, vecA, vecB,
+                     mask, ldm, strideM, (int)grid.x, (int)grid.y, ntile);
+  LAUNCHCHK();
+  return 0;
+}
+
 static int gemm_batched_launch(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
                                long long strideA, const float *B, int ldb, long long strideB,
                                const float *bias, long long strideBias, float *C, int ldc, long long strideC,
@@ -1525,13 +1553,16 @@ static int gemm_batched_launch(int batch, int transA, int transB, int M, int N, 
   // 128-bit loads only where every row of every matrix of the batch starts on a 16-byte boundary
   const int vecA = !((uintptr_t)A & 15) && !(strideA & 3) && !(lda & 3);
   const int vecB = !((uintptr_t)B & 15) && !(strideB & 3) && !(ldb & 3);
-  dim3 grid((N + 63) / 64, (M + 63) / 64, batch), blk(256);
-#define GG(TA, TB) hipLaunchKernelGGL((k_gemm_batched_gen<TA, TB>), grid, blk, 0, s, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc, strideC, relu, accumulate, vecA, vecB, mask, ldm, strideM)
-  if (transA) { if (transB) GG(true, true); else GG(true, false); }
-  else { if (transB) GG(false, true); else GG(false, false); }
+  dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+  const int nslab = (K + 31) / 32;
+  // measured on the SAC update (tools/gemm_bench.py, tools/time_sac.py): 2 groups (74 KB of LDS, two
+  // tiles per CU, so kernels of the update's two streams can share a CU) beat 1 and 4
+  int G = g_gemm_kgroups ? g_gemm_kgroups : (nslab >= 2 ? 2 : 1);
+#define GG(TA, TB, GN) gemm_batched_launch_g<TA, TB, GN>(grid, s, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc, strideC, relu, accumulate, vecA, vecB, mask, ldm, strideM)
+#define GT(GN) (transA ? (transB ? GG(true, true, GN) : GG(true, false, GN)) : (transB ? GG(false, true, GN) : GG(false, false, GN)))
+  return G == 4 ? GT(4) : (G == 2 ? GT(2) : GT(1));
+#undef GT
 #undef GG
-  LAUNCHCHK();
-  return 0;
 }
 
 int aomarl_gemm_batched(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,

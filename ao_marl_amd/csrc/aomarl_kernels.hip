@@ -435,60 +435,93 @@ __device__ __forceinline__ void gg_store(float *S, int tid, const float (&v)[8])
   }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_gemm_batched_gen(int M, int N, int K,
-                                                          const float *__restrict__ A, int lda, long long sA,
-                                                          const float *__restrict__ B, int ldb, long long sB,
-                                                          const float *__restrict__ bias, long long sBias,
-                                                          float *__restrict__ C, int ldc, long long sC,
-                                                          int relu, int accumulate, int vecA, int vecB,
-                                                          const float *__restrict__ mask, int ldm, long long sM) {
+// G k-groups of 4 waves share one 64 x 64 output tile: group g runs the K slabs g, g + G, ... through
+// its own double-buffered LDS stage, so G slabs are in flight per block (these products are small --
+// 224 tiles for the SAC layers -- and with one wave per SIMD every slab paid the full L2 / MALL
+// latency); the partial tiles are summed through LDS in a fixed order.
+template <bool TA, bool TB, int G>
+__global__ __launch_bounds__(256 * G) void k_gemm_batched_gen(int M, int N, int K,
+                                                              const float *__restrict__ A, int lda, long long sA,
+                                                              const float *__restrict__ B, int ldb, long long sB,
+                                                              const float *__restrict__ bias, long long sBias,
+                                                              float *__restrict__ C, int ldc, long long sC,
+                                                              int relu, int accumulate, int vecA, int vecB,
+                                                              const float *__restrict__ mask, int ldm, long long sM,
+                                                              int tn, int tm, int ntile) {
   // mask (the layer's forward output, for the ReLU backward): C = acc where mask > 0, else 0
-  __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2), so
+  // workgroup L runs tile (L % 8) * per + L / 8: the tiles of one matrix -- which share A rows and
+  // B columns -- land on one XCD and fetch them into its L2 once instead of once per XCD.
+  const int per = gridDim.x >> 3;
+  const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (w >= ntile) return;
+  const int bz = w / (tn * tm), wt = w - bz * (tn * tm);
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  float *As = gsm + grp * (4 * 64 * G2_LD), *Bs = As + 2 * 64 * G2_LD;
+  const int lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = (wt / tn) * 64, n0 = (wt % tn) * 64;
+  A += (long long)bz * sA; B += (long long)bz * sB; C += (long long)bz * sC;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const int nslab = (K + 31) / 32, nloop = (nslab + G - 1) / G;      // block-uniform trip count
   float va[8], vb[8];
-  gg_load<TA>(A, lda, M, m0, 0, K, tid, va, vecA);
-  gg_load<TB>(B, ldb, N, n0, 0, K, tid, vb, vecB);
-  gg_store<TA>(As, tid, va);
-  gg_store<TB>(Bs, tid, vb);
+  if (grp < nslab) {
+    gg_load<TA>(A, lda, M, m0, grp * 32, K, tid, va, vecA);
+    gg_load<TB>(B, ldb, N, n0, grp * 32, K, tid, vb, vecB);
+    gg_store<TA>(As, tid, va);
+    gg_store<TB>(Bs, tid, vb);
+  }
   __syncthreads();
   const int ro = (lane & 31) * G2_LD + 16 * (lane >> 5);
   int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += 32, buf ^= 1) {
-    const bool more = k0 + 32 < K;
-    if (more) {
-      gg_load<TA>(A, lda, M, m0, k0 + 32, K, tid, va, vecA);
-      gg_load<TB>(B, ldb, N, n0, k0 + 32, K, tid, vb, vecB);
+  for (int it = 0; it < nloop; it++, buf ^= 1) {
+    const int slab = it * G + grp;
+    const bool live = slab < nslab, more = slab + G < nslab;
+    if (more && !(relu & 512)) {
+      gg_load<TA>(A, lda, M, m0, (slab + G) * 32, K, tid, va, vecA);
+      gg_load<TB>(B, ldb, N, n0, (slab + G) * 32, K, tid, vb, vecB);
     }
-    const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
-    const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
-    float4 a4[4], b4[4];
+    if (live && !(relu & 256)) {
+      const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
+      const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
+      float4 a4[4], b4[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      a4[j] = *reinterpret_cast<const float4 *>(as + 4 * j);
-      b4[j] = *reinterpret_cast<const float4 *>(bs + 4 * j);
-    }
+      for (int j = 0; j < 4; j++) {
+        a4[j] = *reinterpret_cast<const float4 *>(as + 4 * j);
+        b4[j] = *reinterpret_cast<const float4 *>(bs + 4 * j);
+      }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+      for (int j = 0; j < 4; j++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+      }
     }
-    if (more) {
+    if (more && !(relu & 1024)) {
       gg_store<TA>(As + (buf ^ 1) * 64 * G2_LD, tid, va);
       gg_store<TB>(Bs + (buf ^ 1) * 64 * G2_LD, tid, vb);
     }
     __syncthreads();
   }
+  if (G > 1) {
+    // partial tiles of groups 1 .. G-1 -> LDS [g-1][r][256 threads]; group 0 adds them in order
+    if (grp > 0) {
+      float *red = gsm + (grp - 1) * (16 * 256);
+#pragma unroll
+      for (int r = 0; r < 16; r++) red[r * 256 + tid] = acc[r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < G; g++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] += gsm[(g - 1) * (16 * 256) + r * 256 + tid];
+  }
   const int col = n0 + wn * 32 + (lane & 31);
-  const float bv = (bias && col < N) ? bias[(long long)blockIdx.z * sBias + col] : 0.f;
+  const float bv = (bias && col < N) ? bias[(long long)bz * sBias + col] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -496,8 +529,8 @@ __global__ __launch_bounds__(256) void k_gemm_batched_gen(int M, int N, int K,
       float *c = C + (long long)row * ldc + col;
       float v = acc[r] + bv;
       if (accumulate) v += *c;
-      if (relu) v = fmaxf(v, 0.f);
-      if (mask && !(mask[(long long)blockIdx.z * sM + (long long)row * ldm + col] > 0.f)) v = 0.f;
+      if (relu & 1) v = fmaxf(v, 0.f);
+      if (mask && !(mask[(long long)bz * sM + (long long)row * ldm + col] > 0.f)) v = 0.f;
       *c = v;
     }
   }
@@ -546,6 +579,7 @@ __global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const f
 
 static bool g_gemm_legacy = false;    // "gemm_legacy" option: the un-pipelined kernels (A/B tests)
 static int g_gemm_target_blocks = 512;
+static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
 static bool g_gemm_inkernel_reduce = false;  // "gemm_inkernel_reduce": measured 4x SLOWER (per-block L2 write-back of __threadfence)
 #define G_COUNTERS 4096
 

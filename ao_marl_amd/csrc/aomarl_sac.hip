@@ -37,8 +37,13 @@ struct aomarl_sac {
   long long poff[2 * SAC_MAX_HIDDEN + 2], coff[4], plen, clen;
   int32_t *sg = nullptr, *ag = nullptr, *nact = nullptr;
   float *te = nullptr;
-  float *XA, *XP, *X2, *act[SAC_MAX_HIDDEN], *HD, *HQ, *HT, *DQ, *R, *MK, *LP2, *LPI, *SQ, *PL, *DPI, *DHD,
-      *dA[2], *gP, *gC, *gLA;        // gP / gC / gLA: the caller's gradient buffers
+  // act / HD: policy activations of the critic phase (on x'); act2 / HD2: of the actor phase (on x)
+  float *XA, *XP, *X2, *act[SAC_MAX_HIDDEN], *act2[SAC_MAX_HIDDEN], *HD, *HD2, *HQ, *HT, *DQ, *R, *MK, *LP2,
+      *LPI, *SQ, *PL, *DPI, *DHD, *dA[SAC_MAX_HIDDEN], *gP, *gC, *gLA;   // gP / gC / gLA: the caller's buffers
+  // side stream: work off the critical path (see aomarl_sac_update)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_hq = nullptr, ev_actor = nullptr, ev_done = nullptr, ev_d[SAC_MAX_HIDDEN + 1] = {};
+  bool serial = false;
   std::vector<void *> owned;
 };
 
@@ -360,6 +365,9 @@ __global__ __launch_bounds__(256) void k_sac_alpha(int B, int A, const float *__
 int aomarl_sac_destroy(aomarl_sac *s) {
   if (!s) return 0;
   for (void *p : s->owned) (void)hipFree(p);
+  if (s->side) (void)hipStreamDestroy(s->side);
+  for (hipEvent_t e : {s->ev_fork, s->ev_hq, s->ev_actor, s->ev_done}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_d) if (e) (void)hipEventDestroy(e);
   delete s;
   return 0;
 }
@@ -409,13 +417,22 @@ int aomarl_sac_create(const aomarl_sac_desc *d, aomarl_sac **out) {
   s->te = (float *)upload(d->target_entropy, sizeof(float) * A);
   const size_t AB = (size_t)A * B;
   s->XA = alloc(AB * s->ldx); s->XP = alloc(AB * s->ldx); s->X2 = alloc(AB * s->ldx);
-  for (int l = 0; l < SAC_MAX_HIDDEN; l++) s->act[l] = l < s->L ? alloc(AB * H) : nullptr;
-  s->HD = alloc(AB * s->ldhd); s->DHD = alloc(AB * s->ldhd);
+  for (int l = 0; l < SAC_MAX_HIDDEN; l++) {
+    s->act[l] = l < s->L ? alloc(AB * H) : nullptr;
+    s->act2[l] = l < s->L ? alloc(AB * H) : nullptr;
+    s->dA[l] = l < s->L ? alloc(AB * H) : nullptr;
+  }
+  s->HD = alloc(AB * s->ldhd); s->HD2 = alloc(AB * s->ldhd); s->DHD = alloc(AB * s->ldhd);
   s->HQ = alloc(AB * 2 * Hc); s->HT = alloc(AB * 2 * Hc);
   s->DQ = alloc(AB * 2); s->SQ = alloc(AB * 2);
   s->R = alloc(AB); s->MK = alloc(AB); s->LP2 = alloc(AB); s->LPI = alloc(AB); s->PL = alloc(AB);
   s->DPI = alloc(AB * s->ldna);
-  s->dA[0] = alloc(AB * H); s->dA[1] = alloc(AB * H);
+  if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) ok = false;
+  for (hipEvent_t *e : {&s->ev_fork, &s->ev_hq, &s->ev_actor, &s->ev_done})
+    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) ok = false;
+  for (int l = 0; l <= s->L; l++)
+    if (hipEventCreateWithFlags(&s->ev_d[l], hipEventDisableTiming) != hipSuccess) ok = false;
+  { const char *e = getenv("AOMARL_SAC_SERIAL"); s->serial = e && e[0] == '1'; }
   s->gP = d->policy_grad; s->gC = d->critic_grad; s->gLA = d->log_alpha_grad;
   if (!ok) { aomarl_sac_destroy(s); return fail("sac_create: device allocation failed"); }
   *out = s;
@@ -432,18 +449,18 @@ static AdamK sac_adam_consts(const aomarl_sac_desc &d, int step) {
 }
 
 // policy forward on the state columns of X: act[0..L-1] (ReLU) and HD = (mean | log_std)
-static int sac_policy_forward(aomarl_sac *s, const float *X, hipStream_t st) {
+static int sac_policy_forward(aomarl_sac *s, const float *X, float *const *act, float *HD, hipStream_t st) {
   const int A = s->A, B = s->B, I = s->I, H = s->H, Na = s->Na, L = s->L;
   const float *P = s->d.policy;
   if (gemm_batched_launch(A, 0, 1, B, H, I, X, s->ldx, (long long)B * s->ldx, P + s->poff[0], H,
-                          (long long)I * H, P + s->poff[1], H, s->act[0], H, (long long)B * H, 1, 0, nullptr,
+                          (long long)I * H, P + s->poff[1], H, act[0], H, (long long)B * H, 1, 0, nullptr,
                           0, 0, st)) return 1;
   for (int l = 1; l < L; l++)
-    if (gemm_batched_launch(A, 0, 1, B, H, H, s->act[l - 1], H, (long long)B * H, P + s->poff[2 * l], H,
-                            (long long)H * H, P + s->poff[2 * l + 1], H, s->act[l], H, (long long)B * H, 1, 0,
+    if (gemm_batched_launch(A, 0, 1, B, H, H, act[l - 1], H, (long long)B * H, P + s->poff[2 * l], H,
+                            (long long)H * H, P + s->poff[2 * l + 1], H, act[l], H, (long long)B * H, 1, 0,
                             nullptr, 0, 0, st)) return 1;
-  return gemm_batched_launch(A, 0, 1, B, 2 * Na, H, s->act[L - 1], H, (long long)B * H, P + s->poff[2 * L],
-                             2 * Na, (long long)H * 2 * Na, P + s->poff[2 * L + 1], 2 * Na, s->HD, s->ldhd,
+  return gemm_batched_launch(A, 0, 1, B, 2 * Na, H, act[L - 1], H, (long long)B * H, P + s->poff[2 * L],
+                             2 * Na, (long long)H * 2 * Na, P + s->poff[2 * L + 1], 2 * Na, HD, s->ldhd,
                              (long long)B * s->ldhd, 0, 0, nullptr, 0, 0, st);
 }
 
@@ -471,17 +488,35 @@ int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state
   float *C = d.critic, *P = d.policy;
   const long long sH = (long long)B * H;
 
+  // Two streams: `st` carries the critical path, `sd` everything that does not feed the next kernel
+  // on it -- the critic's own hidden layer (needs only the gathered batch), the actor-phase policy
+  // forward (the policy does not change during the critic update) and all weight / bias gradients
+  // of the policy.  These launches are 224 .. 448 tiles of one wave per SIMD with a few
+  // microseconds of fixed cost each: the two queues fill each other's gaps.
+  hipStream_t sd = s->serial ? st : s->side;
+#define SAC_REC(ev, q) do { if (!s->serial) HIPCHK(hipEventRecord(ev, q)); } while (0)
+#define SAC_WAIT(q, ev) do { if (!s->serial) HIPCHK(hipStreamWaitEvent(q, ev, 0)); } while (0)
   hipLaunchKernelGGL(k_sac_gather, dim3(B, A), w256, 0, st, B, I, Na, s->ldx, d.state_dim, d.action_dim, A,
                      s->sg, s->ag, state, next_state, action, reward, mask, replay_rows, idx, seed, counter,
                      s->XA, s->XP, s->X2, s->R, s->MK);
   LAUNCHCHK();
+  SAC_REC(s->ev_fork, st);
+  SAC_WAIT(sd, s->ev_fork);
+  // ---- side: Q(x, a) hidden layer, then pi(x) for the actor phase
+  if (sac_critic_hidden(s, s->XA, C, s->HQ, sd)) return 1;
+  SAC_REC(s->ev_hq, sd);
+  if (sac_policy_forward(s, s->XP, s->act2, s->HD2, sd)) return 1;
+  hipLaunchKernelGGL(k_sac_sample, rows4, w256, 0, sd, B, I, Na, s->ldx, s->ldhd, s->nact, s->HD2, eps_pi, seed,
+                     counter, 13u, d.log_sig_min, d.log_sig_max, d.action_scale, d.action_bias, s->XP, s->LPI);
+  LAUNCHCHK();
+  SAC_REC(s->ev_actor, sd);
   // ---------------- critic ----------------
-  if (sac_policy_forward(s, s->X2, st)) return 1;
+  if (sac_policy_forward(s, s->X2, s->act, s->HD, st)) return 1;
   hipLaunchKernelGGL(k_sac_sample, rows4, w256, 0, st, B, I, Na, s->ldx, s->ldhd, s->nact, s->HD, eps_next, seed,
                      counter, 12u, d.log_sig_min, d.log_sig_max, d.action_scale, d.action_bias, s->X2, s->LP2);
   LAUNCHCHK();
   if (sac_critic_hidden(s, s->X2, d.critic_target, s->HT, st)) return 1;
-  if (sac_critic_hidden(s, s->XA, C, s->HQ, st)) return 1;
+  SAC_WAIT(st, s->ev_hq);
   hipLaunchKernelGGL(k_sac_critic_head, rows4, w256, 0, st, B, Hc, s->HQ, s->HT, C + s->coff[2], C + s->coff[3],
                      d.critic_target + s->coff[2], d.critic_target + s->coff[3], s->R, s->MK, s->LP2, d.alpha,
                      d.gamma, s->DQ, s->SQ);
@@ -498,10 +533,7 @@ int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state
                      (flags & AOMARL_SAC_SOFT_UPDATE) ? (float4 *)d.critic_target : (float4 *)nullptr, ak, d.tau);
   LAUNCHCHK();
   // ---------------- actor ----------------
-  if (sac_policy_forward(s, s->XP, st)) return 1;
-  hipLaunchKernelGGL(k_sac_sample, rows4, w256, 0, st, B, I, Na, s->ldx, s->ldhd, s->nact, s->HD, eps_pi, seed,
-                     counter, 13u, d.log_sig_min, d.log_sig_max, d.action_scale, d.action_bias, s->XP, s->LPI);
-  LAUNCHCHK();
+  SAC_WAIT(st, s->ev_actor);
   if (sac_critic_hidden(s, s->XP, C, s->HQ, st)) return 1;
   hipLaunchKernelGGL(k_sac_actor_head, rows4, w256, 0, st, B, Hc, s->HQ, C + s->coff[2], C + s->coff[3], s->LPI,
                      d.alpha, s->PL);
@@ -510,34 +542,43 @@ int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state
   if (gemm_batched_launch(A, 0, 0, B, Na, 2 * Hc, s->HQ, 2 * Hc, (long long)B * 2 * Hc,
                           C + s->coff[0] + (long long)I * 2 * Hc, 2 * Hc, (long long)NA * 2 * Hc, nullptr, 0, s->DPI,
                           s->ldna, (long long)B * s->ldna, 0, 0, nullptr, 0, 0, st)) return 1;
-  hipLaunchKernelGGL(k_sac_sample_bwd, rows4, w256, 0, st, B, Na, s->ldhd, s->ldna, s->nact, s->HD, s->DPI, eps_pi,
+  hipLaunchKernelGGL(k_sac_sample_bwd, rows4, w256, 0, st, B, Na, s->ldhd, s->ldna, s->nact, s->HD2, s->DPI, eps_pi,
                      seed, counter, 13u, d.alpha, d.log_sig_min, d.log_sig_max, d.action_scale, s->DHD);
   LAUNCHCHK();
-  // heads: dWhead = act^T dhd, dbhead = colsum(dhd), d act = dhd Whead^T [act > 0]
-  if (gemm_batched_launch(A, 1, 1, H, 2 * Na, B, s->act[L - 1], H, sH, s->DHD, s->ldhd, (long long)B * s->ldhd,
+  SAC_REC(s->ev_d[L], st);
+  // main: the chain of activation gradients;  side: dW = act^T d, db = colsum(d) of every layer
+  SAC_WAIT(sd, s->ev_d[L]);
+  if (gemm_batched_launch(A, 1, 1, H, 2 * Na, B, s->act2[L - 1], H, sH, s->DHD, s->ldhd, (long long)B * s->ldhd,
                           nullptr, 0, s->gP + s->poff[2 * L], 2 * Na, (long long)H * 2 * Na, 0, 0, nullptr, 0, 0,
-                          st)) return 1;
-  hipLaunchKernelGGL(k_sac_colsum, dim3((2 * Na + 31) / 32, A), dim3(1024), 0, st, B, 2 * Na, s->ldhd, s->DHD,
+                          sd)) return 1;
+  hipLaunchKernelGGL(k_sac_colsum, dim3((2 * Na + 31) / 32, A), dim3(1024), 0, sd, B, 2 * Na, s->ldhd, s->DHD,
                      s->gP + s->poff[2 * L + 1]);
   LAUNCHCHK();
-  float *dcur = s->dA[0], *dnext = s->dA[1];
   if (gemm_batched_launch(A, 0, 0, B, H, 2 * Na, s->DHD, s->ldhd, (long long)B * s->ldhd, P + s->poff[2 * L],
-                          2 * Na, (long long)H * 2 * Na, nullptr, 0, dcur, H, sH, 0, 0, s->act[L - 1], H, sH, st))
-    return 1;
+                          2 * Na, (long long)H * 2 * Na, nullptr, 0, s->dA[L - 1], H, sH, 0, 0, s->act2[L - 1], H, sH,
+                          st)) return 1;
+  SAC_REC(s->ev_d[L - 1], st);
   for (int l = L - 1; l >= 1; l--) {
-    if (gemm_batched_launch(A, 1, 1, H, H, B, s->act[l - 1], H, sH, dcur, H, sH, nullptr, 0, s->gP + s->poff[2 * l],
-                            H, (long long)H * H, 0, 0, nullptr, 0, 0, st)) return 1;
-    hipLaunchKernelGGL(k_sac_colsum, dim3((H + 31) / 32, A), dim3(1024), 0, st, B, H, H, dcur,
+    // d(layer l pre-activation) = dA[l] is ready on st
+    SAC_WAIT(sd, s->ev_d[l]);
+    if (gemm_batched_launch(A, 1, 1, H, H, B, s->act2[l - 1], H, sH, s->dA[l], H, sH, nullptr, 0,
+                            s->gP + s->poff[2 * l], H, (long long)H * H, 0, 0, nullptr, 0, 0, sd)) return 1;
+    hipLaunchKernelGGL(k_sac_colsum, dim3((H + 31) / 32, A), dim3(1024), 0, sd, B, H, H, s->dA[l],
                        s->gP + s->poff[2 * l + 1]);
     LAUNCHCHK();
-    if (gemm_batched_launch(A, 0, 0, B, H, H, dcur, H, sH, P + s->poff[2 * l], H, (long long)H * H, nullptr, 0,
-                            dnext, H, sH, 0, 0, s->act[l - 1], H, sH, st)) return 1;
-    float *t = dcur; dcur = dnext; dnext = t;
+    if (gemm_batched_launch(A, 0, 0, B, H, H, s->dA[l], H, sH, P + s->poff[2 * l], H, (long long)H * H, nullptr, 0,
+                            s->dA[l - 1], H, sH, 0, 0, s->act2[l - 1], H, sH, st)) return 1;
+    SAC_REC(s->ev_d[l - 1], st);
   }
-  if (gemm_batched_launch(A, 1, 1, I, H, B, s->XP, s->ldx, (long long)B * s->ldx, dcur, H, sH, nullptr, 0,
-                          s->gP + s->poff[0], H, (long long)I * H, 0, 0, nullptr, 0, 0, st)) return 1;
-  hipLaunchKernelGGL(k_sac_colsum, dim3((H + 31) / 32, A), dim3(1024), 0, st, B, H, H, dcur, s->gP + s->poff[1]);
+  SAC_WAIT(sd, s->ev_d[0]);
+  if (gemm_batched_launch(A, 1, 1, I, H, B, s->XP, s->ldx, (long long)B * s->ldx, s->dA[0], H, sH, nullptr, 0,
+                          s->gP + s->poff[0], H, (long long)I * H, 0, 0, nullptr, 0, 0, sd)) return 1;
+  hipLaunchKernelGGL(k_sac_colsum, dim3((H + 31) / 32, A), dim3(1024), 0, sd, B, H, H, s->dA[0], s->gP + s->poff[1]);
   LAUNCHCHK();
+  SAC_REC(s->ev_done, sd);
+  SAC_WAIT(st, s->ev_done);
+#undef SAC_REC
+#undef SAC_WAIT
   hipLaunchKernelGGL(k_sac_adam, dim3((unsigned)((s->plen / 4 + 255) / 256)), w256, 0, st, s->plen / 4,
                      (float4 *)P, (const float4 *)s->gP, (float4 *)d.policy_m, (float4 *)d.policy_v,
                      (float4 *)nullptr, ak, 0.f);

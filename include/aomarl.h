@@ -233,6 +233,8 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
  * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
  * "gemm_legacy" / "gemm_target_blocks" / "gemm_inkernel_reduce" (GEMM variants),
+ * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
+ * ctx may be NULL),
  * "defer_dm_shape" (the composites
  * aomarl_next_part_two / aomarl_next_part_one use AOMARL_APPLY_DEFER_STACK_SHAPE /
  * AOMARL_IMG_DM_FROM_VOLTAGE when available: st->voltage is the DM state and the stack-array
