@@ -479,11 +479,11 @@ __global__ __launch_bounds__(256 * G) void k_gemm_batched_gen(int M, int N, int 
   for (int it = 0; it < nloop; it++, buf ^= 1) {
     const int slab = it * G + grp;
     const bool live = slab < nslab, more = slab + G < nslab;
-    if (more && !(relu & 512)) {
+    if (more) {
       gg_load<TA>(A, lda, M, m0, (slab + G) * 32, K, tid, va, vecA);
       gg_load<TB>(B, ldb, N, n0, (slab + G) * 32, K, tid, vb, vecB);
     }
-    if (live && !(relu & 256)) {
+    if (live) {
       const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
       const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
       float4 a4[4], b4[4];
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256 * G) void k_gemm_batched_gen(int M, int N, int 
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
       }
     }
-    if (more && !(relu & 1024)) {
+    if (more) {
       gg_store<TA>(As + (buf ^ 1) * 64 * G2_LD, tid, va);
       gg_store<TB>(Bs + (buf ^ 1) * 64 * G2_LD, tid, vb);
     }
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256 * G) void k_gemm_batched_gen(int M, int N, int 
       float *c = C + (long long)row * ldc + col;
       float v = acc[r] + bv;
       if (accumulate) v += *c;
-      if (relu & 1) v = fmaxf(v, 0.f);
+      if (relu) v = fmaxf(v, 0.f);
       if (mask && !(mask[(long long)bz * sM + (long long)row * ldm + col] > 0.f)) v = 0.f;
       *c = v;
     }

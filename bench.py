@@ -125,6 +125,28 @@ def cpu_baseline(env, budget_s=15.0):
                       "included" % (frames, s.name, dt)}
 
 
+def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
+    """Secondary figure (not `value`): wall time of one aomarl_sac_update of every agent on a batch of
+    256 replay rows per agent (the learner side of the path)."""
+    from ao_marl_amd.sac import BatchedSAC
+    sac = BatchedSAC(layout, dict(memory_size=rows), device=device)
+    g = torch.Generator(device=device).manual_seed(1)
+    sac.memory.push(torch.randn(rows, layout.state_dim, generator=g, device=device),
+                    torch.rand(rows, layout.action_dim, generator=g, device=device) * 2 - 1,
+                    -torch.rand(rows, layout.n_agents, generator=g, device=device),
+                    torch.randn(rows, layout.state_dim, generator=g, device=device), 1.0)
+    for _ in range(5):
+        sac.update_from_memory(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_updates):
+        sac.update_from_memory(batch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n_updates * 1e3
+    return {"ms_per_update": ms, "agents": layout.n_agents, "batch_per_agent": batch,
+            "updates_per_s": 1e3 / ms, "kernel": "aomarl_sac_update"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,6 +324,10 @@ def main():
                             "frac_hbm_peak": sp["bytes"] / (spot_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS},
             "stage_ms": stage_ms, "mean_strehl_le": sr,
         }
+        try:
+            out["sac_update"] = sac_update_rate(layout, device) if (world == 1 and args.config == WORKLOAD) else None
+        except Exception as e:                      # secondary figure: never fail the bench line
+            out["sac_update"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(env)
         else:
