@@ -54,6 +54,14 @@ struct aomarl_ctx {
   bool force_f32_dft = false;          // frame kernel: fp32 MFMAs through LDS tiles instead of split-fp16
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
   int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
+  // "prefetch_atmos": the composite moves the atmosphere of the NEXT frame on a side stream as soon
+  // as this frame's image kernels are done, so the extrusion chain runs beside do_control / the
+  // agents / next_part_two instead of in front of the next image
+  bool prefetch_atmos = false, premoved = false;
+  hipStream_t atm_stream = nullptr;
+  hipEvent_t ev_frame = nullptr, ev_moved = nullptr;
+  const float *pre_screens = nullptr;
+  int pre_b = 0, pre_n = 0;
   // controller matrices
   float *cmat = nullptr;           // [nactu][ld_s]
   int ld_cmat = 0;
@@ -453,6 +461,9 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
 int aomarl_destroy(aomarl_ctx *c) {
   if (!c) return 0;
   for (void *p : c->owned) (void)hipFree(p);
+  if (c->atm_stream) { (void)hipStreamSynchronize(c->atm_stream); (void)hipStreamDestroy(c->atm_stream); }
+  if (c->ev_frame) (void)hipEventDestroy(c->ev_frame);
+  if (c->ev_moved) (void)hipEventDestroy(c->ev_moved);
   if (c->seed_stage) (void)hipFree(c->seed_stage);
   delete c;
   return 0;
@@ -536,7 +547,7 @@ int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m
 
 // ---- workspace layout (floats)
 struct Work {
-  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, GEMM, gemm_floats, total;
+  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, GEMM, GEMM_ATM, gemm_floats, total;
   int ldz, ldn, ldm, nblk;
 };
 
@@ -562,6 +573,7 @@ static Work work_layout(const aomarl_ctx *c, int nenv) {
     size_t mn = std::max(ncol * (size_t)w.ldn, (size_t)nenv * (size_t)w.ldm);
     w.gemm_floats = 8 * mn + 4096;     // + split-K ticket counters
     w.GEMM = take(w.gemm_floats);
+    w.GEMM_ATM = take(w.gemm_floats);  // the extrusion's own split-K workspace: it may run on the side stream
   }
   w.total = o;
   return w;
@@ -596,12 +608,20 @@ static DevState dev_state(const aomarl_state *st) {
 }
 
 // ---------------------------------------------------------------- atmosphere
+// A prefetched move_atmos may still be running on the side stream: everything that touches the
+// screens on `stream` waits for it first.
+static int atmos_wait_pending(aomarl_ctx *c, void *stream) {
+  if (c->premoved) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_moved, 0));
+  return 0;
+}
+
 int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, const int32_t *layer,
                    const int32_t *dir, void *stream) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
   if (n == 0 || nops == 0) return 0;
   if (nops < 0 || nops > c->nlayers) return fail("nops out of range");
+  if ((hipStream_t)stream != c->atm_stream || !c->atm_stream) { rc = atmos_wait_pending(c, stream); if (rc) return rc; }
   for (int i = 0; i < nops; i++) {
     if (layer[i] < 0 || layer[i] >= c->nlayers) return fail("extrude: bad layer");
     if (!(dir[i] == 1 || dir[i] == -1 || dir[i] == 2 || dir[i] == -2)) return fail("extrude: bad direction");
@@ -627,10 +647,10 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
     LAUNCHCHK();
     int nsp = 0;
     launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
-                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM, w.gemm_floats, nullptr, &nsp);
+                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
-                       ZREF, st->work + w.GEMM, nsp, ncol, dimc);
+                       ZREF, st->work + w.GEMM_ATM, nsp, ncol, dimc);
     LAUNCHCHK();
   }
   return 0;
@@ -666,11 +686,48 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
   return 0;
 }
 
+static int move_atmos_now(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
+                          void *stream);
+
 int aomarl_move_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
                       void *stream) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
   if (!accumx || !accumy) return fail("move_atmos: null accumulators");
+  if (c->premoved) {
+    rc = atmos_wait_pending(c, stream);
+    if (rc) return rc;
+    if (c->pre_screens == st->screens && c->pre_b == b && c->pre_n == n) {   // this frame's move is done
+      c->premoved = false;
+      return 0;
+    }
+  }
+  return move_atmos_now(c, st, b, n, accumx, accumy, stream);
+}
+
+int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
+                          void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!accumx || !accumy) return fail("prefetch_atmos: null accumulators");
+  if (c->premoved) return fail("prefetch_atmos: a prefetched frame is already pending");
+  if (!c->atm_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->atm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_moved, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(c->ev_frame, (hipStream_t)stream));        // readers of the screens are done
+  HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
+  rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
+  c->premoved = true; c->pre_screens = st->screens; c->pre_b = b; c->pre_n = n;
+  return 0;
+}
+
+static int move_atmos_now(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
+                          void *stream) {
+  int rc = 0;
   const int nl = c->nlayers;
   int g0 = b;
   Plan cur;
@@ -711,6 +768,9 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
   if (rc) return rc;
   if (n == 0) return 0;
   if (!seeds || !accumx || !accumy) return fail("reset: null argument");
+  rc = atmos_wait_pending(c, stream);       // the prefetched frame of a finished episode is dropped
+  if (rc) return rc;
+  c->premoved = false;
   hipStream_t s = (hipStream_t)stream;
   DevState ds = dev_state(st);
   if (c->seed_stage_n < n) {
@@ -754,6 +814,8 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
 int aomarl_set_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, const float *src, void *stream) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
+  rc = atmos_wait_pending(c, stream);
+  if (rc) return rc;
   if (layer < 0 || layer >= c->nlayers || !src) return fail("set_screen: bad argument");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_set_screen, dim3(256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, layer, src);
@@ -763,6 +825,8 @@ int aomarl_set_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, 
 
 int aomarl_get_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, float *dst, void *stream) {
   int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  rc = atmos_wait_pending(c, stream);
   if (rc) return rc;
   if (layer < 0 || layer >= c->nlayers || !dst) return fail("get_screen: bad argument");
   if (n == 0) return 0;
@@ -833,6 +897,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "gemm_inkernel_reduce")) { g_gemm_inkernel_reduce = value != 0; return 0; }
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
+  if (!strcmp(name, "prefetch_atmos")) { c->prefetch_atmos = value != 0; return 0; }
   if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
   if (!strcmp(name, "force_f32_dft")) { c->force_f32_dft = value != 0; return 0; }
   if (!strcmp(name, "force_unfused_frame")) { c->force_unfused_frame = value != 0; return 0; }
@@ -845,6 +910,8 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
 int aomarl_raytrace_wfs(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
+  rc = atmos_wait_pending(c, stream);
+  if (rc) return rc;
   if (!st->wfs_phase) return fail("raytrace_wfs needs st->wfs_phase");
   if (n == 0) return 0;
   const int np = c->sys.n * c->sys.n;
@@ -855,6 +922,8 @@ int aomarl_raytrace_wfs(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags
 
 int aomarl_raytrace_target(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
   int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  rc = atmos_wait_pending(c, stream);
   if (rc) return rc;
   if (!st->tar_phase) return fail("raytrace_target needs st->tar_phase");
   if (n == 0) return 0;
@@ -872,6 +941,8 @@ __global__ void k_inc_u32(uint32_t *p, int n) {
 
 int aomarl_comp_image(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
   int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  rc = atmos_wait_pending(c, stream);
   if (rc) return rc;
   if (n == 0) return 0;
   const bool from_buf = flags & AOMARL_IMG_FROM_PHASE_BUFFER;
@@ -1069,6 +1140,7 @@ int aomarl_apply_control(aomarl_ctx *c, aomarl_state *st, int b, int n, int comp
 
 // ---------------------------------------------------------------- target
 static int target_psf_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, bool from_buf, void *stream) {
+  if (!from_buf && atmos_wait_pending(c, stream)) return 1;
   hipStream_t s = (hipStream_t)stream;
   Work w = work_layout(c, st->nenv);
   const int W = 2 * c->sys.hw, RB = 256 / W;
@@ -1402,6 +1474,8 @@ int aomarl_frame_fused_available(aomarl_ctx *c) {
 int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
+  rc = atmos_wait_pending(c, stream);
+  if (rc) return rc;
   if (!c->sys.fused_ok) return fail("frame_fused: geometry not eligible (see aomarl_frame_fused_available)");
   if (flags & (AOMARL_IMG_FROM_PHASE_BUFFER | AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS))
     return fail("frame_fused: FROM_PHASE_BUFFER / NO_ATMOS / NO_DMS are not supported here");
@@ -1467,6 +1541,10 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
   if (aomarl_frame_fused_available(c) && !(fl & AOMARL_IMG_FROM_PHASE_BUFFER)) {
     rc = aomarl_frame_fused(c, st, b, n, fl | (defer ? AOMARL_IMG_DM_FROM_VOLTAGE : 0), stream);
     if (rc) return rc;
+    if (c->prefetch_atmos) {
+      rc = aomarl_prefetch_atmos(c, st, b, n, accumx, accumy, stream);
+      if (rc) return rc;
+    }
     return aomarl_do_control(c, st, b, n, stream);
   }
   rc = aomarl_target_psf(c, st, b, n, stream);
@@ -1478,6 +1556,10 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
   }
   rc = aomarl_comp_image(c, st, b, n, fl, stream);
   if (rc) return rc;
+  if (c->prefetch_atmos) {
+    rc = aomarl_prefetch_atmos(c, st, b, n, accumx, accumy, stream);
+    if (rc) return rc;
+  }
   return aomarl_do_control(c, st, b, n, stream);
 }
 

@@ -56,7 +56,7 @@ class VecRlSupervisor(object):
 
     def __init__(self, config, config_rl, nenv, *, initial_seed=1234, seed_stride=16,
                  device="cuda:0", strehl_halfwin=8, keep_bincube=False, sim_factory=None,
-                 autoencoder=None, geo=False):
+                 autoencoder=None, geo=False, prefetch_atmos=True):
         # autoencoder: a denoiser.SubapDenoiser (rlSupervisor.py:147, :977-978) or None
         self.autoencoder = autoencoder
         self.config = config if not isinstance(config, str) else params.builtin(config)
@@ -93,6 +93,13 @@ class VecRlSupervisor(object):
         # its own DM pair and target (rlSupervisor.py:989-1013); off by default -- it changes
         # nothing controller 0 sees and is only read by evaluation episodes
         self.geo = self.sim.geo_twin(self.cal.IF) if geo else None
+        # move_atmos of frame t+1 runs on a side stream right behind the image kernels of frame t,
+        # beside do_control / the agents / next_part_two (same results, bit for bit; between frames
+        # the screens are one frame ahead).  Not with the GEO twin, which reads the same screens.
+        self.prefetch_atmos = bool(prefetch_atmos) and self.geo is None and \
+            hasattr(self.sim, "prefetch_atmos")
+        if self.prefetch_atmos:
+            self.sim.set_option("prefetch_atmos", 1)
         self.initial_seed, self.seed_stride = int(initial_seed), int(seed_stride)
         self.current_seed = int(initial_seed)
         self.iter = 0
@@ -183,9 +190,10 @@ class VecRlSupervisor(object):
         if self.autoencoder is not None:
             # rlSupervisor.py:975-984 with the denoiser between image formation and centroiding;
             # the bincube never leaves the device (the reference copies it to the host and back)
-            if move_atmos:
-                self.sim.move_atmos()
+            self._move_or_keep(move_atmos)
             self._target_and_image(write_bincube=True, cog=False)
+            if self.prefetch_atmos and move_atmos:
+                self.sim.prefetch_atmos()
             self.autoencoder.denoise_bincube_(self.sim.t["bincube"])
             self.sim.do_centroids()
             if do_control:
@@ -193,14 +201,23 @@ class VecRlSupervisor(object):
         elif move_atmos and do_control and self.geo is None:
             self.sim.next_part_one()
         else:
-            if move_atmos:
-                self.sim.move_atmos()
+            self._move_or_keep(move_atmos)
             self._target_and_image(write_bincube=False, cog=True)
+            if self.prefetch_atmos and move_atmos:
+                self.sim.prefetch_atmos()
             if do_control:
                 self.sim.do_control()
         if self.geo is not None and do_control:
             self.geo.next_part_one_geo()            # next_part_one_geo, after controller 0 (:1038-1049)
         self.iter += 1
+
+    def _move_or_keep(self, move_atmos):
+        if move_atmos:
+            self.sim.move_atmos()
+        elif getattr(self.sim, "pending_atmos", False):
+            raise RuntimeError("the next frame's atmosphere is already moved (prefetch_atmos): "
+                               "build the supervisor with prefetch_atmos=False to image the same "
+                               "atmosphere twice")
 
     def _target_and_image(self, write_bincube, cog):
         """raytrace_target + PSF, raytrace_wfs + comp_image (rlSupervisor.py:829-843)."""
@@ -246,7 +263,7 @@ class VecAoEnv(object):
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
                  strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None,
-                 geo=False):
+                 geo=False, prefetch_atmos=True):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -260,7 +277,8 @@ class VecAoEnv(object):
         self.supervisor = VecRlSupervisor(config, cfg, nenv, initial_seed=initial_seed,
                                           seed_stride=seed_stride, device=device,
                                           strehl_halfwin=strehl_halfwin, sim_factory=sim_factory,
-                                          autoencoder=autoencoder, geo=geo)
+                                          autoencoder=autoencoder, geo=geo,
+                                          prefetch_atmos=prefetch_atmos)
         sup = self.supervisor
         self.nenv, self.device = nenv, sup.device
         self.nmodes = sup.nmodes

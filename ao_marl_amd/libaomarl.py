@@ -83,6 +83,7 @@ SYMBOLS = [
     ("aomarl_dmshape_stride", C.c_size_t, [_vp]),
     ("aomarl_reset", _i, _range + [_up, _fp, _fp, _vp]),
     ("aomarl_move_atmos", _i, _range + [_fp, _fp, _vp]),
+    ("aomarl_prefetch_atmos", _i, _range + [_fp, _fp, _vp]),
     ("aomarl_extrude", _i, _range + [_i, _ip, _ip, _vp]),
     ("aomarl_get_screen", _i, _range + [_i, _vp, _vp]),
     ("aomarl_set_screen", _i, _range + [_i, _vp, _vp]),

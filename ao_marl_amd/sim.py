@@ -40,6 +40,7 @@ class HipSim(object):
         # the library can (next_part_two then skips materialising the shapes; any other consumer
         # of the shapes triggers _ensure_shape() first)
         self.defer_shape = True
+        self.prefetch, self.pending_atmos = False, False     # see prefetch_atmos()
         self._defer_on = False       # the ctx option as currently set
         self._stale = False          # st.dm_shape's stack-array planes are older than st.voltage
         self.ctx = C.c_void_p()
@@ -147,6 +148,8 @@ class HipSim(object):
 
     def set_option(self, name, value):
         la.check(self.lib.aomarl_set_option(self.ctx, name.encode(), int(value)))
+        if name == "prefetch_atmos":
+            self.prefetch = bool(value)
         if name == "force_unfused_frame" and value:
             self._set_defer(False)
 
@@ -224,14 +227,27 @@ class HipSim(object):
         la.check(self.lib.aomarl_reset(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
                                        la.fptr(self.accumx), la.fptr(self.accumy),
                                        self._stream()))
+        self.pending_atmos = False          # a prefetched frame is dropped by the library
         if (b, n) == (0, self.nenv):
             self._stale = False             # commands, voltages and shapes are all zero again
 
     def move_atmos(self, env_begin=0, env_count=None):
+        """Atmos.move_atmos; after `prefetch_atmos` of the same range: only waits for that move."""
         b, n = self._range(env_begin, env_count)
         la.check(self.lib.aomarl_move_atmos(self.ctx, C.byref(self.st), b, n,
                                             la.fptr(self.accumx), la.fptr(self.accumy),
                                             self._stream()))
+        self.pending_atmos = False
+
+    def prefetch_atmos(self, env_begin=0, env_count=None):
+        """Issue the NEXT frame's move_atmos now, on the library's side stream, behind everything
+        enqueued so far (aomarl_prefetch_atmos): call it once the kernels that read this frame's
+        screens are enqueued.  The screens are one frame ahead until the next `move_atmos`."""
+        b, n = self._range(env_begin, env_count)
+        la.check(self.lib.aomarl_prefetch_atmos(self.ctx, C.byref(self.st), b, n,
+                                                la.fptr(self.accumx), la.fptr(self.accumy),
+                                                self._stream()))
+        self.pending_atmos = True
 
     def extrude(self, layers, dirs, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
@@ -446,6 +462,7 @@ class HipSim(object):
             la.check(self.lib.aomarl_next_part_one(self.ctx, C.byref(self.st), b, n,
                                                    la.fptr(self.accumx), la.fptr(self.accumy), fl,
                                                    self._stream()))
+            self.pending_atmos = self.prefetch
             return
         self.move_atmos(b, n)
         self.target_and_wfs(write_bincube=write_bincube, env_begin=b, env_count=n)

@@ -65,13 +65,20 @@ def stage_models(s, nenv, nmodes, nact):
 
 
 class StageTimer(object):
+    """HIP events around stage entry points.  Only the labels in `live` are timed (an event pair is
+    not free: sixteen of them per step cost 7 % of the step); the timed region keeps the image
+    kernel's pair, the per-stage split comes from a short diagnostic pass after it."""
+
     def __init__(self):
         self.pairs = {}
+        self.live = None                   # None: every wrapped stage
 
     def wrap(self, obj, name, label):
         fn = getattr(obj, name)
 
         def timed(*a, **k):
+            if self.live is not None and label not in self.live:
+                return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*a, **k)
@@ -160,6 +167,8 @@ def main():
     ap.add_argument("--denoiser", default=None,
                     help="WFS-image denoiser weights (a state_dict file, or 'golden' for the shipped "
                          "network kept in tests/golden/host_denoiser.pt): BASELINE configs[4]")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="move the atmosphere in front of the image kernels (no side stream)")
     ap.add_argument("--no-defer", action="store_true",
                     help="materialise the stack-array DM shapes instead of evaluating them from the "
                          "voltages inside the frame kernel")
@@ -220,7 +229,7 @@ def main():
         norm_kw = dict(norm=nrm, zn_norm=zn)
     env = VecAoEnv(args.config, args.envs, rl, initial_seed=1234 + 16 * args.envs * rank,
                    seed_stride=16, n_agents_modal=n_modal, device=device, autoencoder=autoencoder,
-                   **norm_kw)
+                   prefetch_atmos=not args.no_prefetch, **norm_kw)
     layout = env.layout
     policy = BatchedGaussianPolicy(layout, last_layer_zero=False, seed=1234 + rank, device=device)
     sim = env.supervisor.sim
@@ -238,12 +247,14 @@ def main():
     def split_part_one(move_atmos=True, do_control=True):
         if autoencoder is not None:
             return orig_np1(move_atmos=move_atmos, do_control=do_control)
-        sim.move_atmos()
+        sim.move_atmos()             # with prefetch: only the wait for the side stream's move
         if fused:
             sim.frame_fused(noise=True, cog=True)
         else:
             sim.target_psf()
             sim.comp_image(noise=True, cog=True)
+        if env.supervisor.prefetch_atmos:
+            sim.prefetch_atmos()     # next frame's extrusions: side stream, beside what follows
         sim.do_control()
         env.supervisor.iter += 1
 
@@ -262,6 +273,8 @@ def main():
         s_next, r, _, _ = env.step(a)
         return s_next
 
+    # the timed region carries the event pair of the image kernel(s) only (-> roofline)
+    timer.live = {"frame_fused", "wfs_spot_cog", "target_psf"}
     for _ in range(args.warmup):
         state = one_step(state)
     timer.clear()
@@ -272,6 +285,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         state = one_step(state)
+    t_enq = time.perf_counter() - t0           # host time to enqueue the K steps (diagnostic)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -284,6 +298,14 @@ def main():
 
     stage_ms = timer.mean_ms()
     sr = sim.strehl[:, 1].mean().item()
+    # diagnostic pass (outside `value`): every stage with its own event pair
+    timer.clear()
+    timer.live = None
+    for _ in range(min(20, args.steps)):
+        state = one_step(state)
+    torch.cuda.synchronize()
+    stage_diag = timer.mean_ms()
+    stage_diag.update(stage_ms)            # the image kernel keeps its timed-region figure
     if rank == 0:
         models = stage_models(env.supervisor.s, args.envs, env.nmodes, layout.action_dim)
         if not any(k in models for k in stage_ms):       # denoiser run: no per-stage split
@@ -322,7 +344,9 @@ def main():
                             "frac_fp32_mfma_peak": sp.get("flops", sp["work"]) / (spot_ms * 1e-3) * 1e-12 / FP32_MFMA_PEAK_TF,
                             "algorithmic_gbs": sp["bytes"] / (spot_ms * 1e-3) * 1e-9,
                             "frac_hbm_peak": sp["bytes"] / (spot_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS},
-            "stage_ms": stage_ms, "mean_strehl_le": sr,
+            "stage_ms": stage_diag, "atmos_prefetch": bool(env.supervisor.prefetch_atmos),
+            "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+            "mean_strehl_le": sr,
         }
         try:
             out["sac_update"] = sac_update_rate(layout, device) if (world == 1 and args.config == WORKLOAD) else None

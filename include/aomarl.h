@@ -161,6 +161,16 @@ int aomarl_reset(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count
 /* Atmos.move_atmos (atmosCompass.py:161). accumx/accumy: host [nenv][nlayers], updated. */
 int aomarl_move_atmos(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                       float *accumx, float *accumy, void *stream);
+/* The same move, issued EARLY: call it after the last kernel of this frame that reads the screens
+ * has been enqueued on `stream`; the extrusions run on a stream of the library behind that point,
+ * beside whatever `stream` does next (do_control, the agents, next_part_two).  The next
+ * aomarl_move_atmos of the same state / range only waits for it (the move is not repeated); every
+ * other entry point that touches the screens waits for it too, aomarl_reset drops it.  Between the
+ * two calls the screens are one frame ahead of the slopes.  The composite aomarl_next_part_one does
+ * this by itself under aomarl_set_option(ctx, "prefetch_atmos", 1); not for states that share their
+ * screens (the GEO twin).  Results are those of the plain call order, bit for bit. */
+int aomarl_prefetch_atmos(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
+                          float *accumx, float *accumy, void *stream);
 /* one parallel round of extrusions: op i extrudes layer[i] in direction dir[i] (+-1 x, +-2 y) */
 int aomarl_extrude(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int nops,
                    const int32_t *layer, const int32_t *dir, void *stream);
@@ -233,6 +243,8 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
  * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
  * "gemm_legacy" / "gemm_target_blocks" / "gemm_inkernel_reduce" (GEMM variants),
+ * "prefetch_atmos" (aomarl_next_part_one moves the next frame's atmosphere on a side stream, see
+ * aomarl_prefetch_atmos),
  * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
  * ctx may be NULL),
  * "defer_dm_shape" (the composites

@@ -166,3 +166,35 @@ def test_stacked_linear_gradients_match_torch():
         assert (y - yr).abs().max().item() < 2e-4
         for u, v in ((gx, rx), (gW, rW), (gb, rb)):
             assert (u - v).abs().max().item() < 3e-4 * max(1.0, v.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_prefetched_atmosphere_gives_the_same_frames():
+    """move_atmos of the next frame on the side stream (aomarl_prefetch_atmos, the default of the
+    vectorised supervisor) against the plain call order: slopes, commands, Strehl and the screens
+    after an explicit move are identical bit for bit, across a reset."""
+    import torch
+    from ao_marl_amd.env import VecRlSupervisor
+    sups = [VecRlSupervisor("production_sh_10x10_2m", {}, 5, initial_seed=77, prefetch_atmos=p)
+            for p in (True, False)]
+    assert sups[0].prefetch_atmos and not sups[1].prefetch_atmos
+    for ep in range(2):
+        for s in sups:
+            s.reset()
+        for it in range(7):
+            outs = []
+            for s in sups:
+                s.next_part_one()
+                s.next_part_two(None, linear_control=True)
+                outs.append((s.get_slopes().clone(), s.get_command().clone(), s.get_strehl().clone()))
+            assert sups[0].sim.pending_atmos and not sups[1].sim.pending_atmos
+            for a, b in zip(*outs):
+                assert torch.equal(a, b), (ep, it)
+    # imaging the same atmosphere twice is refused while a prefetched frame is pending ...
+    with pytest.raises(RuntimeError):
+        sups[0].next_part_one(move_atmos=False)
+    # ... and the explicit move consumes the prefetched one: same screens as two plain moves
+    sups[0].sim.move_atmos()
+    sups[1].sim.move_atmos()
+    for layer in range(sups[0].s.nscreens):
+        assert torch.equal(sups[0].sim.screen(layer), sups[1].sim.screen(layer))
