@@ -712,7 +712,11 @@ int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *
   if (!accumx || !accumy) return fail("prefetch_atmos: null accumulators");
   if (c->premoved) return fail("prefetch_atmos: a prefetched frame is already pending");
   if (!c->atm_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&c->atm_stream, hipStreamNonBlocking));
+    // lowest priority: the extrusions have a whole control / agent chain of slack, the kernels of
+    // that chain should not queue behind them
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->atm_stream, hipStreamNonBlocking, prio_lo));
     HIPCHK(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_moved, hipEventDisableTiming));
   }

@@ -4,10 +4,19 @@ per-kernel mean duration and share, using only dispatches inside the last `--ste
 (located through the k_wfs_spot_fast launches, one per step)."""
 import argparse, csv, collections, sys
 ap = argparse.ArgumentParser(); ap.add_argument("trace"); ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--marker", default="k_wfs_spot"); a = ap.parse_args()
+ap.add_argument("--marker", default="k_wfs_spot")
+ap.add_argument("--skip-last", type=int, default=0, help="marker launches to drop at the end (bench.py's diagnostic pass)")
+ap.add_argument("--before", default=None, help="ignore everything from the first launch of this kernel on")
+a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+if a.before:
+    cut = [i for i, r in enumerate(rows) if a.before in r["Kernel_Name"]]
+    if cut:
+        rows = rows[:cut[0]]
 marks = [int(r["Start_Timestamp"]) for r in rows if a.marker in r["Kernel_Name"]]
+if a.skip_last:
+    marks = marks[:-a.skip_last]
 t0 = marks[-a.steps - 1]; t1 = marks[-1]
 sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 agg = collections.OrderedDict()
