@@ -68,6 +68,8 @@ struct aomarl_ctx {
   int nmodes = 0, nact = 0, ld_v2m = 0, ld_m2v = 0;
   float *v2m = nullptr, *m2v = nullptr, *freedom = nullptr;
   int32_t *amodes = nullptr, *amode_inv = nullptr;   // action modes and their inverse map [nmodes]
+  float *env_gain = nullptr;       // per-environment integrator gains (aomarl_set_env_gains) or null
+  int env_gain_n = 0;
   uint32_t *seed_stage = nullptr;  // device staging for reset seeds
   int seed_stage_n = 0;
   // geometric controller (aomarl_set_geo): host copies of the lattice tables it is built from,
@@ -464,6 +466,7 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (c->atm_stream) { (void)hipStreamSynchronize(c->atm_stream); (void)hipStreamDestroy(c->atm_stream); }
   if (c->ev_frame) (void)hipEventDestroy(c->ev_frame);
   if (c->ev_moved) (void)hipEventDestroy(c->ev_moved);
+  if (c->env_gain) (void)hipFree(c->env_gain);
   if (c->seed_stage) (void)hipFree(c->seed_stage);
   delete c;
   return 0;
@@ -492,6 +495,23 @@ int aomarl_set_cmat(aomarl_ctx *c, const float *cmat) {
 int aomarl_set_gain(aomarl_ctx *c, float gain) {
   if (!c) return fail("null ctx");
   c->gain = gain;
+  return 0;
+}
+
+int aomarl_set_env_gains(aomarl_ctx *c, const float *gains, int nenv) {
+  if (!c) return fail("null ctx");
+  if (!gains) {                      // back to the scalar gain
+    if (c->env_gain) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->env_gain); }
+    c->env_gain = nullptr; c->env_gain_n = 0;
+    return 0;
+  }
+  if (nenv < 1) return fail("set_env_gains: nenv must be positive");
+  if (c->env_gain_n != nenv) {
+    if (c->env_gain) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->env_gain); c->env_gain = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->env_gain, sizeof(float) * (size_t)nenv));
+    c->env_gain_n = nenv;
+  }
+  HIPCHK(hipMemcpy(c->env_gain, gains, sizeof(float) * (size_t)nenv, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -1025,13 +1045,16 @@ int aomarl_do_control(aomarl_ctx *c, aomarl_state *st, int b, int n, void *strea
   // err[env][a] = - sum_s slopes[env][s] cmat[a][s]
   Work w = work_layout(c, st->nenv);
   GemmEpi ep = {};
+  if (c->env_gain && c->env_gain_n != st->nenv)
+    return fail("do_control: %d per-environment gains set, the state has %d environments", c->env_gain_n, st->nenv);
   ep.mode = 1; ep.com = st->com + (size_t)b * st->ld_actu; ep.ldcom = st->ld_actu; ep.gain = c->gain;
+  ep.gain_row = c->env_gain ? c->env_gain + b : nullptr;
   const bool fused = launch_gemm_nt(n, na, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->cmat, c->ld_cmat, 0.0f,
                                     st->err + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM,
                                     w.gemm_floats, &ep);
   LAUNCHCHK();
   if (!fused) {
-    hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b);
+    hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b, c->env_gain);
     LAUNCHCHK();
   }
   return 0;

@@ -555,6 +555,7 @@ __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float
 struct GemmEpi {
   int mode;
   float *com; int ldcom; float gain;
+  const float *gain_row;               // mode 1: per-row (per-environment) integrator gains, or null
   const float *action; int nact; const int32_t *amode_inv; const float *freedom;
 };
 
@@ -569,7 +570,7 @@ __global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const f
   float v = alpha * s;
   if (beta != 0.f) v += beta * (*c);
   if (ep.mode == 1) {
-    ep.com[(long long)row * ep.ldcom + col] += ep.gain * v;
+    ep.com[(long long)row * ep.ldcom + col] += (ep.gain_row ? ep.gain_row[row] : ep.gain) * v;
   } else if (ep.mode == 2) {
     const int j = ep.amode_inv[col];
     if (j >= 0) v += ep.action[(long long)row * ep.nact + j] * ep.freedom[col];
@@ -2090,10 +2091,10 @@ __global__ __launch_bounds__(256) void k_slopes_geom(DevSys sys, DevState st, in
 // =============================================================================================
 // com += gain * err     (err = -cmat.s was produced by the GEMM with alpha = -1)
 __global__ void k_integrate(float *__restrict__ com, const float *__restrict__ err, int nactu,
-                            int ld, float gain, int env_begin) {
+                            int ld, float gain, int env_begin, const float *__restrict__ env_gain) {
   const int e = env_begin + blockIdx.y;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a < nactu) com[(long long)e * ld + a] += gain * err[(long long)e * ld + a];
+  if (a < nactu) com[(long long)e * ld + a] += (env_gain ? env_gain[e] : gain) * err[(long long)e * ld + a];
 }
 
 // voltage = a com + b com1 + c com2 ; com2 <- com1 ; com1 <- com

@@ -86,7 +86,7 @@ class VecRlSupervisor(object):
         self.include_tip_tilt = bool(self.config_rl["include_tip_tilt"])
         self.sim = make(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
         self.freedom_vector = None
-        self.gain = float(self.s.gain)
+        self.gain, self._env_gains = float(self.s.gain), False
         self.last_modes = None
         self._push_modal()
         # controller 1 of the non-noise parameter files: the geometric reference controller with
@@ -155,9 +155,28 @@ class VecRlSupervisor(object):
         self.sim.rl_control(action)
 
     def set_gain(self, gain):
-        """rtc._rtc.d_control[0].set_gain (ao_env.py:950-958)"""
-        self.gain = float(gain)
-        self.sim.set_gain(self.gain)
+        """rtc._rtc.d_control[0].set_gain (ao_env.py:950-958).  A scalar, or one gain per
+        environment ([nenv], integrator control only: the gain scan runs its candidates as one
+        batch)."""
+        g = np.asarray(gain, dtype=np.float32).reshape(-1)
+        if g.size == 1:
+            self.gain = float(g[0])
+            if self._env_gains:
+                self.sim.set_env_gains(None)
+                self._env_gains = False
+            self.sim.set_gain(self.gain)
+        else:
+            self.sim.set_env_gains(g)
+            self.gain, self._env_gains = None, True
+
+    def obtain_and_set_cmat_filtered(self, modes_filtered):
+        """Command matrix through the Btt basis without its last `modes_filtered` (non-TT) modes
+        (rlSupervisor.py:215-234 -> basis.compute_cmat_with_Btt)."""
+        self.n_reverse_filtered_from_cmat = int(modes_filtered)
+        cmat = modal.cmat_with_btt(self.cal.imat, self.cal.Btt, max(int(modes_filtered), 0))
+        self.cal.cmat = cmat
+        self.s.cmat = np.ascontiguousarray(cmat)
+        self.sim.set_cmat(self.s.cmat)
 
     def next_part_two(self, action, linear_control=False, apply_control=True,
                       compute_tar_psf=True, modes_pair=None):
@@ -173,6 +192,8 @@ class VecRlSupervisor(object):
                 action = action * std + mean
             if self.freedom_vector is None:
                 raise RuntimeError("freedom vector not loaded (load_freedom_vector)")
+            if self.gain is None:
+                raise RuntimeError("per-environment gains are for integrator-only runs")
             self.last_modes = self.sim.rl_control_modes(modes_pair[0], modes_pair[1], self.gain, action)
         elif not linear_control:
             self.rl_control(action)

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("aomarl_destroy", _i, [_vp]),
     ("aomarl_set_cmat", _i, [_vp, _fp]),
     ("aomarl_set_gain", _i, [_vp, _f]),
+    ("aomarl_set_env_gains", _i, [_vp, _fp, _i]),
     ("aomarl_set_modal", _i, [_vp, _i, _fp, _fp, _fp, _i, _ip]),
     ("aomarl_workspace_floats", C.c_size_t, [_vp, _i]),
     ("aomarl_screen_stride", C.c_size_t, [_vp]),

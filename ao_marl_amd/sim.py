@@ -199,6 +199,17 @@ class HipSim(object):
     def set_gain(self, gain):
         la.check(self.lib.aomarl_set_gain(self.ctx, float(gain)))
 
+    def set_env_gains(self, gains):
+        """One integrator gain per environment ([nenv]) for do_control, or None for the scalar
+        again (aomarl_set_env_gains)."""
+        if gains is None:
+            la.check(self.lib.aomarl_set_env_gains(self.ctx, None, 0))
+            return
+        g = np.ascontiguousarray(gains, dtype=np.float32).reshape(-1)
+        if g.size != self.nenv:
+            raise ValueError("one gain per environment: expected %d, got %d" % (self.nenv, g.size))
+        la.check(self.lib.aomarl_set_env_gains(self.ctx, la.fptr(g), int(g.size)))
+
     def set_modal(self, v2m, m2v, freedom=None, action_modes=None):
         v2m = np.ascontiguousarray(v2m, dtype=np.float32)
         m2v = np.ascontiguousarray(m2v, dtype=np.float32)

@@ -144,6 +144,11 @@ int aomarl_destroy(aomarl_ctx *ctx);
 /* d_control[0].set_cmat (basis.py:254): cmat is [nactu][nslope] row-major, host memory */
 int aomarl_set_cmat(aomarl_ctx *ctx, const float *cmat);
 int aomarl_set_gain(aomarl_ctx *ctx, float gain); /* d_control[0].set_gain (ao_env.py:957) */
+/* One integrator gain per environment (host [nenv], nenv = st->nenv of the states stepped with this
+ * context) instead of the scalar: the gain scan of obtain_best_gain_and_modes_filtered.py:101-150 as
+ * ONE batch, environment e running the reference's loop with gain gains[e].  NULL: scalar again.
+ * Applies to aomarl_do_control only; the RL control entry points take their gain as an argument. */
+int aomarl_set_env_gains(aomarl_ctx *ctx, const float *gains, int nenv);
 /* volts2modes [nmodes][nactu], modes2volts [nactu][nmodes] (rlSupervisor.py:170-172),
  * freedom vector [nmodes] (rlSupervisor.py:277-278), action_modes[nact]: the modes an action
  * component drives (rlSupervisor.py:677-691); host memory */

@@ -41,6 +41,18 @@ class OracleVecSim(object):
     def set_gain(self, g):
         self.s.gain = float(g)
 
+    def set_env_gains(self, gains):
+        self.env_gains = None if gains is None else np.asarray(gains, dtype=np.float32).reshape(-1)
+
+    def _with_gain(self, e, fn):
+        if getattr(self, "env_gains", None) is None:
+            return fn()
+        g0, self.s.gain = self.s.gain, float(self.env_gains[e])
+        try:
+            return fn()
+        finally:
+            self.s.gain = g0
+
     def set_modal(self, v2m, m2v, freedom=None, action_modes=None):
         self.v2m, self.m2v = np.asarray(v2m, np.float32), np.asarray(m2v, np.float32)
         self.nmodes = self.v2m.shape[0]
@@ -86,8 +98,8 @@ class OracleVecSim(object):
             o.comp_strehl()
 
     def next_part_one(self):
-        for o in self.sims:
-            o.next_part_one()
+        for e, o in enumerate(self.sims):
+            self._with_gain(e, o.next_part_one)
 
     def move_atmos(self):
         for o in self.sims:
@@ -106,8 +118,8 @@ class OracleVecSim(object):
                 o.do_centroids()
 
     def do_control(self):
-        for o in self.sims:
-            o.do_control()
+        for e, o in enumerate(self.sims):
+            self._with_gain(e, o.do_control)
 
     def volts2modes(self, vec):
         return torch.from_numpy(np.asarray(vec, dtype=np.float32) @ self.v2m.T)
