@@ -398,6 +398,31 @@ class BatchedSAC(object):
             put(self.critic, critic_sd)
             put(self.critic_target, critic_target_sd if critic_target_sd is not None else critic_sd)
 
+    def load_model(self, i, actor_path, critic_path=None, map_location="cpu"):
+        """Load agent slot i from checkpoint files, accepting the three actor layouts the reference's
+        loader accepts (src/error_budget/sac/sac.py:187-240): a dict with `alpha` / `log_alpha` /
+        `target_entropy` / `model_state_dict`; the trainer's {`worker_id`, `models_controlled`,
+        `model_state_dict`} (train_rpc.py:1155-1161); or the bare policy state_dict.  The critic
+        file is `critic.state_dict()` (the target critic starts as its copy)."""
+        ck = torch.load(actor_path, map_location=map_location, weights_only=False)
+        if isinstance(ck, dict) and "alpha" in ck:
+            self.policy.load_agent(i, ck["model_state_dict"])
+            with torch.no_grad():
+                self.alpha[i] = float(torch.as_tensor(ck["alpha"]).detach().reshape(-1)[0])
+                self.log_alpha[i] = float(torch.as_tensor(ck["log_alpha"]).detach().reshape(-1)[0])
+                # the reference rebuilds it as -prod(-target_entropy): the stored scalar itself
+                self.target_entropy[i] = float(torch.as_tensor(ck["target_entropy"]).reshape(-1)[0])
+            if self._updaters:
+                raise RuntimeError("load checkpoints before the first update (the native updater "
+                                   "holds a copy of the target entropies)")
+        elif isinstance(ck, dict) and "worker_id" in ck:
+            self.policy.load_agent(i, ck["model_state_dict"])
+        else:
+            self.policy.load_agent(i, ck)
+        if critic_path is not None:
+            sd = torch.load(critic_path, map_location=map_location, weights_only=False)
+            self.load_reference_agent(i, critic_sd=sd)
+
     def export_agent(self, i, target=False):
         """(actor state_dict, critic state_dict) of agent i in the reference's layout
         (target=True: the target critic instead of the critic)."""

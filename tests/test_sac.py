@@ -168,6 +168,41 @@ def test_checkpoints_use_the_references_container(tmp_path):
     assert torch.equal(qa[0], qb[0]) and torch.equal(qa[1], qb[1])
 
 
+def test_load_model_accepts_the_three_actor_file_layouts(tmp_path):
+    """src/error_budget/sac/sac.py:187-240: {'alpha', 'log_alpha', 'target_entropy',
+    'model_state_dict'}, the trainer's {'worker_id', ...}, or the bare policy state_dict."""
+    lay = _layout()
+    cfg = dict(hidden_size_actor=16, hidden_size_critic=16, memory_size=8)
+    src = BatchedSAC(lay, dict(cfg, initialize_last_layer_0=False), seed=1, device="cpu")
+    dst = BatchedSAC(lay, cfg, seed=2, device="cpu")
+    actor0, critic0 = src.export_agent(0)
+    actor1, critic1 = src.export_agent(1)
+    p_full, p_bare, p_crit = (str(tmp_path / n) for n in ("full.pt", "bare.pt", "critic.pt"))
+    torch.save({"model_state_dict": actor0, "alpha": torch.tensor([0.37]),
+                "log_alpha": torch.tensor([-0.99]), "target_entropy": -7.0}, p_full)
+    torch.save(actor1, p_bare)
+    torch.save(critic0, p_crit)
+    dst.load_model(0, p_full, p_crit)
+    dst.load_model(1, p_bare)
+    assert dst.alpha[0].item() == pytest.approx(0.37) and dst.log_alpha[0].item() == pytest.approx(-0.99)
+    assert dst.target_entropy[0].item() == pytest.approx(-7.0)
+    assert dst.alpha[1].item() == pytest.approx(0.2)                  # untouched slot keeps its default
+    paths = src.save_model(str(tmp_path / "exp"), episode=1)
+    dst2 = BatchedSAC(lay, cfg, seed=3, device="cpu")
+    for i, (ap, cp) in enumerate(paths):                               # the 'worker_id' layout
+        dst2.load_model(i, ap, cp)
+    s = torch.randn(4, lay.state_dim)
+    m_src, _ = src.policy.forward(s)
+    m_dst, _ = dst.policy.forward(s)
+    m_dst2, _ = dst2.policy.forward(s)
+    assert torch.equal(m_src, m_dst) and torch.equal(m_src, m_dst2)
+    x = src.policy.split_states(s)
+    act = torch.rand(lay.n_agents, 4, src.act_max) * src.act_mask
+    q_src, q_dst = src._q(src.critic, x, act), dst._q(dst.critic, x, act)
+    assert torch.equal(q_src[0][0], q_dst[0][0]) and torch.equal(q_src[1][0], q_dst[1][0])
+    assert torch.equal(dst.critic_target[0]["Win"][0], dst.critic[0]["Win"][0])
+
+
 @pytest.mark.gpu
 def test_training_episode_on_the_gpu_and_update_rate():
     """End-to-end on the HIP path: rollout with the native batched GEMM actors, replay in HBM,
