@@ -33,6 +33,9 @@ struct DenoiseW {
   const float4 *w3;       // [9][2][4][64]           L3
   const float4 *w4;       // [4][4][4][2][64]        D1: class, tap, group, tile
   const float4 *w5;       // [4][4][2][1][64]        D2
+  // the same four arrays as split-fp16 B operands: per (step, lane) one 16-byte word
+  // [hi(b0..b3) | lo(b0..b3)] (see dup_hl in aomarl_kernels.hip)
+  const float4 *w2h, *w3h, *w4h, *w5h;
   const float *w6;        // [9][16]                 D3 (taps as a plain correlation)
   const float *b1, *b2, *b3, *b4, *b5;
   float b6;
@@ -54,6 +57,29 @@ __device__ __forceinline__ void dn_zero(float *p, int n, int tid) {
   for (int i = tid * 4; i < n; i += 128 * 4) *reinterpret_cast<float4 *>(p + i) = z;
 }
 
+// zero the one-pixel border of an [R][R][S] channel-last grid (S floats per position, S % 4 == 0,
+// or S == 1): 4R - 4 positions; the interior is overwritten by the layer that owns the grid
+template <int R, int S>
+__device__ __forceinline__ void dn_border(float *p, int tid) {
+  constexpr int NP = 4 * R - 4;
+  if (S == 1) {
+    for (int i = tid; i < NP; i += 128) {
+      const int row = i < R ? 0 : (i < 2 * R ? R - 1 : 1 + ((i - 2 * R) >> 1));
+      const int col = i < R ? i : (i < 2 * R ? i - R : (((i - 2 * R) & 1) ? R - 1 : 0));
+      p[row * R + col] = 0.f;
+    }
+  } else {
+    constexpr int V = S / 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < NP * V; i += 128) {
+      const int pi = i / V, k = i - pi * V;
+      const int row = pi < R ? 0 : (pi < 2 * R ? R - 1 : 1 + ((pi - 2 * R) >> 1));
+      const int col = pi < R ? pi : (pi < 2 * R ? pi - R : (((pi - 2 * R) & 1) ? R - 1 : 0));
+      *reinterpret_cast<float4 *>(p + (row * R + col) * S + 4 * k) = z;
+    }
+  }
+}
+
 // four MFMAs: A = 4 consecutive channels of this lane's position, B = the matching weights
 __device__ __forceinline__ f32x4d dn_quad(const float4 a, const float4 b, f32x4d acc) {
   acc = dn_mfma(a.x, b.x, acc);
@@ -63,7 +89,62 @@ __device__ __forceinline__ f32x4d dn_quad(const float4 a, const float4 b, f32x4d
   return acc;
 }
 
-__global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__ cube, int nimg) {
+// Split-fp16 variant (H): a value v is carried as hi = f16(v), lo = f16(v - hi) (22 mantissa bits).
+// The 16 real terms of a quad (4 channels x 4 lane groups) occupy the K = 32 slots of
+// v_mfma_f32_16x16x32_f16 twice:  A = [hi(a0..a3) | lo(a0..a3)],  B = [hi(b) | hi(b)] then
+// [lo(b) | lo(b)], so two 16-cycle instructions give (a_hi + a_lo)(b_hi + b_lo) in fp32 against four
+// 32-cycle fp32 MFMAs.
+//  * the activations A1..A4 live in LDS ALREADY in that form: the 16 bytes of a (position, 4-channel
+//    group) hold [h0 h1 h2 h3 l0 l1 l2 l3] instead of four floats -- same addresses, same strides,
+//    split once by the layer that produces them (each value is consumed 4 to 18 times), so an A
+//    operand is one ds_read_b128 and no arithmetic;
+//  * the weights stream as [hi(b0..b3) | lo(b0..b3)], 16 bytes per lane like the fp32 operand (the
+//    stream out of L2 is what this kernel is closest to), and are expanded with register moves.
+// Values must stay inside the fp16 range (|v| < 65504): photon counts and the activations of this
+// network do by orders of magnitude; aomarl_denoiser_apply_f32 is the all-fp32 kernel otherwise.
+template <bool H> struct DnWt { float4 b; };         // a streamed B operand, as loaded
+template <bool H>
+__device__ __forceinline__ DnWt<H> dn_ldw(const float4 *__restrict__ p, int idx) {
+  DnWt<H> r; r.b = p[idx]; return r;
+}
+template <bool H> struct DnB;                        // a B operand ready for the matrix instruction(s)
+template <> struct DnB<false> { float4 b; };
+template <> struct DnB<true> { hx8 h, l; };
+__device__ __forceinline__ DnB<false> dn_expand(const DnWt<false> w) { DnB<false> r; r.b = w.b; return r; }
+__device__ __forceinline__ DnB<true> dn_expand(const DnWt<true> w) {
+  const hx2 h01 = __builtin_bit_cast(hx2, w.b.x), h23 = __builtin_bit_cast(hx2, w.b.y);
+  const hx2 l01 = __builtin_bit_cast(hx2, w.b.z), l23 = __builtin_bit_cast(hx2, w.b.w);
+  DnB<true> r;
+  r.h = hx8{h01[0], h01[1], h23[0], h23[1], h01[0], h01[1], h23[0], h23[1]};
+  r.l = hx8{l01[0], l01[1], l23[0], l23[1], l01[0], l01[1], l23[0], l23[1]};
+  return r;
+}
+__device__ __forceinline__ f32x4d dn_quadw(const float4 a, const DnB<false> b, f32x4d acc) {
+  return dn_quad(a, b.b, acc);
+}
+__device__ __forceinline__ f32x4d dn_quadw(const float4 a, const DnB<true> b, f32x4d acc) {
+  const hx8 A = __builtin_bit_cast(hx8, a);
+  acc = mfma_h(A, b.h, acc);
+  return mfma_h(A, b.l, acc);
+}
+// store activation v of channel ch at a position whose channel vector starts at `pos`
+template <bool H>
+__device__ __forceinline__ void dn_store(float *pos, int ch, float v) {
+  if (!H) {
+    pos[ch] = v;
+  } else {
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    _Float16 *p = reinterpret_cast<_Float16 *>(pos) + 8 * (ch >> 2) + (ch & 3);
+    p[0] = hi;
+    p[4] = lo;
+  }
+}
+
+template <bool H>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_denoise(DenoiseW w, float *__restrict__ cube, int nimg) {
+  constexpr int PF = DN_PF;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
@@ -84,22 +165,42 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
   const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+  // Synchronisation: one barrier per layer.  A layer reads one region and writes the other; the
+  // border (zero padding) of its output layout is cleared by the layer itself -- the interior is
+  // overwritten completely -- so nothing touches a region between the barrier that ends its last
+  // reader and the barrier that publishes its new contents.
+  constexpr int PF2 = 4;                 // ring depth of the two layers with four quads per step
+  float cur0 = 0.f, cur1 = 0.f;          // this image's two pixels per thread, prefetched
+  if ((int)blockIdx.x < nimg) {
+    const float *t0 = cube + (long long)blockIdx.x * 256;
+    cur0 = t0[tid]; cur1 = t0[tid + 128];
+  }
   for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
     float *tile = cube + (long long)img * 256;
     // the weight pointers are laundered once per image: otherwise every one of the ~130 streamed
     // loads gets its loop-invariant 64-bit address hoisted out of this loop into registers
-    const float4 *w2p = w.w2, *w3p = w.w3, *w4p = w.w4, *w5p = w.w5;
+    const float4 *w2p = H ? w.w2h : w.w2, *w3p = H ? w.w3h : w.w3, *w4p = H ? w.w4h : w.w4,
+                 *w5p = H ? w.w5h : w.w5;
     asm volatile("" : "+s"(w2p), "+s"(w3p), "+s"(w4p), "+s"(w5p));
+    const float4 *w2l = w2p + (wv * 64 + lane);
+    DnWt<H> rb2[PF2];                                        // L2's first weights: in flight during L1
+#pragma unroll
+    for (int s = 0; s < PF2; s++) rb2[s] = dn_ldw<H>(w2l, s * 2 * 64);
     // ================= input (transposed) -> IN = Y[18][18]
-    dn_zero(Y, 324, tid);
-    __syncthreads();
-    for (int p = tid; p < 256; p += 128) {
-      const int ty = p >> 4, tx = p & 15;                    // tile[ty][tx] -> net row tx, col ty
-      Y[(tx + 1) * 18 + (ty + 1)] = tile[p];
+    dn_border<18, 1>(Y, tid);
+    {
+      const int p0 = tid, p1 = tid + 128;                    // tile[ty][tx] -> net row tx, col ty
+      Y[((p0 & 15) + 1) * 18 + ((p0 >> 4) + 1)] = cur0;
+      Y[((p1 & 15) + 1) * 18 + ((p1 >> 4) + 1)] = cur1;
+      const int nxt = img + gridDim.x;
+      if (nxt < nimg) {
+        const float *tn = cube + (long long)nxt * 256;
+        cur0 = tn[tid]; cur1 = tn[tid + 128];
+      }
     }
-    dn_zero(X, 2000, tid);                                   // A1 [10][10][20]
     __syncthreads();
-    // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X
+    // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X [10][10][20]
+    dn_border<10, DN_S16>(X, tid);
     {
       // A operand: lane (q, c): m = c -> window 4*mt + (c >> 2), pixel r = c & 3 of the window
 #pragma unroll
@@ -114,13 +215,14 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
         // D: lane (q, c): window 4*mt + q, channel c, the 4 registers = the 2x2 window
         const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
         const int wo = 4 * mt + q;
-        X[(((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DN_S16 + c] = v;
+        dn_store<H>(X + (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DN_S16, c, v);
       }
     }
-    __syncthreads();                                         // every wave is done reading IN
-    dn_zero(Y, 1296, tid);                                   // A2 [6][6][36]
     __syncthreads();
-    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y ; wave = channel tile
+    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y [6][6][36]; wave = channel tile
+    dn_border<6, DN_S32>(Y, tid);
+    const float4 *wp3 = w3p + (2 * wv * 64 + lane);   // step s = tap * 2 + g: + s * 4 * 64
+    DnWt<H> rb0[PF], rb1[PF];
     {
       f32x4d acc[4] = {Z, Z, Z, Z};
       int abase[4];
@@ -132,65 +234,67 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
       }
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
-        const float4 b = w2p[(tap * 2 + wv) * 64 + lane];
+        const DnB<H> b = dn_expand(rb2[tap % PF2]);
+        if (tap + PF2 < 9) rb2[tap % PF2] = dn_ldw<H>(w2l, (tap + PF2) * 2 * 64);
         const int toff = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * DN_S16;
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
           const float4 a = *reinterpret_cast<const float4 *>(X + abase[mt] + toff);
-          acc[mt] = dn_quad(a, b, acc[mt]);
+          acc[mt] = dn_quadw(a, b, acc[mt]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
+      for (int s = 0; s < PF; s++) { rb0[s] = dn_ldw<H>(wp3, s * 256); rb1[s] = dn_ldw<H>(wp3, s * 256 + 64); }
+#pragma unroll
       for (int mt = 0; mt < 4; mt++) {
         const float v = fmaxf(fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3])) + bias2, 0.f);
         const int wo = 4 * mt + q;                           // window in the 4x4 pooled grid
-        Y[(((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DN_S32 + 16 * wv + c] = v;
+        dn_store<H>(Y + (((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DN_S32, 16 * wv + c, v);
       }
     }
     __syncthreads();
-    dn_zero(X, 2448, tid);                                   // A3 [6][6][68]
-    __syncthreads();
-    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X ; wave = channel tiles 2wv, 2wv+1
+    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X [6][6][68]; wave = channel tiles 2wv, 2wv+1
+    dn_border<6, DN_S64>(X, tid);
+    const float4 *wp4 = w4p + (wv * 64 + lane);       // step s = (cls * 4 + tap) * 4 + g: + s * 2 * 64
+    DnWt<H> rb[PF];
     {
       f32x4d acc0 = Z, acc1 = Z;
       const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DN_S32 + 4 * q;
-      // weights stream from L2 through a ring of DN_PF steps (2 float4 per step), issued that
-      // many steps ahead; the scheduling barriers keep the compiler from hoisting all 36 loads
-      const float4 *wp = w3p + 2 * wv * 64 + lane;          // step s = tap * 2 + g: + s * 4 * 64
-      float4 rb0[DN_PF], rb1[DN_PF];
-#pragma unroll
-      for (int s = 0; s < DN_PF; s++) { rb0[s] = wp[s * 256]; rb1[s] = wp[s * 256 + 64]; }
+      // weights stream from L2 through a ring of PF steps, issued that many steps ahead; the
+      // scheduling barriers keep the compiler from hoisting all the loads to the top
 #pragma unroll
       for (int s = 0; s < 18; s++) {
         const int tap = s >> 1, g = s & 1;
         const int toff = ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DN_S32;
         const float4 a = *reinterpret_cast<const float4 *>(Y + abase + toff + 16 * g);
-        const float4 b0 = rb0[s % DN_PF], b1 = rb1[s % DN_PF];
-        if (s + DN_PF < 18) { rb0[s % DN_PF] = wp[(s + DN_PF) * 256]; rb1[s % DN_PF] = wp[(s + DN_PF) * 256 + 64]; }
-        acc0 = dn_quad(a, b0, acc0);
-        acc1 = dn_quad(a, b1, acc1);
+        const DnB<H> b0 = dn_expand(rb0[s % PF]), b1 = dn_expand(rb1[s % PF]);
+        if (s + PF < 18) {
+          rb0[s % PF] = dn_ldw<H>(wp3, (s + PF) * 256);
+          rb1[s % PF] = dn_ldw<H>(wp3, (s + PF) * 256 + 64);
+        }
+        acc0 = dn_quadw(a, b0, acc0);
+        acc1 = dn_quadw(a, b1, acc1);
         __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int s = 0; s < PF; s++) rb[s] = dn_ldw<H>(wp4, s * 128);
       // D: m = 4q + r -> pixel (q, r)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        float *o = X + ((q + 1) * 6 + r + 1) * DN_S64 + 32 * wv + c;
-        o[0] = fmaxf(acc0[r] + bias3a, 0.f);
-        o[16] = fmaxf(acc1[r] + bias3b, 0.f);
+        float *o = X + ((q + 1) * 6 + r + 1) * DN_S64;
+        dn_store<H>(o, 32 * wv + c, fmaxf(acc0[r] + bias3a, 0.f));
+        dn_store<H>(o, 32 * wv + 16 + c, fmaxf(acc1[r] + bias3b, 0.f));
       }
     }
     __syncthreads();
-    dn_zero(Y, 3600, tid);                                   // A4 [10][10][36]
-    __syncthreads();
-    // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y ; wave = channel tile
+    // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y [10][10][36]; wave = channel tile
+    dn_border<10, DN_S32>(Y, tid);
+    const float4 *w5l = w5p + (16 * wv * 64 + lane);  // wave = output row parity py: step s = px * 8 + tap * 2 + g
+    DnWt<H> rb5[PF2];
     {
       const int a0 = c >> 2, b0 = c & 3;                     // A operand: m = c -> input pixel (a0, b0)
       const int abase = ((a0 + 1) * 6 + b0 + 1) * DN_S64 + 4 * q;
-      const float4 *wp = w4p + wv * 64 + lane;              // step s = (cls * 4 + tap) * 4 + g: + s * 2 * 64
-      float4 rb[DN_PF];
-#pragma unroll
-      for (int s = 0; s < DN_PF; s++) rb[s] = wp[s * 128];
       f32x4d acc = Z;
 #pragma unroll
       for (int s = 0; s < 64; s++) {
@@ -200,23 +304,26 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
         const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
         const int toff = (dy * 6 + dx) * DN_S64;
         const float4 a = *reinterpret_cast<const float4 *>(X + abase + toff + 16 * g);
-        const float4 b = rb[s % DN_PF];
-        if (s + DN_PF < 64) rb[s % DN_PF] = wp[(s + DN_PF) * 128];
-        acc = dn_quad(a, b, acc);
+        const DnB<H> b = dn_expand(rb[s % PF]);
+        if (s + PF < 64) rb[s % PF] = dn_ldw<H>(wp4, (s + PF) * 128);
+        acc = dn_quadw(a, b, acc);
         if ((s & 15) == 15) {
+          if (s == 63) {
+#pragma unroll
+            for (int t = 0; t < PF2; t++) rb5[t] = dn_ldw<H>(w5l, t * 64);
+          }
           // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            Y[((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32 + 16 * wv + c] = fmaxf(acc[r] + bias4, 0.f);
+            dn_store<H>(Y + ((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32, 16 * wv + c, fmaxf(acc[r] + bias4, 0.f));
           acc = Z;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
-    dn_zero(X, 5184, tid);                                   // A5 [18][18][16]
-    __syncthreads();
-    // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X ; wave = output row parity
+    // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X [18][18][16]; wave = output row parity
+    dn_border<18, 16>(X, tid);
     {
       int abase[4];
 #pragma unroll
@@ -225,7 +332,6 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
       const int py = wv;
 #pragma unroll
       for (int px = 0; px < 2; px++) {
-        const int cls = 2 * py + px;
         f32x4d acc[4] = {Z, Z, Z, Z};
 #pragma unroll
         for (int tap = 0; tap < 4; tap++) {
@@ -234,11 +340,13 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
           const int toff = (dy * 10 + dx) * DN_S32;
 #pragma unroll
           for (int g = 0; g < 2; g++) {
-            const float4 b = w5p[((cls * 4 + tap) * 2 + g) * 64 + lane];
+            const int s = px * 8 + tap * 2 + g;
+            const DnB<H> b = dn_expand(rb5[s % PF2]);
+            if (s + PF2 < 16) rb5[s % PF2] = dn_ldw<H>(w5l, (s + PF2) * 64);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) {
               const float4 a = *reinterpret_cast<const float4 *>(Y + abase[mt] + toff + 16 * g);
-              acc[mt] = dn_quad(a, b, acc[mt]);
+              acc[mt] = dn_quadw(a, b, acc[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -255,6 +363,8 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
     }
     __syncthreads();
     // ================= D3: 3x3 correlation 16 -> 1 on the VALU, write back transposed
+    // (no barrier behind it: the next writer of X is the next image's L1, behind that image's
+    // input barrier, which no wave passes before it has finished reading X here)
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int p = tid + 128 * k;                           // net pixel (row p >> 4, col p & 15)
@@ -274,7 +384,6 @@ __global__ __launch_bounds__(128) void k_denoise(DenoiseW w, float *__restrict__
       }
       tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
     }
-    __syncthreads();
   }
 }
 
@@ -365,6 +474,23 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
   if (!rc) { conv_pack(wt[2], 64, 32, h4); rc = dn_upload<float4>(d, h4, &d->w.w3); }
   if (!rc) { convT_pack(wt[3], 64, 32, h4); rc = dn_upload<float4>(d, h4, &d->w.w4); }
   if (!rc) { convT_pack(wt[4], 32, 16, h4); rc = dn_upload<float4>(d, h4, &d->w.w5); }
+  // split-fp16 B operands of the same four arrays
+  auto split_pack = [&](const std::vector<float4> &src, std::vector<float4> &dst) {
+    dst.resize(src.size());
+    for (size_t i = 0; i < src.size(); i++) {
+      const float v[4] = {src[i].x, src[i].y, src[i].z, src[i].w};
+      _Float16 hl[8];
+      for (int j = 0; j < 4; j++) { hl[j] = (_Float16)v[j]; hl[4 + j] = (_Float16)(v[j] - (float)hl[j]); }
+      memcpy(&dst[i], hl, 16);
+    }
+  };
+  {
+    std::vector<float4> hs;
+    if (!rc) { conv_pack(wt[1], 32, 16, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w2h); }
+    if (!rc) { conv_pack(wt[2], 64, 32, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w3h); }
+    if (!rc) { convT_pack(wt[3], 64, 32, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w4h); }
+    if (!rc) { convT_pack(wt[4], 32, 16, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w5h); }
+  }
   if (!rc) {  // D3: out[oy][ox] = sum in[oy + 1 - ky][ox + 1 - kx] w[ci][0][ky][kx]: tap (ty, tx) = (2 - ky, 2 - kx)
     std::vector<float> h(9 * 16);
     for (int ty = 0; ty < 3; ty++)
@@ -384,13 +510,24 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
   return 0;
 }
 
-int aomarl_denoiser_apply(aomarl_denoiser *d, float *cube, long long nimg, void *stream) {
+static int denoiser_launch(aomarl_denoiser *d, float *cube, long long nimg, bool f32, void *stream) {
   if (!d || !cube) return fail("denoiser_apply: null argument");
   if (nimg <= 0) return 0;
   if (nimg > 0x7fffffffLL) return fail("denoiser_apply: too many images");
   const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
   const int blocks = (int)std::min<long long>(nimg, 256 * 4 * 4);
-  hipLaunchKernelGGL(k_denoise, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+  if (f32)
+    hipLaunchKernelGGL(k_denoise<false>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+  else
+    hipLaunchKernelGGL(k_denoise<true>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
   LAUNCHCHK();
   return 0;
+}
+
+int aomarl_denoiser_apply(aomarl_denoiser *d, float *cube, long long nimg, void *stream) {
+  return denoiser_launch(d, cube, nimg, false, stream);
+}
+
+int aomarl_denoiser_apply_f32(aomarl_denoiser *d, float *cube, long long nimg, void *stream) {
+  return denoiser_launch(d, cube, nimg, true, stream);
 }

@@ -87,12 +87,14 @@ class SubapDenoiser(object):
         return x.float()
 
     @torch.no_grad()
-    def denoise_bincube_(self, bincube):
-        """In place on a [nenv, nvalid, 256] bincube of [y][x] tiles."""
+    def denoise_bincube_(self, bincube, f32=False):
+        """In place on a [nenv, nvalid, 256] bincube of [y][x] tiles.  f32: every product on fp32
+        matrix instructions (aomarl_denoiser_apply_f32) instead of fp16 pairs."""
         n, nv, np2 = bincube.shape
         if self.use_native and bincube.is_contiguous() and bincube.dtype == torch.float32:
             from . import libaomarl as la
-            la.check(la.load().aomarl_denoiser_apply(
+            fn = la.load().aomarl_denoiser_apply_f32 if f32 else la.load().aomarl_denoiser_apply
+            la.check(fn(
                     self._native(), bincube.data_ptr(), n * nv,
                     C.c_void_p(torch.cuda.current_stream(bincube.device).cuda_stream)))
             return bincube

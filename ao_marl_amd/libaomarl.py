@@ -117,6 +117,7 @@ SYMBOLS = [
     ("aomarl_agent_rewards", _i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _vp]),
     ("aomarl_denoiser_create", _i, [C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_void_p)]),
     ("aomarl_denoiser_apply", _i, [_vp, _vp, C.c_longlong, _vp]),
+    ("aomarl_denoiser_apply_f32", _i, [_vp, _vp, C.c_longlong, _vp]),
     ("aomarl_denoiser_destroy", _i, [_vp]),
     ("aomarl_target_psf_buffer", _i, _range + [_vp]),
     ("aomarl_set_geo", _i, [_vp, _fp]),

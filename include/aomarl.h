@@ -362,6 +362,11 @@ typedef struct aomarl_denoiser aomarl_denoiser;
 int aomarl_denoiser_create(const float *const *weights, const float *const *biases,
                            aomarl_denoiser **out);
 int aomarl_denoiser_apply(aomarl_denoiser *dn, float *cube, long long nimg, void *stream);
+/* The same network with every product on fp32 matrix instructions (4x the matrix-pipe time).  The
+ * default entry point carries each operand as an fp16 pair (hi + lo, 22 mantissa bits, fp32
+ * accumulation): same results to fp32 rounding as long as inputs and activations stay inside the
+ * fp16 range (|v| < 65504); use this one for data that does not. */
+int aomarl_denoiser_apply_f32(aomarl_denoiser *dn, float *cube, long long nimg, void *stream);
 int aomarl_denoiser_destroy(aomarl_denoiser *dn);
 /* PSF window + phase variance of st->tar_phase as it stands (pending, like aomarl_target_psf) */
 int aomarl_target_psf_buffer(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
