@@ -90,3 +90,27 @@ def test_fused_mfma_denoiser_matches_the_tensor_library_path(golden_dir):
     assert (got - want).abs().max().item() < 2e-5 * scale
     ref = g["y"].reshape(8, 16, 16).transpose(1, 2).reshape(8, 256).cuda()
     assert (got[0, :8] - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("peak", [1.0, 40.0, 3000.0])
+def test_split_fp16_and_fp32_denoiser_kernels_agree_with_fp64(golden_dir, peak):
+    """Both fused kernels (aomarl_denoiser_apply: fp16 hi + lo pairs, fp32 accumulation;
+    aomarl_denoiser_apply_f32: fp32 matrix instructions) against the network evaluated in fp64, from
+    faint to bright spots: the split kernel stays within 3x of the fp32 kernel's own rounding."""
+    from ao_marl_amd.denoiser import SubapDenoiser
+    g = torch.load(os.path.join(golden_dir, "host_denoiser.pt"), weights_only=True)
+    dn = SubapDenoiser(g["state_dict"], device="cuda:0")
+    dn64 = SubapDenoiser(g["state_dict"], device="cpu", dtype=torch.float64)
+    gen = torch.Generator().manual_seed(int(peak))
+    cube = torch.rand(2, 300, 256, generator=gen) * peak
+    cube[1] *= torch.rand(300, 1, generator=gen)               # a mix of faint and bright tiles
+    want = dn64.denoise_bincube_(cube.double().clone())
+    scale = want.abs().max().item()
+    err = {}
+    for f32 in (False, True):
+        got = dn.denoise_bincube_(cube.cuda().clone(), f32=f32).cpu().double()
+        assert torch.isfinite(got).all()
+        err[f32] = (got - want).abs().max().item() / scale
+    assert err[True] < 5e-6
+    assert err[False] < max(3 * err[True], 5e-6), err
