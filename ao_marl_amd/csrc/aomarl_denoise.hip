@@ -24,6 +24,7 @@
 // The network sees the image transposed ([x][y], the reference feeds COMPASS's first-index-fastest
 // arrays); the transpose happens on the way into and out of LDS.
 #include "aomarl_dev.h"
+#include <type_traits>
 
 typedef float f32x4d __attribute__((ext_vector_type(4)));
 
@@ -387,6 +388,260 @@ void k_denoise(DenoiseW w, float *__restrict__ cube, int nimg) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same network with FOUR waves per image (same LDS image: four blocks = sixteen waves per CU
+// instead of eight).  Per-wave work halves, so twice the waves are there to cover the LDS / L2
+// latencies between dependent steps.  Work split (wv = 0..3):
+//   L1  M tiles 4 wv .. 4 wv + 3            L2  N tile wv & 1, M tiles 2 (wv >> 1), + 1
+//   L3  N tile wv                           D1  N tile wv & 1, parity classes 2 (wv >> 1), + 1
+//   D2  parity class wv (py = wv >> 1, px = wv & 1), all four M tiles       D3  one pixel per thread
+// ---------------------------------------------------------------------------------------------
+template <int R, int S>
+__device__ __forceinline__ void dn_border4(float *p, int tid) {
+  constexpr int NP = 4 * R - 4;
+  if (S == 1) {
+    for (int i = tid; i < NP; i += 256) {
+      const int row = i < R ? 0 : (i < 2 * R ? R - 1 : 1 + ((i - 2 * R) >> 1));
+      const int col = i < R ? i : (i < 2 * R ? i - R : (((i - 2 * R) & 1) ? R - 1 : 0));
+      p[row * R + col] = 0.f;
+    }
+  } else {
+    constexpr int V = S / 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < NP * V; i += 256) {
+      const int pi = i / V, k = i - pi * V;
+      const int row = pi < R ? 0 : (pi < 2 * R ? R - 1 : 1 + ((pi - 2 * R) >> 1));
+      const int col = pi < R ? pi : (pi < 2 * R ? pi - R : (((pi - 2 * R) & 1) ? R - 1 : 0));
+      *reinterpret_cast<float4 *>(p + (row * R + col) * S + 4 * k) = z;
+    }
+  }
+}
+
+template <bool H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
+  constexpr int PF = 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, q0 = lane0 >> 4, c0 = lane0 & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int nt2 = wv & 1, hi2 = wv >> 1;
+  for (int i = tid0; i < 144; i += 256) W6[i] = w.w6[i];
+  float b1w[3];
+  int t1off[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    b1w[i] = w.w1[i * 64 + lane0];
+    const int tap = 4 * i + q0;
+    t1off[i] = tap < 9 ? (tap / 3 - 1) * 18 + (tap % 3 - 1) : 0;
+  }
+  const float bias1 = w.b1[c0], bias2 = w.b2[16 * nt2 + c0], bias3 = w.b3[16 * wv + c0],
+              bias4 = w.b4[16 * nt2 + c0], bias5 = w.b5[c0];
+  const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  float cur = 0.f;                       // this image's pixel of this thread, prefetched
+  if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid0];
+  for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+    // per-lane indices laundered once per image: every LDS / global address below is recomputed
+    // where it is used instead of living in a register across the whole loop (~80 of them otherwise)
+    int tid = tid0, q = q0, c = c0;
+    asm volatile("" : "+v"(tid), "+v"(q), "+v"(c));
+    const int lane = tid & 63;
+    float *tile = cube + (long long)img * 256;
+    const float4 *w2p = H ? w.w2h : w.w2, *w3p = H ? w.w3h : w.w3, *w4p = H ? w.w4h : w.w4,
+                 *w5p = H ? w.w5h : w.w5;
+    asm volatile("" : "+s"(w2p), "+s"(w3p), "+s"(w4p), "+s"(w5p));
+    const float4 *w2l = w2p + (nt2 * 64 + lane);             // step tap: + tap * 2 * 64
+    DnWt<H> rb2[PF];
+#pragma unroll
+    for (int s = 0; s < PF; s++) rb2[s] = dn_ldw<H>(w2l, s * 2 * 64);
+    // ================= input (transposed) -> IN = Y[18][18]
+    dn_border4<18, 1>(Y, tid);
+    Y[((tid & 15) + 1) * 18 + ((tid >> 4) + 1)] = cur;       // tile[ty][tx] -> net row tx, col ty
+    {
+      const int nxt = img + gridDim.x;
+      if (nxt < nimg) cur = cube[(long long)nxt * 256 + tid];
+    }
+    __syncthreads();
+    // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X [10][10][20]
+    dn_border4<10, DN_S16>(X, tid);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int mt = 4 * wv + k;
+      const int win = 4 * mt + (c >> 2), r = c & 3;
+      const int py = 2 * (win >> 3) + (r >> 1), px = 2 * (win & 7) + (r & 1);
+      const float *in = Y + (py + 1) * 18 + (px + 1);
+      f32x4d acc = Z;
+#pragma unroll
+      for (int i = 0; i < 3; i++) acc = dn_mfma(in[t1off[i]], b1w[i], acc);
+      const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
+      const int wo = 4 * mt + q;
+      dn_store<H>(X + (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DN_S16, c, v);
+    }
+    __syncthreads();
+    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y [6][6][36]
+    dn_border4<6, DN_S32>(Y, tid);
+    const float4 *wp3 = w3p + (wv * 64 + lane);              // step s = tap * 2 + g: + s * 4 * 64
+    DnWt<H> rb3[PF];
+    {
+      f32x4d acc[2] = {Z, Z};
+      int abase[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const int mt = 2 * hi2 + m;
+        const int win = 4 * mt + (c >> 2), r = c & 3;
+        const int py = 2 * (win >> 2) + (r >> 1), px = 2 * (win & 3) + (r & 1);
+        abase[m] = ((py + 1) * 10 + (px + 1)) * DN_S16 + 4 * q;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const DnB<H> b = dn_expand(rb2[tap % PF]);
+        if (tap + PF < 9) rb2[tap % PF] = dn_ldw<H>(w2l, (tap + PF) * 2 * 64);
+        const int toff = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * DN_S16;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          const float4 a = *reinterpret_cast<const float4 *>(X + abase[m] + toff);
+          acc[m] = dn_quadw(a, b, acc[m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < PF; s++) rb3[s] = dn_ldw<H>(wp3, s * 256);
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const int mt = 2 * hi2 + m;
+        const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])) + bias2, 0.f);
+        const int wo = 4 * mt + q;                           // window in the 4x4 pooled grid
+        dn_store<H>(Y + (((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DN_S32, 16 * nt2 + c, v);
+      }
+    }
+    __syncthreads();
+    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X [6][6][68]; wave = channel tile wv
+    dn_border4<6, DN_S64>(X, tid);
+    // D1: step t = (clsl * 4 + tap) * 4 + g of this wave's two classes: + ((2 hi2) * 16 + t) * 2 * 64
+    const float4 *wp4 = w4p + ((2 * hi2 * 16) * 128 + nt2 * 64 + lane);
+    DnWt<H> rb4[PF];
+    {
+      f32x4d acc = Z;
+      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DN_S32 + 4 * q;
+#pragma unroll
+      for (int s = 0; s < 18; s++) {
+        const int tap = s >> 1, g = s & 1;
+        const int toff = ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DN_S32;
+        const float4 a = *reinterpret_cast<const float4 *>(Y + abase + toff + 16 * g);
+        const DnB<H> b = dn_expand(rb3[s % PF]);
+        if (s + PF < 18) rb3[s % PF] = dn_ldw<H>(wp3, (s + PF) * 256);
+        acc = dn_quadw(a, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < PF; s++) rb4[s] = dn_ldw<H>(wp4, s * 128);
+#pragma unroll
+      for (int r = 0; r < 4; r++)                            // D: m = 4q + r -> pixel (q, r)
+        dn_store<H>(X + ((q + 1) * 6 + r + 1) * DN_S64, 16 * wv + c, fmaxf(acc[r] + bias3, 0.f));
+    }
+    __syncthreads();
+    // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y [10][10][36]
+    dn_border4<10, DN_S32>(Y, tid);
+    const float4 *w5l = w5p + (wv * 8 * 64 + lane);          // D2: class wv, step s = tap * 2 + g: + s * 64
+    DnWt<H> rb5[PF];
+    // the output-row parity of this wave (py) is made a compile-time constant by a wave-uniform
+    // branch: every tap offset stays an immediate of the LDS instruction (as run-time values they
+    // became ~100 hoisted address registers)
+    auto d1_body = [&](auto PYc) {
+      constexpr int py = decltype(PYc)::value;
+      const int a0 = c >> 2, b0 = c & 3;                     // A operand: m = c -> input pixel (a0, b0)
+      const int abase = ((a0 + 1) * 6 + b0 + 1) * DN_S64 + 4 * q;
+      f32x4d acc = Z;
+#pragma unroll
+      for (int s = 0; s < 32; s++) {
+        const int clsl = s >> 4, tap = (s >> 2) & 3, g = s & 3;
+        const int px = clsl;                                 // class 2 py + clsl
+        const int ty = tap >> 1, tx = tap & 1;
+        const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
+        const int toff = (dy * 6 + dx) * DN_S64;
+        const float4 a = *reinterpret_cast<const float4 *>(X + abase + toff + 16 * g);
+        const DnB<H> b = dn_expand(rb4[s % PF]);
+        if (s + PF < 32) rb4[s % PF] = dn_ldw<H>(wp4, (s + PF) * 128);
+        acc = dn_quadw(a, b, acc);
+        if ((s & 15) == 15) {
+          if (s == 31) {
+#pragma unroll
+            for (int t = 0; t < PF; t++) rb5[t] = dn_ldw<H>(w5l, t * 64);
+          }
+          // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            dn_store<H>(Y + ((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32, 16 * nt2 + c,
+                        fmaxf(acc[r] + bias4, 0.f));
+          acc = Z;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (hi2 == 0) d1_body(std::integral_constant<int, 0>{}); else d1_body(std::integral_constant<int, 1>{});
+    __syncthreads();
+    // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X [18][18][16]; wave = class
+    dn_border4<18, 16>(X, tid);
+    auto d2_body = [&](auto PYc, auto PXc) {
+      constexpr int py = decltype(PYc)::value, px = decltype(PXc)::value;
+      int abase[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+        abase[mt] = ((2 * mt + (c >> 3) + 1) * 10 + (c & 7) + 1) * DN_S32 + 4 * q;
+      f32x4d acc[4] = {Z, Z, Z, Z};
+#pragma unroll
+      for (int tap = 0; tap < 4; tap++) {
+        const int ty = tap >> 1, tx = tap & 1;
+        const int toff = ((ty == 0 ? 0 : (2 * py - 1)) * 10 + (tx == 0 ? 0 : (2 * px - 1))) * DN_S32;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          const int s = tap * 2 + g;
+          const DnB<H> b = dn_expand(rb5[s % PF]);
+          if (s + PF < 8) rb5[s % PF] = dn_ldw<H>(w5l, (s + PF) * 64);
+#pragma unroll
+          for (int mt = 0; mt < 4; mt++) {
+            const float4 a = *reinterpret_cast<const float4 *>(Y + abase[mt] + toff + 16 * g);
+            acc[mt] = dn_quadw(a, b, acc[mt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // D: m = 4q + r -> input pixel (2 mt + (q >> 1), 4 (q & 1) + r)
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int a = 2 * mt + (q >> 1), b = 4 * (q & 1) + r;
+          X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r] + bias5, 0.f);
+        }
+    };
+    {
+      std::integral_constant<int, 0> c0; std::integral_constant<int, 1> c1;
+      if (wv == 0) d2_body(c0, c0); else if (wv == 1) d2_body(c0, c1); else if (wv == 2) d2_body(c1, c0); else d2_body(c1, c1);
+    }
+    __syncthreads();
+    // ================= D3: 3x3 correlation 16 -> 1 on the VALU, write back transposed
+    {
+      const int ry = tid >> 4, rx = tid & 15;                // net pixel (row, col)
+      float s0 = w.b6, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const float *in = X + ((ry + tap / 3) * 18 + rx + tap % 3) * 16;
+        const float *wt = W6 + tap * 16;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const float4 a = *reinterpret_cast<const float4 *>(in + 4 * g);
+          const float4 ww = *reinterpret_cast<const float4 *>(wt + 4 * g);
+          s0 += a.x * ww.x; s1 += a.y * ww.y; s2 += a.z * ww.z; s3 += a.w * ww.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 struct aomarl_denoiser {
   DenoiseW w;
@@ -516,10 +771,18 @@ static int denoiser_launch(aomarl_denoiser *d, float *cube, long long nimg, bool
   if (nimg > 0x7fffffffLL) return fail("denoiser_apply: too many images");
   const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
   const int blocks = (int)std::min<long long>(nimg, 256 * 4 * 4);
-  if (f32)
-    hipLaunchKernelGGL(k_denoise<false>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
-  else
-    hipLaunchKernelGGL(k_denoise<true>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+  static const bool two_waves = [] { const char *e = getenv("AOMARL_DENOISE_WAVES"); return e && e[0] == '2'; }();
+  if (two_waves) {
+    if (f32)
+      hipLaunchKernelGGL(k_denoise<false>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+    else
+      hipLaunchKernelGGL(k_denoise<true>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+  } else {
+    if (f32)
+      hipLaunchKernelGGL(k_denoise4<false>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+    else
+      hipLaunchKernelGGL(k_denoise4<true>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+  }
   LAUNCHCHK();
   return 0;
 }
