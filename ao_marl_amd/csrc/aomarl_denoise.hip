@@ -37,6 +37,12 @@ struct DenoiseW {
   // the same four arrays as split-fp16 B operands: per (step, lane) one 16-byte word
   // [hi(b0..b3) | lo(b0..b3)] (see dup_hl in aomarl_kernels.hip)
   const float4 *w2h, *w3h, *w4h, *w5h;
+  // split-fp16 B operands in 32-channel chunks (k_denoise4c): per (chunk, tile, lane) two 16-byte
+  // words, hi then lo, of the lane's 8 consecutive K slots
+  const float4 *w2c;      // [5 tap pairs][2 tiles][64][2]
+  const float4 *w3c;      // [9 taps][4 tiles][64][2]
+  const float4 *w4c;      // [4 classes][4 taps][2 halves][2 tiles][64][2]
+  const float4 *w5c;      // [4 classes][4 taps][64][2]
   const float *w6;        // [9][16]                 D3 (taps as a plain correlation)
   const float *b1, *b2, *b3, *b4, *b5;
   float b6;
@@ -642,6 +648,256 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-fp16 kernel in 32-channel chunks.  The activations A1..A4 live in LDS as two fp16 planes
+// (hi, lo), channel-last: an A operand of v_mfma_f32_16x16x32_f16 is 8 consecutive channels of one
+// pixel = one ds_read_b128 per plane, a B operand 8 consecutive K slots of one output channel = one
+// 16-byte load per part, and a chunk of 32 real channels costs THREE instructions
+//     acc += A_hi B_hi + A_lo B_hi + A_hi B_lo          (lo x lo, 2^-22 of the product, is dropped)
+// against four in k_denoise4<true> (which fills the 32 slots with 16 channels twice), with no operand
+// duplication moves at all.  A chunk is one tap x 32 channels (Cin = 32, 64) or two taps x 16
+// channels (Cin = 16: the second tap of the fifth pair does not exist -- zero weights).
+// LDS: X = A1 / A3 planes or A5 (fp32), Y = IN (fp32) or A2 / A4 planes.
+// ---------------------------------------------------------------------------------------------
+#define DC_S1 24           // halfs per pixel: 16 channels + 8 pad
+#define DC_S2 40           // 32 + 8
+#define DC_S3 72           // 64 + 8
+#define DC_PLX 2592        // halfs: lo plane offset in X (A3: 36 x 72)
+#define DC_PLY 4000        // halfs: lo plane offset in Y (A4: 100 x 40)
+#define DC_Y 4000          // floats of region Y (2 x 4000 halfs)
+
+struct DcB { hx8 h, l; };
+__device__ __forceinline__ DcB dc_ldw(const float4 *__restrict__ p, int idx) {
+  DcB r;
+  r.h = __builtin_bit_cast(hx8, p[2 * idx]);
+  r.l = __builtin_bit_cast(hx8, p[2 * idx + 1]);
+  return r;
+}
+__device__ __forceinline__ f32x4d dc_chunk(const _Float16 *__restrict__ hi, const _Float16 *__restrict__ lo,
+                                           int off, const DcB b, f32x4d acc) {
+  const hx8 ah = *reinterpret_cast<const hx8 *>(hi + off), al = *reinterpret_cast<const hx8 *>(lo + off);
+  acc = mfma_h(ah, b.h, acc);
+  acc = mfma_h(al, b.h, acc);
+  return mfma_h(ah, b.l, acc);
+}
+__device__ __forceinline__ void dc_store(_Float16 *hi, _Float16 *lo, int off, float v) {
+  const _Float16 h = (_Float16)v;
+  hi[off] = h;
+  lo[off] = (_Float16)(v - (float)h);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
+  constexpr int PF = 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *X = lds, *Y = lds + DN_X, *W6 = Y + DC_Y;          // W6: 144 weights of the last layer
+  _Float16 *XH = reinterpret_cast<_Float16 *>(X), *XL = XH + DC_PLX;
+  _Float16 *YH = reinterpret_cast<_Float16 *>(Y), *YL = YH + DC_PLY;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, q0 = lane0 >> 4, c0 = lane0 & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int nt2 = wv & 1, hi2 = wv >> 1;
+  for (int i = tid0; i < 144; i += 256) W6[i] = w.w6[i];
+  float b1w[3];
+  int t1off[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    b1w[i] = w.w1[i * 64 + lane0];
+    const int tap = 4 * i + q0;
+    t1off[i] = tap < 9 ? (tap / 3 - 1) * 18 + (tap % 3 - 1) : 0;
+  }
+  const float bias1 = w.b1[c0], bias2 = w.b2[16 * nt2 + c0], bias3 = w.b3[16 * wv + c0],
+              bias4 = w.b4[16 * nt2 + c0], bias5 = w.b5[c0];
+  const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  float cur = 0.f;                       // this image's pixel of this thread, prefetched
+  if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid0];
+  for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+    // per-lane indices laundered once per image (see k_denoise4)
+    int tid = tid0, q = q0, c = c0;
+    asm volatile("" : "+v"(tid), "+v"(q), "+v"(c));
+    const int lane = tid & 63;
+    float *tile = cube + (long long)img * 256;
+    const float4 *w2p = w.w2c, *w3p = w.w3c, *w4p = w.w4c, *w5p = w.w5c;
+    asm volatile("" : "+s"(w2p), "+s"(w3p), "+s"(w4p), "+s"(w5p));
+    const float4 *w2l = w2p + 2 * (nt2 * 64 + lane);         // chunk j: + j * 2 tiles * 64 (x 2 words)
+    DcB rb2[PF];
+#pragma unroll
+    for (int s = 0; s < PF; s++) rb2[s] = dc_ldw(w2l, s * 128);
+    // ================= input (transposed) -> IN = Y[18][18] (fp32)
+    dn_border4<18, 1>(Y, tid);
+    Y[((tid & 15) + 1) * 18 + ((tid >> 4) + 1)] = cur;       // tile[ty][tx] -> net row tx, col ty
+    {
+      const int nxt = img + gridDim.x;
+      if (nxt < nimg) cur = cube[(long long)nxt * 256 + tid];
+    }
+    __syncthreads();
+    // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X planes [10][10][24]
+    dn_border4<10, DC_S1 / 2>(reinterpret_cast<float *>(XH), tid);
+    dn_border4<10, DC_S1 / 2>(reinterpret_cast<float *>(XL), tid);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int mt = 4 * wv + k;
+      const int win = 4 * mt + (c >> 2), r = c & 3;
+      const int py = 2 * (win >> 3) + (r >> 1), px = 2 * (win & 7) + (r & 1);
+      const float *in = Y + (py + 1) * 18 + (px + 1);
+      f32x4d acc = Z;
+#pragma unroll
+      for (int i = 0; i < 3; i++) acc = dn_mfma(in[t1off[i]], b1w[i], acc);
+      const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
+      const int wo = 4 * mt + q;
+      dc_store(XH, XL, (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DC_S1 + c, v);
+    }
+    __syncthreads();
+    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y planes [6][6][40]
+    dn_border4<6, DC_S2 / 2>(reinterpret_cast<float *>(YH), tid);
+    dn_border4<6, DC_S2 / 2>(reinterpret_cast<float *>(YL), tid);
+    const float4 *wp3 = w3p + 2 * (wv * 64 + lane);          // chunk tap: + tap * 4 tiles * 64 (x 2)
+    DcB rb3[PF];
+    {
+      f32x4d acc[2] = {Z, Z};
+      int abase[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const int mt = 2 * hi2 + m;
+        const int win = 4 * mt + (c >> 2), r = c & 3;
+        const int py = 2 * (win >> 2) + (r >> 1), px = 2 * (win & 3) + (r & 1);
+        abase[m] = ((py + 1) * 10 + (px + 1)) * DC_S1 + 8 * (q & 1);
+      }
+      const int qt = q >> 1;                                 // which tap of the pair this lane group reads
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const DcB b = rb2[j % PF];
+        if (j + PF < 5) rb2[j % PF] = dc_ldw(w2l, (j + PF) * 128);
+        const int ta = 2 * j, tb = (2 * j + 1 < 9) ? 2 * j + 1 : 2 * j;
+        const int offa = ((ta / 3 - 1) * 10 + (ta % 3 - 1)) * DC_S1, offb = ((tb / 3 - 1) * 10 + (tb % 3 - 1)) * DC_S1;
+        const int toff = qt ? offb : offa;
+#pragma unroll
+        for (int m = 0; m < 2; m++) acc[m] = dc_chunk(XH, XL, abase[m] + toff, b, acc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < PF; s++) rb3[s] = dc_ldw(wp3, s * 256);
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const int mt = 2 * hi2 + m;
+        const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])) + bias2, 0.f);
+        const int wo = 4 * mt + q;                           // window in the 4x4 pooled grid
+        dc_store(YH, YL, (((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DC_S2 + 16 * nt2 + c, v);
+      }
+    }
+    __syncthreads();
+    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X planes [6][6][72]; wave = channel tile wv
+    dn_border4<6, DC_S3 / 2>(reinterpret_cast<float *>(XH), tid);
+    dn_border4<6, DC_S3 / 2>(reinterpret_cast<float *>(XL), tid);
+    // D1: chunk t = (clsl * 4 + tap) * 2 + h of this wave's two classes: + ((2 hi2) * 8 + t) * 2 tiles * 64
+    const float4 *wp4 = w4p + 2 * ((2 * hi2 * 8) * 128 + nt2 * 64 + lane);
+    DcB rb4[PF];
+    {
+      f32x4d acc = Z;
+      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DC_S2 + 8 * q;
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const DcB b = rb3[tap % PF];
+        if (tap + PF < 9) rb3[tap % PF] = dc_ldw(wp3, (tap + PF) * 256);
+        acc = dc_chunk(YH, YL, abase + ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DC_S2, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < PF; s++) rb4[s] = dc_ldw(wp4, s * 128);
+#pragma unroll
+      for (int r = 0; r < 4; r++)                            // D: m = 4q + r -> pixel (q, r)
+        dc_store(XH, XL, ((q + 1) * 6 + r + 1) * DC_S3 + 16 * wv + c, fmaxf(acc[r] + bias3, 0.f));
+    }
+    __syncthreads();
+    // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y planes [10][10][40]
+    dn_border4<10, DC_S2 / 2>(reinterpret_cast<float *>(YH), tid);
+    dn_border4<10, DC_S2 / 2>(reinterpret_cast<float *>(YL), tid);
+    const float4 *w5l = w5p + 2 * (wv * 4 * 64 + lane);      // D2: class wv, chunk tap: + tap * 64 (x 2)
+    DcB rb5[PF];
+    auto d1_body = [&](auto PYc) {
+      constexpr int py = decltype(PYc)::value;
+      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DC_S3 + 8 * q;   // m = c -> input pixel
+      f32x4d acc = Z;
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int clsl = s >> 3, tap = (s >> 1) & 3, h = s & 1;
+        const int px = clsl;                                 // class 2 py + clsl
+        const int ty = tap >> 1, tx = tap & 1;
+        const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
+        const DcB b = rb4[s % PF];
+        if (s + PF < 16) rb4[s % PF] = dc_ldw(wp4, (s + PF) * 128);
+        acc = dc_chunk(XH, XL, abase + (dy * 6 + dx) * DC_S3 + 32 * h, b, acc);
+        if ((s & 7) == 7) {
+          if (s == 15) {
+#pragma unroll
+            for (int t = 0; t < PF; t++) rb5[t] = dc_ldw(w5l, t * 64);
+          }
+          // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            dc_store(YH, YL, ((2 * q + py + 1) * 10 + 2 * r + px + 1) * DC_S2 + 16 * nt2 + c,
+                     fmaxf(acc[r] + bias4, 0.f));
+          acc = Z;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (hi2 == 0) d1_body(std::integral_constant<int, 0>{}); else d1_body(std::integral_constant<int, 1>{});
+    __syncthreads();
+    // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X [18][18][16] fp32; wave = class
+    dn_border4<18, 16>(X, tid);
+    auto d2_body = [&](auto PYc, auto PXc) {
+      constexpr int py = decltype(PYc)::value, px = decltype(PXc)::value;
+      int abase[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+        abase[mt] = ((2 * mt + (c >> 3) + 1) * 10 + (c & 7) + 1) * DC_S2 + 8 * q;
+      f32x4d acc[4] = {Z, Z, Z, Z};
+#pragma unroll
+      for (int tap = 0; tap < 4; tap++) {
+        const int ty = tap >> 1, tx = tap & 1;
+        const int toff = ((ty == 0 ? 0 : (2 * py - 1)) * 10 + (tx == 0 ? 0 : (2 * px - 1))) * DC_S2;
+        const DcB b = rb5[tap % PF];
+        if (tap + PF < 4) rb5[tap % PF] = dc_ldw(w5l, (tap + PF) * 64);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[mt] = dc_chunk(YH, YL, abase[mt] + toff, b, acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // D: m = 4q + r -> input pixel (2 mt + (q >> 1), 4 (q & 1) + r)
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int a = 2 * mt + (q >> 1), b = 4 * (q & 1) + r;
+          X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r] + bias5, 0.f);
+        }
+    };
+    {
+      std::integral_constant<int, 0> k0; std::integral_constant<int, 1> k1;
+      if (wv == 0) d2_body(k0, k0); else if (wv == 1) d2_body(k0, k1); else if (wv == 2) d2_body(k1, k0); else d2_body(k1, k1);
+    }
+    __syncthreads();
+    // ================= D3: 3x3 correlation 16 -> 1 on the VALU, write back transposed
+    {
+      const int ry = tid >> 4, rx = tid & 15;                // net pixel (row, col)
+      float s0 = w.b6, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const float *in = X + ((ry + tap / 3) * 18 + rx + tap % 3) * 16;
+        const float *wt = W6 + tap * 16;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const float4 a = *reinterpret_cast<const float4 *>(in + 4 * g);
+          const float4 ww = *reinterpret_cast<const float4 *>(wt + 4 * g);
+          s0 += a.x * ww.x; s1 += a.y * ww.y; s2 += a.z * ww.z; s3 += a.w * ww.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 struct aomarl_denoiser {
   DenoiseW w;
@@ -746,6 +1002,67 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
     if (!rc) { convT_pack(wt[3], 64, 32, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w4h); }
     if (!rc) { convT_pack(wt[4], 32, 16, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w5h); }
   }
+  // ---- 32-channel chunk operands of k_denoise4c: lane (n = lane & 15, kg = lane >> 4) holds K slots
+  //      8 kg .. 8 kg + 7 of output channel 16 nt + n, as 8 hi halfs then 8 lo halfs
+  auto put_chunk = [](std::vector<float4> &h, size_t idx, const float v[8]) {
+    _Float16 hi[8], lo[8];
+    for (int i = 0; i < 8; i++) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
+    memcpy(&h[2 * idx], hi, 16);
+    memcpy(&h[2 * idx + 1], lo, 16);
+  };
+  auto convT_k = [](int py, int ty) { return py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0); };
+  if (!rc) {  // L2: chunk j = taps 2j, 2j + 1 x 16 channels; slot: tap 2j + (kg >> 1), channel 8 (kg & 1) + i
+    std::vector<float4> h((size_t)5 * 2 * 64 * 2);
+    for (int j = 0; j < 5; j++)
+      for (int nt = 0; nt < 2; nt++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int kg = lane >> 4, co = 16 * nt + (lane & 15), tap = 2 * j + (kg >> 1);
+          float v[8];
+          for (int i = 0; i < 8; i++) v[i] = tap < 9 ? wt[1][((size_t)co * 16 + 8 * (kg & 1) + i) * 9 + tap] : 0.f;
+          put_chunk(h, ((size_t)j * 2 + nt) * 64 + lane, v);
+        }
+    rc = dn_upload<float4>(d, h, &d->w.w2c);
+  }
+  if (!rc) {  // L3: chunk = tap x 32 channels; slot: channel 8 kg + i
+    std::vector<float4> h((size_t)9 * 4 * 64 * 2);
+    for (int tap = 0; tap < 9; tap++)
+      for (int nt = 0; nt < 4; nt++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int kg = lane >> 4, co = 16 * nt + (lane & 15);
+          float v[8];
+          for (int i = 0; i < 8; i++) v[i] = wt[2][((size_t)co * 32 + 8 * kg + i) * 9 + tap];
+          put_chunk(h, ((size_t)tap * 4 + nt) * 64 + lane, v);
+        }
+    rc = dn_upload<float4>(d, h, &d->w.w3c);
+  }
+  if (!rc) {  // D1: chunk = (class, tap, half of the 64 channels); ConvTranspose2d weight [Cin][Cout][4][4]
+    std::vector<float4> h((size_t)4 * 4 * 2 * 2 * 64 * 2);
+    for (int cls = 0; cls < 4; cls++)
+      for (int tap = 0; tap < 4; tap++)
+        for (int hf = 0; hf < 2; hf++)
+          for (int nt = 0; nt < 2; nt++)
+            for (int lane = 0; lane < 64; lane++) {
+              const int kg = lane >> 4, co = 16 * nt + (lane & 15);
+              const int ky = convT_k(cls >> 1, tap >> 1), kx = convT_k(cls & 1, tap & 1);
+              float v[8];
+              for (int i = 0; i < 8; i++) v[i] = wt[3][(((size_t)(32 * hf + 8 * kg + i) * 32 + co) * 4 + ky) * 4 + kx];
+              put_chunk(h, ((((size_t)cls * 4 + tap) * 2 + hf) * 2 + nt) * 64 + lane, v);
+            }
+    rc = dn_upload<float4>(d, h, &d->w.w4c);
+  }
+  if (!rc) {  // D2: chunk = (class, tap) x 32 channels; weight [32][16][4][4]
+    std::vector<float4> h((size_t)4 * 4 * 64 * 2);
+    for (int cls = 0; cls < 4; cls++)
+      for (int tap = 0; tap < 4; tap++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int kg = lane >> 4, co = lane & 15;
+          const int ky = convT_k(cls >> 1, tap >> 1), kx = convT_k(cls & 1, tap & 1);
+          float v[8];
+          for (int i = 0; i < 8; i++) v[i] = wt[4][(((size_t)(8 * kg + i) * 16 + co) * 4 + ky) * 4 + kx];
+          put_chunk(h, ((size_t)cls * 4 + tap) * 64 + lane, v);
+        }
+    rc = dn_upload<float4>(d, h, &d->w.w5c);
+  }
   if (!rc) {  // D3: out[oy][ox] = sum in[oy + 1 - ky][ox + 1 - kx] w[ci][0][ky][kx]: tap (ty, tx) = (2 - ky, 2 - kx)
     std::vector<float> h(9 * 16);
     for (int ty = 0; ty < 3; ty++)
@@ -771,7 +1088,16 @@ static int denoiser_launch(aomarl_denoiser *d, float *cube, long long nimg, bool
   if (nimg > 0x7fffffffLL) return fail("denoiser_apply: too many images");
   const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
   const int blocks = (int)std::min<long long>(nimg, 256 * 4 * 4);
-  static const bool two_waves = [] { const char *e = getenv("AOMARL_DENOISE_WAVES"); return e && e[0] == '2'; }();
+  static const int variant = [] { const char *e = getenv("AOMARL_DENOISE_KERNEL"); return e ? atoi(e) : 0; }();
+  // 0 (default): split-fp16 in 32-channel chunks, four waves per image; 4: k_denoise4 (16-channel
+  // quads, four waves); 2: k_denoise (two waves) -- kept for comparison
+  if (!f32 && variant == 0) {
+    const size_t smc = sizeof(float) * (DN_X + DC_Y + 144);
+    hipLaunchKernelGGL(k_denoise4c, dim3(blocks), dim3(256), smc, (hipStream_t)stream, d->w, cube, (int)nimg);
+    LAUNCHCHK();
+    return 0;
+  }
+  const bool two_waves = variant == 2;
   if (two_waves) {
     if (f32)
       hipLaunchKernelGGL(k_denoise<false>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
