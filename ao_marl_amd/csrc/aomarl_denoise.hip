@@ -878,22 +878,35 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
     }
     __syncthreads();
     // ================= D3: 3x3 correlation 16 -> 1 on the VALU, write back transposed
+    // Thread t = (pixel group t >> 2, channel group g = t & 3): the four lanes of a quad read the
+    // four 16-byte channel groups of ONE pixel (64 contiguous bytes), a 16-lane pass of the LDS
+    // 256 contiguous bytes -- one thread per pixel reading its 64 bytes was a 4-way bank conflict
+    // on every read.  Each thread accumulates 4 pixels (p = (t >> 2) + 64 j) of its group, the quad
+    // is summed with two DPP adds and lane g writes pixel j = g.
     {
-      const int ry = tid >> 4, rx = tid & 15;                // net pixel (row, col)
-      float s0 = w.b6, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      const int g = tid & 3, pg = tid >> 2;                  // pg: 0..63 -> pixels pg + 64 j
+      float4 wg[9];                                          // this group's weights of the 9 taps
 #pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        const float *in = X + ((ry + tap / 3) * 18 + rx + tap % 3) * 16;
-        const float *wt = W6 + tap * 16;
+      for (int tap = 0; tap < 9; tap++) wg[tap] = *reinterpret_cast<const float4 *>(W6 + tap * 16 + 4 * g);
+      float res = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const float4 a = *reinterpret_cast<const float4 *>(in + 4 * g);
-          const float4 ww = *reinterpret_cast<const float4 *>(wt + 4 * g);
-          s0 += a.x * ww.x; s1 += a.y * ww.y; s2 += a.z * ww.z; s3 += a.w * ww.w;
+      for (int j = 0; j < 4; j++) {
+        const int p = pg + 64 * j;                           // net pixel (row p >> 4, col p & 15)
+        const float *in = X + ((p >> 4) * 18 + (p & 15)) * 16 + 4 * g;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+          const float4 a = *reinterpret_cast<const float4 *>(in + ((tap / 3) * 18 + tap % 3) * 16);
+          s0 += a.x * wg[tap].x; s1 += a.y * wg[tap].y; s2 += a.z * wg[tap].z; s3 += a.w * wg[tap].w;
         }
+        float sum = (s0 + s1) + (s2 + s3);
+        sum += dpp_f<0xB1>(sum);                             // quad_perm [1,0,3,2]
+        sum += dpp_f<0x4E>(sum);                             // quad_perm [2,3,0,1]
+        if (j == g) res = sum;
         __builtin_amdgcn_sched_barrier(0);
       }
-      tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
+      const int p = pg + 64 * g;
+      tile[(p & 15) * 16 + (p >> 4)] = res + w.b6;           // tile[ty = net col][tx = net row]
     }
   }
 }
