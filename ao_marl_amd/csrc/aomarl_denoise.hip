@@ -658,11 +658,17 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
 // duplication moves at all.  A chunk is one tap x 32 channels (Cin = 32, 64) or two taps x 16
 // channels (Cin = 16: the second tap of the fifth pair does not exist -- zero weights).
 // LDS: X = A1 / A3 planes or A5 (fp32), Y = IN (fp32) or A2 / A4 planes.
+// LDS banks: a 128-bit read is served in passes of 16 lanes over the 64 banks, so the 16 pixels of an
+// M tile must fall into 16 different 16-byte groups (mod 16).  With an odd pixel stride that means 16
+// pixel indices distinct mod 16: the 4 x 4 grids use a row pitch of 12 (pitch 6 puts two pairs of
+// pixels 16 apart), and the M tiles of the 8 x 8 grids are 8 rows x 2 columns (rows 10 apart: residues
+// 0, 10, 4, 14, 8, 2, 12, 6), not 2 rows x 8 columns.  Every A-operand read is then one pass per 16 lanes.
 // ---------------------------------------------------------------------------------------------
 #define DC_S1 24           // halfs per pixel: 16 channels + 8 pad
 #define DC_S2 40           // 32 + 8
 #define DC_S3 72           // 64 + 8
-#define DC_PLX 2592        // halfs: lo plane offset in X (A3: 36 x 72)
+#define DC_P 12            // row pitch (pixels) of the 6-row grids A2, A3 (see the bank note below)
+#define DC_PLX 5184        // halfs: lo plane offset in X (A3: 6 x 12 x 72)
 #define DC_PLY 4000        // halfs: lo plane offset in Y (A4: 100 x 40)
 #define DC_Y 4000          // floats of region Y (2 x 4000 halfs)
 
@@ -684,6 +690,19 @@ __device__ __forceinline__ void dc_store(_Float16 *hi, _Float16 *lo, int off, fl
   const _Float16 h = (_Float16)v;
   hi[off] = h;
   lo[off] = (_Float16)(v - (float)h);
+}
+
+// zero the one-pixel border of the 6 x 6 window of a grid with row pitch DC_P (S floats per pixel)
+template <int S>
+__device__ __forceinline__ void dc_border6(float *p, int tid) {
+  constexpr int V = S / 4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < 20 * V; i += 256) {
+    const int pi = i / V, k = i - pi * V;
+    const int row = pi < 6 ? 0 : (pi < 12 ? 5 : 1 + ((pi - 12) >> 1));
+    const int col = pi < 6 ? pi : (pi < 12 ? pi - 6 : (((pi - 12) & 1) ? 5 : 0));
+    *reinterpret_cast<float4 *>(p + (row * DC_P + col) * S + 4 * k) = z;
+  }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -749,8 +768,8 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
     }
     __syncthreads();
     // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y planes [6][6][40]
-    dn_border4<6, DC_S2 / 2>(reinterpret_cast<float *>(YH), tid);
-    dn_border4<6, DC_S2 / 2>(reinterpret_cast<float *>(YL), tid);
+    dc_border6<DC_S2 / 2>(reinterpret_cast<float *>(YH), tid);
+    dc_border6<DC_S2 / 2>(reinterpret_cast<float *>(YL), tid);
     const float4 *wp3 = w3p + 2 * (wv * 64 + lane);          // chunk tap: + tap * 4 tiles * 64 (x 2)
     DcB rb3[PF];
     {
@@ -758,9 +777,10 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
       int abase[2];
 #pragma unroll
       for (int m = 0; m < 2; m++) {
-        const int mt = 2 * hi2 + m;
-        const int win = 4 * mt + (c >> 2), r = c & 3;
-        const int py = 2 * (win >> 2) + (r >> 1), px = 2 * (win & 3) + (r & 1);
+        // M tile mt = the four pooling windows of window COLUMN mt (8 pixel rows x 2 columns):
+        // m = c -> window row c >> 2, pixel r = c & 3 of the window
+        const int mt = 2 * hi2 + m, r = c & 3;
+        const int py = 2 * (c >> 2) + (r >> 1), px = 2 * mt + (r & 1);
         abase[m] = ((py + 1) * 10 + (px + 1)) * DC_S1 + 8 * (q & 1);
       }
       const int qt = q >> 1;                                 // which tap of the pair this lane group reads
@@ -781,32 +801,32 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
       for (int m = 0; m < 2; m++) {
         const int mt = 2 * hi2 + m;
         const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])) + bias2, 0.f);
-        const int wo = 4 * mt + q;                           // window in the 4x4 pooled grid
-        dc_store(YH, YL, (((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DC_S2 + 16 * nt2 + c, v);
+        // D: lane group q = window row q of column mt in the 4x4 pooled grid
+        dc_store(YH, YL, ((q + 1) * DC_P + mt + 1) * DC_S2 + 16 * nt2 + c, v);
       }
     }
     __syncthreads();
     // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X planes [6][6][72]; wave = channel tile wv
-    dn_border4<6, DC_S3 / 2>(reinterpret_cast<float *>(XH), tid);
-    dn_border4<6, DC_S3 / 2>(reinterpret_cast<float *>(XL), tid);
+    dc_border6<DC_S3 / 2>(reinterpret_cast<float *>(XH), tid);
+    dc_border6<DC_S3 / 2>(reinterpret_cast<float *>(XL), tid);
     // D1: chunk t = (clsl * 4 + tap) * 2 + h of this wave's two classes: + ((2 hi2) * 8 + t) * 2 tiles * 64
     const float4 *wp4 = w4p + 2 * ((2 * hi2 * 8) * 128 + nt2 * 64 + lane);
     DcB rb4[PF];
     {
       f32x4d acc = Z;
-      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DC_S2 + 8 * q;
+      const int abase = (((c >> 2) + 1) * DC_P + (c & 3) + 1) * DC_S2 + 8 * q;
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
         const DcB b = rb3[tap % PF];
         if (tap + PF < 9) rb3[tap % PF] = dc_ldw(wp3, (tap + PF) * 256);
-        acc = dc_chunk(YH, YL, abase + ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DC_S2, b, acc);
+        acc = dc_chunk(YH, YL, abase + ((tap / 3 - 1) * DC_P + (tap % 3 - 1)) * DC_S2, b, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int s = 0; s < PF; s++) rb4[s] = dc_ldw(wp4, s * 128);
 #pragma unroll
       for (int r = 0; r < 4; r++)                            // D: m = 4q + r -> pixel (q, r)
-        dc_store(XH, XL, ((q + 1) * 6 + r + 1) * DC_S3 + 16 * wv + c, fmaxf(acc[r] + bias3, 0.f));
+        dc_store(XH, XL, ((q + 1) * DC_P + r + 1) * DC_S3 + 16 * wv + c, fmaxf(acc[r] + bias3, 0.f));
     }
     __syncthreads();
     // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y planes [10][10][40]
@@ -816,7 +836,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
     DcB rb5[PF];
     auto d1_body = [&](auto PYc) {
       constexpr int py = decltype(PYc)::value;
-      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DC_S3 + 8 * q;   // m = c -> input pixel
+      const int abase = (((c >> 2) + 1) * DC_P + (c & 3) + 1) * DC_S3 + 8 * q;   // m = c -> input pixel
       f32x4d acc = Z;
 #pragma unroll
       for (int s = 0; s < 16; s++) {
@@ -826,7 +846,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
         const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
         const DcB b = rb4[s % PF];
         if (s + PF < 16) rb4[s % PF] = dc_ldw(wp4, (s + PF) * 128);
-        acc = dc_chunk(XH, XL, abase + (dy * 6 + dx) * DC_S3 + 32 * h, b, acc);
+        acc = dc_chunk(XH, XL, abase + (dy * DC_P + dx) * DC_S3 + 32 * h, b, acc);
         if ((s & 7) == 7) {
           if (s == 15) {
 #pragma unroll
@@ -851,7 +871,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
       int abase[4];
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
-        abase[mt] = ((2 * mt + (c >> 3) + 1) * 10 + (c & 7) + 1) * DC_S2 + 8 * q;
+        abase[mt] = (((c >> 1) + 1) * 10 + 2 * mt + (c & 1) + 1) * DC_S2 + 8 * q;   // M tile = columns 2mt, 2mt + 1
       f32x4d acc[4] = {Z, Z, Z, Z};
 #pragma unroll
       for (int tap = 0; tap < 4; tap++) {
@@ -863,12 +883,12 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
         for (int mt = 0; mt < 4; mt++) acc[mt] = dc_chunk(YH, YL, abase[mt] + toff, b, acc[mt]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // D: m = 4q + r -> input pixel (2 mt + (q >> 1), 4 (q & 1) + r)
+      // D: m = 4q + r -> input pixel (row 2q + (r >> 1), column 2 mt + (r & 1))
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int a = 2 * mt + (q >> 1), b = 4 * (q & 1) + r;
+          const int a = 2 * q + (r >> 1), b = 2 * mt + (r & 1);
           X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r] + bias5, 0.f);
         }
     };

@@ -1022,6 +1022,19 @@ __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
   return v < 0.f ? 0.f : v;
 }
 
+// photon + read noise of one pixel: ONE Philox block per (pixel, frame) -- word 0: uniform of the
+// Poisson inversion, words 1, 2: a Box-Muller pair (cosine branch: rounded-normal Poisson for
+// lam >= 30, sine branch: read noise).  Same rule as oracle/aoref.c:aoref_sh_noise.
+__device__ __forceinline__ float sh_noise(float lam, float sigma, uint32_t seed, uint32_t frame, uint32_t idx) {
+  uint32_t x[4];
+  philox4x32_10(idx, frame, 0u, 4u, seed, 0x414F4D52u, x);
+  const float r = sqrtf(-2.0f * logf(u01(x[1])));
+  const float a = 6.28318530717958647692f * u01(x[2]);
+  float v = poisson_draw(lam, u01(x[0]), r * cosf(a));
+  if (sigma > 0.f) v += sigma * (r * sinf(a));
+  return v;
+}
+
 // MFMA stages + binning + normalisation (+noise) + COG of one sub-aperture whose complex amplitude
 // tile b = mask * exp(i phi 2pi/lambda) is in sAr/sAi[wv]; shared by the generic and fast kernels.
 //
@@ -1234,32 +1247,43 @@ __device__ __forceinline__ void spot_finish_v(const DevSys &sys, const DevState 
   tot = wave_sum(owner ? tot : 0.f);
   const float g = tot > 0.f ? sys.nphot * flux_i / tot : 0.f;
   float s0 = 0.f, sx = 0.f, sy = 0.f;
+  if (NOISE) {
+    // the two lanes of a pair hold the same 8 pixels: lane parity h takes pixel h of each (ty, tx),
+    // so every pixel gets its noise once and all 64 lanes work
+    const int hh = c & 1;
+    const uint32_t sd = st.seeds[e], fr = st.frame[e];
 #pragma unroll
-  for (int ty_ = 0; ty_ < 2; ty_++)
+    for (int ty_ = 0; ty_ < 2; ty_++)
 #pragma unroll
-    for (int tx_ = 0; tx_ < 2; tx_++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int Y = ty_ ? 7 - (2 * q + h) : 8 + 2 * q + h, X = tx_ ? Xm : Xp;
-        float val = v[ty_][tx_][h] * g;
-        if (NOISE) {
-          const uint32_t idx = (uint32_t)i * 256u + (uint32_t)(Y * 16 + X);
-          const uint32_t sd = st.seeds[e], fr = st.frame[e];
-          float u = philox_uniform(sd, 1u, fr, 0u, idx);
-          float zn = philox_normal(sd, 2u, fr, 0u, idx);
-          val = poisson_draw(val, u, zn);
-          if (sys.noise > 0.f) val += sys.noise * philox_normal(sd, 3u, fr, 0u, idx);
-        }
-        if (WRITE_CUBE && owner)
-          st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
+      for (int tx_ = 0; tx_ < 2; tx_++) {
+        const int Y = ty_ ? 7 - (2 * q + hh) : 8 + 2 * q + hh, X = tx_ ? Xm : Xp;
+        const uint32_t idx = (uint32_t)i * 256u + (uint32_t)(Y * 16 + X);
+        const float val = sh_noise((hh ? v[ty_][tx_][1] : v[ty_][tx_][0]) * g, sys.noise, sd, fr, idx);
+        if (WRITE_CUBE) st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
         s0 += val;
         sx += val * (float)X;
         sy += val * (float)Y;
       }
+  } else {
+#pragma unroll
+    for (int ty_ = 0; ty_ < 2; ty_++)
+#pragma unroll
+      for (int tx_ = 0; tx_ < 2; tx_++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int Y = ty_ ? 7 - (2 * q + h) : 8 + 2 * q + h, X = tx_ ? Xm : Xp;
+          const float val = v[ty_][tx_][h] * g;
+          if (WRITE_CUBE && owner)
+            st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
+          s0 += val;
+          sx += val * (float)X;
+          sy += val * (float)Y;
+        }
+  }
   if (do_cog) {
-    s0 = wave_sum(owner ? s0 : 0.f);
-    sx = wave_sum(owner ? sx : 0.f);
-    sy = wave_sum(owner ? sy : 0.f);
+    s0 = wave_sum((NOISE || owner) ? s0 : 0.f);
+    sx = wave_sum((NOISE || owner) ? sx : 0.f);
+    sy = wave_sum((NOISE || owner) ? sy : 0.f);
     if (lane == 0) {
       float *sl = st.slopes + (long long)e * sys.nslope;
       if (s0 != 0.f) {
@@ -1652,32 +1676,42 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
       tot = wave_sum(owner ? tot : 0.f);
       const float g = tot > 0.f ? sys.nphot * flux_cur / tot : 0.f;
       float s0 = 0.f, sx = 0.f, sy = 0.f;
+      if (NOISE) {
+        // lane parity h takes pixel h of each (ty, tx) of the pair's 8 pixels (see spot_finish)
+        const int hh = c & 1;
+        const uint32_t sd = st.seeds[e], fr = st.frame[e];
 #pragma unroll
-      for (int ty_ = 0; ty_ < 2; ty_++)
+        for (int ty_ = 0; ty_ < 2; ty_++)
 #pragma unroll
-        for (int tx_ = 0; tx_ < 2; tx_++)
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const int Y = ty_ ? 7 - (2 * q + h) : 8 + 2 * q + h, X = tx_ ? Xm : Xp;
-            float val = v[ty_][tx_][h] * g;
-            if (NOISE) {
-              const uint32_t idx = (uint32_t)i * 256u + (uint32_t)(Y * 16 + X);
-              const uint32_t sd = st.seeds[e], fr = st.frame[e];
-              float u = philox_uniform(sd, 1u, fr, 0u, idx);
-              float zn = philox_normal(sd, 2u, fr, 0u, idx);
-              val = poisson_draw(val, u, zn);
-              if (sys.noise > 0.f) val += sys.noise * philox_normal(sd, 3u, fr, 0u, idx);
-            }
-            if (WRITE_CUBE && owner)
-              st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
+          for (int tx_ = 0; tx_ < 2; tx_++) {
+            const int Y = ty_ ? 7 - (2 * q + hh) : 8 + 2 * q + hh, X = tx_ ? Xm : Xp;
+            const uint32_t idx = (uint32_t)i * 256u + (uint32_t)(Y * 16 + X);
+            const float val = sh_noise((hh ? v[ty_][tx_][1] : v[ty_][tx_][0]) * g, sys.noise, sd, fr, idx);
+            if (WRITE_CUBE) st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
             s0 += val;
             sx += val * (float)X;
             sy += val * (float)Y;
           }
+      } else {
+#pragma unroll
+        for (int ty_ = 0; ty_ < 2; ty_++)
+#pragma unroll
+          for (int tx_ = 0; tx_ < 2; tx_++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int Y = ty_ ? 7 - (2 * q + h) : 8 + 2 * q + h, X = tx_ ? Xm : Xp;
+              const float val = v[ty_][tx_][h] * g;
+              if (WRITE_CUBE && owner)
+                st.bincube[((long long)e * sys.nvalid + i) * 256 + Y * 16 + X] = val;
+              s0 += val;
+              sx += val * (float)X;
+              sy += val * (float)Y;
+            }
+      }
       if (do_cog) {
-        s0 = wave_sum(owner ? s0 : 0.f);
-        sx = wave_sum(owner ? sx : 0.f);
-        sy = wave_sum(owner ? sy : 0.f);
+        s0 = wave_sum((NOISE || owner) ? s0 : 0.f);
+        sx = wave_sum((NOISE || owner) ? sx : 0.f);
+        sy = wave_sum((NOISE || owner) ? sy : 0.f);
         if (lane == 0) {
           sl[i] = s0 != 0.f ? (sx / s0 - sys.cog_offset) * sys.cog_scale : 0.f;
           sl[sys.nvalid + i] = s0 != 0.f ? (sy / s0 - sys.cog_offset) * sys.cog_scale : 0.f;

@@ -249,22 +249,25 @@ static float poisson_draw(float lam, float u, float zn) {
   return v < 0.f ? 0.f : v;
 }
 
+/* Photon + read noise of one bincube.  Pixel idx of frame `frame` owns ONE Philox block
+ * (counter {idx, frame, stream 4}): word 0 -> the uniform of the Poisson inversion, words 1, 2 -> a
+ * Box-Muller pair: its cosine branch drives the rounded-normal Poisson for lam >= 30, its sine
+ * branch is the read noise.  (COMPASS draws from cuRAND: parity with it is distributional.) */
 void aoref_sh_noise(float *bincube, int nvalid, int npix2, float noise, uint32_t seed,
                     uint64_t frame) {
   if (noise < 0.f) return;
   int n = nvalid * npix2;
-  float *u = (float *)malloc(sizeof(float) * (size_t)n);
-  float *z = (float *)malloc(sizeof(float) * (size_t)n);
-  float *g = (float *)malloc(sizeof(float) * (size_t)n);
-  aoref_uniforms(seed, 1u, frame, n, u);
-  aoref_normals(seed, 2u, frame, n, z);
-  aoref_normals(seed, 3u, frame, n, g);
+  uint32_t key[2] = {seed, AOREF_KEY1};
   for (int i = 0; i < n; i++) {
-    float v = poisson_draw(bincube[i], u[i], z[i]);
-    if (noise > 0.f) v += noise * g[i];
+    uint32_t ctr[4] = {(uint32_t)i, (uint32_t)frame, (uint32_t)(frame >> 32), 4u}, x[4];
+    aoref_philox4x32_10(ctr, key, x);
+    float u = u01(x[0]);
+    float r = sqrtf(-2.0f * logf(u01(x[1])));
+    float a = 6.28318530717958647692f * u01(x[2]);
+    float v = poisson_draw(bincube[i], u, r * cosf(a));
+    if (noise > 0.f) v += noise * (r * sinf(a));
     bincube[i] = v;
   }
-  free(u); free(z); free(g);
 }
 
 void aoref_cog(const float *bincube, int nvalid, int npix, float offset, float scale,
