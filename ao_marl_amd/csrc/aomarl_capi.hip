@@ -1568,7 +1568,7 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
   if (aomarl_frame_fused_available(c) && !(fl & AOMARL_IMG_FROM_PHASE_BUFFER)) {
     rc = aomarl_frame_fused(c, st, b, n, fl | (defer ? AOMARL_IMG_DM_FROM_VOLTAGE : 0), stream);
     if (rc) return rc;
-    if (c->prefetch_atmos) {
+    if (c->prefetch_atmos && !c->premoved) {     // one frame ahead for ONE range at a time
       rc = aomarl_prefetch_atmos(c, st, b, n, accumx, accumy, stream);
       if (rc) return rc;
     }
@@ -1583,7 +1583,7 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
   }
   rc = aomarl_comp_image(c, st, b, n, fl, stream);
   if (rc) return rc;
-  if (c->prefetch_atmos) {
+  if (c->prefetch_atmos && !c->premoved) {
     rc = aomarl_prefetch_atmos(c, st, b, n, accumx, accumy, stream);
     if (rc) return rc;
   }

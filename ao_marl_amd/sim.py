@@ -473,7 +473,8 @@ class HipSim(object):
             la.check(self.lib.aomarl_next_part_one(self.ctx, C.byref(self.st), b, n,
                                                    la.fptr(self.accumx), la.fptr(self.accumy), fl,
                                                    self._stream()))
-            self.pending_atmos = self.prefetch
+            # the library prefetches for one range at a time (a second range steps in plain order)
+            self.pending_atmos = self.pending_atmos or self.prefetch
             return
         self.move_atmos(b, n)
         self.target_and_wfs(write_bincube=write_bincube, env_begin=b, env_count=n)

@@ -198,3 +198,26 @@ def test_prefetched_atmosphere_gives_the_same_frames():
     sups[1].sim.move_atmos()
     for layer in range(sups[0].s.nscreens):
         assert torch.equal(sups[0].sim.screen(layer), sups[1].sim.screen(layer))
+
+
+@pytest.mark.gpu
+def test_prefetch_with_partial_ranges_equals_batch_stepping():
+    """prefetch_atmos on, the batch stepped as two halves through the composite: the first half runs
+    one frame ahead, the second in plain order -- same bits as stepping the whole batch."""
+    import torch
+    from ao_marl_amd import geometry as G, params, system
+    from ao_marl_amd.sim import HipSim
+    s = system.from_system(G.build_system(params.builtin("production_sh_10x10_2m")))
+    s.cmat = (np.random.default_rng(0).standard_normal((s.nactu, s.nslope)) * 1e-3).astype(np.float32)
+    a, b = HipSim(s, nenv=4), HipSim(s, nenv=4)
+    b.set_option("prefetch_atmos", 1)
+    for x in (a, b):
+        x.reset([5, 6, 7, 8])
+    for it in range(4):
+        a.next_part_two(None)
+        a.next_part_one()
+        for (e0, cnt) in ((0, 2), (2, 2)):
+            b.next_part_two(None, env_begin=e0, env_count=cnt)
+            b.next_part_one(env_begin=e0, env_count=cnt)
+    assert torch.equal(a.slopes, b.slopes) and torch.equal(a.com, b.com)
+    assert torch.equal(a.strehl, b.strehl)
