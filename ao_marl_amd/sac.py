@@ -55,7 +55,10 @@ class BatchedReplay(object):
         self.next_state = torch.zeros(self.capacity, state_dim, **f32)
         self.action = torch.zeros(self.capacity, action_dim, **f32)
         self.reward = torch.zeros(self.capacity, n_agents, **f32)
-        self.mask = torch.zeros(self.capacity, 1, **f32)
+        # masks are 1 for every transition the trainer stores (episodes end by step count,
+        # train_rpc.py:514, 745): the column starts as ones and is only written when that changes
+        self.mask = torch.ones(self.capacity, 1, **f32)
+        self._mask_ones = True
         self.position, self.size = 0, 0
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
 
@@ -72,19 +75,36 @@ class BatchedReplay(object):
             state, action, reward, next_state = (t[-self.capacity:] for t in
                                                  (state, action, reward, next_state))
             n = self.capacity
-        idx = (self.position + torch.arange(n, device=self.device)) % self.capacity
-        self.state[idx], self.action[idx] = state, action
-        self.reward[idx], self.next_state[idx] = reward, next_state
         if not torch.is_tensor(mask):
-            mask = torch.full((n, 1), float(mask), dtype=torch.float32, device=self.device)
+            mask = None if float(mask) == 1.0 and self._mask_ones else \
+                torch.full((n, 1), float(mask), dtype=torch.float32, device=self.device)
         elif mask.numel() == 1:
             mask = mask.reshape(1, 1).expand(n, 1)
-        self.mask[idx] = mask.reshape(-1, 1)[-n:].to(torch.float32)
+        if self.position + n <= self.capacity:
+            # the common case: one contiguous block of rows -> plain slice copies
+            sl = slice(self.position, self.position + n)
+            self.state[sl], self.action[sl] = state, action
+            self.reward[sl], self.next_state[sl] = reward, next_state
+            if mask is not None:
+                self.mask[sl] = mask.reshape(-1, 1)[-n:].to(torch.float32)
+                self._mask_ones = False
+        else:
+            idx = (self.position + torch.arange(n, device=self.device)) % self.capacity
+            self.state[idx], self.action[idx] = state, action
+            self.reward[idx], self.next_state[idx] = reward, next_state
+            if mask is None:
+                mask = torch.ones(n, 1, dtype=torch.float32, device=self.device)
+            self.mask[idx] = mask.reshape(-1, 1)[-n:].to(torch.float32)
         self.position = (self.position + n) % self.capacity
         self.size = min(self.size + n, self.capacity)
 
     def rows(self, begin, count):
         """`count` rows starting at logical row `begin` (insertion order while not wrapped)."""
+        begin %= self.capacity
+        if begin + count <= self.capacity:                   # contiguous: views, no gather
+            sl = slice(begin, begin + count)
+            return (self.state[sl], self.action[sl], self.reward[sl], self.next_state[sl],
+                    self.mask[sl])
         idx = (begin + torch.arange(count, device=self.device)) % self.capacity
         return (self.state[idx], self.action[idx], self.reward[idx], self.next_state[idx],
                 self.mask[idx])
