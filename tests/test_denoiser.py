@@ -114,3 +114,25 @@ def test_split_fp16_and_fp32_denoiser_kernels_agree_with_fp64(golden_dir, peak):
         err[f32] = (got - want).abs().max().item() / scale
     assert err[True] < 5e-6
     assert err[False] < max(3 * err[True], 5e-6), err
+
+
+@pytest.mark.gpu
+def test_supervisor_with_denoiser_is_independent_of_the_atmosphere_prefetch(golden_dir):
+    """rlSupervisor's autoencoder branch (image -> denoiser -> centroids) with the next frame's
+    move_atmos issued on the side stream right behind the image kernel, against the plain order."""
+    from ao_marl_amd.denoiser import SubapDenoiser
+    from ao_marl_amd.env import VecRlSupervisor
+    g = torch.load(os.path.join(golden_dir, "host_denoiser.pt"), weights_only=True)
+    outs = []
+    for pre in (True, False):
+        dn = SubapDenoiser(g["state_dict"], device="cuda:0")
+        sup = VecRlSupervisor("production_sh_40x40_8m_3layers_d0_noise", {}, 3, initial_seed=21,
+                              autoencoder=dn, prefetch_atmos=pre)
+        assert sup.prefetch_atmos == pre
+        sup.reset()
+        for _ in range(4):
+            sup.next_part_one()
+            sup.next_part_two(None, linear_control=True)
+        outs.append((sup.get_slopes().clone(), sup.get_command().clone(), sup.get_strehl().clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
