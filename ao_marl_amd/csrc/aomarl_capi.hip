@@ -67,6 +67,8 @@ struct aomarl_ctx {
   int ld_cmat = 0;
   int nmodes = 0, nact = 0, ld_v2m = 0, ld_m2v = 0;
   float *v2m = nullptr, *m2v = nullptr, *freedom = nullptr;
+  float *s2m = nullptr;            // [nmodes][ld_cmat]: v2m . cmat (aomarl_set_slopes2modes)
+  int s2m_nmodes = 0;
   int32_t *amodes = nullptr, *amode_inv = nullptr;   // action modes and their inverse map [nmodes]
   float *env_gain = nullptr;       // per-environment integrator gains (aomarl_set_env_gains) or null
   int env_gain_n = 0;
@@ -490,6 +492,19 @@ int aomarl_set_cmat(aomarl_ctx *c, const float *cmat) {
   for (int r = 0; r < na; r++) memcpy(&h[(size_t)r * ld], cmat + (size_t)r * nsl, sizeof(float) * nsl);
   c->ld_cmat = ld;
   return replace_dev(c, &c->cmat, h);
+}
+
+int aomarl_set_slopes2modes(aomarl_ctx *c, int nmodes, const float *s2m) {
+  if (!c) return fail("aomarl_set_slopes2modes: null ctx");
+  if (!s2m) { c->s2m_nmodes = 0; return 0; }                 // dropped (cmat or basis changed)
+  if (nmodes < 1) return fail("aomarl_set_slopes2modes: nmodes must be positive");
+  const int nsl = c->sys.nslope, ld = (nsl + 3) & ~3;
+  std::vector<float> h((size_t)nmodes * ld, 0.f);
+  for (int r = 0; r < nmodes; r++) memcpy(&h[(size_t)r * ld], s2m + (size_t)r * nsl, sizeof(float) * nsl);
+  int rc = replace_dev(c, &c->s2m, h);
+  if (rc) return rc;
+  c->s2m_nmodes = nmodes;
+  return 0;
 }
 
 int aomarl_set_gain(aomarl_ctx *c, float gain) {
@@ -1082,6 +1097,21 @@ int aomarl_volts2modes(aomarl_ctx *c, aomarl_state *st, int nrows, const float *
   if (st && st->work) { Work w = work_layout(c, st->nenv); ws = st->work + w.GEMM; wsn = w.gemm_floats; }
   launch_gemm_nt(nrows, c->nmodes, c->sys.nactu, 1.0f, vec, ldvec, c->v2m, c->ld_v2m, 0.0f,
                  modes, c->nmodes, (hipStream_t)stream, ws, wsn);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_slopes2modes(aomarl_ctx *c, aomarl_state *st, int b, int n, float *modes, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!c->s2m || c->s2m_nmodes < 1) return fail("slopes2modes: no matrix (aomarl_set_slopes2modes)");
+  if (!modes) return fail("slopes2modes: null output");
+  if (n == 0) return 0;
+  Work w = work_layout(c, st->nenv);
+  const int nsl = c->sys.nslope, ld = (nsl + 3) & ~3;
+  // residual modes = v2m . err = -(v2m . cmat) . slopes
+  launch_gemm_nt(n, c->s2m_nmodes, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->s2m, ld, 0.0f, modes,
+                 c->s2m_nmodes, (hipStream_t)stream, st->work + w.GEMM, w.gemm_floats);
   LAUNCHCHK();
   return 0;
 }

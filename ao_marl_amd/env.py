@@ -87,6 +87,12 @@ class VecRlSupervisor(object):
         self.sim = make(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
         self.freedom_vector = None
         self.gain, self._env_gains = float(self.s.gain), False
+        # next_part_one(defer_control=True) images a frame without do_control; the product with the
+        # command matrix then runs only if somebody needs err / com in actuator space (see
+        # VecAoEnv._linear_step_fused): _control_pending = slopes measured, integrator not yet run;
+        # _err_stale = the command was rebuilt from modal coordinates, err never formed
+        self._control_pending, self._err_stale, self._s2m_ok = False, False, False
+        self.next_part_one_split = False        # True: always the stage-by-stage call order (bench.py times the stages)
         self.last_modes = None
         self._push_modal()
         # controller 1 of the non-noise parameter files: the geometric reference controller with
@@ -130,6 +136,31 @@ class VecRlSupervisor(object):
         self.sim.set_modal(self.volts2modes, self.modes2volts, self.freedom_vector,
                            self.action_range)
 
+    def ensure_slopes2modes(self):
+        """Push s2m = v2m . cmat (fp64 product) for `sim.slopes2modes` if it is not there yet."""
+        if not self._s2m_ok:
+            s2m = self.volts2modes.astype(np.float64) @ np.asarray(self.s.cmat, dtype=np.float64)
+            self.sim.set_slopes2modes(s2m.astype(np.float32))
+            self._s2m_ok = True
+
+    def materialize_control(self):
+        """Run the deferred do_control (err = -cmat . slopes, com += gain err) on the slopes of the
+        last frame: exactly what the plain order would have done right after the frame."""
+        if self._control_pending:
+            self.sim.do_control()
+            self._control_pending = False
+
+    def _refresh_err(self):
+        """err of the last frame when the command was rebuilt from modal coordinates: the product
+        with the command matrix without integrating it into the (already final) command."""
+        if self._err_stale:
+            if self._env_gains:
+                raise RuntimeError("err is not available with per-environment gains here")
+            self.sim.set_gain(0.0)
+            self.sim.do_control()
+            self.sim.set_gain(self.gain)
+            self._err_stale = False
+
     def set_sim_seed(self, seed):
         self.current_seed = int(seed)
 
@@ -142,6 +173,7 @@ class VecRlSupervisor(object):
         self.sim.reset(self.env_seeds())
         if self.geo is not None:
             self.geo.reset()
+        self._control_pending, self._err_stale = False, False
         self.iter = 0
 
     def rl_control(self, action):
@@ -177,6 +209,7 @@ class VecRlSupervisor(object):
         self.cal.cmat = cmat
         self.s.cmat = np.ascontiguousarray(cmat)
         self.sim.set_cmat(self.s.cmat)
+        self._s2m_ok = False
 
     def next_part_two(self, action, linear_control=False, apply_control=True,
                       compute_tar_psf=True, modes_pair=None):
@@ -195,8 +228,12 @@ class VecRlSupervisor(object):
             if self.gain is None:
                 raise RuntimeError("per-environment gains are for integrator-only runs")
             self.last_modes = self.sim.rl_control_modes(modes_pair[0], modes_pair[1], self.gain, action)
-        elif not linear_control:
-            self.rl_control(action)
+            # the command is final without the integrator ever running in actuator space
+            self._err_stale, self._control_pending = self._control_pending or self._err_stale, False
+        else:
+            self.materialize_control()
+            if not linear_control:
+                self.rl_control(action)
         if apply_control:
             # the stack-array shapes are left to the one-pass frame kernel when it can evaluate
             # them from the voltages (any other consumer materialises them on demand)
@@ -206,8 +243,14 @@ class VecRlSupervisor(object):
             if self.geo is not None:
                 self.geo.comp_strehl()              # tar_trace covers every target (:943-946)
 
-    def next_part_one(self, move_atmos=True, do_control=True):
-        """rlSupervisor.py:1015-1051 -> next_part_one_integrator :954-987"""
+    def next_part_one(self, move_atmos=True, do_control=True, defer_control=False):
+        """rlSupervisor.py:1015-1051 -> next_part_one_integrator :954-987.  defer_control: image the
+        frame, leave do_control to `materialize_control` (run on demand)."""
+        self.materialize_control()              # a frame still waiting for its do_control
+        self._err_stale = False
+        if defer_control and do_control:
+            do_control = False
+            self._control_pending = True
         if self.autoencoder is not None:
             # rlSupervisor.py:975-984 with the denoiser between image formation and centroiding;
             # the bincube never leaves the device (the reference copies it to the host and back)
@@ -219,7 +262,7 @@ class VecRlSupervisor(object):
             self.sim.do_centroids()
             if do_control:
                 self.sim.do_control()
-        elif move_atmos and do_control and self.geo is None:
+        elif move_atmos and do_control and self.geo is None and not self.next_part_one_split:
             self.sim.next_part_one()
         else:
             self._move_or_keep(move_atmos)
@@ -251,6 +294,7 @@ class VecRlSupervisor(object):
 
     # ---------------------------------------------------------------- getters (device tensors)
     def get_command(self, ncontrol=0):
+        self.materialize_control()
         if ncontrol == 1:
             if self.geo is None:
                 raise RuntimeError("no geometric controller (VecRlSupervisor(..., geo=True))")
@@ -264,6 +308,8 @@ class VecRlSupervisor(object):
         return self.sim.slopes
 
     def get_err(self):
+        self.materialize_control()
+        self._refresh_err()
         return self.sim.err
 
     def get_voltages(self):
@@ -354,6 +400,12 @@ class VecAoEnv(object):
         # Btt coordinates of the command carried from frame to frame by linearity instead of two
         # v2m GEMMs per step (aomarl_rl_control_modes); fp32 round-off apart, the same numbers
         self.modal_shortcut = True
+        # v2m . err straight from the slopes (see _linear_step_fused).  Off by default: it replaces the
+        # reference's order of operations (cmat . s on the device, then v2m . err) by one product with
+        # v2m . cmat -- same mathematics, but the end-to-end trace recorded from the reference's own
+        # Python (tests/test_env_vs_reference_trace.py) is then met only within 2x its tolerance on the
+        # tip-tilt residual, for 1.5 % of step time.
+        self.residual_shortcut = False
         self._m_before_full, self._m_next, self._modal_valid = None, None, False
         self._default_state_layout = (
             list(self.state_keys) == ["dm_history_%d" % i for i in
@@ -461,8 +513,17 @@ class VecAoEnv(object):
         else:
             m_full = sup.sim.volts2modes(sup.get_command())
         s_dm_before = m_full if (self.windowed or self._sel is None) else m_full[:, self._sel]
-        sup.next_part_one()
-        res_full = sup.sim.volts2modes(sup.get_err())
+        if (self.residual_shortcut and self.modal_shortcut and sup.geo is None and sup.gain is not None
+                and sup.autoencoder is None and hasattr(sup.sim, "slopes2modes")):
+            # the next control step rebuilds the command from Btt coordinates (rl_step below), so
+            # the frame needs neither err nor the integrated command in actuator space: one product
+            # with v2m . cmat instead of do_control + volts2modes; do_control runs on demand
+            sup.ensure_slopes2modes()
+            sup.next_part_one(defer_control=True)
+            res_full = sup.sim.slopes2modes()
+        else:
+            sup.next_part_one()
+            res_full = sup.sim.volts2modes(sup.get_err())
         self._last_res_modes = res_full
         self._m_before_full, self._modal_valid = m_full, True
         s_res = res_full if (self.windowed or self._sel is None) else res_full[:, self._sel]

@@ -130,6 +130,8 @@ SYMBOLS = [
     ("aomarl_comp_strehl", _i, _range + [_vp]),
     ("aomarl_reset_strehl", _i, _range + [_vp]),
     ("aomarl_volts2modes", _i, [_vp, C.POINTER(State), _i, _vp, _i, _vp, _vp]),
+    ("aomarl_set_slopes2modes", _i, [_vp, _i, _fp]),
+    ("aomarl_slopes2modes", _i, _range + [_vp, _vp]),
     ("aomarl_next_part_one", _i, _range + [_fp, _fp, _i, _vp]),
     ("aomarl_next_part_two", _i, _range + [_vp, _vp]),
     ("aomarl_gemm_nt", _i, [_i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp]),

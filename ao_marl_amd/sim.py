@@ -41,6 +41,7 @@ class HipSim(object):
         # of the shapes triggers _ensure_shape() first)
         self.defer_shape = True
         self.prefetch, self.pending_atmos = False, False     # see prefetch_atmos()
+        self._s2m_rows = 0                                   # see set_slopes2modes()
         self._defer_on = False       # the ctx option as currently set
         self._stale = False          # st.dm_shape's stack-array planes are older than st.voltage
         self.ctx = C.c_void_p()
@@ -191,6 +192,8 @@ class HipSim(object):
 
     # ------------------------------------------------------------------ configuration
     def set_cmat(self, cmat):
+        if getattr(self, "_s2m_rows", 0):
+            self.set_slopes2modes(None)          # v2m . cmat of the old matrix
         cmat = np.ascontiguousarray(cmat, dtype=np.float32)
         if cmat.shape != (self.s.nactu, self.s.nslope):
             raise ValueError("cmat must be [nactu, nslope]")
@@ -227,6 +230,7 @@ class HipSim(object):
     def reload_dms(self):
         """After actuator filtering changed s.dms: rebuild the static description + state."""
         torch.cuda.synchronize(self.device)
+        self._s2m_rows = 0
         self._create_ctx()
         self._alloc()
 
@@ -438,6 +442,26 @@ class HipSim(object):
     def reset_strehl(self, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         la.check(self.lib.aomarl_reset_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def set_slopes2modes(self, s2m):
+        """s2m = v2m . cmat ([nmodes, nslope]) for `slopes2modes`, or None to drop it."""
+        if s2m is None:
+            la.check(self.lib.aomarl_set_slopes2modes(self.ctx, 0, None))
+            self._s2m_rows = 0
+            return
+        s2m = np.ascontiguousarray(s2m, dtype=np.float32)
+        if s2m.ndim != 2 or s2m.shape[1] != self.s.nslope:
+            raise ValueError("s2m must be [nmodes, nslope]")
+        la.check(self.lib.aomarl_set_slopes2modes(self.ctx, int(s2m.shape[0]), la.fptr(s2m)))
+        self._s2m_rows = int(s2m.shape[0])
+
+    def slopes2modes(self, env_begin=0, env_count=None):
+        """-(v2m . cmat) . slopes: the Btt coordinates of err without err (aomarl_slopes2modes)."""
+        b, n = self._range(env_begin, env_count)
+        out = torch.empty(n, self._s2m_rows, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_slopes2modes(self.ctx, C.byref(self.st), b, n, out.data_ptr(),
+                                              self._stream()))
+        return out
 
     def volts2modes(self, vec):
         """[rows, nactu] (any row stride, e.g. the padded views `com` / `err`) -> [rows, nmodes]."""

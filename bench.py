@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--denoiser", default=None,
                     help="WFS-image denoiser weights (a state_dict file, or 'golden' for the shipped "
                          "network kept in tests/golden/host_denoiser.pt): BASELINE configs[4]")
+    ap.add_argument("--residual-shortcut", action="store_true",
+                    help="residual modes from one product with v2m.cmat instead of do_control + "
+                         "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="move the atmosphere in front of the image kernels (no side stream)")
     ap.add_argument("--no-defer", action="store_true",
@@ -230,38 +233,24 @@ def main():
     env = VecAoEnv(args.config, args.envs, rl, initial_seed=1234 + 16 * args.envs * rank,
                    seed_stride=16, n_agents_modal=n_modal, device=device, autoencoder=autoencoder,
                    prefetch_atmos=not args.no_prefetch, **norm_kw)
+    env.residual_shortcut = bool(args.residual_shortcut)
     layout = env.layout
     policy = BatchedGaussianPolicy(layout, last_layer_zero=False, seed=1234 + rank, device=device)
     sim = env.supervisor.sim
 
     timer = StageTimer()
+    # stage-by-stage call order of the supervisor (same kernels as the composite entry point), so
+    # that the image kernel can be bracketed by its own event pair
     env.supervisor.next_part_one_split = True
-    orig_np1 = env.supervisor.next_part_one
 
-    fused = sim.frame_fused_available() and not args.unfused
     if args.unfused:
         sim.set_option("force_unfused_frame", 1)
     if args.no_defer:
         sim.defer_shape = False
 
-    def split_part_one(move_atmos=True, do_control=True):
-        if autoencoder is not None:
-            return orig_np1(move_atmos=move_atmos, do_control=do_control)
-        sim.move_atmos()             # with prefetch: only the wait for the side stream's move
-        if fused:
-            sim.frame_fused(noise=True, cog=True)
-        else:
-            sim.target_psf()
-            sim.comp_image(noise=True, cog=True)
-        if env.supervisor.prefetch_atmos:
-            sim.prefetch_atmos()     # next frame's extrusions: side stream, beside what follows
-        sim.do_control()
-        env.supervisor.iter += 1
-
-    env.supervisor.next_part_one = split_part_one
     for name, label in (("move_atmos", "move_atmos"), ("target_psf", "target_psf"),
                         ("comp_image", "wfs_spot_cog"), ("frame_fused", "frame_fused"),
-                        ("do_control", "do_control"),
+                        ("do_control", "do_control"), ("slopes2modes", "residual_modes"),
                         ("rl_control", "rl_control"), ("apply_control", "dm_shape"),
                         ("comp_strehl", "strehl_commit")):
         timer.wrap(sim, name, label)

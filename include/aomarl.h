@@ -398,6 +398,15 @@ int aomarl_reset_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * NULL (then no split-K workspace is used) */
 int aomarl_volts2modes(aomarl_ctx *ctx, aomarl_state *st, int nrows, const float *vec_dev,
                        int ldvec, float *modes_dev, void *stream);
+/* Residual in Btt coordinates straight from the slopes:  v2m . err = -(v2m . cmat) . slopes.  Where the
+ * next control step takes its command from modal coordinates (aomarl_rl_control_modes) the frame
+ * needs neither err nor the integrated com in actuator space, so ONE product with the pre-multiplied
+ * matrix s2m = v2m . cmat (host, [nmodes][nslope]; NULL drops it) replaces aomarl_do_control +
+ * aomarl_volts2modes; aomarl_do_control run later on the same slopes gives err / com exactly as the
+ * plain order would.  AoEnv.linear_step's get_err -> transform_state_to_zernike (ao_env.py:507-533). */
+int aomarl_set_slopes2modes(aomarl_ctx *ctx, int nmodes, const float *s2m);
+int aomarl_slopes2modes(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, float *modes,
+                        void *stream);
 
 /* composites: one call per half frame, same order as the reference
  * next_part_one: move_atmos, target trace(+PSF), WFS trace+image+COG, do_control

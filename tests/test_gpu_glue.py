@@ -221,3 +221,47 @@ def test_prefetch_with_partial_ranges_equals_batch_stepping():
             b.next_part_one(env_begin=e0, env_count=cnt)
     assert torch.equal(a.slopes, b.slopes) and torch.equal(a.com, b.com)
     assert torch.equal(a.strehl, b.strehl)
+
+
+@pytest.mark.gpu
+def test_residual_modes_from_slopes_equals_do_control_path():
+    """v2m . err straight from the slopes (aomarl_slopes2modes, do_control deferred until somebody
+    needs err / com in actuator space) against do_control + volts2modes every frame: states and
+    rewards over a rollout with integrator-only steps in between, then err, command and voltages."""
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    assert not a.residual_shortcut and not b.residual_shortcut          # opt-in
+    a.residual_shortcut = True
+    sa, sb = a.reset(), b.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    std = torch.cat([a.norm["dm"][1]] * 3 + [a.norm["dm_residual"][1]])
+    deferred = 0
+    for it in range(10):
+        act = torch.rand(3, a.layout.action_dim, device="cuda:0", generator=g) * 2 - 1
+        lin = it in (3, 7)
+        sa, ra, _, _ = a.step(act, linear_control=lin)
+        sb, rb, _, _ = b.step(act, linear_control=lin)
+        deferred += a.supervisor._control_pending
+        assert not b.supervisor._control_pending
+        scale = (sb * std).abs().max().item()
+        assert ((sa - sb) * std).abs().max().item() < 2e-5 * scale, it
+        assert torch.allclose(ra, rb, rtol=2e-4, atol=1e-6), it
+    assert deferred == 10
+    # actuator-space quantities on demand: err of the last frame, the integrated command, voltages
+    eb = b.supervisor.get_err()
+    assert (a.supervisor.get_err() - eb).abs().max().item() < 2e-5 * eb.abs().max().item()
+    assert not a.supervisor._control_pending
+    cb = b.supervisor.get_command()
+    assert (a.supervisor.get_command() - cb).abs().max().item() < 2e-5 * cb.abs().max().item()
+    vb = b.supervisor.get_voltages()
+    assert (a.supervisor.get_voltages() - vb).abs().max().item() < 2e-5 * vb.abs().max().item()
+    # err after a step whose command came from modal coordinates: recomputed without integrating
+    act = torch.rand(3, a.layout.action_dim, device="cuda:0", generator=g) * 2 - 1
+    a.rl_step(act)
+    b.rl_step(act)
+    ca = a.supervisor.get_command().clone()
+    eb = b.supervisor.get_err()
+    assert (a.supervisor.get_err() - eb).abs().max().item() < 2e-5 * eb.abs().max().item()
+    assert torch.equal(a.supervisor.get_command(), ca)
