@@ -606,7 +606,7 @@ static Work work_layout(const aomarl_ctx *c, int nenv) {
   w.PEND = take((size_t)nenv * (W * W + 4));
   {
     size_t mn = std::max(ncol * (size_t)w.ldn, (size_t)nenv * (size_t)w.ldm);
-    w.gemm_floats = 8 * mn + 4096;     // + split-K ticket counters
+    w.gemm_floats = 8 * mn;            // up to 8 partial tiles of the split-K GEMM
     w.GEMM = take(w.gemm_floats);
     w.GEMM_ATM = take(w.gemm_floats);  // the extrusion's own split-K workspace: it may run on the side stream
   }
@@ -807,9 +807,21 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
   if (rc) return rc;
   if (n == 0) return 0;
   if (!seeds || !accumx || !accumy) return fail("reset: null argument");
-  rc = atmos_wait_pending(c, stream);       // the prefetched frame of a finished episode is dropped
+  rc = atmos_wait_pending(c, stream);
   if (rc) return rc;
-  c->premoved = false;
+  if (c->premoved && c->pre_screens == st->screens) {
+    // a prefetched frame is pending on these screens.  A reset of (at least) the prefetched range
+    // drops it -- the episode is over.  A reset of a part of it cannot: the other environments'
+    // screens and accumulators have already advanced, dropping the flag would make the next
+    // move_atmos advance them a second time (they would silently skip an atmosphere frame).
+    const bool covers = b <= c->pre_b && b + n >= c->pre_b + c->pre_n;
+    const bool disjoint = b + n <= c->pre_b || b >= c->pre_b + c->pre_n;
+    if (covers) c->premoved = false;
+    else if (!disjoint)
+      return fail("reset of environments [%d, %d) while the prefetched atmosphere frame of [%d, %d) is pending: "
+                  "reset the whole prefetched range, or call aomarl_move_atmos on it first",
+                  b, b + n, c->pre_b, c->pre_b + c->pre_n);
+  }
   hipStream_t s = (hipStream_t)stream;
   DevState ds = dev_state(st);
   if (c->seed_stage_n < n) {
@@ -932,8 +944,6 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
-  if (!strcmp(name, "gemm_legacy")) { g_gemm_legacy = value != 0; return 0; }
-  if (!strcmp(name, "gemm_inkernel_reduce")) { g_gemm_inkernel_reduce = value != 0; return 0; }
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
   if (!strcmp(name, "prefetch_atmos")) { c->prefetch_atmos = value != 0; return 0; }
@@ -1649,7 +1659,7 @@ int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int l
   if (batch == 0 || M == 0 || N == 0) return 0;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return fail("gemm_nt_batched: A and B must be 16-byte aligned");
   const bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0);
-  if (al && !g_gemm_legacy)
+  if (al)
     hipLaunchKernelGGL(k_gemm_nt_batched2, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0,
                        (hipStream_t)stream, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias,
                        C, ldc, strideC, relu);

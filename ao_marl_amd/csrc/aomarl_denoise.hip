@@ -46,6 +46,7 @@ struct DenoiseW {
   const float *w6;        // [9][16]                 D3 (taps as a plain correlation)
   const float *b1, *b2, *b3, *b4, *b5;
   float b6;
+  unsigned *ovf;           // device counter: images whose activations left the fp16 range (k_denoise4c)
 };
 
 #define DN_X 5184          // floats of region X (A1 2000, A3 2448, A5 5184)
@@ -53,7 +54,6 @@ struct DenoiseW {
 #define DN_S16 20          // padded channel strides
 #define DN_S32 36
 #define DN_S64 68
-#define DN_PF 6           // weight prefetch distance (steps) of the streamed layers
 
 __device__ __forceinline__ f32x4d dn_mfma(float a, float b, f32x4d c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -148,256 +148,10 @@ __device__ __forceinline__ void dn_store(float *pos, int ch, float v) {
   }
 }
 
-template <bool H>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_denoise(DenoiseW w, float *__restrict__ cube, int nimg) {
-  constexpr int PF = DN_PF;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer
-  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 144; i += 128) W6[i] = w.w6[i];
-  // ---- per-lane constants
-  // L1: B operand (3 k-steps), A-operand tap offsets (tap 4i+q of the 3x3 stencil; taps >= 9 unused)
-  float b1w[3];
-  int t1off[3];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    b1w[i] = w.w1[i * 64 + lane];
-    const int tap = 4 * i + q;
-    t1off[i] = tap < 9 ? (tap / 3 - 1) * 18 + (tap % 3 - 1) : 0;
-  }
-  const float bias1 = w.b1[c], bias2 = w.b2[16 * wv + c], bias4 = w.b4[16 * wv + c], bias5 = w.b5[c];
-  const float bias3a = w.b3[32 * wv + c], bias3b = w.b3[32 * wv + 16 + c];
-  const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-  // Synchronisation: one barrier per layer.  A layer reads one region and writes the other; the
-  // border (zero padding) of its output layout is cleared by the layer itself -- the interior is
-  // overwritten completely -- so nothing touches a region between the barrier that ends its last
-  // reader and the barrier that publishes its new contents.
-  constexpr int PF2 = 4;                 // ring depth of the two layers with four quads per step
-  float cur0 = 0.f, cur1 = 0.f;          // this image's two pixels per thread, prefetched
-  if ((int)blockIdx.x < nimg) {
-    const float *t0 = cube + (long long)blockIdx.x * 256;
-    cur0 = t0[tid]; cur1 = t0[tid + 128];
-  }
-  for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
-    float *tile = cube + (long long)img * 256;
-    // the weight pointers are laundered once per image: otherwise every one of the ~130 streamed
-    // loads gets its loop-invariant 64-bit address hoisted out of this loop into registers
-    const float4 *w2p = H ? w.w2h : w.w2, *w3p = H ? w.w3h : w.w3, *w4p = H ? w.w4h : w.w4,
-                 *w5p = H ? w.w5h : w.w5;
-    asm volatile("" : "+s"(w2p), "+s"(w3p), "+s"(w4p), "+s"(w5p));
-    const float4 *w2l = w2p + (wv * 64 + lane);
-    DnWt<H> rb2[PF2];                                        // L2's first weights: in flight during L1
-#pragma unroll
-    for (int s = 0; s < PF2; s++) rb2[s] = dn_ldw<H>(w2l, s * 2 * 64);
-    // ================= input (transposed) -> IN = Y[18][18]
-    dn_border<18, 1>(Y, tid);
-    {
-      const int p0 = tid, p1 = tid + 128;                    // tile[ty][tx] -> net row tx, col ty
-      Y[((p0 & 15) + 1) * 18 + ((p0 >> 4) + 1)] = cur0;
-      Y[((p1 & 15) + 1) * 18 + ((p1 >> 4) + 1)] = cur1;
-      const int nxt = img + gridDim.x;
-      if (nxt < nimg) {
-        const float *tn = cube + (long long)nxt * 256;
-        cur0 = tn[tid]; cur1 = tn[tid + 128];
-      }
-    }
-    __syncthreads();
-    // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X [10][10][20]
-    dn_border<10, DN_S16>(X, tid);
-    {
-      // A operand: lane (q, c): m = c -> window 4*mt + (c >> 2), pixel r = c & 3 of the window
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int mt = 8 * wv + k;
-        const int win = 4 * mt + (c >> 2), r = c & 3;
-        const int py = 2 * (win >> 3) + (r >> 1), px = 2 * (win & 7) + (r & 1);
-        const float *in = Y + (py + 1) * 18 + (px + 1);
-        f32x4d acc = Z;
-#pragma unroll
-        for (int i = 0; i < 3; i++) acc = dn_mfma(in[t1off[i]], b1w[i], acc);
-        // D: lane (q, c): window 4*mt + q, channel c, the 4 registers = the 2x2 window
-        const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
-        const int wo = 4 * mt + q;
-        dn_store<H>(X + (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DN_S16, c, v);
-      }
-    }
-    __syncthreads();
-    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y [6][6][36]; wave = channel tile
-    dn_border<6, DN_S32>(Y, tid);
-    const float4 *wp3 = w3p + (2 * wv * 64 + lane);   // step s = tap * 2 + g: + s * 4 * 64
-    DnWt<H> rb0[PF], rb1[PF];
-    {
-      f32x4d acc[4] = {Z, Z, Z, Z};
-      int abase[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; mt++) {
-        const int win = 4 * mt + (c >> 2), r = c & 3;
-        const int py = 2 * (win >> 2) + (r >> 1), px = 2 * (win & 3) + (r & 1);
-        abase[mt] = ((py + 1) * 10 + (px + 1)) * DN_S16 + 4 * q;
-      }
-#pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        const DnB<H> b = dn_expand(rb2[tap % PF2]);
-        if (tap + PF2 < 9) rb2[tap % PF2] = dn_ldw<H>(w2l, (tap + PF2) * 2 * 64);
-        const int toff = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * DN_S16;
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-          const float4 a = *reinterpret_cast<const float4 *>(X + abase[mt] + toff);
-          acc[mt] = dn_quadw(a, b, acc[mt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int s = 0; s < PF; s++) { rb0[s] = dn_ldw<H>(wp3, s * 256); rb1[s] = dn_ldw<H>(wp3, s * 256 + 64); }
-#pragma unroll
-      for (int mt = 0; mt < 4; mt++) {
-        const float v = fmaxf(fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3])) + bias2, 0.f);
-        const int wo = 4 * mt + q;                           // window in the 4x4 pooled grid
-        dn_store<H>(Y + (((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DN_S32, 16 * wv + c, v);
-      }
-    }
-    __syncthreads();
-    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X [6][6][68]; wave = channel tiles 2wv, 2wv+1
-    dn_border<6, DN_S64>(X, tid);
-    const float4 *wp4 = w4p + (wv * 64 + lane);       // step s = (cls * 4 + tap) * 4 + g: + s * 2 * 64
-    DnWt<H> rb[PF];
-    {
-      f32x4d acc0 = Z, acc1 = Z;
-      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DN_S32 + 4 * q;
-      // weights stream from L2 through a ring of PF steps, issued that many steps ahead; the
-      // scheduling barriers keep the compiler from hoisting all the loads to the top
-#pragma unroll
-      for (int s = 0; s < 18; s++) {
-        const int tap = s >> 1, g = s & 1;
-        const int toff = ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DN_S32;
-        const float4 a = *reinterpret_cast<const float4 *>(Y + abase + toff + 16 * g);
-        const DnB<H> b0 = dn_expand(rb0[s % PF]), b1 = dn_expand(rb1[s % PF]);
-        if (s + PF < 18) {
-          rb0[s % PF] = dn_ldw<H>(wp3, (s + PF) * 256);
-          rb1[s % PF] = dn_ldw<H>(wp3, (s + PF) * 256 + 64);
-        }
-        acc0 = dn_quadw(a, b0, acc0);
-        acc1 = dn_quadw(a, b1, acc1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int s = 0; s < PF; s++) rb[s] = dn_ldw<H>(wp4, s * 128);
-      // D: m = 4q + r -> pixel (q, r)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float *o = X + ((q + 1) * 6 + r + 1) * DN_S64;
-        dn_store<H>(o, 32 * wv + c, fmaxf(acc0[r] + bias3a, 0.f));
-        dn_store<H>(o, 32 * wv + 16 + c, fmaxf(acc1[r] + bias3b, 0.f));
-      }
-    }
-    __syncthreads();
-    // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y [10][10][36]; wave = channel tile
-    dn_border<10, DN_S32>(Y, tid);
-    const float4 *w5l = w5p + (16 * wv * 64 + lane);  // wave = output row parity py: step s = px * 8 + tap * 2 + g
-    DnWt<H> rb5[PF2];
-    {
-      const int a0 = c >> 2, b0 = c & 3;                     // A operand: m = c -> input pixel (a0, b0)
-      const int abase = ((a0 + 1) * 6 + b0 + 1) * DN_S64 + 4 * q;
-      f32x4d acc = Z;
-#pragma unroll
-      for (int s = 0; s < 64; s++) {
-        const int cls = s >> 4, tap = (s >> 2) & 3, g = s & 3;
-        const int py = cls >> 1, px = cls & 1;
-        const int ty = tap >> 1, tx = tap & 1;
-        const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
-        const int toff = (dy * 6 + dx) * DN_S64;
-        const float4 a = *reinterpret_cast<const float4 *>(X + abase + toff + 16 * g);
-        const DnB<H> b = dn_expand(rb[s % PF]);
-        if (s + PF < 64) rb[s % PF] = dn_ldw<H>(wp4, (s + PF) * 128);
-        acc = dn_quadw(a, b, acc);
-        if ((s & 15) == 15) {
-          if (s == 63) {
-#pragma unroll
-            for (int t = 0; t < PF2; t++) rb5[t] = dn_ldw<H>(w5l, t * 64);
-          }
-          // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            dn_store<H>(Y + ((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32, 16 * wv + c, fmaxf(acc[r] + bias4, 0.f));
-          acc = Z;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();
-    // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X [18][18][16]; wave = output row parity
-    dn_border<18, 16>(X, tid);
-    {
-      int abase[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; mt++)
-        abase[mt] = ((2 * mt + (c >> 3) + 1) * 10 + (c & 7) + 1) * DN_S32 + 4 * q;
-      const int py = wv;
-#pragma unroll
-      for (int px = 0; px < 2; px++) {
-        f32x4d acc[4] = {Z, Z, Z, Z};
-#pragma unroll
-        for (int tap = 0; tap < 4; tap++) {
-          const int ty = tap >> 1, tx = tap & 1;
-          const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
-          const int toff = (dy * 10 + dx) * DN_S32;
-#pragma unroll
-          for (int g = 0; g < 2; g++) {
-            const int s = px * 8 + tap * 2 + g;
-            const DnB<H> b = dn_expand(rb5[s % PF2]);
-            if (s + PF2 < 16) rb5[s % PF2] = dn_ldw<H>(w5l, (s + PF2) * 64);
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-              const float4 a = *reinterpret_cast<const float4 *>(Y + abase[mt] + toff + 16 * g);
-              acc[mt] = dn_quadw(a, b, acc[mt]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        // D: m = 4q + r -> input pixel (2 mt + (q >> 1), 4 (q & 1) + r)
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int a = 2 * mt + (q >> 1), b = 4 * (q & 1) + r;
-            X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r] + bias5, 0.f);
-          }
-      }
-    }
-    __syncthreads();
-    // ================= D3: 3x3 correlation 16 -> 1 on the VALU, write back transposed
-    // (no barrier behind it: the next writer of X is the next image's L1, behind that image's
-    // input barrier, which no wave passes before it has finished reading X here)
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const int p = tid + 128 * k;                           // net pixel (row p >> 4, col p & 15)
-      const int ry = p >> 4, rx = p & 15;
-      float s0 = w.b6, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        const float *in = X + ((ry + tap / 3) * 18 + rx + tap % 3) * 16;
-        const float *wt = W6 + tap * 16;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const float4 a = *reinterpret_cast<const float4 *>(in + 4 * g);
-          const float4 ww = *reinterpret_cast<const float4 *>(wt + 4 * g);
-          s0 += a.x * ww.x; s1 += a.y * ww.y; s2 += a.z * ww.z; s3 += a.w * ww.w;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same network with FOUR waves per image (same LDS image: four blocks = sixteen waves per CU
-// instead of eight).  Per-wave work halves, so twice the waves are there to cover the LDS / L2
-// latencies between dependent steps.  Work split (wv = 0..3):
+// FOUR waves per image (four blocks = sixteen waves per CU; a two-wave-per-image version of this
+// kernel was measured at 6.1 ms per 307 200 images against 5.8 ms, profiles/r01h_*, and retired).
+// Work split (wv = 0..3):
 //   L1  M tiles 4 wv .. 4 wv + 3            L2  N tile wv & 1, M tiles 2 (wv >> 1), + 1
 //   L3  N tile wv                           D1  N tile wv & 1, parity classes 2 (wv >> 1), + 1
 //   D2  parity class wv (py = wv >> 1, px = wv & 1), all four M tiles       D3  one pixel per thread
@@ -654,7 +408,7 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
 // pixel = one ds_read_b128 per plane, a B operand 8 consecutive K slots of one output channel = one
 // 16-byte load per part, and a chunk of 32 real channels costs THREE instructions
 //     acc += A_hi B_hi + A_lo B_hi + A_hi B_lo          (lo x lo, 2^-22 of the product, is dropped)
-// against four in k_denoise4<true> (which fills the 32 slots with 16 channels twice), with no operand
+// against four for 16-channel quads (the 32 slots filled with 16 channels twice; retired), with no operand
 // duplication moves at all.  A chunk is one tap x 32 channels (Cin = 32, 64) or two taps x 16
 // channels (Cin = 16: the second tap of the fifth pair does not exist -- zero weights).
 // LDS: X = A1 / A3 planes or A5 (fp32), Y = IN (fp32) or A2 / A4 planes.
@@ -686,7 +440,8 @@ __device__ __forceinline__ f32x4d dc_chunk(const _Float16 *__restrict__ hi, cons
   acc = mfma_h(al, b.h, acc);
   return mfma_h(ah, b.l, acc);
 }
-__device__ __forceinline__ void dc_store(_Float16 *hi, _Float16 *lo, int off, float v) {
+__device__ __forceinline__ void dc_store(_Float16 *hi, _Float16 *lo, int off, float v, float &vmax) {
+  vmax = fmaxf(vmax, v);                 // activations are >= 0 (ReLU); checked against the fp16 range at the end
   const _Float16 h = (_Float16)v;
   hi[off] = h;
   lo[off] = (_Float16)(v - (float)h);
@@ -729,6 +484,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
   const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   float cur = 0.f;                       // this image's pixel of this thread, prefetched
+  float vmax = 0.f;                      // largest activation this thread stored as an fp16 pair
   if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid0];
   for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
     // per-lane indices laundered once per image (see k_denoise4)
@@ -764,7 +520,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
       for (int i = 0; i < 3; i++) acc = dn_mfma(in[t1off[i]], b1w[i], acc);
       const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
       const int wo = 4 * mt + q;
-      dc_store(XH, XL, (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DC_S1 + c, v);
+      dc_store(XH, XL, (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DC_S1 + c, v, vmax);
     }
     __syncthreads();
     // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y planes [6][6][40]
@@ -802,7 +558,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
         const int mt = 2 * hi2 + m;
         const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])) + bias2, 0.f);
         // D: lane group q = window row q of column mt in the 4x4 pooled grid
-        dc_store(YH, YL, ((q + 1) * DC_P + mt + 1) * DC_S2 + 16 * nt2 + c, v);
+        dc_store(YH, YL, ((q + 1) * DC_P + mt + 1) * DC_S2 + 16 * nt2 + c, v, vmax);
       }
     }
     __syncthreads();
@@ -826,7 +582,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
       for (int s = 0; s < PF; s++) rb4[s] = dc_ldw(wp4, s * 128);
 #pragma unroll
       for (int r = 0; r < 4; r++)                            // D: m = 4q + r -> pixel (q, r)
-        dc_store(XH, XL, ((q + 1) * DC_P + r + 1) * DC_S3 + 16 * wv + c, fmaxf(acc[r] + bias3, 0.f));
+        dc_store(XH, XL, ((q + 1) * DC_P + r + 1) * DC_S3 + 16 * wv + c, fmaxf(acc[r] + bias3, 0.f), vmax);
     }
     __syncthreads();
     // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y planes [10][10][40]
@@ -856,7 +612,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
 #pragma unroll
           for (int r = 0; r < 4; r++)
             dc_store(YH, YL, ((2 * q + py + 1) * 10 + 2 * r + px + 1) * DC_S2 + 16 * nt2 + c,
-                     fmaxf(acc[r] + bias4, 0.f));
+                     fmaxf(acc[r] + bias4, 0.f), vmax);
           acc = Z;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -929,6 +685,9 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
       tile[(p & 15) * 16 + (p >> 4)] = res + w.b6;           // tile[ty = net col][tx = net row]
     }
   }
+  // fp16 pairs saturate silently above 65504 (v_cvt rounds to the largest finite value): count it,
+  // the host refuses to go on (aomarl_denoiser_overflow).  !(x <= limit) also catches NaN.
+  if (!(vmax <= 65000.f)) atomicAdd(w.ovf, 1u);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -1110,6 +869,12 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
     rc = dn_upload<float>(d, h, bdev[i]);
   }
   d->w.b6 = bs[5][0];
+  if (!rc) {
+    void *fl = nullptr;
+    if (hipMalloc(&fl, sizeof(unsigned)) != hipSuccess || hipMemset(fl, 0, sizeof(unsigned)) != hipSuccess)
+      rc = fail("denoiser: hipMalloc failed");
+    else { d->owned.push_back(fl); d->w.ovf = reinterpret_cast<unsigned *>(fl); }
+  }
   if (rc) { aomarl_denoiser_destroy(d); return rc; }
   *out = d;
   return 0;
@@ -1119,28 +884,14 @@ static int denoiser_launch(aomarl_denoiser *d, float *cube, long long nimg, bool
   if (!d || !cube) return fail("denoiser_apply: null argument");
   if (nimg <= 0) return 0;
   if (nimg > 0x7fffffffLL) return fail("denoiser_apply: too many images");
-  const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
   const int blocks = (int)std::min<long long>(nimg, 256 * 4 * 4);
-  static const int variant = [] { const char *e = getenv("AOMARL_DENOISE_KERNEL"); return e ? atoi(e) : 0; }();
-  // 0 (default): split-fp16 in 32-channel chunks, four waves per image; 4: k_denoise4 (16-channel
-  // quads, four waves); 2: k_denoise (two waves) -- kept for comparison
-  if (!f32 && variant == 0) {
+  if (!f32) {
+    // split-fp16 operands in 32-channel chunks, four waves per image
     const size_t smc = sizeof(float) * (DN_X + DC_Y + 144);
     hipLaunchKernelGGL(k_denoise4c, dim3(blocks), dim3(256), smc, (hipStream_t)stream, d->w, cube, (int)nimg);
-    LAUNCHCHK();
-    return 0;
-  }
-  const bool two_waves = variant == 2;
-  if (two_waves) {
-    if (f32)
-      hipLaunchKernelGGL(k_denoise<false>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
-    else
-      hipLaunchKernelGGL(k_denoise<true>, dim3(blocks), dim3(128), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
   } else {
-    if (f32)
-      hipLaunchKernelGGL(k_denoise4<false>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
-    else
-      hipLaunchKernelGGL(k_denoise4<true>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+    const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
+    hipLaunchKernelGGL(k_denoise4<false>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
   }
   LAUNCHCHK();
   return 0;
@@ -1152,4 +903,13 @@ int aomarl_denoiser_apply(aomarl_denoiser *d, float *cube, long long nimg, void 
 
 int aomarl_denoiser_apply_f32(aomarl_denoiser *d, float *cube, long long nimg, void *stream) {
   return denoiser_launch(d, cube, nimg, true, stream);
+}
+
+int aomarl_denoiser_overflow(aomarl_denoiser *d, unsigned *count, void *stream) {
+  if (!d || !count) return fail("denoiser_overflow: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(count, d->w.ovf, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (*count) HIPCHK(hipMemsetAsync(d->w.ovf, 0, sizeof(unsigned), s));
+  return 0;
 }

@@ -284,10 +284,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alp
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb, float beta,
                                                   float *__restrict__ C, int ldc, int kchunk,
-                                                  float *__restrict__ P, unsigned *counters) {
+                                                  float *__restrict__ P) {
   __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
-  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
@@ -311,32 +310,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alp
       }
     }
   }
-  if (!split || !counters) return;
-  // ---- split-K epilogue without a second launch: the block that arrives last at this tile sums
-  // the partial tiles in z order (deterministic) and writes C; the ticket counter resets itself
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(&counters[blockIdx.y * gridDim.x + blockIdx.x], 1u);
-    s_last = (t == gridDim.z - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const volatile float *Pv = P;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < M && col < N) {
-      float v = 0.f;
-      for (int z = 0; z < (int)gridDim.z; z++) v += Pv[((long long)z * M + row) * N + col];
-      float *c = C + (long long)row * ldc + col;
-      v *= alpha;
-      if (beta != 0.f) v += beta * (*c);
-      *c = v;
-    }
-  }
-  if (threadIdx.x == 0) counters[blockIdx.y * gridDim.x + blockIdx.x] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
@@ -578,11 +551,12 @@ __global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const f
   *c = v;
 }
 
-static bool g_gemm_legacy = false;    // "gemm_legacy" option: the un-pipelined kernels (A/B tests)
 static int g_gemm_target_blocks = 512;
 static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
-static bool g_gemm_inkernel_reduce = false;  // "gemm_inkernel_reduce": measured 4x SLOWER (per-block L2 write-back of __threadfence)
-#define G_COUNTERS 4096
+// Retired after their A/B runs (profiles/r01g_*): the un-pipelined aligned kernel (30 us vs 22 us per
+// call) and an in-kernel split-K reduction through ticket counters (4x slower: every block pays an
+// L2 write-back for its __threadfence).  k_gemm_nt<false> / k_gemm_nt_batched stay as the fallback
+// for operands that are not 16-byte aligned.
 
 // ws / ws_floats: optional split-K workspace (NULL: never split)
 // epi: applied by the split-K reduce when there is one (returns true), else left to the caller
@@ -606,20 +580,9 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   dim3 grid(bx, by, nsplit);
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
-  // in-kernel split-K reduction: ticket counters live in the last G_COUNTERS floats of the (zero
-  // initialised, self-resetting) workspace
-  unsigned *counters = nullptr;
-  if (al && !g_gemm_legacy && nsplit > 1 && g_gemm_inkernel_reduce && bx * by <= G_COUNTERS &&
-      (size_t)nsplit * M * N + G_COUNTERS <= ws_floats)
-    counters = reinterpret_cast<unsigned *>(ws + ws_floats - G_COUNTERS);
-  if (al && !g_gemm_legacy) {
+  if (al)
     hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                       ldc, kchunk, ws, counters);
-    if (counters) return false;
-  }
-  else if (al)
-    hipLaunchKernelGGL(k_gemm_nt<true>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
-                       C, ldc, kchunk, ws);
+                       ldc, kchunk, ws);
   else
     hipLaunchKernelGGL(k_gemm_nt<false>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb,
                        beta, C, ldc, kchunk, ws);

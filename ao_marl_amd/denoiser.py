@@ -23,6 +23,20 @@ import torch.nn.functional as F
 
 KEYS = ("encoder1", "encoder2", "encoder3", "decoder1", "decoder2", "decoder3")
 
+# The default kernel carries activations as fp16 pairs: |v| must stay below 65504.  Activations of
+# this architecture's trained weights reach at most ~2x the brightest input pixel (measured on the
+# shipped network in fp64: faint, bright, uniform, single-pixel and random images); inputs whose
+# bound is above FP16_INPUT_LIMIT go to the all-fp32 kernel.  What slips through is counted by the
+# kernel itself and raised by `check_range`.
+FP16_INPUT_LIMIT = 65504.0 / 4.0
+
+
+def shipped_weights_path():
+    """The reference's trained single-sub-aperture autoencoder (its state_dict, re-saved as plain
+    tensors by tools/import_denoiser_weights.py)."""
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "denoiser_subap_16x16.pt")
+
 
 class SubapDenoiser(object):
     def __init__(self, state_dict, device="cuda:0", dtype=torch.float32, chunk=65536):
@@ -40,6 +54,8 @@ class SubapDenoiser(object):
         if shapes != want:
             raise ValueError("unexpected autoencoder layout %r" % (shapes,))
         self._handle = None
+        self.input_bound = None          # largest pixel value the caller can produce (set_input_bound)
+        self._used_fp16 = False
         self.use_native = self.device.type == "cuda" and dtype == torch.float32
         self._host = {k: state_dict[k].detach().to("cpu", torch.float32).contiguous().numpy()
                       for k in ["%s.%s" % (a, b) for a in KEYS for b in ("weight", "bias")]}
@@ -65,9 +81,39 @@ class SubapDenoiser(object):
             pass
 
     @classmethod
-    def load(cls, path, **kw):
-        sd = torch.load(path, map_location="cpu", weights_only=True)
-        return cls(sd, **kw)
+    def load(cls, path=None, **kw):
+        sd = torch.load(path or shipped_weights_path(), map_location="cpu", weights_only=True)
+        return cls(sd.get("state_dict", sd), **kw)
+
+    def set_input_bound(self, bound):
+        """Largest pixel value the images can hold (e.g. photons of the brightest sub-aperture + noise
+        margin).  Decides between the split-fp16 kernel and the all-fp32 one."""
+        self.input_bound = float(bound)
+
+    def wants_f32(self, bincube=None):
+        """True when the images may leave the range the split-fp16 kernel is exact in.  Without a
+        declared bound the cube itself is measured (one device reduction + sync)."""
+        if self.input_bound is None:
+            if bincube is None:
+                return False
+            return float(bincube.abs().max()) >= FP16_INPUT_LIMIT
+        return self.input_bound >= FP16_INPUT_LIMIT
+
+    def check_range(self):
+        """Raise if any split-fp16 launch since the last check saturated (aomarl_denoiser_overflow).
+        Synchronises; the supervisor calls it at episode boundaries."""
+        if not (self._handle and self._used_fp16):
+            return
+        from . import libaomarl as la
+        n = C.c_uint(0)
+        la.check(la.load().aomarl_denoiser_overflow(
+                self._handle, C.byref(n), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self._used_fp16 = False
+        if n.value:
+            raise FloatingPointError(
+                    "WFS-image denoiser: activations left the fp16 range in %d kernel threads since the "
+                    "last check; those frames are wrong.  Declare the input range (set_input_bound) or "
+                    "call denoise_bincube_(..., f32=True)" % n.value)
 
     @torch.no_grad()
     def forward(self, x):
@@ -87,12 +133,16 @@ class SubapDenoiser(object):
         return x.float()
 
     @torch.no_grad()
-    def denoise_bincube_(self, bincube, f32=False):
-        """In place on a [nenv, nvalid, 256] bincube of [y][x] tiles.  f32: every product on fp32
-        matrix instructions (aomarl_denoiser_apply_f32) instead of fp16 pairs."""
+    def denoise_bincube_(self, bincube, f32=None):
+        """In place on a [nenv, nvalid, 256] bincube of [y][x] tiles.  f32 = True: every product on
+        fp32 matrix instructions (aomarl_denoiser_apply_f32); False: fp16 pairs; None (default):
+        fp16 pairs unless the declared / measured input range says otherwise (wants_f32)."""
         n, nv, np2 = bincube.shape
         if self.use_native and bincube.is_contiguous() and bincube.dtype == torch.float32:
             from . import libaomarl as la
+            if f32 is None:
+                f32 = self.wants_f32(bincube)
+            self._used_fp16 = self._used_fp16 or not f32
             fn = la.load().aomarl_denoiser_apply_f32 if f32 else la.load().aomarl_denoiser_apply
             la.check(fn(
                     self._native(), bincube.data_ptr(), n * nv,

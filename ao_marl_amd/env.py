@@ -85,6 +85,11 @@ class VecRlSupervisor(object):
         self.n_modes_start_end = list(self.config_rl["n_zernike_start_end"])
         self.include_tip_tilt = bool(self.config_rl["include_tip_tilt"])
         self.sim = make(self.s, nenv=nenv, device=device, keep_bincube=keep_bincube)
+        if autoencoder is not None and hasattr(autoencoder, "set_input_bound"):
+            # brightest possible pixel: every photon of the best-lit sub-aperture in one pixel, plus
+            # six sigma of photon and read-out noise -> picks the denoiser kernel (fp16 pairs / fp32)
+            tot = float(self.s.nphot) * float(np.max(self.s.flux))
+            autoencoder.set_input_bound(tot + 6.0 * np.sqrt(max(tot, 0.0)) + 6.0 * max(float(self.s.noise), 0.0))
         self.freedom_vector = None
         self.gain, self._env_gains = float(self.s.gain), False
         # next_part_one(defer_control=True) images a frame without do_control; the product with the
@@ -162,14 +167,32 @@ class VecRlSupervisor(object):
             self._err_stale = False
 
     def set_sim_seed(self, seed):
+        """rlSupervisor.py:207-213: the seed the NEXT reset starts from (environment e gets
+        seed + seed_stride * e, its layer k seed + seed_stride * e + k)."""
         self.current_seed = int(seed)
 
     def env_seeds(self):
         return self.current_seed + self.seed_stride * np.arange(self.nenv)
 
+    def seed_block(self):
+        """Seeds one reset of this batch consumes: [current_seed, current_seed + seed_block())."""
+        return self.seed_stride * self.nenv
+
+    def next_seed_block(self, world_size=1):
+        """The batched counterpart of the trainer's `seed += 1; set_sim_seed(seed)` after every
+        episode (train_rpc.py:486-487, 495-496): every environment of every rank moves on to
+        seeds nobody has used.  The reference's +1 would not do here: with a stride of 16 between
+        environments, environment e of episode k + 16 would replay environment e + 1 of episode k.
+        Ranks own consecutive blocks (dist.shard_seeds), so one episode of the whole job consumes
+        world_size blocks."""
+        self.set_sim_seed(self.current_seed + self.seed_block() * int(world_size))
+        return self.current_seed
+
     # ---------------------------------------------------------------- loop
     def reset(self):
         """rlSupervisor.py:236-246 for every environment (seed e: current_seed + stride*e)."""
+        if self.autoencoder is not None and hasattr(self.autoencoder, "check_range"):
+            self.autoencoder.check_range()      # a saturated fp16 launch of the last episode is an error
         self.sim.reset(self.env_seeds())
         if self.geo is not None:
             self.geo.reset()
@@ -448,6 +471,13 @@ class VecAoEnv(object):
         return m[:, self._sel]
 
     # ------------------------------------------------------------------ gym-like API
+    def set_sim_seed(self, seed):
+        """ao_env.py:454-459"""
+        self.supervisor.set_sim_seed(seed)
+
+    def next_seed_block(self, world_size=1):
+        return self.supervisor.next_seed_block(world_size)
+
     def reset(self):
         """ao_env.py:316-359"""
         cfg = self.config_rl

@@ -118,6 +118,7 @@ SYMBOLS = [
     ("aomarl_denoiser_create", _i, [C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_void_p)]),
     ("aomarl_denoiser_apply", _i, [_vp, _vp, C.c_longlong, _vp]),
     ("aomarl_denoiser_apply_f32", _i, [_vp, _vp, C.c_longlong, _vp]),
+    ("aomarl_denoiser_overflow", _i, [_vp, C.POINTER(C.c_uint), _vp]),
     ("aomarl_denoiser_destroy", _i, [_vp]),
     ("aomarl_target_psf_buffer", _i, _range + [_vp]),
     ("aomarl_set_geo", _i, [_vp, _fp]),

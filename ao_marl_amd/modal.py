@@ -120,7 +120,8 @@ def compute_btt(IFpzt, IFtt):
     mirror as the last two modes (basis.py:362-443)."""
     N, n = IFpzt.shape
     if n > N:
-        raise ValueError("Influence functions must be arrange as (Npts_pup x nactus)")
+        raise ValueError("IF matrix is transposed: expected pupil pixels down the rows, one column per "
+                         "actuator (got %d x %d)" % (N, n))
     delta = (IFpzt.T @ IFpzt).toarray() / N
     Tp = np.ones((N, 3))
     Tp[:, :2] = IFtt

@@ -50,17 +50,45 @@ class BatchedReplay(object):
 
     def __init__(self, state_dim, action_dim, n_agents, capacity, device, seed=0):
         self.capacity, self.device = int(capacity), torch.device(device)
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self.state = torch.zeros(self.capacity, state_dim, **f32)
-        self.next_state = torch.zeros(self.capacity, state_dim, **f32)
-        self.action = torch.zeros(self.capacity, action_dim, **f32)
-        self.reward = torch.zeros(self.capacity, n_agents, **f32)
-        # masks are 1 for every transition the trainer stores (episodes end by step count,
-        # train_rpc.py:514, 745): the column starts as ones and is only written when that changes
-        self.mask = torch.ones(self.capacity, 1, **f32)
+        self._dims = (int(state_dim), int(action_dim), int(n_agents))
+        self._buf = None                    # allocated on first use (see _alloc)
         self._mask_ones = True
         self.position, self.size = 0, 0
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
+
+    def row_bytes(self):
+        sd, ad, na = self._dims
+        return 4 * (2 * sd + ad + na + 1)
+
+    def _alloc(self):
+        """The ring is allocated when the first transition arrives, not at construction: the
+        reference's default of 1e6 rows is ~46 GB at the 40x40 windowed layout, far more than a
+        rollout-only or short run ever touches."""
+        if self._buf is None:
+            sd, ad, na = self._dims
+            nbytes = self.capacity * self.row_bytes()
+            if self.device.type == "cuda":
+                total = torch.cuda.get_device_properties(self.device).total_memory
+                if nbytes > 0.25 * total:
+                    import warnings
+                    warnings.warn("replay ring of %d rows needs %.1f GB (%.0f %% of this GPU's memory); "
+                                  "pass memory_size to BatchedSAC" %
+                                  (self.capacity, nbytes / 1e9, 100.0 * nbytes / total))
+            f32 = dict(dtype=torch.float32, device=self.device)
+            # masks are 1 for every transition the trainer stores (episodes end by step count,
+            # train_rpc.py:514, 745): the column starts as ones and is only written when that changes
+            self._buf = dict(state=torch.zeros(self.capacity, sd, **f32),
+                             next_state=torch.zeros(self.capacity, sd, **f32),
+                             action=torch.zeros(self.capacity, ad, **f32),
+                             reward=torch.zeros(self.capacity, na, **f32),
+                             mask=torch.ones(self.capacity, 1, **f32))
+        return self._buf
+
+    state = property(lambda self: self._alloc()["state"])
+    next_state = property(lambda self: self._alloc()["next_state"])
+    action = property(lambda self: self._alloc()["action"])
+    reward = property(lambda self: self._alloc()["reward"])
+    mask = property(lambda self: self._alloc()["mask"])
 
     def __len__(self):
         return self.size
@@ -424,23 +452,28 @@ class BatchedSAC(object):
         `target_entropy` / `model_state_dict`; the trainer's {`worker_id`, `models_controlled`,
         `model_state_dict`} (train_rpc.py:1155-1161); or the bare policy state_dict.  The critic
         file is `critic.state_dict()` (the target critic starts as its copy)."""
-        ck = torch.load(actor_path, map_location=map_location, weights_only=False)
-        if isinstance(ck, dict) and "alpha" in ck:
+        # all three layouts are plain containers of tensors / numbers: no pickled code is accepted
+        ck = torch.load(actor_path, map_location=map_location, weights_only=True)
+        sd = None
+        if critic_path is not None:
+            sd = torch.load(critic_path, map_location=map_location, weights_only=True)
+        has_alpha = isinstance(ck, dict) and "alpha" in ck
+        if has_alpha and self._updaters:
+            # checked before anything is written: a rejected load leaves the object as it was
+            raise RuntimeError("load checkpoints before the first update (the native updater "
+                               "holds a copy of the target entropies)")
+        if has_alpha:
             self.policy.load_agent(i, ck["model_state_dict"])
             with torch.no_grad():
                 self.alpha[i] = float(torch.as_tensor(ck["alpha"]).detach().reshape(-1)[0])
                 self.log_alpha[i] = float(torch.as_tensor(ck["log_alpha"]).detach().reshape(-1)[0])
                 # the reference rebuilds it as -prod(-target_entropy): the stored scalar itself
                 self.target_entropy[i] = float(torch.as_tensor(ck["target_entropy"]).reshape(-1)[0])
-            if self._updaters:
-                raise RuntimeError("load checkpoints before the first update (the native updater "
-                                   "holds a copy of the target entropies)")
         elif isinstance(ck, dict) and "worker_id" in ck:
             self.policy.load_agent(i, ck["model_state_dict"])
         else:
             self.policy.load_agent(i, ck)
-        if critic_path is not None:
-            sd = torch.load(critic_path, map_location=map_location, weights_only=False)
+        if sd is not None:
             self.load_reference_agent(i, critic_sd=sd)
 
     def export_agent(self, i, target=False):
@@ -675,7 +708,45 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
         out["r_geo_per_agent"] = geo_sq @ env._reward_mat
         out["r_geo_total"] = out["r_geo_per_agent"].sum(dim=1)
         out["sr_le_geo"] = env.supervisor.get_strehl(1)[:, 1].clone()
+    # the only collective of the path: every rank sees every environment's return, in global seed
+    # order (E floats per rank per episode; no-op in a single-process run)
+    from .dist import gather_episode_returns
+    out["r_total_all"] = gather_episode_returns(out["r_total"])
+    out["sr_le_all"] = gather_episode_returns(out["sr_le"])
     if train:
         out["updates"] = sac.update_parameters(master, batch_size=batch_size, n_updates=n_updates)
         master.reset()
     return out
+
+
+def train_agent(env, sac, n_episodes, max_steps=None, test_every=50, n_updates=None, batch_size=None,
+                on_episode=None):
+    """TrainerRPC.train_agent (train_rpc.py:452-501), batched: training episodes, every
+    `test_every` episodes one RL evaluation and one integrator evaluation on fresh seeds, and after
+    EVERY episode (training or test) the simulation moves on to a seed block no environment of no
+    rank has seen -- the reference's `self.seed += 1; env.set_sim_seed(self.seed)` (:486-487,
+    :495-496) for a batch of environments spread over ranks.  Returns the per-episode log."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    log = []
+    for ep in range(int(n_episodes)):
+        seed = env.supervisor.current_seed
+        out = run_episode(env, sac, max_steps=max_steps, train=True, n_updates=n_updates,
+                          batch_size=batch_size)
+        rec = dict(episode=ep, seed=seed, r_total=float(out["r_total_all"].mean()),
+                   sr_le=float(out["sr_le_all"].mean()), updates=out.get("updates", 0))
+        if test_every and ep % int(test_every) == 0:
+            env.next_seed_block(world)
+            rec["test_seed"] = env.supervisor.current_seed
+            rl = run_episode(env, sac, max_steps=max_steps, train=False, eval_mode=True)
+            # the integrator baseline sees the same atmosphere as the RL evaluation
+            # (test_episode("Integrator") follows test_episode("RL") without a new seed, :487-489)
+            lin = run_episode(env, sac, max_steps=max_steps, train=False, linear_control=True)
+            rec.update(test_r_rl=float(rl["r_total_all"].mean()), test_sr_le_rl=float(rl["sr_le_all"].mean()),
+                       test_r_integrator=float(lin["r_total_all"].mean()),
+                       test_sr_le_integrator=float(lin["sr_le_all"].mean()))
+        env.next_seed_block(world)
+        log.append(rec)
+        if on_episode is not None:
+            on_episode(rec)
+    return log

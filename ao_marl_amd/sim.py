@@ -41,6 +41,7 @@ class HipSim(object):
         # of the shapes triggers _ensure_shape() first)
         self.defer_shape = True
         self.prefetch, self.pending_atmos = False, False     # see prefetch_atmos()
+        self._pending_range = (0, 0)
         self._s2m_rows = 0                                   # see set_slopes2modes()
         self._defer_on = False       # the ctx option as currently set
         self._stale = False          # st.dm_shape's stack-array planes are older than st.voltage
@@ -242,7 +243,12 @@ class HipSim(object):
         la.check(self.lib.aomarl_reset(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
                                        la.fptr(self.accumx), la.fptr(self.accumy),
                                        self._stream()))
-        self.pending_atmos = False          # a prefetched frame is dropped by the library
+        # the library drops a prefetched frame only when the reset covers its range (a reset of a
+        # range disjoint from it leaves it pending, one that cuts into it is refused above)
+        if self.pending_atmos:
+            pb, pn = self._pending_range
+            if b <= pb and b + n >= pb + pn:
+                self.pending_atmos = False
         if (b, n) == (0, self.nenv):
             self._stale = False             # commands, voltages and shapes are all zero again
 
@@ -262,7 +268,7 @@ class HipSim(object):
         la.check(self.lib.aomarl_prefetch_atmos(self.ctx, C.byref(self.st), b, n,
                                                 la.fptr(self.accumx), la.fptr(self.accumy),
                                                 self._stream()))
-        self.pending_atmos = True
+        self.pending_atmos, self._pending_range = True, (b, n)
 
     def extrude(self, layers, dirs, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
@@ -498,7 +504,8 @@ class HipSim(object):
                                                    la.fptr(self.accumx), la.fptr(self.accumy), fl,
                                                    self._stream()))
             # the library prefetches for one range at a time (a second range steps in plain order)
-            self.pending_atmos = self.pending_atmos or self.prefetch
+            if self.prefetch and not self.pending_atmos:
+                self.pending_atmos, self._pending_range = True, (b, n)
             return
         self.move_atmos(b, n)
         self.target_and_wfs(write_bincube=write_bincube, env_begin=b, env_count=n)

@@ -247,7 +247,7 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * "force_generic_spot" / "force_generic_target" (layout-agnostic kernels), "force_unfused_frame"
  * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
  * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
- * "gemm_legacy" / "gemm_target_blocks" / "gemm_inkernel_reduce" (GEMM variants),
+ * "gemm_target_blocks" (split-K target of the fp32 GEMM),
  * "prefetch_atmos" (aomarl_next_part_one moves the next frame's atmosphere on a side stream, see
  * aomarl_prefetch_atmos),
  * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
@@ -367,6 +367,11 @@ int aomarl_denoiser_apply(aomarl_denoiser *dn, float *cube, long long nimg, void
  * accumulation): same results to fp32 rounding as long as inputs and activations stay inside the
  * fp16 range (|v| < 65504); use this one for data that does not. */
 int aomarl_denoiser_apply_f32(aomarl_denoiser *dn, float *cube, long long nimg, void *stream);
+/* Number of kernel threads of aomarl_denoiser_apply calls since the last query that saw an activation
+ * outside the fp16 range (the split-fp16 operands saturate there instead of overflowing loudly);
+ * synchronises `stream`, clears the counter.  Non-zero: those results are wrong -- rerun on
+ * aomarl_denoiser_apply_f32.  ao_marl_amd.denoiser checks it at every episode boundary. */
+int aomarl_denoiser_overflow(aomarl_denoiser *dn, unsigned *count, void *stream);
 int aomarl_denoiser_destroy(aomarl_denoiser *dn);
 /* PSF window + phase variance of st->tar_phase as it stands (pending, like aomarl_target_psf) */
 int aomarl_target_psf_buffer(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,

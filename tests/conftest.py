@@ -15,6 +15,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long CPU test")
 
 
+def _gpu_unavailable_reason():
+    """Why gpu-marked tests cannot run here, or None.  On a GPU box a missing library is NOT a
+    reason to skip: those tests must then fail loudly (the product has no fallback)."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return "no GPU in this process (torch.cuda.is_available() is False)"
+    except Exception as e:                                   # pragma: no cover
+        return "torch unavailable: %s" % e
+    return None
+
+
+def pytest_collection_modifyitems(config, items):
+    reason = _gpu_unavailable_reason()
+    if reason is None:
+        return
+    skip = pytest.mark.skip(reason=reason)
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

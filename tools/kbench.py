@@ -46,15 +46,13 @@ print("part_one unfused  %.3f ms" % timeit(lambda: sim.next_part_one()))
 sim.set_option("force_unfused_frame", 0)
 print("part_two          %.3f ms" % timeit(lambda: sim.next_part_two(None)))
 
-for legacy in (1, 0):
-    sim.set_option("gemm_legacy", legacy)
-    for (M, N, K) in ((256, 1296, 2624), (256, 1286, 2400), (256, 1276, 1288)):
-        A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); Cc = torch.zeros(M, N, device="cuda")
-        t = timeit(lambda: sim.gemm_nt(A, B, Cout=Cc))
-        print("gemm legacy=%d no-split %dx%dx%d  %.1f us  %.1f TFLOP/s" % (legacy, M, N, K, t * 1e3, 2e-9 * M * N * K / t))
-    for tb in (256, 512, 768, 1024):
-        sim.set_option("gemm_target_blocks", tb)
-        print("legacy=%d target_blocks=%d: do_control %.1f us  rl_control %.1f us  v2m %.1f us  move_atmos %.1f us" % (
-            legacy, tb, 1e3 * timeit(lambda: sim.do_control()), 1e3 * timeit(lambda: sim.rl_control(a)),
-            1e3 * timeit(lambda: sim.volts2modes(sim.com)), 1e3 * timeit(lambda: sim.move_atmos())))
-    sim.set_option("gemm_target_blocks", 512)
+for (M, N, K) in ((256, 1296, 2624), (256, 1286, 2400), (256, 1276, 1288)):
+    A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); Cc = torch.zeros(M, N, device="cuda")
+    t = timeit(lambda: sim.gemm_nt(A, B, Cout=Cc))
+    print("gemm no-split %dx%dx%d  %.1f us  %.1f TFLOP/s" % (M, N, K, t * 1e3, 2e-9 * M * N * K / t))
+for tb in (256, 512, 768, 1024):
+    sim.set_option("gemm_target_blocks", tb)
+    print("target_blocks=%d: do_control %.1f us  rl_control %.1f us  v2m %.1f us  move_atmos %.1f us" % (
+        tb, 1e3 * timeit(lambda: sim.do_control()), 1e3 * timeit(lambda: sim.rl_control(a)),
+        1e3 * timeit(lambda: sim.volts2modes(sim.com)), 1e3 * timeit(lambda: sim.move_atmos())))
+sim.set_option("gemm_target_blocks", 512)
