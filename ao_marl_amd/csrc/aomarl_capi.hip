@@ -58,6 +58,12 @@ struct aomarl_ctx {
   // as this frame's image kernels are done, so the extrusion chain runs beside do_control / the
   // agents / next_part_two instead of in front of the next image
   bool prefetch_atmos = false, premoved = false;
+  int fw_variant[6] = {0, 0, 0, 0, 0, 0};   // template arguments of the last k_frame_wave launch
+  char fw_name[96] = {0};
+  // "time_frame_kernel": a HIP event pair around every k_frame_wave launch (aomarl_frame_kernel_time)
+  bool time_fw = false;
+  std::vector<hipEvent_t> fw_ev;            // 2 per timed launch, created on demand
+  size_t fw_ev_used = 0;
   hipStream_t atm_stream = nullptr;
   hipEvent_t ev_frame = nullptr, ev_moved = nullptr;
   const float *pre_screens = nullptr;
@@ -470,6 +476,7 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (c->ev_moved) (void)hipEventDestroy(c->ev_moved);
   if (c->env_gain) (void)hipFree(c->env_gain);
   if (c->seed_stage) (void)hipFree(c->seed_stage);
+  for (hipEvent_t e : c->fw_ev) (void)hipEventDestroy(e);
   delete c;
   return 0;
 }
@@ -946,6 +953,17 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
+  if (!strcmp(name, "time_frame_kernel")) {
+    // value = number of launches to keep event pairs for (0: off)
+    c->time_fw = value > 0;
+    c->fw_ev_used = 0;
+    while (c->fw_ev.size() < 2 * (size_t)std::max(value, 0)) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      c->fw_ev.push_back(e);
+    }
+    return 0;
+  }
   if (!strcmp(name, "prefetch_atmos")) { c->prefetch_atmos = value != 0; return 0; }
   if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
   if (!strcmp(name, "force_f32_dft")) { c->force_f32_dft = value != 0; return 0; }
@@ -1532,6 +1550,29 @@ int aomarl_target_psf_buffer(aomarl_ctx *c, aomarl_state *st, int b, int n, void
 }
 
 // ---------------------------------------------------------------- composites
+const char *aomarl_frame_kernel_name(aomarl_ctx *c) {
+  if (!c || !c->fw_variant[0]) return "";
+  snprintf(c->fw_name, sizeof(c->fw_name), "k_frame_wave<%d, %d, %s, %s, %s, %s>", c->fw_variant[0], c->fw_variant[1],
+           c->fw_variant[2] ? "true" : "false", c->fw_variant[3] ? "true" : "false",
+           c->fw_variant[4] ? "true" : "false", c->fw_variant[5] ? "true" : "false");
+  return c->fw_name;
+}
+
+int aomarl_frame_kernel_time(aomarl_ctx *c, double *total_ms, int *launches) {
+  if (!c || !total_ms || !launches) return fail("frame_kernel_time: null argument");
+  double tot = 0.0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < c->fw_ev_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventSynchronize(c->fw_ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, c->fw_ev[i], c->fw_ev[i + 1]));
+    tot += ms; n++;
+  }
+  c->fw_ev_used = 0;
+  *total_ms = tot; *launches = n;
+  return 0;
+}
+
 int aomarl_frame_fused_available(aomarl_ctx *c) {
   return c && c->sys.fused_ok && !c->force_unfused_frame ? 1 : 0;
 }
@@ -1580,7 +1621,12 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     else if (nb == 1) FW_NC(NL, 1, true);                                 \
     else FW_NC(NL, 2, true);                                              \
   } while (0)
+  const bool timed = c->time_fw && c->fw_ev_used + 2 <= c->fw_ev.size();
+  if (timed) HIPCHK(hipEventRecord(c->fw_ev[c->fw_ev_used], s));
   if (c->nlayers == 1) FW_L(1); else FW_L(3);
+  if (timed) { HIPCHK(hipEventRecord(c->fw_ev[c->fw_ev_used + 1], s)); c->fw_ev_used += 2; }
+  c->fw_variant[0] = c->nlayers == 1 ? 1 : 3; c->fw_variant[1] = otf ? nb : 1; c->fw_variant[2] = otf;
+  c->fw_variant[3] = noise; c->fw_variant[4] = cube; c->fw_variant[5] = hp;
 #undef FW_L
 #undef FW_NC
 #undef FW_H

@@ -115,6 +115,8 @@ SYMBOLS = [
     ("aomarl_assemble_state", _i, [_i, _i, C.POINTER(C.c_void_p), _ip, _ip, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), _vp, _vp]),
     ("aomarl_agent_rewards", _i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _vp]),
+    ("aomarl_frame_kernel_name", C.c_char_p, [_vp]),
+    ("aomarl_frame_kernel_time", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     ("aomarl_denoiser_create", _i, [C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_void_p)]),
     ("aomarl_denoiser_apply", _i, [_vp, _vp, C.c_longlong, _vp]),
     ("aomarl_denoiser_apply_f32", _i, [_vp, _vp, C.c_longlong, _vp]),

@@ -441,6 +441,18 @@ class HipSim(object):
             fl |= la.IMG_COG
         la.check(self.lib.aomarl_frame_fused(self.ctx, C.byref(self.st), b, n, fl, self._stream()))
 
+    def frame_kernel_name(self):
+        """Instantiation of the one-pass frame kernel the last frame_fused launched, as rocprofv3
+        prints it (aomarl_frame_kernel_name)."""
+        return self.lib.aomarl_frame_kernel_name(self.ctx).decode()
+
+    def frame_kernel_time(self):
+        """(sum of launch durations in ms, launches) recorded under set_option("time_frame_kernel",
+        n) since the last call (aomarl_frame_kernel_time)."""
+        tot, n = C.c_double(0.0), C.c_int(0)
+        la.check(self.lib.aomarl_frame_kernel_time(self.ctx, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
     def comp_strehl(self, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         la.check(self.lib.aomarl_comp_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))

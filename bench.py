@@ -4,102 +4,132 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, one
+process per GPU, before anything in this process touches a GPU.
+
 One step = one pass of the hot path over one batch of synthetic environments per GPU:
     batched 14-agent SAC actor forward  ->  next_part_two (Btt correction, delay, DM shapes,
     Strehl)  ->  per-agent rewards  ->  next_part_one (phase-screen extrusion, target trace + PSF,
     WFS trace + spot images + COG, integrator)  ->  state assembly.
 Workload (BASELINE.json configs[2]): production_sh_40x40_8m_3layers, 256 atmosphere seeds per
 GPU, 14 agents (13 x 98 Btt modes + tip-tilt), windowed states (w = 20).  Environments are
-independent, so N GPUs run N x 256 seeds with no data-path collective (weak scaling); the only
-collective is the MAX over ranks of the timed region.
+independent, so N GPUs run N x 256 seeds with no data-path collective (weak scaling); the
+collectives are the MAX over ranks of the timed region and one all_gather of per-environment
+returns in the epilogue.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step, timed live
-with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a C restatement of the
-COMPASS frame the reference drives, oracle/aoref.c) timed on this host's cores on a bounded sample.
+What the ONE JSON line (rank 0) says:
+  value            env steps/s with the metric's episode structure: one env.reset() per
+                   `--episode-len` (1000) frames, timed in this run, amortised into the K timed steps:
+                   N_env * K / (T_K + K / 1000 * T_reset).  `value_no_reset` is N_env * K / T_K.
+  dtype            arithmetic of the dominant kernel.  Default build: both DFTs of the frame kernel on
+                   split-fp16 operand pairs (hi + lo, 22-bit mantissa) with fp32 accumulation;
+                   `f32_pass` times the same loop with the fp32-MFMA variant ("force_f32_dft").
+  roofline         the one-pass frame kernel: algorithmic bytes / the kernel's
+                   launch duration from HIP event pairs recorded by the library around that launch
+                   on its own stream (aomarl_frame_kernel_time) inside the timed region, against the
+                   8 TB/s HBM peak; `traffic` = HBM bytes per launch from rocprofv3 --pmc passes kept
+                   under profiles/ -- refused (null) unless that file names the kernel instantiation
+                   this run launched.
+  configs          side figures of BASELINE configs[1] (10x10, 64 envs, 2 agents) and configs[4]
+                   (noise + denoiser) from the same process (not `value`).
+  cpu_baseline     the CPU oracle (C restatement of the COMPASS frame, oracle/aoref.c) on this host:
+                   1 thread and all cores, bounded samples.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 WORKLOAD = "production_sh_40x40_8m_3layers"
+SMALL = "production_sh_10x10_2m"
+NOISY = "production_sh_40x40_8m_3layers_d0_noise"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PMC_FILE = "r02_pmc_frame_kernel.json"
 
 
-def stage_models(s, nenv, nmodes, nact):
-    """Algorithmic bytes / flops per launch of each stage (DESIGN.md section 4 derives them)."""
-    n2, p2 = s.n * s.n, s.pupdiam * s.pupdiam
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=256, help="environments per GPU")
+    ap.add_argument("--config", default=WORKLOAD)
+    ap.add_argument("--episode-len", type=int, default=1000,
+                    help="frames per episode: one reset is amortised over this many steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the configs[1] / configs[4] side figures and the fp32 pass")
+    ap.add_argument("--unfused", action="store_true",
+                    help="separate science / WFS passes instead of the one-pass frame kernel")
+    ap.add_argument("--denoiser", default=None,
+                    help="WFS-image denoiser in the loop: 'shipped' (the reference's trained network, "
+                         "ao_marl_amd/data) or a state_dict file: BASELINE configs[4] as the workload")
+    ap.add_argument("--residual-shortcut", action="store_true",
+                    help="residual modes from one product with v2m.cmat instead of do_control + "
+                         "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="move the atmosphere in front of the image kernels (no side stream)")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="materialise the stack-array DM shapes instead of evaluating them from the "
+                         "voltages inside the frame kernel")
+    ap.add_argument("--f32-dft", action="store_true",
+                    help="fp32-MFMA DFTs in the frame kernel for the MAIN timed pass")
+    ap.add_argument("--pmc", default=PMC_FILE,
+                    help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------ launcher
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start N ranks of this script, one per GPU, and pass rank 0's
+    line through.  Runs before this process has touched a GPU (no HIP call, no torch.cuda query);
+    children are fresh processes -- nothing is re-exec'd."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    sys.exit(rc)
+
+
+# ------------------------------------------------------------------------------------ models
+def frame_kernel_model(s, nenv):
+    """Algorithmic bytes / flops of one launch of the one-pass frame kernel:
+    every lit 16x16 tile of the pupil grid is read once per layer (1 KiB), 2 slopes per sub-aperture
+    and 16 complex PSF-row values per pupil row are written; tip-tilt planes, masks and twiddles are
+    shared by all environments (L2 / Infinity-Cache resident)."""
     nl = s.nscreens
-    shape_px = sum(d.dim * d.dim for d in s.dms)
-    # A4+A3+A5 fused: phase of every layer + DM planes in, 2 slopes per sub-aperture out;
-    # flops: pruned radix-2 FFT count for 16 non-zero rows -> 32x32 kept outputs of a 64^2 grid
-    fft_flops = 16 * 5 * 64 * 6 + 32 * 5 * 64 * 6
-    spot = dict(bound="mfma", unit="TFLOP/s", peak=FP32_MFMA_PEAK_TF,
-                work=nenv * s.nvalid * float(fft_flops + 256 * 20),
-                bytes=nenv * s.nvalid * 2048.0)
-    dm = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
-              work=nenv * (s.nactu * 4.0 + shape_px * 4.0))
-    tgt = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
-               work=nenv * ((nl + len(s.dms)) * p2 * 4.0))
-    # one-pass frame kernel: every lit 16x16 tile of the pupil grid is read once (layers + stack
-    # array) and feeds the spot DFT (valid sub-apertures) and the 16-column PSF row DFT (16 kx x
-    # 256 pixels x 8 flop); the tip-tilt planes and the mask are shared by all environments
     lit = int((s.spupil.reshape(s.pupdiam // 16, 16, s.pupdiam // 16, 16).sum(axis=(1, 3)) > 0).sum()) \
         if s.pupdiam % 16 == 0 else 0
-    # with both DFTs on split-fp16 MFMAs the matrix roof is an order of magnitude away; the kernel
-    # is bounded by getting the phase in: roofline against HBM (algorithmic bytes), the flop view is
-    # kept in `image_kernel`
-    fused = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
-                 work=nenv * (lit * nl * 1024.0 + s.nvalid * 8.0 + s.pupdiam * 16 * 8.0),
-                 flops=nenv * (s.nvalid * float(fft_flops + 256 * 20) + lit * 256 * 16 * 8.0),
-                 bytes=nenv * (lit * nl * 1024.0 + s.nvalid * 8.0 + s.pupdiam * 16 * 8.0))
-    return {"wfs_spot_cog": spot, "dm_shape": dm, "target_psf": tgt, "frame_fused": fused}
+    fft_flops = 16 * 5 * 64 * 6 + 32 * 5 * 64 * 6        # pruned radix-2 count: 16 rows -> 32x32 of 64^2
+    byts = nenv * (lit * nl * 1024.0 + s.nvalid * 8.0 + s.pupdiam * 16 * 8.0)
+    flops = nenv * (s.nvalid * float(fft_flops + 256 * 20) + lit * 256 * 16 * 8.0)
+    return dict(bytes=byts, flops=flops, lit_tiles=lit)
 
 
-class StageTimer(object):
-    """HIP events around stage entry points.  Only the labels in `live` are timed (an event pair is
-    not free: sixteen of them per step cost 7 % of the step); the timed region keeps the image
-    kernel's pair, the per-stage split comes from a short diagnostic pass after it."""
-
-    def __init__(self):
-        self.pairs = {}
-        self.live = None                   # None: every wrapped stage
-
-    def wrap(self, obj, name, label):
-        fn = getattr(obj, name)
-
-        def timed(*a, **k):
-            if self.live is not None and label not in self.live:
-                return fn(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            self.pairs.setdefault(label, []).append((e0, e1))
-            return r
-
-        setattr(obj, name, timed)
-
-    def mean_ms(self):
-        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.pairs.items()}
-
-    def clear(self):
-        self.pairs = {}
-
-
-def cpu_baseline(env, budget_s=15.0):
-    """The CPU oracle stepping ONE environment of the same configuration (same calibrated
-    command matrix) on this host; bounded to ~budget_s seconds of frames."""
+def cpu_baseline(s, budget_s=8.0):
+    """The CPU oracle stepping ONE environment of the workload (same calibrated command matrix) on
+    this host: single thread, then every core; each bounded to ~budget_s seconds of frames."""
+    import numpy as np
     from oracle import aoref
-    s = env.supervisor.s
+    L = aoref.lib()
 
     class Sim(aoref.OracleSim):
         def reset(self, seed):          # short refresh: frame cost does not depend on content
@@ -114,27 +144,35 @@ def cpu_baseline(env, budget_s=15.0):
             self.reset_strehl()
 
     o = Sim(s, seed=1234)
-    o.next_part_two(None)
-    o.next_part_one()                   # warm caches / OpenMP pool
-    t0, frames = time.time(), 0
-    while True:
+
+    def run(threads):
+        got = L.aoref_set_threads(threads)
         o.next_part_two(None)
-        o.next_part_one()
-        frames += 1
-        dt = time.time() - t0
-        if dt > budget_s or frames >= 200:
-            break
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": frames / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d integrator frames of 1 environment of %s (extrusion, 2 raytraces, "
-                      "1200 zero-padded 64x64 FFT spots, COG, cmat GEMV, delay, DM shapes, "
-                      "2048^2 FFT PSF) in %.1f s, OpenMP over rows/sub-apertures; SAC actor not "
-                      "included" % (frames, s.name, dt)}
+        o.next_part_one()                   # warm caches / thread pool
+        t0, frames = time.time(), 0
+        while True:
+            o.next_part_two(None)
+            o.next_part_one()
+            frames += 1
+            dt = time.time() - t0
+            if dt > budget_s or frames >= 200:
+                break
+        return got, frames, dt
+    ncores = L.aoref_max_threads()
+    t1, f1, d1 = run(1)
+    tn, fn, dn = run(ncores)
+    return {"value": fn / dn, "unit": "env steps/s", "cores": tn, "kind": "port",
+            "value_1_thread": f1 / d1, "host_cores": ncores,
+            "sample": "integrator frames of 1 environment of %s (extrusion, 2 raytraces, %d zero-padded "
+                      "64x64 FFT spots, COG, cmat GEMV, delay, DM shapes, %d^2 FFT PSF; SAC actor not "
+                      "included): %d frames in %.1f s on 1 thread, %d frames in %.1f s on %d OpenMP threads"
+                      % (s.name, s.nvalid, s.npsf, f1, d1, fn, dn, tn)}
 
 
 def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
     """Secondary figure (not `value`): wall time of one aomarl_sac_update of every agent on a batch of
     256 replay rows per agent (the learner side of the path)."""
+    import torch
     from ao_marl_amd.sac import BatchedSAC
     sac = BatchedSAC(layout, dict(memory_size=rows), device=device)
     g = torch.Generator(device=device).manual_seed(1)
@@ -154,41 +192,152 @@ def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
             "updates_per_s": 1e3 / ms, "kernel": "aomarl_sac_update"}
 
 
+# ------------------------------------------------------------------------------------ one workload
+class Workload(object):
+    """A VecAoEnv + random-init batched SAC actors for one BASELINE configuration."""
+
+    def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True):
+        import torch
+        from ao_marl_amd.agents import BatchedGaussianPolicy
+        from ao_marl_amd.env import VecAoEnv, load_norm
+        self.config, self.envs, self.device = config, envs, device
+        if "10x10" in config:
+            rl, n_modal = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5), 1
+        else:
+            rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5,
+                      window_n_zernike=20, include_tip_tilt_windowed=True)
+            n_modal = 13
+        autoencoder = None
+        if denoiser:
+            from ao_marl_amd.denoiser import SubapDenoiser
+            autoencoder = SubapDenoiser.load(None if denoiser == "shipped" else denoiser, device=device)
+        norm_kw = {}
+        try:
+            load_norm(config)
+        except FileNotFoundError:
+            # no recorded statistics for this configuration: borrow the closest one's (synthetic
+            # benchmark data; the arithmetic per step is identical)
+            nrm, zn = load_norm("production_sh_40x40_8m_3layers_d1_noise" if "noise" in config
+                                else WORKLOAD)
+            norm_kw = dict(norm=nrm, zn_norm=zn)
+        # independent shards: rank r owns seeds [r*envs, (r+1)*envs) of the global seed sequence
+        from ao_marl_amd.dist import shard_seeds
+        self.first_seed = shard_seeds(1234, envs, rank, stride=16)
+        self.env = VecAoEnv(config, envs, rl, initial_seed=self.first_seed, seed_stride=16,
+                            n_agents_modal=n_modal, device=device, autoencoder=autoencoder,
+                            prefetch_atmos=prefetch, **norm_kw)
+        self.layout = self.env.layout
+        # random-init actors (last layer NOT zeroed, so actions are non-trivial): the cost of a step
+        # does not depend on the weights; the loop is not expected to converge (Strehl is reported
+        # only to show the numbers are finite)
+        self.policy = BatchedGaussianPolicy(self.layout, last_layer_zero=False, seed=1234 + rank,
+                                            device=device)
+        self.sim = self.env.supervisor.sim
+        self.state = None
+        self.torch = torch
+
+    def one_step(self):
+        a, _ = self.policy.select_action(self.state)
+        self.state, self.last_r, _, _ = self.env.step(a)
+
+    def reset(self):
+        self.state = self.env.reset()
+
+    def timed(self, steps, warmup, dist=None, backend="nccl", time_frame=True):
+        """W untimed + exactly K timed steps between barriers + synchronisations.  Returns (elapsed s
+        -- MAX over ranks --, host enqueue s, frame-kernel ms per launch from the library's events)."""
+        torch = self.torch
+        for _ in range(warmup):
+            self.one_step()
+        torch.cuda.synchronize()
+        if time_frame:
+            self.sim.set_option("time_frame_kernel", steps)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.one_step()
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        fk_ms = None
+        if time_frame:
+            tot, n = self.sim.frame_kernel_time()
+            self.sim.set_option("time_frame_kernel", 0)
+            fk_ms = tot / n if n else None
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64,
+                             device=self.device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, t_enq, fk_ms
+
+    def time_reset(self, dist=None, backend="nccl"):
+        """One env.reset() (RlSupervisor.reset: 2n extrusions per layer + the first frame), MAX over ranks."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        self.reset()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+
+def amortised(envs_total, steps, elapsed, reset_s, episode_len):
+    return envs_total * steps / (elapsed + steps / float(episode_len) * reset_s)
+
+
+def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None):
+    """A BASELINE configuration other than the headline one, same loop, same accounting (1 GPU)."""
+    w = Workload(config, envs, 0, 1, device, denoiser=denoiser)
+    w.reset()
+    reset_s = w.time_reset()
+    elapsed, _, fk = w.timed(steps, warmup, time_frame=True)
+    out = {"workload": config + (" + shipped denoiser" if denoiser else ""), "envs": envs,
+           "agents": w.layout.n_agents, "steps": steps,
+           "value": amortised(envs, steps, elapsed, reset_s, episode_len),
+           "value_no_reset": envs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+           "reset_ms": reset_s * 1e3, "frame_kernel_ms": fk,
+           "frame_kernel": w.sim.frame_kernel_name(),
+           "mean_strehl_le": float(w.sim.strehl[:, 1].mean())}
+    if denoiser:
+        w.env.supervisor.autoencoder.check_range()
+    del w
+    return out
+
+
+# ------------------------------------------------------------------------------------ main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs", type=int, default=256, help="environments per GPU")
-    ap.add_argument("--config", default=WORKLOAD)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true",
-                    help="separate science / WFS passes instead of the one-pass frame kernel")
-    ap.add_argument("--denoiser", default=None,
-                    help="WFS-image denoiser weights (a state_dict file, or 'golden' for the shipped "
-                         "network kept in tests/golden/host_denoiser.pt): BASELINE configs[4]")
-    ap.add_argument("--residual-shortcut", action="store_true",
-                    help="residual modes from one product with v2m.cmat instead of do_control + "
-                         "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="move the atmosphere in front of the image kernels (no side stream)")
-    ap.add_argument("--no-defer", action="store_true",
-                    help="materialise the stack-array DM shapes instead of evaluating them from the "
-                         "voltages inside the frame kernel")
-    ap.add_argument("--pmc", default="r01g_pmc_counters_256env.json",
-                    help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes")
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                   # does not return
+
+    import numpy as np  # noqa: F401
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     # one rank per GPU over RCCL (backend "nccl").  AOMARL_DIST_BACKEND=gloo lets the multi-rank path
     # be rehearsed on a box with fewer GPUs than ranks (ranks then share devices round-robin).
     backend = os.environ.get("AOMARL_DIST_BACKEND", "nccl")
     ndev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible (AOMARL_DIST_BACKEND=gloo shares devices "
+                         "for rehearsals)" % (world, ndev))
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     device = "cuda:%d" % dev_index
     torch.cuda.set_device(device)
@@ -201,153 +350,169 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from ao_marl_amd.agents import BatchedGaussianPolicy
-    from ao_marl_amd.env import VecAoEnv
-
-    small = "10x10" in args.config
-    if small:
-        rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
-        n_modal = 1
-    else:
-        rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5,
-                  window_n_zernike=20, include_tip_tilt_windowed=True)
-        n_modal = 13
-    # independent shards: rank r owns seeds [r*envs, (r+1)*envs) of the global seed sequence
-    autoencoder = None
-    if args.denoiser:
-        from ao_marl_amd.denoiser import SubapDenoiser
-        path = os.path.join(ROOT, "tests", "golden", "host_denoiser.pt") if args.denoiser == "golden" \
-            else args.denoiser
-        sd = torch.load(path, map_location="cpu", weights_only=True)
-        autoencoder = SubapDenoiser(sd.get("state_dict", sd), device=device)
-    norm_kw = {}
-    try:
-        from ao_marl_amd.env import load_norm
-        load_norm(args.config)
-    except FileNotFoundError:
-        # no recorded statistics for this configuration: borrow the closest one's (synthetic
-        # benchmark data; the arithmetic per step is identical)
-        nrm, zn = load_norm("production_sh_40x40_8m_3layers_d1_noise" if "noise" in args.config
-                            else WORKLOAD)
-        norm_kw = dict(norm=nrm, zn_norm=zn)
-    env = VecAoEnv(args.config, args.envs, rl, initial_seed=1234 + 16 * args.envs * rank,
-                   seed_stride=16, n_agents_modal=n_modal, device=device, autoencoder=autoencoder,
-                   prefetch_atmos=not args.no_prefetch, **norm_kw)
+    from ao_marl_amd.dist import gather_episode_returns
+    denoiser = args.denoiser
+    if denoiser == "golden":                # the old spelling
+        denoiser = "shipped"
+    w = Workload(args.config, args.envs, rank, world, device, denoiser=denoiser,
+                 prefetch=not args.no_prefetch)
+    env, sim, layout = w.env, w.sim, w.layout
     env.residual_shortcut = bool(args.residual_shortcut)
-    layout = env.layout
-    policy = BatchedGaussianPolicy(layout, last_layer_zero=False, seed=1234 + rank, device=device)
-    sim = env.supervisor.sim
-
-    timer = StageTimer()
-    # stage-by-stage call order of the supervisor (same kernels as the composite entry point), so
-    # that the image kernel can be bracketed by its own event pair
-    env.supervisor.next_part_one_split = True
-
+    env.supervisor.next_part_one_split = True      # stage-by-stage call order (same kernels)
     if args.unfused:
         sim.set_option("force_unfused_frame", 1)
     if args.no_defer:
         sim.defer_shape = False
+    if args.f32_dft:
+        sim.set_option("force_f32_dft", 1)
 
-    for name, label in (("move_atmos", "move_atmos"), ("target_psf", "target_psf"),
-                        ("comp_image", "wfs_spot_cog"), ("frame_fused", "frame_fused"),
-                        ("do_control", "do_control"), ("slopes2modes", "residual_modes"),
-                        ("rl_control", "rl_control"), ("apply_control", "dm_shape"),
-                        ("comp_strehl", "strehl_commit")):
-        timer.wrap(sim, name, label)
+    w.reset()
+    reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
+    elapsed, t_enq, fk_ms = w.timed(args.steps, args.warmup, dist, backend)
+    envs_total = args.envs * world
+    value = amortised(envs_total, args.steps, elapsed, reset_s, args.episode_len)
+    kernel_name = sim.frame_kernel_name()
+    sr = float(sim.strehl[:, 1].mean())
 
-    state = env.reset()
-
-    def one_step(st):
-        a, _ = policy.select_action(st)
-        s_next, r, _, _ = env.step(a)
-        return s_next
-
-    # the timed region carries the event pair of the image kernel(s) only (-> roofline)
-    timer.live = {"frame_fused", "wfs_spot_cog", "target_psf"}
-    for _ in range(args.warmup):
-        state = one_step(state)
-    timer.clear()
-    torch.cuda.synchronize()
+    # epilogue collective of the path: per-environment returns of every rank, in global seed order
+    # (here: the reward of the last step summed over agents, and the long-exposure Strehl)
+    ret_all = gather_episode_returns(w.last_r.sum(dim=1))
+    sr_all = gather_episode_returns(sim.strehl[:, 1].contiguous())
+    shards = [dict(rank=rank, first_seed=int(w.first_seed), envs=args.envs)]
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        state = one_step(state)
-    t_enq = time.perf_counter() - t0           # host time to enqueue the K steps (diagnostic)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        got = [None] * world
+        dist.all_gather_object(got, shards[0])
+        shards = got
 
-    stage_ms = timer.mean_ms()
-    sr = sim.strehl[:, 1].mean().item()
     # diagnostic pass (outside `value`): every stage with its own event pair
-    timer.clear()
-    timer.live = None
-    for _ in range(min(20, args.steps)):
-        state = one_step(state)
-    torch.cuda.synchronize()
-    stage_diag = timer.mean_ms()
-    stage_diag.update(stage_ms)            # the image kernel keeps its timed-region figure
+    stage_diag = stage_split(w, min(20, args.steps))
+
+    out = None
     if rank == 0:
-        models = stage_models(env.supervisor.s, args.envs, env.nmodes, layout.action_dim)
-        if not any(k in models for k in stage_ms):       # denoiser run: no per-stage split
-            stage_ms["frame_fused"] = float("nan")
-        dom = max((k for k in stage_ms if k in models), key=lambda k: (stage_ms[k] == stage_ms[k], stage_ms[k]))
-        m, ms = models[dom], stage_ms[dom]
-        scale = 1e-12 if m["unit"] == "TFLOP/s" else 1e-9
-        achieved = m["work"] / (ms * 1e-3) * scale
-        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-        # MI355X_MICROARCH.md), measured off-line at 256 envs and scaled to this batch
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", args.pmc)))
-            if dom in pmc and args.config == WORKLOAD:
-                traffic = pmc[dom]["hbm_traffic_bytes_per_launch"] * args.envs / pmc["_envs"]
-        except Exception:
-            traffic = None
-        roof = {"kernel": dom, "bound": m["bound"], "achieved": achieved, "peak": m["peak"],
-                "unit": m["unit"], "frac": achieved / m["peak"], "traffic": traffic,
-                "avg_launch_ms": ms}
-        img = "frame_fused" if "frame_fused" in stage_ms else "wfs_spot_cog"
-        spot_ms = stage_ms[img]
-        sp = models[img]
+        s = env.supervisor.s
+        model = frame_kernel_model(s, args.envs)
+        roof = None
+        if fk_ms:
+            achieved = model["bytes"] / (fk_ms * 1e-3) * 1e-9
+            roof = {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(args.pmc, kernel_name, args.envs, args.config),
+                    "avg_launch_ms": fk_ms, "algorithmic_bytes_per_launch": model["bytes"],
+                    "algorithmic_tflops": model["flops"] / (fk_ms * 1e-3) * 1e-12,
+                    "timing": "HIP event pair around each k_frame_wave launch on its stream, inside the timed region"}
+        hp = kernel_name.endswith("true>")
         out = {
-            "metric": "env steps/sec (AO frames/sec)", "value": args.envs * world * args.steps / elapsed,
-            "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.config, "envs_per_gpu": args.envs,
-                       "agents": layout.n_agents, "state_dims": layout.state_shapes()[:1] +
-                       layout.state_shapes()[-1:], "action_dim": layout.action_dim,
+            "metric": "env steps/sec (AO frames/sec)", "value": value, "unit": "env steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": args.envs * world / value * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f16x2-split operands (hi+lo, 22-bit mantissa), f32 accumulate" if hp
+                      else "f32") + "; control / projection / actor GEMMs f32",
+            "data": "synthetic",
+            "config": {"workload": args.config + (" + denoiser" if denoiser else ""),
+                       "envs_per_gpu": args.envs, "agents": layout.n_agents,
+                       "state_dims": layout.state_shapes()[:1] + layout.state_shapes()[-1:],
+                       "action_dim": layout.action_dim, "episode_len": args.episode_len,
+                       "policy": "random-init actors (step cost does not depend on the weights)",
                        "parallelism": "independent env shards x%d" % world},
+            "value_no_reset": envs_total * args.steps / elapsed,
+            "ms_per_step_no_reset": elapsed / args.steps * 1e3,
+            "reset_ms": reset_s * 1e3,
             "roofline": roof,
-            "image_kernel": {"kernel": img, "avg_launch_ms": spot_ms,
-                            "algorithmic_tflops": sp.get("flops", sp["work"]) / (spot_ms * 1e-3) * 1e-12,
-                            "frac_fp32_mfma_peak": sp.get("flops", sp["work"]) / (spot_ms * 1e-3) * 1e-12 / FP32_MFMA_PEAK_TF,
-                            "algorithmic_gbs": sp["bytes"] / (spot_ms * 1e-3) * 1e-9,
-                            "frac_hbm_peak": sp["bytes"] / (spot_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS},
             "stage_ms": stage_diag, "atmos_prefetch": bool(env.supervisor.prefetch_atmos),
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "mean_strehl_le": sr,
+            "gathered": {"n": int(ret_all.numel()), "mean_last_step_reward": float(ret_all.mean()),
+                         "mean_strehl_le": float(sr_all.mean())},
+            "shards": shards,
         }
+    if dist is not None:
+        dist.barrier()
+
+    # ---- everything below is single-GPU side information (rank 0 of an N = 1 run)
+    if rank == 0 and world == 1:
+        main_is_headline = args.config == WORKLOAD and not denoiser
+        if not args.no_side_configs and main_is_headline and not args.f32_dft:
+            try:        # the same loop on the fp32-MFMA frame kernel (exact fp32 operands)
+                sim.set_option("force_f32_dft", 1)
+                w.reset()
+                e32, _, fk32 = w.timed(args.steps, args.warmup)
+                out["f32_pass"] = {"dtype": "f32", "kernel": sim.frame_kernel_name(),
+                                   "value": amortised(args.envs, args.steps, e32, reset_s, args.episode_len),
+                                   "value_no_reset": args.envs * args.steps / e32,
+                                   "ms_per_step_no_reset": e32 / args.steps * 1e3, "frame_kernel_ms": fk32}
+                sim.set_option("force_f32_dft", 0)
+            except Exception as e:
+                out["f32_pass"] = {"error": str(e)[:200]}
         try:
-            out["sac_update"] = sac_update_rate(layout, device) if (world == 1 and args.config == WORKLOAD) else None
+            out["sac_update"] = sac_update_rate(layout, device) if main_is_headline else None
         except Exception as e:                      # secondary figure: never fail the bench line
             out["sac_update"] = {"error": str(e)[:200]}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(env)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+        s_main = env.supervisor.s
+        del w, env, sim
+        torch.cuda.empty_cache()
+        if not args.no_side_configs and main_is_headline:
+            out["configs"] = {}
+            for key, cfg, ne, dn, st in (("configs[1]", SMALL, 64, None, 200),
+                                         ("configs[4]", NOISY, args.envs, "shipped", 30)):
+                try:
+                    out["configs"][key] = side_config(cfg, ne, device, st, 5, args.episode_len, dn)
+                except Exception as e:
+                    out["configs"][key] = {"error": str(e)[:300]}
+                torch.cuda.empty_cache()
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(s_main)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def stage_split(w, steps):
+    """Per-stage durations (ms) from event pairs around the supervisor's stage entry points; a
+    diagnostic pass AFTER the timed region (sixteen event records per step cost 7 % of a step)."""
+    import numpy as np
+    torch = w.torch
+    sim, pairs = w.sim, {}
+    names = (("move_atmos", "move_atmos"), ("target_psf", "target_psf"), ("comp_image", "wfs_spot_cog"),
+             ("frame_fused", "frame_fused"), ("do_control", "do_control"),
+             ("slopes2modes", "residual_modes"), ("rl_control", "rl_control"),
+             ("apply_control", "dm_shape"), ("comp_strehl", "strehl_commit"))
+    saved = {}
+    for name, label in names:
+        fn = getattr(sim, name)
+        saved[name] = fn
+
+        def timed(*a, _fn=fn, _label=label, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = _fn(*a, **k)
+            e1.record()
+            pairs.setdefault(_label, []).append((e0, e1))
+            return r
+        setattr(sim, name, timed)
+    for _ in range(steps):
+        w.one_step()
+    torch.cuda.synchronize()
+    for name in saved:
+        delattr(sim, name)                  # back to the class methods
+    return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in pairs.items()}
+
+
+def pmc_traffic(fname, kernel_name, envs, config):
+    """HBM bytes per launch of the frame kernel from the rocprofv3 --pmc passes summarised in
+    profiles/<fname> (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md; collected by
+    tools/pmc_collect.py).  None unless the file was measured on the kernel instantiation and the
+    configuration this run launched."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        rec = pmc["frame_fused"]
+        if pmc.get("_config") != config or rec.get("kernel") != kernel_name:
+            return None
+        return rec["hbm_traffic_bytes_per_launch"] * envs / pmc["_envs"]
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":

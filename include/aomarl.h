@@ -248,6 +248,7 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
  * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
  * "gemm_target_blocks" (split-K target of the fp32 GEMM),
+ * "time_frame_kernel" (see aomarl_frame_kernel_time),
  * "prefetch_atmos" (aomarl_next_part_one moves the next frame's atmosphere on a side stream, see
  * aomarl_prefetch_atmos),
  * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
@@ -270,6 +271,16 @@ int aomarl_target_psf(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_
  * (and "force_unfused_frame" was not set).  flags as aomarl_comp_image minus FROM_PHASE_BUFFER /
  * NO_ATMOS / NO_DMS.  aomarl_next_part_one uses it automatically when available. */
 int aomarl_frame_fused_available(aomarl_ctx *ctx);
+/* Name of the kernel instantiation the last aomarl_frame_fused of this context launched, spelled
+ * as rocprofv3 prints it ("k_frame_wave<3, 1, true, false, false, true>": layers, lattice blocks,
+ * DM from voltage, noise, bincube, split-fp16 DFT); "" before the first launch.  bench.py matches
+ * it against the kernel name recorded in the profiles/ file it takes the HBM traffic from. */
+const char *aomarl_frame_kernel_name(aomarl_ctx *ctx);
+/* Under aomarl_set_option(ctx, "time_frame_kernel", nlaunches) every k_frame_wave launch is bracketed
+ * by a HIP event pair on its own stream (the first `nlaunches` launches after the option is set or the
+ * times were last read).  This reads them: sum of the launch durations and their count; waits for the
+ * recorded launches, then starts over.  bench.py's roofline.achieved comes from here. */
+int aomarl_frame_kernel_time(aomarl_ctx *ctx, double *total_ms, int *launches);
 int aomarl_frame_fused(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int flags,
                        void *stream);
 /* General batched fp32 GEMM (forward and backward passes of the stacked SAC networks):

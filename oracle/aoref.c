@@ -397,3 +397,22 @@ float aoref_phase_var(const float *phase, const float *pupil, int n) {
     if (pupil[p] > 0.f) { double d = phase[p] - m; v += d * d; }
   return (float)(v / c);
 }
+
+/* ------------------------------------------------------------------ threading */
+#ifdef _OPENMP
+#include <omp.h>
+int aoref_set_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  int got = 1;
+#pragma omp parallel
+  {
+#pragma omp single
+    got = omp_get_num_threads();
+  }
+  return got;
+}
+int aoref_max_threads(void) { return omp_get_num_procs(); }
+#else
+int aoref_set_threads(int n) { (void)n; return 1; }
+int aoref_max_threads(void) { return 1; }
+#endif

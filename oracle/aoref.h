@@ -84,6 +84,11 @@ void aoref_psf(const float *phase, const float *pupil, int n, int nfft, float la
                float *peak_win);
 float aoref_phase_var(const float *phase, const float *pupil, int n); /* um^2 over pupil>0 */
 
+/* ---- threading of the OpenMP loops above (bench.py's cpu_baseline times 1 and N threads):
+ * set: threads of the following calls, returns the count in effect; max: what the host offers */
+int aoref_set_threads(int n);
+int aoref_max_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,9 @@ def lib():
                                 C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.aoref_phase_var.argtypes = [_f, _f, C.c_int]
         L.aoref_phase_var.restype = C.c_float
+        L.aoref_set_threads.argtypes = [C.c_int]
+        L.aoref_set_threads.restype = C.c_int
+        L.aoref_max_threads.restype = C.c_int
         _lib = L
     return _lib
 

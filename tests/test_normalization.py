@@ -82,3 +82,41 @@ def test_statistics_match_the_references_recorded_compass_runs(name):
     assert abs(r_res - 1) < 0.10
     assert abs(r_zn - 1) < 0.20
     assert np.abs(norm["wfs"]["mean"]).max() < 0.2 * norm["wfs"]["std"].max()
+
+
+@pytest.mark.gpu
+def test_noisy_configuration_against_the_references_d1_noise_statistics():
+    """The only reference-held fixture of the noisy configuration family: the normalisation the
+    reference recorded from real COMPASS for production_sh_40x40_8m_3layers_d1_noise (magnitude 9,
+    3 e- read-out noise, delay 1, gain 0.65).  Its recipe takes an optional autoencoder_path
+    (obtain_normalization.py:10-42, :258) and the file name does not say whether one was given, so
+    the recipe runs both ways on the HIP path -- noisy sensor alone and noisy sensor + the shipped
+    denoiser (k_frame_wave<noise> -> k_denoise4c -> k_cog) -- and the recorded statistics must be
+    met, +-10 % on the standard deviations and +-20 % on the action bounds, by
+    the variant the reference ran; the other one is reported.  This is also the independent check
+    of the photon / read-out noise model (the oracle shares the kernel's noise rule)."""
+    from ao_marl_amd.denoiser import SubapDenoiser
+    name = "production_sh_40x40_8m_3layers_d1_noise"
+    ref, zn_ref = load_norm(name)
+    nm = zn_ref.shape[0]
+    live = np.arange(nm) < nm - 5 - 2
+    live[-2:] = True
+    ratios = {}
+    for label in ("denoiser", "plain"):
+        dn = SubapDenoiser.load(device="cuda:0") if label == "denoiser" else None
+        norm, zn, sr = N.obtain_normalization(name, modes_filtered=5, episodes=20, frames=1000,
+                                              autoencoder=dn)
+        if dn is not None:
+            dn.check_range()
+        r = dict(wfs=float(np.median(norm["wfs"]["std"] / ref["wfs"]["std"])),
+                 dm=float(np.median(norm["dm"]["std"][live] / ref["dm"]["std"][live])),
+                 res=float(np.median(norm["dm_residual"]["std"][live] / ref["dm_residual"]["std"][live])),
+                 zn=float(np.median(zn[live] / zn_ref[live])), sr=float(sr.mean()))
+        ratios[label] = r
+        print("%s [%s]: median std ratio  slopes %.3f  command modes %.3f  residual modes %.3f  "
+              "zn_norm %.3f  LE Strehl %.3f" % (name, label, r["wfs"], r["dm"], r["res"], r["zn"], r["sr"]))
+
+    def ok(r):
+        return (abs(r["wfs"] - 1) < 0.10 and abs(r["dm"] - 1) < 0.10 and abs(r["res"] - 1) < 0.10 and
+                abs(r["zn"] - 1) < 0.20)
+    assert ok(ratios["denoiser"]) or ok(ratios["plain"]), ratios
