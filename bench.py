@@ -124,6 +124,37 @@ def frame_kernel_model(s, nenv):
     return dict(bytes=byts, flops=flops, lit_tiles=lit)
 
 
+def usable_cores(host_cores):
+    """Cores this process may actually run on: the scheduler affinity and the cgroup CPU quota of the
+    box's share (a 256-core host hands a 1-GPU job 16 of them; 256 OpenMP threads on 16 cores ran 5x
+    SLOWER than one thread)."""
+    n = host_cores
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    if "OMP_NUM_THREADS" in os.environ:
+        try:
+            n = min(n, int(os.environ["OMP_NUM_THREADS"]))
+        except ValueError:
+            pass
+    # the GPU pool's rule of thumb is 16 host cores per GPU: never spin more threads than that
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(s, budget_s=8.0):
     """The CPU oracle stepping ONE environment of the workload (same calibrated command matrix) on
     this host: single thread, then every core; each bounded to ~budget_s seconds of frames."""
@@ -158,11 +189,11 @@ def cpu_baseline(s, budget_s=8.0):
             if dt > budget_s or frames >= 200:
                 break
         return got, frames, dt
-    ncores = L.aoref_max_threads()
+    ncores = usable_cores(L.aoref_max_threads())
     t1, f1, d1 = run(1)
     tn, fn, dn = run(ncores)
     return {"value": fn / dn, "unit": "env steps/s", "cores": tn, "kind": "port",
-            "value_1_thread": f1 / d1, "host_cores": ncores,
+            "value_1_thread": f1 / d1, "host_cores": L.aoref_max_threads(),
             "sample": "integrator frames of 1 environment of %s (extrusion, 2 raytraces, %d zero-padded "
                       "64x64 FFT spots, COG, cmat GEMV, delay, DM shapes, %d^2 FFT PSF; SAC actor not "
                       "included): %d frames in %.1f s on 1 thread, %d frames in %.1f s on %d OpenMP threads"

@@ -2,11 +2,20 @@
 """G10: the reference's OWN RlSupervisor + AoEnv, unmodified, executed over the oracle facade
 (tools/ref_facade.py) -> golden (state, per-agent reward, slopes, command, Strehl) traces.
 
-Build container only.  The parameter file is tools/par/production_aomarl_sh_10x10_2m_single.py (the 10x10
-system reduced to its controller-0 path, because the GEO reference controller of the stock files is
-not in the oracle); it is staged, together with copies of the reference's 10x10 normalisation DATA
-under that name, in a scratch directory laid out like the reference expects.
-Writes tests/golden/trace_10x10_single.npz.
+Build container only.  Two runs:
+  single  tools/par/production_aomarl_sh_10x10_2m_single.py (the 10x10 system reduced to its
+          controller-0 path) -> tests/golden/trace_10x10_single.npz
+  stock   the reference's own production_sh_10x10_2m.py, UNMODIFIED (2 WFS, 4 DMs, 2 targets, LS +
+          GEO controllers: the reference loops over all controllers every frame,
+          rlSupervisor.py:1038-1049) -> tests/golden/trace_10x10_stock.npz, which also carries the
+          geometric controller's command and the second target's Strehl.
+The parameter file is staged, with the reference's normalisation DATA, in a scratch directory laid
+out like the reference expects (nothing of the reference is written into this repository).
+With --record-calls the whole Appendix-B call sequence the reference makes (constructors, array
+loads, per-frame calls, reads) is logged through tools/record_calls.py ->
+tests/golden/calls_10x10_<run>.pkl.gz: the input of the facade replay tests.
+
+Usage: python tools/gen_golden_trace.py [single|stock] [--record-calls]
 """
 import os
 import shutil
@@ -24,13 +33,14 @@ import ref_facade  # noqa: E402
 import numpy as np  # noqa: E402
 
 REF = _ref_shims.REF
-NAME = "production_aomarl_sh_10x10_2m_single"
 NORM = "src/reinforcement_learning/helper_functions/preprocessing/normalization"
+RUNS = {"single": ("production_aomarl_sh_10x10_2m_single", os.path.join(HERE, "par")),
+        "stock": ("production_sh_10x10_2m", os.path.join(REF, "data/par/par4rl/production"))}
 
 
-def stage(tmp):
+def stage(tmp, NAME, src_dir):
     os.makedirs(os.path.join(tmp, "data/par/par4rl/production"))
-    shutil.copy(os.path.join(HERE, "par", NAME + ".py"), os.path.join(tmp, "data/par/par4rl/production"))
+    shutil.copy(os.path.join(src_dir, NAME + ".py"), os.path.join(tmp, "data/par/par4rl/production"))
     for sub in ("state_normalization", "normalization_action_zernike"):
         os.makedirs(os.path.join(tmp, NORM, sub))
     shutil.copy(os.path.join(REF, NORM, "state_normalization",
@@ -43,11 +53,17 @@ def stage(tmp):
     os.makedirs(os.path.join(tmp, "output/debug"))
 
 
-def main(nframes=30, seed=1234):
-    ref_facade.install()
+def main(run="single", nframes=30, seed=1234, record=False):
+    NAME, src_dir = RUNS[run]
+    sw, cw = ref_facade.install()
+    rec = None
+    if record:
+        import record_calls
+        rec = record_calls.Recorder()
+        rec.install(sw, cw)
     _ref_shims.install()
     tmp = tempfile.mkdtemp(prefix="aomarl_ref_")
-    stage(tmp)
+    stage(tmp, NAME, src_dir)
     os.chdir(tmp)
     from src.reinforcement_learning.config.GlobalConfig import Config
     from src.reinforcement_learning.environment.ao_env import AoEnv
@@ -66,8 +82,10 @@ def main(nframes=30, seed=1234):
     fake = types.SimpleNamespace(env=env, world_size=3)
     agents, total, local, total_existing = TrainerRPC.create_agents_dictionary_original(fake, cfg)
     rng = np.random.default_rng(99)
+    geo = len(sup.config.p_controllers) > 1
+    rec_ = rec
     rec = {k: [] for k in ("state", "reward", "slopes", "com", "err", "voltage", "strehl",
-                           "action")}
+                           "action", "com_geo", "strehl_geo")}
     s = env.reset()
     rec["state"].append(np.asarray(s, dtype=np.float64))
     rec["slopes"].append(sup.rtc.get_slopes(0))
@@ -90,7 +108,10 @@ def main(nframes=30, seed=1234):
         rec["err"].append(sup.rtc.get_err(0))
         rec["voltage"].append(sup.rtc.get_voltages(0))
         rec["strehl"].append(np.asarray(sup.target.get_strehl(0), dtype=np.float64))
-    out = {k: np.asarray(v) for k, v in rec.items()}
+        if geo:
+            rec["com_geo"].append(sup.rtc.get_command(1))
+            rec["strehl_geo"].append(np.asarray(sup.target.get_strehl(1), dtype=np.float64))
+    out = {k: np.asarray(v) for k, v in rec.items() if len(v)}
     out["modes2volts"], out["volts2modes"] = sup.modes2volts, sup.volts2modes
     out["cmat"] = np.array(sup.rtc._rtc.d_control[0].d_cmat)
     out["imat"] = np.array(sup.rtc._rtc.d_control[0].d_imat)
@@ -98,8 +119,10 @@ def main(nframes=30, seed=1234):
     out["seed"] = np.array(seed)
     out["agents"] = np.array([agents[w] for w in agents])
     out["nactu"] = np.array(out["com"].shape[1])
-    dst = os.path.join(ROOT, "tests", "golden", "trace_10x10_single.npz")
+    dst = os.path.join(ROOT, "tests", "golden", "trace_10x10_%s.npz" % run)
     np.savez_compressed(dst, **out)
+    if rec_ is not None:
+        rec_.save(os.path.join(ROOT, "tests", "golden", "calls_10x10_%s.pkl.gz" % run))
     print("wrote", dst, {k: v.shape for k, v in out.items()})
     print("SR se/le last:", out["strehl"][-1][:2], "state absmax", np.abs(out["state"]).max())
     os.chdir(ROOT)
@@ -107,4 +130,5 @@ def main(nframes=30, seed=1234):
 
 
 if __name__ == "__main__":
-    main()
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    main(run=args[0] if args else "single", record="--record-calls" in sys.argv)

@@ -415,6 +415,27 @@ class Controller(object):
             for a in (self.com, self.com1, self.com2, self.err, self.voltage):
                 a[:] = 0
 
+    def init_proj_sparse(self, dms, indx_dm, unitpervolt, indx_pup, indx_mpup, roket=False):
+        """rtc_init.py:418-448: influence functions of the controller's DMs on the pupil pixels
+        (indx_dm: per DM, the pupil pixels in that DM's support, flat first-index-fastest = this
+        module's C-order [y][x] arrays)."""
+        import scipy.sparse as sp
+        indx_dm = np.asarray(indx_dm).reshape(len(self.ndm), -1)
+        cols = []
+        for j, k in enumerate(self.ndm):
+            d = dms.d_dms[k]
+            keep_com, keep_shape = d.com.copy(), d.shape.copy()
+            for i in range(d.nactu):
+                d.comp_oneactu(i, 1.0)
+                cols.append(d.shape.reshape(-1)[indx_dm[j]].astype(np.float64))
+            d.com[:], d.shape[:] = keep_com, keep_shape
+        self.geo_IF = sp.csc_matrix(np.stack(cols, axis=1))
+        self.geo_pup = np.asarray(indx_pup, dtype=np.int64)
+
+    def comp_dphi(self, source, is_wfs=False):
+        """rtcCompass.py:545-546: the phase of `source` on the pupil pixels, kept for do_control."""
+        self._dphi = source.phase.reshape(-1)[self.geo_pup].astype(np.float64)
+
     def svdec_imat(self):
         w = np.linalg.eigvalsh(self.imat.astype(np.float64).T @ self.imat.astype(np.float64))
         self.eigenvals = w[::-1].astype(f32)           # descending
@@ -438,8 +459,6 @@ class Rtc_FFF(object):
 
     def add_controller(self, ctx, nvalid, nslope, nactu, delay, dev, typ, dms=None, ndm=(), ndm_size=0,
                        nwfs=(), nwfs_size=0, Nphi=0, roket=False, nstates=0):
-        if str(typ) == "geo":
-            raise NotImplementedError("GEO controller (SURVEY 8f item 1) is not in the oracle")
         self.d_control.append(Controller(self, nvalid, nslope, nactu, delay, typ, dms, ndm, nwfs))
 
     def _wfs_of(self, n):
@@ -459,6 +478,12 @@ class Rtc_FFF(object):
 
     def do_control(self, n, *a, **k):
         c = self.d_control[n]
+        if c.type == "geo":
+            # sutra_controller_geo restated (ao_marl_amd.modal.geo_command, unpinned like every
+            # native stage): least-squares projection of the pupil phase comp_dphi captured
+            from ao_marl_amd import modal
+            c.com[:] = modal.geo_command(c.geo_IF, c._dphi).astype(f32)
+            return
         if c.open_loop:
             L.aoref_gemv(c.cmat, c.nactu, c.nslope, c.centroids, c.err)
             c.err[:] = -c.err
