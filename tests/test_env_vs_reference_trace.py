@@ -19,13 +19,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAR = os.path.join(ROOT, "tools", "par", "production_aomarl_sh_10x10_2m_single.py")
 
 
-def _run(golden_dir, sim_factory, device, tol_scale=1.0):
-    z = np.load(os.path.join(golden_dir, "trace_10x10_single.npz"))
-    ps = params.load_param_file(PAR)
+def _run(golden_dir, sim_factory, device, tol_scale=1.0, stock=False, geo=False):
+    """stock: the trace of the reference on its UNMODIFIED production_sh_10x10_2m.py (2 WFS, 4 DMs,
+    LS + GEO controllers; tests/golden/trace_10x10_stock.npz) against this package's built-in
+    restatement of that file; geo: with the geometric controller's twin (command and Strehl of
+    target 1 are compared too)."""
+    z = np.load(os.path.join(golden_dir, "trace_10x10_%s.npz" % ("stock" if stock else "single")))
+    ps = params.builtin("production_sh_10x10_2m") if stock else params.load_param_file(PAR)
     norm, zn = load_norm("production_sh_10x10_2m")      # the data the reference run used
     env = VecAoEnv(ps, 2, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5),
                    initial_seed=int(z["seed"]), seed_stride=0, n_agents_modal=1, device=device,
-                   norm=norm, zn_norm=zn, sim_factory=sim_factory)
+                   norm=norm, zn_norm=zn, sim_factory=sim_factory, geo=geo)
     sup = env.supervisor
     # --- init-time products vs the reference's (its Btt / cmat were computed by ITS code on ITS
     #     imat through the facade)
@@ -80,6 +84,13 @@ def _run(golden_dir, sim_factory, device, tol_scale=1.0):
         assert abs(st[0] - z["strehl"][it][0]) < 2e-4 * tol_scale
         assert abs(st[1] - z["strehl"][it][1]) < 2e-4 * tol_scale
         check_state(s, z["state"][it + 1], it)
+        if geo:
+            # controller 1 (rlSupervisor.py:989-1013): the geometric command of this frame and the
+            # Strehl of its own target, published by this step's next_part_two
+            close(sup.get_command(1)[0].cpu().numpy(), z["com_geo"][it], 5e-4, "geo com", it)
+            sg = sup.get_strehl(1)[0].cpu().numpy()
+            assert abs(sg[0] - z["strehl_geo"][it][0]) < 5e-4 * tol_scale, (it, sg, z["strehl_geo"][it])
+            assert abs(sg[1] - z["strehl_geo"][it][1]) < 5e-4 * tol_scale
     return env
 
 
@@ -88,6 +99,18 @@ def test_env_host_logic_matches_reference_trace_cpu(golden_dir):
     _run(golden_dir, OracleVecSim, "cpu")
 
 
+def test_env_host_logic_matches_the_stock_file_trace_cpu(golden_dir):
+    """Controller 0 of the stock two-controller file == the reduced single-controller file (the
+    reference's second controller path shares nothing with the first but the atmosphere)."""
+    from tests.oracle_vecsim import OracleVecSim
+    _run(golden_dir, OracleVecSim, "cpu", stock=True)
+
+
 @pytest.mark.gpu
 def test_env_product_path_matches_reference_trace_gpu(golden_dir):
     _run(golden_dir, None, "cuda:0", tol_scale=8.0)
+
+
+@pytest.mark.gpu
+def test_env_product_path_matches_the_stock_file_trace_with_geo_gpu(golden_dir):
+    _run(golden_dir, None, "cuda:0", tol_scale=8.0, stock=True, geo=True)

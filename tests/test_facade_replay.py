@@ -1,0 +1,95 @@
+"""The `sutraWrap`-shaped facades against the call sequence the reference's own Python makes.
+
+tests/golden/calls_10x10_stock.pkl.xz is the complete Appendix-B call log of the reference's
+UNMODIFIED RlSupervisor + AoEnv on its stock production_sh_10x10_2m.py (2 WFS, 4 DMs, 2 targets,
+LS + GEO controllers; init, calibration, reset, 30 closed-loop frames with RL actions), recorded
+over the oracle facade by tools/gen_golden_trace.py --record-calls: inputs of every call and the
+value of every read.  No reference code is needed to replay it.
+
+CPU: replayed on the oracle facade itself -> every read must come back bit for bit (the recorder /
+replayer are exact).  GPU: replayed on ao_marl_amd.sutra_facade (libaomarl_hip.so, batch size 1) ->
+the HIP library behind the reference's own API reproduces the recorded run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import record_calls as rc  # noqa: E402
+
+LOG = os.path.join(ROOT, "tests", "golden", "calls_10x10_stock.pkl.xz")
+
+
+class Tally(object):
+    def __init__(self):
+        self.worst, self.n = {}, 0
+
+    def __call__(self, entry, got):
+        want = entry.get("value", entry.get("result"))
+        key = rc.path_str([tuple(p) for p in entry["path"]])
+        self.n += 1
+        if isinstance(want, (str, bytes, bool, type(None))) or isinstance(got, str):
+            if want != got:
+                self.worst[key] = ("mismatch", want, got)
+            return
+        w, g = np.asarray(want, dtype=np.float64), np.asarray(got, dtype=np.float64)
+        if w.shape != g.shape:
+            self.worst[key] = ("shape", w.shape, g.shape)
+            return
+        if w.size == 0:
+            return
+        err = float(np.abs(w - g).max())
+        scale = float(np.abs(w).max())
+        old = self.worst.get(key, (0.0, 0.0))
+        if not isinstance(old[0], str) and err >= old[0]:
+            self.worst[key] = (err, scale)
+
+
+def test_replay_on_the_oracle_facade_is_exact():
+    import ref_facade
+    log = rc.load(LOG)
+    sw, cw = ref_facade.install()
+    tally = Tally()
+    rc.replay(log, sw, cw, tally)
+    assert tally.n > 1400
+    bad = {k: v for k, v in tally.worst.items() if isinstance(v[0], str) or v[0] != 0.0}
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_replay_on_the_hip_facade_reproduces_the_recorded_run(golden_dir):
+    """The same call sequence on ao_marl_amd.sutra_facade: every value the reference read during
+    init, calibration, reset and 30 closed-loop RL frames comes back from libaomarl_hip.so within
+    fp32 tolerances of the oracle-backed run (whose end-to-end trace is
+    tests/golden/trace_10x10_stock.npz)."""
+    from ao_marl_amd import sutra_facade
+    sutra_facade.reset_hub()
+    log = rc.load(LOG)
+    sw, cw = sutra_facade.install()
+    tally = Tally()
+    rc.replay(log, sw, cw, tally)
+    assert tally.n > 1400
+    # relative tolerances per family of reads (fraction of the largest recorded magnitude)
+    tol = {"d_slopes": 2e-4, "d_centroids": 2e-4, "d_com": 5e-4, "d_err": 5e-4, "d_voltage": 5e-4,
+           "d_imat": 5e-4, "d_cmat": 5e-3, "d_eigenvals": 2e-3, "d_shape": 2e-5, "d_phase": 2e-5,
+           "strehl_se": 1e-3, "strehl_le": 1e-3, "phase_var": 2e-3, "phase_var_avg": 2e-3}
+    bad, report = {}, []
+    for key, v in sorted(tally.worst.items()):
+        if isinstance(v[0], str):
+            bad[key] = v
+            continue
+        err, scale = v
+        fam = key.split(".")[-1]
+        rel = err / scale if scale > 0 else err
+        report.append("%-40s max |d| %.3e of %.3e (%.1e)" % (key, err, scale, rel))
+        limit = tol.get(fam)
+        if limit is None:
+            if err != 0.0:                      # integers, flags, counters: exact
+                bad[key] = v
+        elif rel > limit:
+            bad[key] = (v, limit)
+    print("\n".join(report))
+    assert not bad, bad
+    sutra_facade.reset_hub()

@@ -416,21 +416,43 @@ class Controller(object):
                 a[:] = 0
 
     def init_proj_sparse(self, dms, indx_dm, unitpervolt, indx_pup, indx_mpup, roket=False):
-        """rtc_init.py:418-448: influence functions of the controller's DMs on the pupil pixels
-        (indx_dm: per DM, the pupil pixels in that DM's support, flat first-index-fastest = this
-        module's C-order [y][x] arrays)."""
+        """rtc_init.py:418-448: influence functions of the controller's DMs on the pupil pixels.
+
+        indx_pup: the lit pixels of the pupil grid (flat, first-index-fastest = this module's
+        C-order [y][x]).  indx_dm is meant to hold, per DM, those pixels' indices inside the DM's
+        own support -- but the reference builds block j from p_dms[j], the j-th mirror of the FILE,
+        not from p_dms[ndm[j]], the j-th mirror of the CONTROLLER (rtc_init.py:431-436).  With the
+        stock files (ndm = [1, 3]) the tip-tilt block is therefore computed for a stack array's
+        258-pixel support and would address a 288-pixel tip-tilt array: meaningless pixels.  What
+        COMPASS's native code does with it is not in the tree (unpinned).  Both facades take the
+        geometry the indices are meant to encode instead: every DM support is centred on the pupil,
+        so pupil pixel (x, y) is DM pixel (x + o, y + o), o = (dim - pupdiam) / 2 -- the offsets the
+        reference itself gives the target (target_init.py:119-141).  Where the handed-in block is
+        usable (the stack array's), it is checked to say the same."""
         import scipy.sparse as sp
         indx_dm = np.asarray(indx_dm).reshape(len(self.ndm), -1)
+        pup = np.asarray(indx_pup, dtype=np.int64)
         cols = []
         for j, k in enumerate(self.ndm):
             d = dms.d_dms[k]
+            npup = self.rtc_pupdiam(dms)
+            o = (d.dim - npup) // 2
+            py, px = pup // npup, pup % npup
+            own = (py + o) * d.dim + (px + o)                 # this DM's pixels under the lit pupil
+            given = indx_dm[j]
+            if given.max() < d.dim * d.dim and j == 0:
+                assert np.array_equal(np.sort(given), np.sort(own)), "indx_dm disagrees with the DM geometry"
             keep_com, keep_shape = d.com.copy(), d.shape.copy()
             for i in range(d.nactu):
                 d.comp_oneactu(i, 1.0)
-                cols.append(d.shape.reshape(-1)[indx_dm[j]].astype(np.float64))
+                cols.append(d.shape.reshape(-1)[own].astype(np.float64))
             d.com[:], d.shape[:] = keep_com, keep_shape
         self.geo_IF = sp.csc_matrix(np.stack(cols, axis=1))
-        self.geo_pup = np.asarray(indx_pup, dtype=np.int64)
+        self.geo_pup = pup
+
+    def rtc_pupdiam(self, dms):
+        """Side of the pupil grid the GEO projection works on (the science target's grid)."""
+        return int(self._pupdiam)
 
     def comp_dphi(self, source, is_wfs=False):
         """rtcCompass.py:545-546: the phase of `source` on the pupil pixels, kept for do_control."""
@@ -460,6 +482,8 @@ class Rtc_FFF(object):
     def add_controller(self, ctx, nvalid, nslope, nactu, delay, dev, typ, dms=None, ndm=(), ndm_size=0,
                        nwfs=(), nwfs_size=0, Nphi=0, roket=False, nstates=0):
         self.d_control.append(Controller(self, nvalid, nslope, nactu, delay, typ, dms, ndm, nwfs))
+        if self.d_centro:                     # pupil grid of the science path = the sensors' telescope
+            self.d_control[-1]._pupdiam = self.d_centro[0].wfs.tel.spupil.shape[0]
 
     def _wfs_of(self, n):
         c = self.d_control[n]
