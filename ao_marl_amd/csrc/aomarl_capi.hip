@@ -411,6 +411,19 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
         }
       UP(int32_t, tinfo.data(), tinfo.size(), s.tile_info);
       {
+        if (nt > 127) { aomarl_destroy(c); return fail("pupil too wide for the frame kernel's tile list"); }
+        std::vector<int32_t> linfo((size_t)nt * (nt + 4), 0), lcount(nt, 0);
+        for (int r = 0; r < nt; r++) {
+          int k = 0;
+          for (int t = 0; t < nt; t++)
+            if (tinfo[(size_t)r * nt + t] & 0x10000) linfo[(size_t)r * (nt + 4) + k++] = tinfo[(size_t)r * nt + t] | (t << 24);
+          lcount[r] = k;
+          for (int kk = k; kk < nt + 4; kk++) linfo[(size_t)r * (nt + 4) + kk] = k ? linfo[(size_t)r * (nt + 4) + k - 1] : 0;
+        }
+        UP(int32_t, linfo.data(), linfo.size(), s.lit_info);
+        UP(int32_t, lcount.data(), lcount.size(), s.lit_count);
+      }
+      {
         std::vector<int32_t> order(nt), work(nt, 0);
         for (int r = 0; r < nt; r++) {
           order[r] = r;
@@ -1606,7 +1619,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   const int nb = otf ? c->sys.otf_nb : 1;
   const bool hp = !c->force_f32_dft;
   const size_t smm = sizeof(float) * (2 * 128 + (hp ? 0 : 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD) +
-                                      (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + (hp ? 8192 + 16 : 0);
+                                      (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + (hp ? 8192 + 128 : 0);
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
 #define FW(NL, NB, OTF, NZ, WC, HP) hipLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm, s, c->sys, ds, b, n, cog, TR, TP, w.nblk)
 #define FW_H(NL, NB, OTF, NZ, WC) do { if (hp) FW(NL, NB, OTF, NZ, WC, true); else FW(NL, NB, OTF, NZ, WC, false); } while (0)

@@ -62,6 +62,9 @@ struct DevSys {
   int fused_ok, ntiles;          // ntiles = pupdiam / 16 tiles per axis
   const int32_t *stripe_order;   // [ntiles] stripes by decreasing number of lit tiles
   const int32_t *tile_info;      // [ntiles][ntiles] (stripe, tile): sub-aperture | lit / full / has-sub bits
+  const int32_t *lit_info;       // [ntiles][ntiles + 4]: the stripe's LIT tiles in x order, compact: tile_info | tile << 24;
+                                 //   entries past the last one repeat it
+  const int32_t *lit_count;      // [ntiles] lit tiles per stripe
   const uint16_t *tile_mask;     // [pupdiam][ntiles]: bit b = spupil[y][16 t + b] != 0
   // stack-array DM phase from the command lattice inside the frame kernel (separable lattice whose
   // pitch divides the tile size): nodes per axis that reach a tile <= 4 otf_nb

@@ -30,8 +30,11 @@ __device__ __forceinline__ float wave_sum_last(float v) {
   v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
   v += dpp_f<0x141>(v);     // row_half_mirror
   v += dpp_f<0x140>(v);     // row_mirror -> every lane holds its 16-lane row sum
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31
+  // rows 1, 3 += last lane of the row before; rows 2, 3 += last lane of row 1: ONE instruction each
+  // (dst == src, the rows the mask leaves out keep their value) -- written through update_dpp with a
+  // zero `old` the compiler needs v_mov 0 + v_mov_dpp + v_add per step
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
   return v;
 }
 
@@ -1024,6 +1027,7 @@ __device__ __forceinline__ float sh_noise(float lam, float sigma, uint32_t seed,
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
 typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ hx2 cvt_h2(float a, float b) {
   return __builtin_bit_cast(hx2, __builtin_amdgcn_cvt_pkrtz(a, b));
@@ -1155,8 +1159,21 @@ __device__ __forceinline__ void spot_dft_h_v(const SpotTwH &tw, const float (&br
     const f32x4 QCi = mfma_h(tw.CL, ti, mfma_h(tw.CH, ti, z4));
     const f32x4 QSr = mfma_h(tw.SL, tr, mfma_h(tw.SH, tr, z4));
     const f32x4 QSi = mfma_h(tw.SL, ti, mfma_h(tw.SH, ti, z4));
-    spot_bin(QCr + QSi, QCi - QSr, v[0][m]);
-    spot_bin(QCr - QSi, QCi + QSr, v[1][m]);
+    // X(+ky) = (QCr + QSi, QCi - QSr), X(-ky) = (QCr - QSi, QCi + QSr):
+    //   |X(+-ky)|^2 = P +- 2 D,  P = QCr^2 + QSi^2 + QCi^2 + QSr^2,  D = QCr QSi - QCi QSr
+    // and the 2 x 2 binning adds register pairs (2h, 2h + 1) and lane pairs (c, c ^ 1): P and D are
+    // summed over the register pair first (14 instructions per pair for both signs instead of 20)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int a = 2 * h, b = 2 * h + 1;
+      float P = QCr[a] * QCr[a];
+      P = fmaf(QSi[a], QSi[a], P); P = fmaf(QCi[a], QCi[a], P); P = fmaf(QSr[a], QSr[a], P);
+      P = fmaf(QCr[b], QCr[b], P); P = fmaf(QSi[b], QSi[b], P); P = fmaf(QCi[b], QCi[b], P); P = fmaf(QSr[b], QSr[b], P);
+      float D = QCr[a] * QSi[a];
+      D = fmaf(-QCi[a], QSr[a], D); D = fmaf(QCr[b], QSi[b], D); D = fmaf(-QCi[b], QSr[b], D);
+      v[0][m][h] = add_xor1(fmaf(2.f, D, P));
+      v[1][m][h] = add_xor1(fmaf(-2.f, D, P));
+    }
   }
 }
 
@@ -1177,21 +1194,20 @@ __device__ __forceinline__ void spot_finish_v(const DevSys &sys, const DevState 
   const int Xp = 8 + (c >> 1), Xm = 7 - (c >> 1);
   if (!NOISE && !WRITE_CUBE) {
     // only the slopes are wanted and nothing depends on the normalised pixel values: the COG is
-    // invariant to the flux scale, so reduce (sum, sum x, sum y) of the raw image in ONE pass
-    float sx_ = 0.f, sy_ = 0.f;
-#pragma unroll
-    for (int sy = 0; sy < 2; sy++)
-#pragma unroll
-      for (int sx = 0; sx < 2; sx++)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int Y = sy ? 7 - (2 * q + h) : 8 + 2 * q + h;
-          sx_ += v[sy][sx][h] * (float)(sx ? Xm : Xp);
-          sy_ += v[sy][sx][h] * (float)Y;
-        }
-    tot = wave_sum_last(owner ? tot : 0.f);
-    sx_ = wave_sum_last(owner ? sx_ : 0.f);
-    sy_ = wave_sum_last(owner ? sy_ : 0.f);
+    // invariant to the flux scale, so reduce (sum, sum x, sum y) of the raw image in ONE pass.  Every
+    // binned pixel sits in both lanes of a pair (c, c ^ 1) with the same bits, so the sums over all
+    // 64 lanes are exactly twice the image's: the factor drops out of the ratios, no lane is masked.
+    const float A0 = (v[0][0][0] + v[0][0][1]) + (v[1][0][0] + v[1][0][1]);        // columns Xp
+    const float A1 = (v[0][1][0] + v[0][1][1]) + (v[1][1][0] + v[1][1][1]);        // columns Xm
+    float sx_ = (float)Xp * A0;
+    sx_ = fmaf((float)Xm, A1, sx_);
+    float sy_ = (float)(8 + 2 * q) * (v[0][0][0] + v[0][1][0]);
+    sy_ = fmaf((float)(9 + 2 * q), v[0][0][1] + v[0][1][1], sy_);
+    sy_ = fmaf((float)(7 - 2 * q), v[1][0][0] + v[1][1][0], sy_);
+    sy_ = fmaf((float)(6 - 2 * q), v[1][0][1] + v[1][1][1], sy_);
+    tot = wave_sum_last(A0 + A1);
+    sx_ = wave_sum_last(sx_);
+    sy_ = wave_sum_last(sy_);
     if (do_cog && lane == 63) {
       float *sl = st.slopes + (long long)e * sys.nslope;
       if (tot > 0.f) {
@@ -1718,6 +1734,14 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
 #define FW_LIT 0x10000
 #define FW_FULL 0x20000
 #define FW_SUB 0x40000
+// science-path phase in revolutions for v_sin / v_cos.  The instructions reduce their argument
+// themselves for |x| <= 256 revolutions (ISA: valid input domain [-256, 256], 0 outside); the
+// science wavelength sees |phase| / lambda of a few tens at most (an 8 m pupil at r0 = 0.16 m has
+// 2 um rms of optical path, 1.65 um wavelength: 422 um would be needed to leave the domain), so
+// the explicit round-and-subtract the WFS path keeps (its fused multiply-subtract also saves one
+// rounding, which the 2e-5 image tolerance needs) is dropped here.
+__device__ __forceinline__ float sci_rev(float ph, float inv_lambda) { return ph * inv_lambda; }
+
 template <int NL, bool OTF, bool HP>
 struct FrameRaw {
   float L[NL][4];
@@ -1733,7 +1757,8 @@ struct FrameRaw {
 // quarter a tile ahead, parks it in a double-buffered LDS slot, one barrier per lit tile -- instead
 // of once per wave from L2.  HP = false: fp32 MFMAs through transposed LDS tiles.
 template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
-__global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int env_begin,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))  // 3 waves per SIMD: <= 168 VGPRs
+void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     int env_count, int do_cog,
                                                     float *__restrict__ TR,
                                                     float *__restrict__ TPART, int nblk) {
@@ -1748,6 +1773,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // HP: [2][4][64]
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
+  constexpr int PD = HP ? 2 : 1;                   // tiles of loads in flight per wave
   // blocks are dispatched x-fastest: x = group of 4 environments, y = rank of the stripe by
   // decreasing number of lit tiles -- the longest stripes start first and the launch ends on the
   // shortest ones (longest-processing-time order: smaller tail)
@@ -1775,7 +1801,6 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   if (HP) twh = spot_tw_h(Cc, Ss);
   // shared loads: wave 0 / 1: the two 16-byte halves of the lane's tip-tilt pairs, wave 2 / 3: the
   // split-fp16 PSF cos / sin vectors [t][2][64] x 16 B
-  const char *shsrc;
   unsigned shstep;
   float *Twr = tiles + wv * 4 * 16 * FW_LD, *Twi = Twr + 16 * FW_LD;   // WFS amplitude [x][y]
   float *Tar = Twi + 16 * FW_LD, *Tai = Tar + 16 * FW_LD;              // target amplitude [x][y]
@@ -1784,12 +1809,17 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   // Every load address is  scalar base (advances with the tile)  +  per-lane byte offset (fixed
   // for the stripe): rows carry RING_PAD = 16 mirror columns, so the 16-byte load of a lane may
   // start up to 12 floats past the scalar wrap point without wrapping itself.
+  // Loads go through buffer descriptors (scalar base + 32-bit per-lane offset + scalar offset of
+  // the tile): no 64-bit address arithmetic on the vector unit, no address registers.
   const char *layb[NL];
+  __amdgpu_buffer_rsrc_t lrs[NL];
   unsigned lpxs[NL], ldim[NL], lvo[NL];
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     const DevLayer &L = sys.layers[l];
     layb[l] = reinterpret_cast<const char *>(st.screens + (long long)e * sys.screen_stride + L.screen_off);
+    lrs[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(layb[l]), 0,
+                                               4 * L.dim * (L.dim + RING_PAD), 0x00020000);
     ldim[l] = (unsigned)L.dim;
     int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
     int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
@@ -1808,8 +1838,15 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
   const char *pztb = reinterpret_cast<const char *>(pzt);
   const char *ttb = reinterpret_cast<const char *>(D1.influ);
   const char *mkb = reinterpret_cast<const char *>(sys.tile_mask);
-  if (wv < 2) { shsrc = ttb + tvo + 16u * (unsigned)wv; shstep = 128u; }
-  else { shsrc = reinterpret_cast<const char *>(sys.psf_tw_h) + 16u * (unsigned)lane + 1024u * (unsigned)(wv - 2); shstep = 2048u; }
+  __amdgpu_buffer_rsrc_t shrs;
+  unsigned shvo;
+  if (wv < 2) {
+    shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ttb), 0, 8 * D1.dim * D1.dim, 0x00020000);
+    shvo = tvo + 16u * (unsigned)wv; shstep = 128u;
+  } else {
+    shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(sys.psf_tw_h), 0, ntl * 2048, 0x00020000);
+    shvo = 16u * (unsigned)lane + 1024u * (unsigned)(wv - 2); shstep = 2048u;
+  }
   // pivot of the variance sums: phase at the grid centre (ttslot[2]: stack-array value there)
   float pivot;
   {
@@ -1854,22 +1891,27 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     __builtin_amdgcn_wave_barrier();
   }
   const float *latq = lat + (jm_ok ? jm : 0);
-  const int *tinfo = sys.tile_info + r * ntl;
   const float wfs_il = sys.wfs_inv_lambda, tar_il = sys.tar_inv_lambda;
   const f32x4 Z4 = opaque_zero4();
-  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f}, Ri2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  f32x4 Ri2 = {0.f, 0.f, 0.f, 0.f};
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int kxf = c - 8;
   int nlit = 0;
 
-  auto fetch = [&](int t, int info, FrameRaw<NL, OTF, HP> &raw) {
-    if (!(info & FW_LIT) || (dbg & 4)) return;               // wave-uniform
+  // Loads of one lit tile.  UNCONDITIONAL: the loops below walk the compact list of this stripe's
+  // lit tiles (sys.lit_info), so no load sits under a branch and the prefetch registers need no
+  // copies where control flow joins (those copies were 9 % of the vector instructions).
+  auto fetch = [&](int info, FrameRaw<NL, OTF, HP> &raw) {
+    const int t = (info >> 24) & 0x7F;
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       unsigned sx = 16u * (unsigned)t + lpxs[l]; sx -= (sx >= ldim[l]) ? ldim[l] : 0u;   // scalar
-      const f4u v4 = *reinterpret_cast<const f4u *>(layb[l] + 4u * sx + lvo[l]);
+      // (whole-vector bit cast: a per-element __builtin_bit_cast of the result is narrowed to ONE dword
+      // load by this compiler, ROCm 7.2)
+      const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs[l], lvo[l], 4u * sx, 0));
 #pragma unroll
-      for (int j = 0; j < 4; j++) raw.L[l][j] = v4.v[j];
+      for (int j = 0; j < 4; j++) raw.L[l][j] = v4[j];
     }
     if (!OTF) {
       const f4u p4 = *reinterpret_cast<const f4u *>(pztb + 64u * (unsigned)t + pvo);
@@ -1877,7 +1919,9 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
       for (int j = 0; j < 4; j++) raw.P[OTF ? 0 : j] = p4.v[j];
     }
     if (HP) {
-      raw.SH = *reinterpret_cast<const f4u *>(shsrc + shstep * (unsigned)t);
+      const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, shstep * (unsigned)t, 0));
+#pragma unroll
+      for (int j = 0; j < 4; j++) raw.SH.v[j] = v4[j];
     } else {
       const char *tb = ttb + 128u * (unsigned)t;
       const f4u t0 = *reinterpret_cast<const f4u *>(tb + tvo);
@@ -1885,13 +1929,13 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
 #pragma unroll
       for (int j = 0; j < 4; j++) { raw.T[j] = t0.v[j]; raw.T[4 + j] = t1.v[j]; }
     }
-    raw.mrow = (info & FW_FULL) ? 0xFFFFu : *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)t + mvo);
-    raw.F = (info & FW_SUB) ? sys.flux[info & 0xFFFF] : 0.f;
+    raw.mrow = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)t + mvo);
+    raw.F = sys.flux[info & 0xFFFF];                         // no sub-aperture: index 0, unused
   };
 
-  // one tile: consume `cur`, prefetch tile t + 1 into `nxt`
-  auto tile = [&](int t, int info, int infon, FrameRaw<NL, OTF, HP> &cur, FrameRaw<NL, OTF, HP> &nxt) {
-    if (!(info & FW_LIT)) { fetch(t + 1, infon, nxt); return; }
+  // one lit tile: consume `cur`, then issue the loads of the tile `infon` describes into `nxt`
+  auto tile = [&](int info, int infon, FrameRaw<NL, OTF, HP> &cur, FrameRaw<NL, OTF, HP> &nxt) {
+    const int t = (info >> 24) & 0x7F;
     // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
     f32x4 S = Z4;
     if (OTF) {
@@ -1917,7 +1961,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
       cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
       cosP = __builtin_bit_cast(hx8, slot[128 + lane]);
       sinP = __builtin_bit_cast(hx8, slot[192 + lane]);
-      if (!active) { fetch(t + 1, infon, nxt); return; }
+      if (!active) { fetch(infon, nxt); return; }
     }
     // ---- phase of the 4 pixels, both complex amplitudes (registers; LDS tiles for the fp32 path)
     float wr[4], wi[4], ar[4], ai[4];
@@ -1928,7 +1972,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
 #pragma unroll
         for (int l = 0; l < NL; l++) ph += cur.L[l][j];
         float a_ = ph * wfs_il; a_ -= rintf(a_);
-        float b_ = ph * tar_il; b_ -= rintf(b_);
+        const float b_ = sci_rev(ph, tar_il);
         wr[j] = __builtin_amdgcn_cosf(a_); wi[j] = __builtin_amdgcn_sinf(a_);
         ar[j] = __builtin_amdgcn_cosf(b_); ai[j] = __builtin_amdgcn_sinf(b_);
         const float d = ph - pivot;
@@ -1943,7 +1987,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
         for (int l = 0; l < NL; l++) ph += cur.L[l][j];
         const bool m = (cur.mrow >> (4 * q + j)) & 1u;
         float a_ = ph * wfs_il; a_ -= rintf(a_);
-        float b_ = ph * tar_il; b_ -= rintf(b_);
+        const float b_ = sci_rev(ph, tar_il);
         wr[j] = m ? __builtin_amdgcn_cosf(a_) : 0.f; wi[j] = m ? __builtin_amdgcn_sinf(a_) : 0.f;
         ar[j] = m ? __builtin_amdgcn_cosf(b_) : 0.f; ai[j] = m ? __builtin_amdgcn_sinf(b_) : 0.f;
         const float d = m ? ph - pivot : 0.f;
@@ -1951,7 +1995,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
       }
     }
     if (HP) {
-      fetch(t + 1, infon, nxt);                              // next tile's loads fly during the MFMAs
+      fetch(infon, nxt);                                     // these loads fly during the MFMAs
       // ---- science path: R[y][kx] += sum_x a(y, x) exp(-2 pi i kx x / Npsf), split-fp16
       if (!(dbg & 2)) {
         hx8 arH, arL, aiH, aiL;
@@ -1975,7 +2019,7 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
       const int o = (4 * q + j) * FW_LD + c;
       Twr[o] = wr[j]; Twi[o] = wi[j]; Tar[o] = ar[j]; Tai[o] = ai[j];
     }
-    fetch(t + 1, infon, nxt);                                // next tile's loads fly during the MFMAs
+    fetch(infon, nxt);                                       // these loads fly during the MFMAs
     __builtin_amdgcn_wave_barrier();
     // ---- science path: R[y][kx] += sum_{x in tile} a(y, x) exp(-2 pi i kx x / Npsf)
     if (!(dbg & 2)) {
@@ -2000,13 +2044,41 @@ __global__ __launch_bounds__(256) void k_frame_wave(DevSys sys, DevState st, int
     __builtin_amdgcn_wave_barrier();
   };
 
-  FrameRaw<NL, OTF, HP> raw;
-  int info = tinfo[0];
-  fetch(0, info, raw);
-  for (int t = 0; t < ntl; t++) {
-    const int infon = t + 1 < ntl ? tinfo[t + 1] : 0;
-    tile(t, info, infon, raw, raw);
-    info = infon;
+  // The stripe's lit tiles, compact (sys.lit_info[r][k], tile index in bits 24..30; the entries past
+  // the last one repeat it, so the prefetch at the end of the list needs no test: the last tile is
+  // loaded again, from L2, and dropped).  Prefetch distance PD: the HP path keeps TWO tiles of loads
+  // in flight (two register sets, list walked in pairs; an odd first tile goes on its own).
+  const int nl = sys.lit_count[r];
+  const int *linfo = sys.lit_info + r * (ntl + 4);
+  if (PD == 2) {
+    FrameRaw<NL, OTF, HP> raw0, raw1;
+    int k = 0;
+    if (nl & 1) {
+      const int i0 = linfo[0];
+      fetch(i0, raw0);
+      tile(i0, i0, raw0, raw0);
+      k = 1;
+    }
+    if (k < nl) {
+      int i0 = linfo[k], i1 = linfo[k + 1];
+      fetch(i0, raw0);
+      fetch(i1, raw1);
+      for (; k < nl; k += 2) {
+        const int i2 = linfo[k + 2], i3 = linfo[k + 3];
+        tile(i0, i2, raw0, raw0);
+        tile(i1, i3, raw1, raw1);
+        i0 = i2; i1 = i3;
+      }
+    }
+  } else if (nl > 0) {
+    FrameRaw<NL, OTF, HP> raw;
+    int info = linfo[0];
+    fetch(info, raw);
+    for (int k = 0; k < nl; k++) {
+      const int infon = linfo[k + 1];
+      tile(info, infon, raw, raw);
+      info = infon;
+    }
   }
   if (HP && !active) return;
   if (HP) Ri = Ri - Ri2;
@@ -2319,6 +2391,7 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
     pivot = v;
   }
   f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  f32x4 Ri2 = {0.f, 0.f, 0.f, 0.f};
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int fy = tid >> 4, fx0 = (tid & 15) * 4;     // fill: row fy, 4 consecutive columns
   const int y = y0 + fy;
@@ -2510,6 +2583,7 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
   };
 
   f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
+  f32x4 Ri2 = {0.f, 0.f, 0.f, 0.f};
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int kxf = c - 8;
   fetch(0);

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libaomarl_hip.so")
+# AOMARL_LIB: another build of the same library (A/B measurements of kernel variants, csrc/Makefile `variant`)
+LIB_PATH = os.environ.get("AOMARL_LIB") or os.path.join(HERE, "libaomarl_hip.so")
 MAX_LAYERS, MAX_DMS, ABI_VERSION = 8, 4, 1
 
 DM_PZT, DM_TT = 0, 1
