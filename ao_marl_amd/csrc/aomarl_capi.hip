@@ -58,6 +58,8 @@ struct aomarl_ctx {
   // as this frame's image kernels are done, so the extrusion chain runs beside do_control / the
   // agents / next_part_two instead of in front of the next image
   bool prefetch_atmos = false, premoved = false;
+  // power-of-two scales of the static matrices for the split-f16 GEMM (gemm_scale)
+  float cmat_scale = 1.f, v2m_scale = 1.f, m2v_scale = 1.f, s2m_scale = 1.f, ab_scale[AOMARL_MAX_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   int fw_variant[6] = {0, 0, 0, 0, 0, 0};   // template arguments of the last k_frame_wave launch
   char fw_name[96] = {0};
   // "time_frame_kernel": a HIP event pair around every k_frame_wave launch (aomarl_frame_kernel_time)
@@ -230,6 +232,7 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
       float *p;
       UP(float, ab.data(), ab.size(), p);
       devAB[cls] = p; ldab[cls] = ld;
+      c->ab_scale[cls] = gemm_scale(ab.data(), ab.size());
     }
     c->abclass[l] = cls;
     D.AB = devAB[cls]; D.ldab = ldab[cls];
@@ -511,6 +514,7 @@ int aomarl_set_cmat(aomarl_ctx *c, const float *cmat) {
   std::vector<float> h((size_t)na * ld, 0.f);
   for (int r = 0; r < na; r++) memcpy(&h[(size_t)r * ld], cmat + (size_t)r * nsl, sizeof(float) * nsl);
   c->ld_cmat = ld;
+  c->cmat_scale = gemm_scale(h.data(), h.size());
   return replace_dev(c, &c->cmat, h);
 }
 
@@ -523,6 +527,7 @@ int aomarl_set_slopes2modes(aomarl_ctx *c, int nmodes, const float *s2m) {
   for (int r = 0; r < nmodes; r++) memcpy(&h[(size_t)r * ld], s2m + (size_t)r * nsl, sizeof(float) * nsl);
   int rc = replace_dev(c, &c->s2m, h);
   if (rc) return rc;
+  c->s2m_scale = gemm_scale(h.data(), h.size());
   c->s2m_nmodes = nmodes;
   return 0;
 }
@@ -565,6 +570,8 @@ int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m
   if (rc) return rc;
   rc = replace_dev(c, &c->m2v, b);
   if (rc) return rc;
+  c->v2m_scale = gemm_scale(a.data(), a.size());
+  c->m2v_scale = gemm_scale(b.data(), b.size());
   std::vector<float> f(nmodes, 0.f);
   if (freedom) memcpy(f.data(), freedom, sizeof(float) * nmodes);
   rc = replace_dev(c, &c->freedom, f);
@@ -701,11 +708,13 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
                        ops, Z, w.ldz, ZREF);
     LAUNCHCHK();
     int nsp = 0;
+    float pscale = 1.f;
     launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
-                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp);
+                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp,
+                   /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
-                       ZREF, st->work + w.GEMM_ATM, nsp, ncol, dimc);
+                       ZREF, st->work + w.GEMM_ATM, nsp, ncol, dimc, pscale);
     LAUNCHCHK();
   }
   return 0;
@@ -966,6 +975,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
+  if (!strcmp(name, "gemm_split_f16")) { g_gemm_split_f16 = value != 0; return 0; }
   if (!strcmp(name, "time_frame_kernel")) {
     // value = number of launches to keep event pairs for (0: off)
     c->time_fw = value > 0;
@@ -1107,7 +1117,7 @@ int aomarl_do_control(aomarl_ctx *c, aomarl_state *st, int b, int n, void *strea
   ep.gain_row = c->env_gain ? c->env_gain + b : nullptr;
   const bool fused = launch_gemm_nt(n, na, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->cmat, c->ld_cmat, 0.0f,
                                     st->err + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM,
-                                    w.gemm_floats, &ep);
+                                    w.gemm_floats, &ep, nullptr, /* slopes (arcsec): unscaled, saturation only beyond 65504" */ true, 1.f, c->cmat_scale);
   LAUNCHCHK();
   if (!fused) {
     hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b, c->env_gain);
@@ -1137,7 +1147,7 @@ int aomarl_volts2modes(aomarl_ctx *c, aomarl_state *st, int nrows, const float *
   size_t wsn = 0;
   if (st && st->work) { Work w = work_layout(c, st->nenv); ws = st->work + w.GEMM; wsn = w.gemm_floats; }
   launch_gemm_nt(nrows, c->nmodes, c->sys.nactu, 1.0f, vec, ldvec, c->v2m, c->ld_v2m, 0.0f,
-                 modes, c->nmodes, (hipStream_t)stream, ws, wsn);
+                 modes, c->nmodes, (hipStream_t)stream, ws, wsn, nullptr, nullptr, /* volts */ true, 1.f, c->v2m_scale);
   LAUNCHCHK();
   return 0;
 }
@@ -1172,13 +1182,14 @@ int aomarl_rl_control(aomarl_ctx *c, aomarl_state *st, int b, int n, const float
   GemmEpi ep = {};
   ep.mode = 2; ep.action = action; ep.nact = c->nact; ep.amode_inv = c->amode_inv; ep.freedom = c->freedom;
   const bool fused = launch_gemm_nt(n, nm, na, 1.0f, com, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, modes, w.ldm, s,
-                                    st->work + w.GEMM, w.gemm_floats, &ep);
+                                    st->work + w.GEMM, w.gemm_floats, &ep, nullptr, true, 1.f, c->v2m_scale);
   LAUNCHCHK();
   if (!fused) {
     hipLaunchKernelGGL(k_modal_add, dim3((c->nact + 255) / 256, n), dim3(256), 0, s, modes, w.ldm, action, c->nact, c->amodes, c->freedom);
     LAUNCHCHK();
   }
-  launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, com, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats);
+  launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, com, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats,
+                 nullptr, nullptr, /* Btt coordinates x 2^4 */ true, 16.f, c->m2v_scale);
   LAUNCHCHK();
   return 0;
 }
@@ -1217,7 +1228,8 @@ int aomarl_rl_control_modes(aomarl_ctx *c, aomarl_state *st, int b, int n, const
                      c->nact, c->amode_inv, c->freedom, modes, w.ldm, modes_out);
   LAUNCHCHK();
   launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f,
-                 st->com + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats);
+                 st->com + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats,
+                 nullptr, nullptr, /* Btt coordinates x 2^4 */ true, 16.f, c->m2v_scale);
   LAUNCHCHK();
   return 0;
 }
@@ -1705,6 +1717,24 @@ int aomarl_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, co
   if (!A || !B || !C) return fail("gemm_nt: null pointer");
   if (M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) return fail("gemm_nt: bad sizes");
   launch_gemm_nt(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, (hipStream_t)stream);
+  LAUNCHCHK();
+  return 0;
+}
+
+int aomarl_gemm_nt_split(int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb,
+                         float beta, float *C, int ldc, float scale_a, float scale_b, float *work,
+                         long long work_floats, void *stream) {
+  if (!A || !B || !C) return fail("gemm_nt_split: null pointer");
+  if (M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) return fail("gemm_nt_split: bad sizes");
+  if ((lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
+    return fail("gemm_nt_split: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  auto pow2 = [](float v) { int e; return v > 0.f && frexpf(v, &e) == 0.5f; };
+  if (!pow2(scale_a) || !pow2(scale_b)) return fail("gemm_nt_split: scales must be powers of two");
+  const bool keep = g_gemm_split_f16;
+  g_gemm_split_f16 = true;
+  launch_gemm_nt(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, (hipStream_t)stream, work, (size_t)std::max(0LL, work_floats),
+                 nullptr, nullptr, true, scale_a, scale_b);
+  g_gemm_split_f16 = keep;
   LAUNCHCHK();
   return 0;
 }

@@ -38,6 +38,28 @@ __device__ __forceinline__ float wave_sum_last(float v) {
   return v;
 }
 
+// ---- split-fp16 helpers (used by the GEMM below and by the frame kernel; see the frame kernel's notes)
+typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ hx2 cvt_h2(float a, float b) {
+  return __builtin_bit_cast(hx2, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// a - f32(h.lo) and a - f32(h.hi) as single mixed-precision FMAs (v_fma_mix_f32 reads the f16 half
+// directly; the compiler will not form it from a - (float)h).  Operands always come out of ordinary
+// VALU instructions (v_cvt_pkrtz of the same value sits in between any producer and this read).
+__device__ __forceinline__ float sub_lo(hx2 h, float a) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float sub_hi(hx2 h, float a) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+  return r;
+}
+
 // 4 consecutive floats at a dword-aligned (not necessarily 16-byte aligned) address: one
 // global_load_dwordx4 (gfx950 supports unaligned vector access; the compiler emits it for this type)
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
@@ -315,6 +337,131 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alp
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same GEMM on the f16 matrix pipe with SPLIT operands: every fp32 value v is carried as
+// hi = f16(v), lo = f16(v - hi), both rounded to nearest (23 significant bits, unbiased) and a product
+// as hi.hi + lo.hi + hi.lo with fp32 accumulation (lo.lo, <= 2^-24 of a product, dropped): three v_mfma_f32_32x32x16_f16 of 32 cycles
+// each per 16 k against sixteen 64-cycle v_mfma_f32_32x32x2_f32 (fp32 matrix instructions run at the
+// packed-fp32 vector rate on this chip) -- 10x less matrix-pipe time; what is left is the splitting
+// (2 vector instructions per element as it is staged into LDS) and the LDS traffic.
+// Operands stay fp32 in memory, same interface as k_gemm_nt2 plus a power-of-two scale per operand
+// (sa, sb; applied as the values are staged, undone through alpha): the scaled values must stay
+// below 65504 (they saturate above) and lose low bits of `lo` below 6e-5 (absolute error <= 3e-8
+// of the scaled value).  gemm_scale() picks the scale of a static matrix from its largest entry.
+// LDS: hi and lo planes of the A and B tiles as f16, [row][32 k] with a row stride of 40 halfs (a
+// 16-lane pass of a 128-bit read -- 8 k of one row per lane -- covers the 64 banks exactly once).
+// ---------------------------------------------------------------------------------------------
+#define GH_LD 40
+typedef _Float16 hx4 __attribute__((ext_vector_type(4)));
+// round-to-nearest-even pair (v_cvt_pk_f16_f32): unbiased, unlike the truncating v_cvt_pkrtz -- a GEMM
+// adds thousands of products, a truncation bias would add up linearly
+typedef float fx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hx2 cvt_rn2(float a, float b) {
+  const fx2 v = {a, b};
+  return __builtin_convertvector(v, hx2);
+}
+__device__ __forceinline__ void gh_split(float4 v, const float scale, hx4 &hi, hx4 &lo) {
+  // power of two: exact; clamped to the f16 range (a value beyond it -- a centroid whose total flux
+  // came out ~0 -- saturates instead of turning into inf - inf = NaN)
+  v.x = __builtin_amdgcn_fmed3f(v.x * scale, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y * scale, -65504.f, 65504.f);
+  v.z = __builtin_amdgcn_fmed3f(v.z * scale, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w * scale, -65504.f, 65504.f);
+  const hx2 h01 = cvt_rn2(v.x, v.y), h23 = cvt_rn2(v.z, v.w);
+  const hx2 l01 = cvt_rn2(sub_lo(h01, v.x), sub_hi(h01, v.y));   // |v - hi| <= 2^-12 |v|, lo keeps 11 bits of it
+  const hx2 l23 = cvt_rn2(sub_lo(h23, v.z), sub_hi(h23, v.w));
+  hi = hx4{h01[0], h01[1], h23[0], h23[1]};
+  lo = hx4{l01[0], l01[1], l23[0], l23[1]};
+}
+
+__device__ __forceinline__ void gh_mainloop(const float *__restrict__ A, int lda,
+                                            const float *__restrict__ B, int ldb, int M, int N,
+                                            int m0, int n0, int kb, int ke, _Float16 *S, f32x16 &acc,
+                                            const float sa, const float sb) {
+  // S: [2 buffers][4 planes: A hi, A lo, B hi, B lo][64 rows][GH_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;
+  const float *pa0 = A + (long long)min(m0 + lr, M - 1) * lda + lc;
+  const float *pa1 = A + (long long)min(m0 + lr + 32, M - 1) * lda + lc;
+  const float *pb0 = B + (long long)min(n0 + lr, N - 1) * ldb + lc;
+  const float *pb1 = B + (long long)min(n0 + lr + 32, N - 1) * ldb + lc;
+  float4 ra0, ra1, rb0, rb1;
+  auto gload_full = [&](int k0) {
+    ra0 = *reinterpret_cast<const float4 *>(pa0 + k0); ra1 = *reinterpret_cast<const float4 *>(pa1 + k0);
+    rb0 = *reinterpret_cast<const float4 *>(pb0 + k0); rb1 = *reinterpret_cast<const float4 *>(pb1 + k0);
+  };
+  auto gload_tail = [&](int k0) {
+    ra0 = g2_load4(pa0 - lc, k0 + lc, ke, true); ra1 = g2_load4(pa1 - lc, k0 + lc, ke, true);
+    rb0 = g2_load4(pb0 - lc, k0 + lc, ke, true); rb1 = g2_load4(pb1 - lc, k0 + lc, ke, true);
+  };
+  constexpr int PL = 64 * GH_LD;                 // halfs per plane
+  auto lstore = [&](int buf) {
+    _Float16 *s = S + buf * 4 * PL;
+    hx4 h, l;
+    gh_split(ra0, sa, h, l);
+    *reinterpret_cast<hx4 *>(s + lr * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + PL + lr * GH_LD + lc) = l;
+    gh_split(ra1, sa, h, l);
+    *reinterpret_cast<hx4 *>(s + (lr + 32) * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + PL + (lr + 32) * GH_LD + lc) = l;
+    gh_split(rb0, sb, h, l);
+    *reinterpret_cast<hx4 *>(s + 2 * PL + lr * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + 3 * PL + lr * GH_LD + lc) = l;
+    gh_split(rb1, sb, h, l);
+    *reinterpret_cast<hx4 *>(s + 2 * PL + (lr + 32) * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + 3 * PL + (lr + 32) * GH_LD + lc) = l;
+  };
+  // operand of lane l for k-chunk c (16 k): row (l & 31) of the wave's 32, k = 16 c + 8 (l >> 5) .. + 7
+  const int ro = (lane & 31) * GH_LD + 8 * (lane >> 5);
+  if (kb + 32 <= ke) gload_full(kb); else gload_tail(kb);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += 32, buf ^= 1) {
+    const int kn = k0 + 32;
+    if (kn + 32 <= ke) gload_full(kn);            // wave-uniform branches
+    else if (kn < ke) gload_tail(kn);
+    const _Float16 *s = S + buf * 4 * PL;
+    const _Float16 *ah = s + wm * 32 * GH_LD + ro, *al = ah + PL;
+    const _Float16 *bh = s + 2 * PL + wn * 32 * GH_LD + ro, *bl = bh + PL;
+#pragma unroll
+    for (int cch = 0; cch < 2; cch++) {
+      const hx8 Ah = *reinterpret_cast<const hx8 *>(ah + 16 * cch), Al = *reinterpret_cast<const hx8 *>(al + 16 * cch);
+      const hx8 Bh = *reinterpret_cast<const hx8 *>(bh + 16 * cch), Bl = *reinterpret_cast<const hx8 *>(bl + 16 * cch);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+    }
+    if (kn < ke) lstore(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt_h(int M, int N, int K, float alpha,
+                                                   const float *__restrict__ A, int lda,
+                                                   const float *__restrict__ B, int ldb, float beta,
+                                                   float *__restrict__ C, int ldc, int kchunk,
+                                                   float *__restrict__ P, float sa, float sb) {
+  __shared__ __attribute__((aligned(16))) _Float16 S[2 * 4 * 64 * GH_LD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  gh_mainloop(A, lda, B, ldb, M, N, m0, n0, kb, ke, S, acc, sa, sb);
+  const int col = n0 + wn * 32 + (lane & 31);
+  const bool split = gridDim.z > 1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      if (split) {
+        P[((long long)blockIdx.z * M + row) * N + col] = acc[r];
+      } else {
+        float *c = C + (long long)row * ldc + col;
+        float v = alpha * acc[r];
+        if (beta != 0.f) v += beta * (*c);
+        *c = v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
                                                           const float *__restrict__ A, int lda, long long sA,
                                                           const float *__restrict__ B, int ldb, long long sB,
@@ -555,6 +702,16 @@ __global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const f
 }
 
 static int g_gemm_target_blocks = 512;
+// power-of-two scale that brings the largest magnitude of a matrix to ~4096 (f16: 11 bits, max 65504)
+static float gemm_scale(const float *h, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; i++) m = std::max(m, fabsf(h[i]));
+  if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+  int e = (int)floorf(log2f(4096.f / m));
+  e = std::max(-10, std::min(24, e));
+  return ldexpf(1.f, e);
+}
+static bool g_gemm_split_f16 = true;  // "gemm_split_f16": the internal GEMMs (extrusion, command matrix, Btt projections) on k_gemm_nt_h
 static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
 // Retired after their A/B runs (profiles/r01g_*): the un-pipelined aligned kernel (30 us vs 22 us per
 // call) and an in-kernel split-K reduction through ticket counters (4x slower: every block pays an
@@ -566,10 +723,14 @@ static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 
 //      (returns false).  nsplit_out: when non-null and the GEMM was split, NO reduce is launched and
 //      the caller's next kernel sums the partial tiles ws[z][M][N] itself (*nsplit_out = count,
 //      0 = C is final).
+// fast: the split-f16 kernel may be used (internal call sites whose operands are inside its range)
 bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
                     int ldb, float beta, float *C, int ldc, hipStream_t s, float *ws = nullptr,
-                    size_t ws_floats = 0, const GemmEpi *epi = nullptr, int *nsplit_out = nullptr) {
+                    size_t ws_floats = 0, const GemmEpi *epi = nullptr, int *nsplit_out = nullptr,
+                    bool fast = false, float sa = 1.f, float sb = 1.f, float *alpha_out = nullptr) {
+  // alpha_out: the factor the caller must apply to the partial tiles when it sums them itself
   if (nsplit_out) *nsplit_out = 0;
+  if (alpha_out) *alpha_out = alpha;
   if (M <= 0 || N <= 0) return false;
   const int bx = (N + 63) / 64, by = (M + 63) / 64;
   int nsplit = 1;
@@ -583,7 +744,13 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   dim3 grid(bx, by, nsplit);
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
-  if (al)
+  if (al && fast && g_gemm_split_f16) {
+    alpha /= (sa * sb);                            // also what the split-K reduce below applies
+    if (alpha_out) *alpha_out = alpha;
+    hipLaunchKernelGGL(k_gemm_nt_h, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
+                       ldc, kchunk, ws, sa, sb);
+  }
+  else if (al)
     hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
                        ldc, kchunk, ws);
   else
@@ -651,8 +818,9 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
                                                          const float *__restrict__ NEWL, int ldn,
                                                          const float *__restrict__ ZREF,
                                                          const float *__restrict__ P, int nsplit,
-                                                         int ncol, int pn) {
+                                                         int ncol, int pn, float pscale) {
   // nsplit > 0: the new lines are still split-K partial tiles P[z][ncol][pn] of the extrusion GEMM
+  // (times 1 / pscale when the split-f16 kernel produced them from scaled operands)
   const int col = blockIdx.x;
   const int e = env_begin + col / ops.nops, op = col % ops.nops;
   const int li = ops.layer[op], dir = ops.dir[op];
@@ -668,7 +836,7 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
     if (nsplit > 0) {
       float acc = 0.f;
       for (int z = 0; z < nsplit; z++) acc += P[((long long)z * ncol + col) * pn + r];
-      v += acc;
+      v += acc * pscale;
     } else {
       v += NEWL[(long long)col * ldn + r];
     }
@@ -1025,26 +1193,6 @@ __device__ __forceinline__ float sh_noise(float lam, float sigma, uint32_t seed,
 // values (row c, k = 4q .. 4q+3) of an operand -- for the amplitude tile those are exactly the 4
 // pixels the lane computed, and for stage 2 exactly its 4 accumulator registers of stage 1: no LDS.
 // ---------------------------------------------------------------------------------------------
-typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
-typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ hx2 cvt_h2(float a, float b) {
-  return __builtin_bit_cast(hx2, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-// a - f32(h.lo) and a - f32(h.hi) as single mixed-precision FMAs (v_fma_mix_f32 reads the f16 half
-// directly; the compiler will not form it from a - (float)h).  Operands always come out of ordinary
-// VALU instructions (v_cvt_pkrtz of the same value sits in between any producer and this read).
-__device__ __forceinline__ float sub_lo(hx2 h, float a) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
-  return r;
-}
-__device__ __forceinline__ float sub_hi(hx2 h, float a) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
-  return r;
-}
 // [hi(a0..a3) | lo(a0..a3)]
 __device__ __forceinline__ hx8 pack_hl(float a0, float a1, float a2, float a3) {
   const hx2 h01 = cvt_h2(a0, a1), h23 = cvt_h2(a2, a3);

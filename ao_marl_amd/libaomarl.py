@@ -139,6 +139,7 @@ SYMBOLS = [
     ("aomarl_next_part_one", _i, _range + [_fp, _fp, _i, _vp]),
     ("aomarl_next_part_two", _i, _range + [_vp, _vp]),
     ("aomarl_gemm_nt", _i, [_i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp]),
+    ("aomarl_gemm_nt_split", _i, [_i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _f, _f, _vp, C.c_longlong, _vp]),
     ("aomarl_gemm_nt_batched", _i, [_i, _i, _i, _i, _vp, _i, C.c_longlong, _vp, _i, C.c_longlong,
                                     _vp, C.c_longlong, _vp, _i, C.c_longlong, _i, _vp]),
 ]

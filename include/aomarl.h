@@ -249,6 +249,7 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
  * "gemm_target_blocks" (split-K target of the fp32 GEMM),
  * "time_frame_kernel" (see aomarl_frame_kernel_time),
+ * "gemm_split_f16" (default 1: see aomarl_gemm_nt_split; 0: every product on fp32 matrix instructions),
  * "prefetch_atmos" (aomarl_next_part_one moves the next frame's atmosphere on a side stream, see
  * aomarl_prefetch_atmos),
  * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
@@ -438,6 +439,15 @@ int aomarl_next_part_two(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int e
  * C[M][N] = alpha * A[M][K] . B[N][K]^T + beta * C ; device pointers, row-major, ld in floats */
 int aomarl_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
                    int ldb, float beta, float *C, int ldc, void *stream);
+
+/* The same product on the f16 matrix pipe with split operands (hi + lo fp16 pairs, 22 mantissa bits,
+ * fp32 accumulation; the kernel behind the library's own extrusion / command-matrix / Btt-projection
+ * products unless aomarl_set_option(ctx, "gemm_split_f16", 0)): A and B are scaled by the powers of two
+ * scale_a / scale_b as they are staged (undone in the result), the scaled magnitudes must stay below
+ * 65504.  work (device, may be NULL): split-K workspace of work_floats floats.  Exported for tests. */
+int aomarl_gemm_nt_split(int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb,
+                         float beta, float *C, int ldc, float scale_a, float scale_b, float *work,
+                         long long work_floats, void *stream);
 
 /* batched fp32 MFMA GEMM with fused bias + ReLU for the stacked SAC MLPs (one batch entry per
  * agent): C[b][M][N] = act(A[b][M][K] . B[b][N][K]^T + bias[b][N]); B is in nn.Linear layout

@@ -184,7 +184,14 @@ def test_control_chain_matches_oracle(setup):
         o.do_control()
         for rep in range(3):
             o.apply_control()
-        assert np.abs(sim.err[e].cpu().numpy() - o.err).max() < 2e-5
+        # err = -cmat . s: against the exact product, by the standard bound of a dot product in fp32
+        # (the library's kernel carries operands as fp16 hi + lo pairs, 23 significant bits, fp32
+        # accumulation; the oracle sums 128 fp32 products in order and is itself 5-10 ulp off on the
+        # tip-tilt rows, so the two are compared at that level, not at 2e-5 absolute)
+        exact = -(s.cmat.astype(np.float64) @ sl[e].astype(np.float64))
+        bound = np.abs(s.cmat.astype(np.float64)) @ np.abs(sl[e].astype(np.float64))
+        assert np.all(np.abs(sim.err[e].cpu().numpy() - exact) <= 4e-7 * bound + 1e-6)
+        assert np.abs(sim.err[e].cpu().numpy() - o.err).max() < 2e-5 + 1e-6 * np.abs(o.err).max()
         assert np.abs(sim.com[e].cpu().numpy() - o.com).max() < 2e-6 * np.abs(o.com).max() + 1e-5
         assert np.abs(sim.voltage[e].cpu().numpy() - o.voltage).max() < 2e-6 * np.abs(o.com).max() + 1e-5
         for k in range(len(s.dms)):
@@ -379,3 +386,37 @@ def test_batched_policy_native_gemm_matches_torch(setup):
     pol.use_native = True
     a, mu = pol.select_action(st)
     assert a.shape == (37, 1276) and mu.abs().max() <= 1.0
+
+
+@pytest.mark.parametrize("shape", [(256, 1286, 2400), (256, 1283, 1286), (768, 648, 1960), (5, 90, 130), (64, 87, 90)])
+def test_split_f16_gemm_against_float64(shape):
+    """k_gemm_nt_h (hi + lo fp16 operand pairs on the f16 matrix pipe, fp32 accumulation): within a
+    few fp32 roundings of the exact product, with and without split-K, for operands with the dynamic
+    range of the loop's matrices (entries from 1e-6 of the largest one up, scaled by powers of two)."""
+    import ctypes as C
+    from ao_marl_amd import libaomarl as la
+    lib = la.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g))            # heavy-tailed
+    B = torch.randn(N, K, generator=g) * torch.exp(2.0 * torch.randn(N, K, generator=g)) * 3e-4
+    Kp = (K + 3) // 4 * 4
+    Ad = torch.zeros(M, Kp, device="cuda"); Ad[:, :K] = A.cuda()
+    Bd = torch.zeros(N, Kp, device="cuda"); Bd[:, :K] = B.cuda()
+    want = A.double() @ B.double().T
+    bound = (A.double().abs() @ B.double().abs().T)             # sum |a| |b|
+    sa = 2.0 ** int(np.floor(np.log2(4096.0 / A.abs().max().item())))
+    sb = 2.0 ** int(np.floor(np.log2(4096.0 / B.abs().max().item())))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for ws_floats in (0, 8 * M * N):
+        Cd = torch.full((M, N), 7.0, device="cuda")
+        ws = torch.zeros(max(ws_floats, 1), device="cuda")
+        la.check(lib.aomarl_gemm_nt_split(M, N, K, 0.5, Ad.data_ptr(), Kp, Bd.data_ptr(), Kp, 2.0, Cd.data_ptr(), N,
+                                          sa, sb, ws.data_ptr() if ws_floats else None, ws_floats, stream))
+        got = Cd.cpu().double()
+        err = (got - (0.5 * want + 14.0)).abs()
+        # split operands carry 2^-21 of each product at worst (two truncations of 2^-22), fp32
+        # accumulation adds its own roundings: 1e-6 of sum |a||b| covers both
+        assert (err <= 1e-6 * bound + 1e-5).all(), (ws_floats, float((err / (bound + 1e-30)).max()))
+        # and it is as good as fp32 arithmetic in the usual sense
+        assert float(err.max() / want.abs().max()) < 2e-6
