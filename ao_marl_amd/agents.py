@@ -195,6 +195,7 @@ class BatchedGaussianPolicy(object):
         self.seed, self._draws = int(seed), 0
         self._native = None          # stacked nn.Linear-layout copies for the HIP batched GEMM
         self.use_native = self.device.type == "cuda"
+        self.native_forward, self._desc = True, None     # select_action as one library call
 
     def _refresh_native(self):
         """[A, out, in] (K-contiguous) copies + merged mean|log_std head for
@@ -244,6 +245,54 @@ class BatchedGaussianPolicy(object):
             x = la.linear_batched(x, W, b, relu=True)
         return la.linear_batched(x, n["Whead"], n["bhead"], relu=False)
 
+    def _actor_desc(self, nenv):
+        """aomarl_actor_desc + scratch for `nenv` environments (rebuilt when the weights or the batch
+        size change)."""
+        from . import libaomarl as la
+        import ctypes as C
+        if self._native is None:
+            self._refresh_native()
+        if self._desc is not None and self._desc[0].nenv == nenv and self._desc[4] is self._native:
+            return self._desc[0]
+        n, A, H = self._native, self.A, self.H
+        d = la.ActorDesc()
+        d.n_agents, d.nenv, d.state_dim, d.in_max, d.act_max = A, nenv, self.layout.state_dim, \
+            self.in_max, self.act_max
+        d.hidden, d.n_hidden, d.action_dim = H, self.L, self.layout.action_dim
+        z = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=self.device)  # noqa: E731
+        scratch = dict(x=z(A, nenv, self.in_max), h0=z(A, nenv, H), h1=z(A, nenv, H),
+                       head=z(A, nenv, 2 * self.act_max))
+        nh = max(self.L - 1, 1)
+        Wh = (C.c_void_p * nh)(*[w.data_ptr() for w in n["Wh"]])
+        bh = (C.c_void_p * nh)(*[b.data_ptr() for b in n["bh"]])
+        d.gather, d.W1, d.b1 = self.gather_i32.data_ptr(), n["W1"].data_ptr(), n["b1"].data_ptr()
+        d.Wh, d.bh = Wh, bh
+        d.Whead, d.bhead = n["Whead"].data_ptr(), n["bhead"].data_ptr()
+        d.sc_agent, d.sc_local = self.sc_agent_i32.data_ptr(), self.sc_local_i32.data_ptr()
+        d.log_sig_min, d.log_sig_max, d.scale, d.bias = LOG_SIG_MIN, self.log_sig_max, self.scale, self.bias
+        for k, t in scratch.items():
+            setattr(d, k, t.data_ptr())
+        self._desc = (d, scratch, Wh, bh, n)        # keeps every pointer alive
+        return d
+
+    def _select_action_one_call(self, state, eval_mode, eps):
+        """TrainerRPC.choose_action for all agents in ONE library call (aomarl_actor_forward): the
+        same kernels as _native_head + policy_sample, issued from C."""
+        from . import libaomarl as la
+        import ctypes as C
+        nenv = state.shape[0]
+        d = self._actor_desc(nenv)
+        self._draws += 1
+        a = torch.empty(nenv, self.layout.action_dim, dtype=torch.float32, device=self.device)
+        m = torch.empty_like(a)
+        if eps is not None:
+            eps = eps.to(torch.float32).contiguous()
+        la.check(la.load().aomarl_actor_forward(
+                C.byref(d), state.data_ptr(), eps.data_ptr() if eps is not None else None,
+                self.seed & 0xFFFFFFFF, self._draws & 0xFFFFFFFF, a.data_ptr(), m.data_ptr(),
+                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return (m if eval_mode else a), m
+
     def forward(self, state):
         if self.use_native:
             head = self._native_head(state)
@@ -269,6 +318,9 @@ class BatchedGaussianPolicy(object):
         On the GPU the whole tail (clamp, exp, sample, tanh, scale, scatter into the global action
         vector) is one kernel with its own counter-based normals (Philox keyed by this policy's
         seed and draw count); `eps` [nenv, action_dim] overrides the draws."""
+        if self.use_native and self.native_forward and state.dtype == torch.float32 and \
+                state.dim() == 2 and state.shape[1] == self.layout.state_dim:
+            return self._select_action_one_call(state.contiguous(), eval_mode, eps)
         if self.use_native:
             from . import libaomarl as la
             head = self._native_head(state)

@@ -67,7 +67,8 @@ struct aomarl_ctx {
   std::vector<hipEvent_t> fw_ev;            // 2 per timed launch, created on demand
   size_t fw_ev_used = 0;
   hipStream_t atm_stream = nullptr;
-  hipEvent_t ev_frame = nullptr, ev_moved = nullptr;
+  hipEvent_t ev_frame = nullptr, ev_moved = nullptr, ev_psf = nullptr;
+  bool psf_side = false;                // a k_target_finish_mfma launched on the side stream may still run
   const float *pre_screens = nullptr;
   int pre_b = 0, pre_n = 0;
   // controller matrices
@@ -490,6 +491,7 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (c->atm_stream) { (void)hipStreamSynchronize(c->atm_stream); (void)hipStreamDestroy(c->atm_stream); }
   if (c->ev_frame) (void)hipEventDestroy(c->ev_frame);
   if (c->ev_moved) (void)hipEventDestroy(c->ev_moved);
+  if (c->ev_psf) (void)hipEventDestroy(c->ev_psf);
   if (c->env_gain) (void)hipFree(c->env_gain);
   if (c->seed_stage) (void)hipFree(c->seed_stage);
   for (hipEvent_t e : c->fw_ev) (void)hipEventDestroy(e);
@@ -669,6 +671,31 @@ static DevState dev_state(const aomarl_state *st) {
   return d;
 }
 
+// ---------------------------------------------------------------- side stream
+// One low-priority stream of the library carries what is off the control chain's critical path: the
+// next frame's extrusions (aomarl_prefetch_atmos) and the second axis of the PSF window
+// (k_target_finish_mfma, whose result nobody reads before the end-of-step Strehl commit).
+static int side_stream(aomarl_ctx *c) {
+  if (!c->atm_stream) {
+    // lowest priority: this work has a whole control / agent chain of slack, the kernels of that
+    // chain should not queue behind it
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->atm_stream, hipStreamNonBlocking, prio_lo));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_moved, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_psf, hipEventDisableTiming));
+  }
+  return 0;
+}
+// everything that reads (or overwrites) the pending PSF window on `stream` waits for a finish kernel
+// that may still be running on the side stream
+static int psf_wait_pending(aomarl_ctx *c, void *stream) {
+  if (c->psf_side) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_psf, 0));
+  c->psf_side = false;
+  return 0;
+}
+
 // ---------------------------------------------------------------- atmosphere
 // A prefetched move_atmos may still be running on the side stream: everything that touches the
 // screens on `stream` waits for it first.
@@ -775,15 +802,8 @@ int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *
   if (rc) return rc;
   if (!accumx || !accumy) return fail("prefetch_atmos: null accumulators");
   if (c->premoved) return fail("prefetch_atmos: a prefetched frame is already pending");
-  if (!c->atm_stream) {
-    // lowest priority: the extrusions have a whole control / agent chain of slack, the kernels of
-    // that chain should not queue behind them
-    int prio_lo = 0, prio_hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->atm_stream, hipStreamNonBlocking, prio_lo));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_moved, hipEventDisableTiming));
-  }
+  rc = side_stream(c);
+  if (rc) return rc;
   HIPCHK(hipEventRecord(c->ev_frame, (hipStream_t)stream));        // readers of the screens are done
   HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
   rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
@@ -1162,7 +1182,8 @@ int aomarl_slopes2modes(aomarl_ctx *c, aomarl_state *st, int b, int n, float *mo
   const int nsl = c->sys.nslope, ld = (nsl + 3) & ~3;
   // residual modes = v2m . err = -(v2m . cmat) . slopes
   launch_gemm_nt(n, c->s2m_nmodes, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->s2m, ld, 0.0f, modes,
-                 c->s2m_nmodes, (hipStream_t)stream, st->work + w.GEMM, w.gemm_floats);
+                 c->s2m_nmodes, (hipStream_t)stream, st->work + w.GEMM, w.gemm_floats, nullptr, nullptr,
+                 /* slopes (arcsec), unscaled */ true, 1.f, c->s2m_scale);
   LAUNCHCHK();
   return 0;
 }
@@ -1251,6 +1272,7 @@ int aomarl_apply_control(aomarl_ctx *c, aomarl_state *st, int b, int n, int comp
 // ---------------------------------------------------------------- target
 static int target_psf_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, bool from_buf, void *stream) {
   if (!from_buf && atmos_wait_pending(c, stream)) return 1;
+  if (psf_wait_pending(c, stream)) return 1;
   hipStream_t s = (hipStream_t)stream;
   Work w = work_layout(c, st->nenv);
   const int W = 2 * c->sys.hw, RB = 256 / W;
@@ -1310,6 +1332,8 @@ int aomarl_comp_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stre
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
   if (n == 0) return 0;
+  rc = psf_wait_pending(c, stream);
+  if (rc) return rc;
   Work w = work_layout(c, st->nenv);
   const int W = 2 * c->sys.hw;
   float *PEND = st->work + w.PEND + (size_t)b * (W * W + 4);
@@ -1352,6 +1376,7 @@ struct StateBlocks {
   const float *src[8], *mean[8], *std[8];
   int ld[8], dim[8], off[8];
   int nblocks, total;
+  const int32_t *sel;           // optional: column sel[i] of the source instead of column i (every block)
 };
 
 __global__ void k_assemble_state(int nenv, StateBlocks sb, float *__restrict__ out) {
@@ -1361,7 +1386,7 @@ __global__ void k_assemble_state(int nenv, StateBlocks sb, float *__restrict__ o
 #pragma unroll
   for (int k = 1; k < 8; k++) if (k < sb.nblocks && j >= sb.off[k]) b = k;
   const int i = j - sb.off[b];
-  float v = sb.src[b][(long long)e * sb.ld[b] + i];
+  float v = sb.src[b][(long long)e * sb.ld[b] + (sb.sel ? sb.sel[i] : i)];
   if (sb.mean[b]) v = (v - sb.mean[b][i]) / sb.std[b][i];
   out[(long long)e * sb.total + j] = v;
 }
@@ -1400,9 +1425,25 @@ int aomarl_policy_sample(int nenv, int act_max, int action_dim, const float *hea
   return 0;
 }
 
+static int assemble_state_impl(int nenv, int nblocks, const float *const *src, const int32_t *ld,
+                               const int32_t *dim, const float *const *mean, const float *const *std_,
+                               const int32_t *sel, float *out, void *stream);
+
 int aomarl_assemble_state(int nenv, int nblocks, const float *const *src, const int32_t *ld,
                           const int32_t *dim, const float *const *mean, const float *const *std_,
                           float *out, void *stream) {
+  return assemble_state_impl(nenv, nblocks, src, ld, dim, mean, std_, nullptr, out, stream);
+}
+
+int aomarl_assemble_state_cols(int nenv, int nblocks, const float *const *src, const int32_t *ld,
+                               const int32_t *dim, const float *const *mean, const float *const *std_,
+                               const int32_t *sel, float *out, void *stream) {
+  return assemble_state_impl(nenv, nblocks, src, ld, dim, mean, std_, sel, out, stream);
+}
+
+static int assemble_state_impl(int nenv, int nblocks, const float *const *src, const int32_t *ld,
+                               const int32_t *dim, const float *const *mean, const float *const *std_,
+                               const int32_t *sel, float *out, void *stream) {
   if (!src || !ld || !dim || !out) return fail("assemble_state: null pointer");
   if (nblocks < 1 || nblocks > 8) return fail("assemble_state: 1..8 blocks");
   StateBlocks sb;
@@ -1413,12 +1454,12 @@ int aomarl_assemble_state(int nenv, int nblocks, const float *const *src, const 
     sb.mean[k] = (on && mean) ? mean[k] : nullptr; sb.std[k] = (on && std_) ? std_[k] : nullptr;
     sb.off[k] = off;
     if (on) {
-      if (!src[k] || dim[k] <= 0 || ld[k] < dim[k]) return fail("assemble_state: bad block %d", k);
+      if (!src[k] || dim[k] <= 0 || (!sel && ld[k] < dim[k])) return fail("assemble_state: bad block %d", k);
       if ((sb.mean[k] == nullptr) != (sb.std[k] == nullptr)) return fail("assemble_state: mean/std must come together");
       off += dim[k];
     }
   }
-  sb.nblocks = nblocks; sb.total = off;
+  sb.nblocks = nblocks; sb.total = off; sb.sel = sel;
   if (nenv <= 0) return 0;
   hipLaunchKernelGGL(k_assemble_state, dim3((off + 255) / 256, nenv), dim3(256), 0, (hipStream_t)stream,
                      nenv, sb, out);
@@ -1434,6 +1475,101 @@ int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_mo
   hipLaunchKernelGGL(k_agent_rewards, dim3(n_agents, nenv), dim3(64), 0, (hipStream_t)stream, nenv, nmodes,
                      n_agents, res_modes, ld, lohi, factor, out);
   LAUNCHCHK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- one call per half of a training step
+// The per-step host work of the reference is a chain of ~25 tiny operations; here each of them is a
+// native launch already, but issuing them one by one from Python costs ~10 us each -- more than the
+// kernels themselves at small batch sizes.  These two entry points issue the same launches, in the
+// same order, from C.
+int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const float *eps, uint32_t seed,
+                         uint32_t counter, float *action, float *mean, void *stream) {
+  if (!d || !state || !action || !mean) return fail("actor_forward: null argument");
+  if (d->n_hidden < 1 || d->n_hidden > 8) return fail("actor_forward: 1..8 hidden layers");
+  const int A = d->n_agents, n = d->nenv, H = d->hidden;
+  int rc = aomarl_split_states(n, d->state_dim, A, d->in_max, d->gather, state, d->x, stream);
+  if (rc) return rc;
+  rc = aomarl_gemm_nt_batched(A, n, H, d->in_max, d->x, d->in_max, (long long)n * d->in_max, d->W1, d->in_max,
+                              (long long)H * d->in_max, d->b1, H, d->h0, H, (long long)n * H, 1, stream);
+  if (rc) return rc;
+  float *cur = d->h0, *nxt = d->h1;
+  for (int l = 0; l + 1 < d->n_hidden; l++) {
+    rc = aomarl_gemm_nt_batched(A, n, H, H, cur, H, (long long)n * H, d->Wh[l], H, (long long)H * H, d->bh[l], H,
+                                nxt, H, (long long)n * H, 1, stream);
+    if (rc) return rc;
+    std::swap(cur, nxt);
+  }
+  const int no = 2 * d->act_max;
+  rc = aomarl_gemm_nt_batched(A, n, no, H, cur, H, (long long)n * H, d->Whead, H, (long long)no * H, d->bhead, no,
+                              d->head, no, (long long)n * no, 0, stream);
+  if (rc) return rc;
+  return aomarl_policy_sample(n, d->act_max, d->action_dim, d->head, d->log_sig_min, d->log_sig_max, d->scale,
+                              d->bias, d->sc_agent, d->sc_local, eps, seed, counter, action, mean, stream);
+}
+
+int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
+                    float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
+  if (!c || !st || !g || !state_out) return fail("env_step: null argument");
+  if (g->nhist < 0 || g->nhist > 5) return fail("env_step: 0..5 command histories");
+  const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1;
+  if (g->ring_pos < 0 || g->ring_pos >= R) return fail("env_step: ring position out of range");
+  const size_t slot = (size_t)n * nm;
+  float *newest = g->modes_ring + (size_t)g->ring_pos * slot;
+  const int nxt = (g->ring_pos + 1) % R;
+  float *mnew = g->modes_ring + (size_t)nxt * slot;
+  // ---- AoEnv.rl_step: Btt correction from the coordinates at hand, delay line, Strehl
+  int rc = aomarl_rl_control_modes(c, st, 0, n, newest, g->res_modes, gain, action, mnew, stream);
+  if (rc) return rc;
+  rc = aomarl_apply_control(c, st, 0, n, AOMARL_APPLY_COMP_VOLTAGE | (c->defer_dm_shape ? AOMARL_APPLY_DEFER_STACK_SHAPE : 0), stream);
+  if (rc) return rc;
+  rc = aomarl_comp_strehl(c, st, 0, n, stream);
+  if (rc) return rc;
+  // ---- per-agent rewards from the residual measured before this action reached the DM
+  if (reward_out) {
+    rc = aomarl_agent_rewards(n, nm, g->n_agents, g->res_modes, nm, g->lohi, g->reward_factor, reward_out, stream);
+    if (rc) return rc;
+  }
+  // ---- AoEnv.linear_step
+  if (g->denoiser) {
+    // rlSupervisor.py:975-984: image -> autoencoder -> centroids -> do_control, the cube staying on the device
+    if (!st->bincube) return fail("env_step: the denoiser needs st->bincube");
+    if (!aomarl_frame_fused_available(c)) return fail("env_step: denoiser branch needs the one-pass frame kernel");
+    rc = aomarl_move_atmos(c, st, 0, n, accumx, accumy, stream);
+    if (rc) return rc;
+    const bool defer = c->defer_dm_shape && aomarl_dm_from_voltage_available(c);
+    rc = aomarl_frame_fused(c, st, 0, n, AOMARL_IMG_NOISE | AOMARL_IMG_WRITE_BINCUBE | (defer ? AOMARL_IMG_DM_FROM_VOLTAGE : 0), stream);
+    if (rc) return rc;
+    if (c->prefetch_atmos && !c->premoved) {
+      rc = aomarl_prefetch_atmos(c, st, 0, n, accumx, accumy, stream);
+      if (rc) return rc;
+    }
+    const long long nimg = (long long)n * c->sys.nvalid;
+    rc = g->denoiser_f32 ? aomarl_denoiser_apply_f32((aomarl_denoiser *)g->denoiser, st->bincube, nimg, stream)
+                         : aomarl_denoiser_apply((aomarl_denoiser *)g->denoiser, st->bincube, nimg, stream);
+    if (rc) return rc;
+    rc = aomarl_do_centroids(c, st, 0, n, stream);
+    if (rc) return rc;
+    rc = aomarl_do_control(c, st, 0, n, stream);
+  } else {
+    rc = aomarl_next_part_one(c, st, 0, n, accumx, accumy, 0, stream);
+  }
+  if (rc) return rc;
+  rc = aomarl_volts2modes(c, st, n, st->err, st->ld_actu, g->res_modes, stream);
+  if (rc) return rc;
+  const float *src[8], *mean[8], *sd[8];
+  int32_t ld[8], dim[8];
+  int nb = 0;
+  for (int h = g->nhist; h >= 1; h--) {                       // oldest first
+    src[nb] = g->modes_ring + (size_t)((nxt - h + R * 8) % R) * slot;
+    mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+  }
+  src[nb] = mnew; mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+  src[nb] = g->res_modes; mean[nb] = g->mean_res; sd[nb] = g->std_res; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+  const bool norm = g->mean_dm && g->std_dm && g->mean_res && g->std_res;
+  rc = assemble_state_impl(n, nb, src, ld, dim, norm ? mean : nullptr, norm ? sd : nullptr, g->sel, state_out, stream);
+  if (rc) return rc;
+  g->ring_pos = nxt;
   return 0;
 }
 
@@ -1609,6 +1745,8 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   if (rc) return rc;
   rc = atmos_wait_pending(c, stream);
   if (rc) return rc;
+  rc = psf_wait_pending(c, stream);
+  if (rc) return rc;
   if (!c->sys.fused_ok) return fail("frame_fused: geometry not eligible (see aomarl_frame_fused_available)");
   if (flags & (AOMARL_IMG_FROM_PHASE_BUFFER | AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS))
     return fail("frame_fused: FROM_PHASE_BUFFER / NO_ATMOS / NO_DMS are not supported here");
@@ -1657,6 +1795,19 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
 #undef FW_H
 #undef FW
   LAUNCHCHK();
+  if (c->prefetch_atmos) {
+    // second axis of the PSF window: off the critical path (read by aomarl_comp_strehl at the end of
+    // the step), so it goes to the side stream, in front of the next frame's extrusions
+    rc = side_stream(c);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_frame, s));
+    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
+    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->atm_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
+    LAUNCHCHK();
+    HIPCHK(hipEventRecord(c->ev_psf, c->atm_stream));
+    c->psf_side = true;
+    return 0;
+  }
   hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, s, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
   LAUNCHCHK();
   return 0;

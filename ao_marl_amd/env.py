@@ -235,11 +235,11 @@ class VecRlSupervisor(object):
         self._s2m_ok = False
 
     def next_part_two(self, action, linear_control=False, apply_control=True,
-                      compute_tar_psf=True, modes_pair=None):
+                      compute_tar_psf=True, modes_pair=None, modes_out=None):
         """rlSupervisor.py:900-947.  modes_pair = (v2m . com_before, v2m . err) of the last
         integrator frame: the Btt coordinates of the current command follow by linearity
         (aomarl_rl_control_modes) and the coordinates after the action come back in
-        `self.last_modes`."""
+        `self.last_modes` (written into `modes_out` when given)."""
         self.last_modes = None
         if not linear_control and modes_pair is not None and hasattr(self.sim, "rl_control_modes"):
             std = self.config_rl["normalization_std_inside_environment"]
@@ -250,7 +250,8 @@ class VecRlSupervisor(object):
                 raise RuntimeError("freedom vector not loaded (load_freedom_vector)")
             if self.gain is None:
                 raise RuntimeError("per-environment gains are for integrator-only runs")
-            self.last_modes = self.sim.rl_control_modes(modes_pair[0], modes_pair[1], self.gain, action)
+            self.last_modes = self.sim.rl_control_modes(modes_pair[0], modes_pair[1], self.gain, action,
+                                                        out=modes_out)
             # the command is final without the integrator ever running in actuator space
             self._err_stale, self._control_pending = self._control_pending or self._err_stale, False
         else:
@@ -429,7 +430,13 @@ class VecAoEnv(object):
         # Python (tests/test_env_vs_reference_trace.py) is then met only within 2x its tolerance on the
         # tip-tilt residual, for 1.5 % of step time.
         self.residual_shortcut = False
-        self._m_before_full, self._m_next, self._modal_valid = None, None, False
+        # one library call per environment step (aomarl_env_step) when the configuration is the one it
+        # covers (see _native_step_ok); the same launches in the same order as the call-by-call path
+        self.native_step = True
+        # Btt coordinates of the last number_of_previous_dm + 1 commands, newest in slot _ring_pos
+        self._ring, self._ring_pos, self._ring_next_valid = None, 0, False
+        self._res_modes, self._glue, self._glue_keep = None, None, None
+        self._modal_valid = False
         self._default_state_layout = (
             list(self.state_keys) == ["dm_history_%d" % i for i in
                                       range(cfg["number_of_previous_dm"], 0, -1)] +
@@ -482,25 +489,51 @@ class VecAoEnv(object):
         """ao_env.py:316-359"""
         cfg = self.config_rl
         self.supervisor.reset()
-        self._m_next, self._modal_valid = None, False
+        self._ring_next_valid, self._modal_valid = False, False
         z = lambda d: torch.zeros(self.nenv, d, device=self.device)  # noqa: E731
         self._hist_dm = [z(self.dm_dim) for _ in range(cfg["number_of_previous_dm"])]
         self._hist_wfs = [z(self.wfs_dim) for _ in range(cfg["number_of_previous_wfs"])]
         self._hist_res = [z(self.dm_dim) for _ in range(cfg["number_of_previous_dm_residuals"])]
+        if self._native_glue and self._default_state_layout:
+            if self._ring is None:
+                self._ring = torch.zeros(cfg["number_of_previous_dm"] + 1, self.nenv, self.nmodes,
+                                         device=self.device)
+                self._res_modes = torch.zeros(self.nenv, self.nmodes, device=self.device)
+                self._sel_i32 = None if self._sel is None else self._sel.to(torch.int32)
+            else:
+                self._ring.zero_()
+            self._ring_pos, self._glue = 0, None
         return self.linear_step()
 
     def linear_step(self, return_dict=False):
         """ao_env.py:871-909"""
         cfg, sup = self.config_rl, self.supervisor
-        if self._native_glue and not return_dict and self._default_state_layout:
+        if self._ring is not None and not return_dict:
             return self._linear_step_fused()
-        s_dm_before = self.transform_state_to_zernike(sup.get_command())
+        pick = lambda m: m if (self.windowed or self._sel is None) else m[:, self._sel]  # noqa: E731
+        if self._ring is not None:
+            # the dictionary form of the default layout: same ring as the fused path, so the two can
+            # be mixed freely within an episode
+            R = self._ring.shape[0]
+            nxt = (self._ring_pos + 1) % R
+            if not self._ring_next_valid:
+                sup.sim.volts2modes(sup.get_command(), out=self._ring[nxt])
+            self._ring_next_valid = False
+            self._hist_dm = [pick(self._ring_slot(h)) for h in range(R - 2, -1, -1)]
+            self._ring_pos = nxt
+            s_dm_before = pick(self._ring[nxt])
+        else:
+            s_dm_before = self.transform_state_to_zernike(sup.get_command())
         sup.next_part_one()
         s_dm_after = self.transform_state_to_zernike(sup.get_command()) \
             if cfg["state_dm_after_linear"] else None
-        res_full = sup.sim.volts2modes(sup.get_err())
+        if self._ring is not None:
+            res_full = sup.sim.volts2modes(sup.get_err(), out=self._res_modes)
+            self._modal_valid = True
+        else:
+            res_full = sup.sim.volts2modes(sup.get_err())
         self._last_res_modes = res_full
-        s_res = res_full if (self.windowed or self._sel is None) else res_full[:, self._sel]
+        s_res = pick(res_full)
         s_wfs = sup.get_slopes()
         out = OrderedDict()
         # add_wfs_to_state (ao_env.py:563-583)
@@ -533,16 +566,24 @@ class VecAoEnv(object):
             return out
         return torch.cat(list(out.values()), dim=1)
 
+    def _ring_slot(self, back):
+        """Btt coordinates of the command `back` steps before the newest one (a view of the ring)."""
+        return self._ring[(self._ring_pos - back) % self._ring.shape[0]]
+
     def _linear_step_fused(self):
-        """linear_step for the default state layout on the GPU: the four blocks are standardised
-        and concatenated by one kernel (aomarl_assemble_state) instead of ~10 tensor operations."""
+        """linear_step for the default state layout on the GPU: the blocks are sub-selected,
+        standardised and concatenated by one kernel (aomarl_assemble_state_cols) instead of ~10 tensor
+        operations.  The Btt coordinates of the commands live in a ring ([number_of_previous_dm + 1,
+        nenv, nmodes]) shared with the one-call step (aomarl_env_step)."""
         from . import libaomarl as la
-        cfg, sup = self.config_rl, self.supervisor
-        if self._m_next is not None:            # v2m . com came back from rl_control_modes
-            m_full, self._m_next = self._m_next, None
+        sup = self.supervisor
+        R = self._ring.shape[0]
+        nxt = (self._ring_pos + 1) % R
+        if self._ring_next_valid:               # v2m . com came back from rl_control_modes
+            self._ring_next_valid = False
         else:
-            m_full = sup.sim.volts2modes(sup.get_command())
-        s_dm_before = m_full if (self.windowed or self._sel is None) else m_full[:, self._sel]
+            sup.sim.volts2modes(sup.get_command(), out=self._ring[nxt])
+        self._ring_pos = nxt
         if (self.residual_shortcut and self.modal_shortcut and sup.geo is None and sup.gain is not None
                 and sup.autoencoder is None and hasattr(sup.sim, "slopes2modes")):
             # the next control step rebuilds the command from Btt coordinates (rl_step below), so
@@ -550,20 +591,76 @@ class VecAoEnv(object):
             # with v2m . cmat instead of do_control + volts2modes; do_control runs on demand
             sup.ensure_slopes2modes()
             sup.next_part_one(defer_control=True)
-            res_full = sup.sim.slopes2modes()
+            self._res_modes.copy_(sup.sim.slopes2modes())
         else:
             sup.next_part_one()
-            res_full = sup.sim.volts2modes(sup.get_err())
-        self._last_res_modes = res_full
-        self._m_before_full, self._modal_valid = m_full, True
-        s_res = res_full if (self.windowed or self._sel is None) else res_full[:, self._sel]
-        blocks = list(self._hist_dm) + [s_dm_before, s_res]
+            sup.sim.volts2modes(sup.get_err(), out=self._res_modes)
+        self._last_res_modes = self._res_modes
+        self._modal_valid = True
+        blocks = [self._ring_slot(h) for h in range(R - 1, -1, -1)] + [self._res_modes]
         norms = None
         if self.normalization_bool:
-            norms = [self.norm["dm"]] * (len(self._hist_dm) + 1) + [self.norm["dm_residual"]]
-        state = la.assemble_state(blocks, norms)
-        self._hist_dm = self._hist_dm[1:] + [s_dm_before]
-        return state
+            norms = [self.norm["dm"]] * R + [self.norm["dm_residual"]]
+        return la.assemble_state(blocks, norms, sel_i32=self._sel_i32)
+
+    # ------------------------------------------------------------------ one library call per step
+    def _native_step_ok(self, linear_control):
+        sup = self.supervisor
+        return (self.native_step and self._native_glue and self._default_state_layout and
+                self.modal_shortcut and self._modal_valid and not linear_control and
+                not self.residual_shortcut and sup.geo is None and sup.gain is not None and
+                sup.freedom_vector is not None and not sup.next_part_one_split and
+                not sup._control_pending and hasattr(sup.sim, "env_step") and
+                (sup.autoencoder is None or (getattr(sup.autoencoder, "use_native", False) and
+                                             sup.autoencoder.input_bound is not None)))
+
+    def _make_glue(self):
+        from . import libaomarl as la
+        sup, cfg = self.supervisor, self.config_rl
+        g = la.EnvGlue()
+        g.nmodes, g.dm_dim, g.nhist = self.nmodes, self.dm_dim, cfg["number_of_previous_dm"]
+        g.sel = self._sel_i32.data_ptr() if self._sel_i32 is not None else None
+        if self.normalization_bool:
+            (g.mean_dm, g.std_dm), (g.mean_res, g.std_res) = \
+                [tuple(t.data_ptr() for t in self.norm[k]) for k in ("dm", "dm_residual")]
+        if self.layout is not None:
+            g.n_agents, g.lohi, g.reward_factor = self.layout.n_agents, self._lohi_i32.data_ptr(), \
+                self._reward_factor
+        g.modes_ring, g.res_modes = self._ring.data_ptr(), self._res_modes.data_ptr()
+        ae = sup.autoencoder
+        if ae is not None:
+            g.denoiser, g.denoiser_f32 = ae._native().value, int(bool(ae.wants_f32()))
+            sup.sim._need_bincube()
+        self._glue = g
+
+    def _step_native(self, action):
+        sup = self.supervisor
+        std = sup.config_rl["normalization_std_inside_environment"]
+        mean = sup.config_rl["normalization_mean_inside_environment"]
+        action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        if std != 1.0 or mean != 0.0:
+            action = action * std + mean
+        action = action.contiguous()
+        if action.shape != (self.nenv, self.action_dim):
+            raise ValueError("action must be [nenv, %d]" % self.action_dim)
+        if self._glue is None:
+            self._make_glue()
+        g = self._glue
+        g.ring_pos = self._ring_pos
+        state = torch.empty(self.nenv, self.state_dim, dtype=torch.float32, device=self.device)
+        r = None
+        if self.layout is not None:
+            r = torch.empty(self.nenv, self.layout.n_agents, dtype=torch.float32, device=self.device)
+        ae = sup.autoencoder
+        if ae is not None:
+            ae._used_fp16 = ae._used_fp16 or not g.denoiser_f32
+        sup.sim.env_step(g, action, sup.gain, state, r)
+        self._ring_pos = g.ring_pos
+        self._last_res_modes = self._res_modes
+        sup.last_modes = None
+        sup._err_stale, sup._control_pending = False, False
+        sup.iter += 1
+        return state, r, False, ""
 
     def calculate_reward(self):
         """ao_env.py:585-860, the branches the shipped configurations use."""
@@ -585,14 +682,15 @@ class VecAoEnv(object):
                 compute_env_reward=False):
         """ao_env.py:911-939. The reference computes the env-level reward and the trainer throws
         it away (train_rpc.py:641); it is only evaluated here on request."""
-        pair = None
+        pair, out = None, None
         if (self.modal_shortcut and self._native_glue and self._default_state_layout and
                 self._modal_valid and not linear_control):
-            pair = (self._m_before_full, self._last_res_modes)
+            pair = (self._ring_slot(0), self._res_modes)
+            out = self._ring_slot(-1)           # the slot the next linear_step makes the newest
         self.supervisor.next_part_two(action, linear_control=linear_control,
                                       apply_control=apply_control,
-                                      compute_tar_psf=compute_tar_psf, modes_pair=pair)
-        self._m_next = self.supervisor.last_modes
+                                      compute_tar_psf=compute_tar_psf, modes_pair=pair, modes_out=out)
+        self._ring_next_valid = self.supervisor.last_modes is not None
         self._modal_valid = False               # re-established by the next linear_step
         r = self.calculate_reward() if compute_env_reward else None
         return r, False, ""
@@ -611,6 +709,8 @@ class VecAoEnv(object):
 
     def step(self, action, linear_control=False):
         """TrainerRPC.env_step (train_rpc.py:633-648): (s_next, per-agent reward, done, info)."""
+        if self._native_step_ok(linear_control):
+            return self._step_native(action)
         _, done, info = self.rl_step(action, linear_control)
         r = self.divide_rewards_for_agents() if self.layout is not None else None
         s_next = self.linear_step()

@@ -115,7 +115,11 @@ SYMBOLS = [
                                   _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     ("aomarl_assemble_state", _i, [_i, _i, C.POINTER(C.c_void_p), _ip, _ip, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), _vp, _vp]),
+    ("aomarl_assemble_state_cols", _i, [_i, _i, C.POINTER(C.c_void_p), _ip, _ip, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), _vp, _vp, _vp]),
     ("aomarl_agent_rewards", _i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _vp]),
+    ("aomarl_actor_forward", _i, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    ("aomarl_env_step", _i, [_vp, C.POINTER(State), _vp, _vp, _f, _fp, _fp, _vp, _vp, _vp]),
     ("aomarl_frame_kernel_name", C.c_char_p, [_vp]),
     ("aomarl_frame_kernel_time", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     ("aomarl_denoiser_create", _i, [C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_void_p)]),
@@ -160,6 +164,26 @@ class SacDesc(C.Structure):
                                           "critic_m", "critic_v", "critic_grad", "critic_target",
                                           "log_alpha", "log_alpha_m", "log_alpha_v", "log_alpha_grad",
                                           "alpha")]
+
+
+class ActorDesc(C.Structure):
+    """aomarl_actor_desc (include/aomarl.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("n_agents", "nenv", "state_dim", "in_max", "act_max", "hidden",
+                                         "n_hidden", "action_dim")] + \
+               [("gather", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p),
+                ("Wh", C.POINTER(C.c_void_p)), ("bh", C.POINTER(C.c_void_p)),
+                ("Whead", C.c_void_p), ("bhead", C.c_void_p), ("sc_agent", C.c_void_p),
+                ("sc_local", C.c_void_p)] + \
+               [(n, C.c_float) for n in ("log_sig_min", "log_sig_max", "scale", "bias")] + \
+               [(n, C.c_void_p) for n in ("x", "h0", "h1", "head")]
+
+
+class EnvGlue(C.Structure):
+    """aomarl_env_glue (include/aomarl.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("nmodes", "dm_dim", "n_agents", "nhist", "ring_pos")] + \
+               [(n, C.c_void_p) for n in ("sel", "mean_dm", "std_dm", "mean_res", "std_res", "lohi")] + \
+               [("reward_factor", C.c_float), ("modes_ring", C.c_void_p), ("res_modes", C.c_void_p),
+                ("denoiser", C.c_void_p), ("denoiser_f32", C.c_int32)]
 
 
 class AomarlError(RuntimeError):
@@ -337,9 +361,10 @@ def policy_sample(head, act_max, sc_agent_i32, sc_local_i32, log_sig_min, log_si
     return action, mean
 
 
-def assemble_state(blocks, norms=None, out=None):
+def assemble_state(blocks, norms=None, out=None, sel_i32=None):
     """blocks: list of [nenv, d_k] tensors (row stride free, unit column stride); norms: list of
-    (mean, std) tensors or None per block -> [nenv, sum d_k] (aomarl_assemble_state)."""
+    (mean, std) tensors or None per block -> [nenv, sum d_k] (aomarl_assemble_state).  sel_i32: every
+    block contributes its columns sel (aomarl_assemble_state_cols)."""
     import torch
     n = len(blocks)
     nenv = blocks[0].shape[0]
@@ -347,16 +372,18 @@ def assemble_state(blocks, norms=None, out=None):
         assert b.stride(1) == 1 and b.shape[0] == nenv and b.dtype == torch.float32
     src = (C.c_void_p * n)(*[b.data_ptr() for b in blocks])
     ld = (C.c_int32 * n)(*[b.stride(0) for b in blocks])
-    dim = (C.c_int32 * n)(*[b.shape[1] for b in blocks])
+    widths = [b.shape[1] if sel_i32 is None else int(sel_i32.numel()) for b in blocks]
+    dim = (C.c_int32 * n)(*widths)
     mean = std = None
     if norms is not None:
         mean = (C.c_void_p * n)(*[(m[0].data_ptr() if m is not None else None) for m in norms])
         std = (C.c_void_p * n)(*[(m[1].data_ptr() if m is not None else None) for m in norms])
-    total = sum(b.shape[1] for b in blocks)
+    total = sum(widths)
     if out is None:
         out = torch.empty(nenv, total, dtype=torch.float32, device=blocks[0].device)
-    check(load().aomarl_assemble_state(nenv, n, src, ld, dim, mean, std, out.data_ptr(),
-                                       _stream_of(blocks[0])))
+    check(load().aomarl_assemble_state_cols(nenv, n, src, ld, dim, mean, std,
+                                            sel_i32.data_ptr() if sel_i32 is not None else None,
+                                            out.data_ptr(), _stream_of(blocks[0])))
     return out
 
 

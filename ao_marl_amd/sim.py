@@ -158,6 +158,20 @@ class HipSim(object):
     def dm_from_voltage_available(self):
         return bool(self.lib.aomarl_dm_from_voltage_available(self.ctx))
 
+    def env_step(self, glue, action, gain, state_out, reward_out=None):
+        """One TrainerRPC.env_step for every environment in ONE library call (aomarl_env_step):
+        rl_control from Btt coordinates, apply_control, Strehl, per-agent rewards, next_part_one,
+        v2m . err, state assembly.  `glue` is a libaomarl.EnvGlue the caller owns."""
+        self._set_defer(self.defer_shape and self.dm_from_voltage_available())
+        la.check(self.lib.aomarl_env_step(self.ctx, C.byref(self.st), C.byref(glue), action.data_ptr(),
+                                          float(gain), la.fptr(self.accumx), la.fptr(self.accumy),
+                                          state_out.data_ptr(),
+                                          reward_out.data_ptr() if reward_out is not None else None,
+                                          self._stream()))
+        self._stale = self._defer_on
+        if self.prefetch and not self.pending_atmos:
+            self.pending_atmos, self._pending_range = True, (0, self.nenv)
+
     def _set_defer(self, on):
         on = bool(on)
         if on != self._defer_on:
@@ -358,7 +372,7 @@ class HipSim(object):
         la.check(self.lib.aomarl_rl_control(self.ctx, C.byref(self.st), b, n, action.data_ptr(),
                                             self._stream()))
 
-    def rl_control_modes(self, m0, m1, g, action=None, env_begin=0, env_count=None):
+    def rl_control_modes(self, m0, m1, g, action=None, env_begin=0, env_count=None, out=None):
         """rl_control from known Btt coordinates: modes = m0 + g m1 (+ action); com = m2v . modes.
         Returns the modes ([env_count, nmodes]) -- they are v2m . com of the new command."""
         b, n = self._range(env_begin, env_count)
@@ -371,7 +385,8 @@ class HipSim(object):
             if action.shape != (n, self.nact):
                 raise ValueError("action must be [env_count, %d]" % self.nact)
             ptr = action.data_ptr()
-        out = torch.empty(n, self.nmodes, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(n, self.nmodes, dtype=torch.float32, device=self.device)
         la.check(self.lib.aomarl_rl_control_modes(self.ctx, C.byref(self.st), b, n, m0.data_ptr(),
                                                   m1.data_ptr(), float(g), ptr, out.data_ptr(),
                                                   self._stream()))
@@ -481,11 +496,12 @@ class HipSim(object):
                                               self._stream()))
         return out
 
-    def volts2modes(self, vec):
+    def volts2modes(self, vec, out=None):
         """[rows, nactu] (any row stride, e.g. the padded views `com` / `err`) -> [rows, nmodes]."""
         if vec.stride(1) != 1:
             vec = vec.contiguous()
-        out = torch.empty(vec.shape[0], self.nmodes, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(vec.shape[0], self.nmodes, dtype=torch.float32, device=self.device)
         la.check(self.lib.aomarl_volts2modes(self.ctx, C.byref(self.st), vec.shape[0],
                                              vec.data_ptr(), vec.stride(0), out.data_ptr(),
                                              self._stream()))

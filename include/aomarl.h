@@ -361,8 +361,56 @@ int aomarl_policy_sample(int nenv, int act_max, int action_dim, const float *hea
 int aomarl_assemble_state(int nenv, int nblocks, const float *const *src, const int32_t *ld,
                           const int32_t *dim, const float *const *mean, const float *const *std_,
                           float *out, void *stream);
+/* The same with a column selection: out block k = standardise(src_k[:, sel[0 .. dim_k)]) (the
+ * action-range sub-selection of transform_state_to_zernike, ao_env.py:482-505). sel NULL = identity. */
+int aomarl_assemble_state_cols(int nenv, int nblocks, const float *const *src, const int32_t *ld,
+                          const int32_t *dim, const float *const *mean, const float *const *std_,
+                          const int32_t *sel, float *out, void *stream);
 int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_modes, int ld,
                          const int32_t *lohi, float factor, float *out, void *stream);
+/* ---- one native call per half of a training step.  Same launches, same order as the entry points
+ * above; what they save is the host: ~25 calls per step at ~10 us each from the Python side.
+ *
+ * aomarl_actor_forward   TrainerRPC.choose_action for every agent (train_rpc.py:650-675):
+ *                        divide_states_for_agents -> GaussianPolicy.forward (Linear + ReLU stack, merged
+ *                        mean | log_std head) -> sample(only_choosing_action) -> the global action vector.
+ *                        Weights in nn.Linear layout, stacked over agents, zero-padded to in_max / act_max. */
+typedef struct {
+  int32_t n_agents, nenv, state_dim, in_max, act_max, hidden, n_hidden, action_dim;
+  const int32_t *gather;               /* device [A][in_max]: state column, state_dim = zero pad      */
+  const float *W1, *b1;                /* device [A][H][in_max], [A][H]                               */
+  const float *const *Wh, *const *bh;  /* HOST arrays of n_hidden - 1 device pointers [A][H][H], [A][H] */
+  const float *Whead, *bhead;          /* device [A][2 act_max][H], [A][2 act_max]                    */
+  const int32_t *sc_agent, *sc_local;  /* device [action_dim]                                         */
+  float log_sig_min, log_sig_max, scale, bias;
+  float *x, *h0, *h1, *head;           /* device scratch [A][nenv][in_max], [A][nenv][H] x 2, [A][nenv][2 act_max] */
+} aomarl_actor_desc;
+int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const float *eps, uint32_t seed,
+                         uint32_t counter, float *action, float *mean, void *stream);
+/* aomarl_env_step        TrainerRPC.env_step (train_rpc.py:633-648) for the default state layout
+ *                        (dm_history_n .. 1, dm_before_linear, dm_residual; parameters.cfg:31-37), all
+ *                        environments of the state:  rl_step (Btt correction through
+ *                        aomarl_rl_control_modes, apply_control, Strehl)  ->  per-agent rewards  ->
+ *                        linear_step (aomarl_next_part_one, v2m . err, standardise + concatenate).
+ *                        The Btt coordinates of the last nhist + 1 commands live in a ring the caller
+ *                        owns; ring_pos (slot of the newest) is advanced by the call. */
+typedef struct {
+  int32_t nmodes, dm_dim, n_agents, nhist;
+  int32_t ring_pos;
+  const int32_t *sel;                  /* device [dm_dim]: modes that enter the state, or NULL = all  */
+  const float *mean_dm, *std_dm, *mean_res, *std_res;   /* device [dm_dim], or all NULL: raw states  */
+  const int32_t *lohi;                 /* device [n_agents][2] mode ranges of the agents' rewards     */
+  float reward_factor;
+  float *modes_ring;                   /* device [nhist + 1][nenv][nmodes]                            */
+  float *res_modes;                    /* device [nenv][nmodes]: v2m . err of the last frame (in/out) */
+  void *denoiser;                      /* aomarl_denoiser* or NULL: the autoencoder branch of
+                                          next_part_one_integrator (rlSupervisor.py:975-984); needs st->bincube */
+  int32_t denoiser_f32;                /* 1: aomarl_denoiser_apply_f32                                 */
+} aomarl_env_glue;
+int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, const float *action_dev,
+                    float gain, float *accumx, float *accumy, float *state_out, float *reward_out,
+                    void *stream);
+
 /* WFS-image denoiser in the loop (RlSupervisor.autoencoder_denoising, rlSupervisor.py:876-891;
  * DenoisingAutoencoderCNN2DSingleSubapeture.forward, src/autoencoder/autoencoder_models.py:130-197):
  * every 16 x 16 spot image of a bincube goes through the conv autoencoder, in place, in one fused

@@ -99,6 +99,7 @@ def test_modal_shortcut_equals_full_projection_path():
     a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
     b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
     b.modal_shortcut = False
+    a.native_step = False                        # call by call: supervisor.last_modes is observable
     sa, sb = a.reset(), b.reset()
     assert torch.equal(sa, sb)
     g = torch.Generator(device="cuda:0").manual_seed(5)
@@ -117,6 +118,67 @@ def test_modal_shortcut_equals_full_projection_path():
         cb = b.supervisor.get_command()
         assert (a.supervisor.get_command() - cb).abs().max().item() < 2e-5 * cb.abs().max().item()
     assert used == 10
+
+
+@pytest.mark.parametrize("denoise", [False, True])
+def test_one_call_step_is_the_call_by_call_step(denoise):
+    """aomarl_env_step issues the launches of rl_step + rewards + linear_step from C: states, rewards,
+    commands, Strehl of a rollout are those of the call-by-call path BIT FOR BIT, also when the two
+    are mixed (integrator-only steps and dictionary states go call by call), with per-agent rewards
+    for several agents, and through the denoiser branch."""
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.denoiser import SubapDenoiser
+    name = "production_sh_40x40_8m_3layers_d0_noise" if denoise else "production_sh_10x10_2m"
+    rl = dict(n_zernike_start_end=[0, 1274] if denoise else [0, 80], n_reverse_filtered_from_cmat=5)
+    nag = 13 if denoise else 2
+    mk = lambda: VecAoEnv(name, 3, rl, n_agents_modal=nag,                       # noqa: E731
+                          autoencoder=SubapDenoiser.load(device="cuda:0") if denoise else None)
+    a, b = mk(), mk()
+    b.native_step = False
+    sa, sb = a.reset(), b.reset()
+    assert torch.equal(sa, sb)
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    native = 0
+    for it in range(10):
+        act = torch.rand(3, a.layout.action_dim, device="cuda:0", generator=g) * 2 - 1
+        lin = it in (3, 4)
+        native += a._native_step_ok(lin) and it != 7
+        if it == 7:                              # the pieces, by hand, with a dictionary state
+            for e in (a, b):
+                e.rl_step(act)
+                e._r = e.divide_rewards_for_agents()
+                e._s = torch.cat(list(e.linear_step(return_dict=True).values()), dim=1)
+            sa, ra, sb, rb = a._s, a._r, b._s, b._r
+        else:
+            sa, ra, _, _ = a.step(act, linear_control=lin)
+            sb, rb, _, _ = b.step(act, linear_control=lin)
+        assert torch.equal(sa, sb), it
+        assert torch.equal(ra, rb), it
+        assert torch.equal(a.supervisor.sim.t["voltage"], b.supervisor.sim.t["voltage"]), it
+        assert torch.equal(a.supervisor.sim.t["strehl"], b.supervisor.sim.t["strehl"]), it
+    assert native == 7                           # steps 3, 4 (integrator only) and 7 (by hand) go call by call
+    assert torch.equal(a.supervisor.get_command(), b.supervisor.get_command())
+    assert torch.equal(a.supervisor.get_err(), b.supervisor.get_err())
+
+
+def test_one_call_actor_is_the_layer_by_layer_actor():
+    lay = _layout()
+    a = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=5, device="cuda:0")
+    b = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=5, device="cuda:0")
+    b.native_forward = False
+    for nenv in (33, 256):
+        st = torch.randn(nenv, lay.state_dim, device="cuda:0")
+        for ev in (False, True):
+            x, mx = a.select_action(st, eval_mode=ev)
+            y, my = b.select_action(st, eval_mode=ev)
+            assert torch.equal(x, y) and torch.equal(mx, my)
+    eps = torch.randn(256, lay.action_dim, device="cuda:0")
+    assert torch.equal(a.select_action(st, eps=eps)[0], b.select_action(st, eps=eps)[0])
+    # new weights are picked up (the update invalidates the inference copies)
+    with torch.no_grad():
+        a.W1.mul_(0.5); b.W1.mul_(0.5)
+    a._native = b._native = None
+    assert torch.equal(a.select_action(st)[0], b.select_action(st)[0])
 
 
 @pytest.mark.gpu
