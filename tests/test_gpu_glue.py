@@ -131,8 +131,12 @@ def test_one_call_step_is_the_call_by_call_step(denoise):
     name = "production_sh_40x40_8m_3layers_d0_noise" if denoise else "production_sh_10x10_2m"
     rl = dict(n_zernike_start_end=[0, 1274] if denoise else [0, 80], n_reverse_filtered_from_cmat=5)
     nag = 13 if denoise else 2
+    kw = {}
+    if denoise:     # no statistics shipped for the d0 file: those of its d1 sibling (same system) do
+        from ao_marl_amd.env import load_norm
+        kw["norm"], kw["zn_norm"] = load_norm("production_sh_40x40_8m_3layers_d1_noise")
     mk = lambda: VecAoEnv(name, 3, rl, n_agents_modal=nag,                       # noqa: E731
-                          autoencoder=SubapDenoiser.load(device="cuda:0") if denoise else None)
+                          autoencoder=SubapDenoiser.load(device="cuda:0") if denoise else None, **kw)
     a, b = mk(), mk()
     b.native_step = False
     sa, sb = a.reset(), b.reset()
