@@ -196,6 +196,7 @@ class BatchedGaussianPolicy(object):
         self._native = None          # stacked nn.Linear-layout copies for the HIP batched GEMM
         self.use_native = self.device.type == "cuda"
         self.native_forward, self._desc = True, None     # select_action as one library call
+        self.layer_by_layer = False                      # ... and (False) as one kernel
 
     def _refresh_native(self):
         """[A, out, in] (K-contiguous) copies + merged mean|log_std head for
@@ -252,7 +253,8 @@ class BatchedGaussianPolicy(object):
         import ctypes as C
         if self._native is None:
             self._refresh_native()
-        if self._desc is not None and self._desc[0].nenv == nenv and self._desc[4] is self._native:
+        if self._desc is not None and self._desc[0].nenv == nenv and self._desc[4] is self._native and \
+                bool(self._desc[0].flags) == self.layer_by_layer:
             return self._desc[0]
         n, A, H = self._native, self.A, self.H
         d = la.ActorDesc()
@@ -272,7 +274,15 @@ class BatchedGaussianPolicy(object):
         d.log_sig_min, d.log_sig_max, d.scale, d.bias = LOG_SIG_MIN, self.log_sig_max, self.scale, self.bias
         for k, t in scratch.items():
             setattr(d, k, t.data_ptr())
-        self._desc = (d, scratch, Wh, bh, n)        # keeps every pointer alive
+        d.flags = la.ACTOR_LAYER_BY_LAYER if self.layer_by_layer else 0
+        tiled = None
+        if not self.layer_by_layer and H % 16 == 0:
+            tiled = dict(W1=la.tile_weights(n["W1"]), Wh=[la.tile_weights(w) for w in n["Wh"]],
+                         Whead=la.tile_weights(n["Whead"]))
+            tiled["ptrs"] = (C.c_void_p * nh)(*[w.data_ptr() for w in tiled["Wh"]])
+            d.W1_tiled, d.Wh_tiled, d.Whead_tiled = tiled["W1"].data_ptr(), tiled["ptrs"], \
+                tiled["Whead"].data_ptr()
+        self._desc = (d, scratch, Wh, bh, n, tiled)        # keeps every pointer alive
         return d
 
     def _select_action_one_call(self, state, eval_mode, eps):

@@ -1372,6 +1372,177 @@ __global__ void k_policy_sample(int nenv, int act_max, int action_dim, const flo
   mean[(long long)e * action_dim + g] = tanhf(m) * scale + bias;
 }
 
+// ---- the whole actor in one launch -----------------------------------------------------------
+// One workgroup = one agent x 16 environments: gather the agent's state columns into LDS, run the
+// Linear + ReLU stack and the merged head with the activations staying in LDS (fp32 matrix
+// instructions, 16 x 16 x 4), then clamp / exp / sample / tanh / scatter.  Replaces k_split_states +
+// (n_hidden + 1) k_gemm_nt_batched2 + k_policy_sample: launch-latency-bound kernels of ~0.3-1 GFLOP.
+//
+// Every workgroup streams its agent's ~1 MB of weights from L2 (each agent's workgroups sit on one
+// XCD, so HBM sees them once); what bounds the kernel is the number of cache lines a load instruction
+// touches, so the weights come PRE-TILED in the operand order of the matrix instruction
+// (aomarl_actor_tile_weights): tile (n, s) = rows 16 n .. 16 n + 15, columns 16 s .. 16 s + 15, stored as
+// 64 x float4 with lane l = (row l & 15, columns 4 (l >> 4) .. + 3) -- one 1 KB contiguous read per
+// wave and k step.  Read row-major, the same loads touch 64 lines instead of 8 and the kernel runs at
+// half the speed.  The activations use the same tiling in LDS (conflict-free 128-bit reads).
+struct ActorArgs {
+  int A, nenv, state_dim, in_max, act_max, H, n_hidden, action_dim;
+  const int32_t *gather;
+  const float *W1, *b1, *Wh[8], *bh[8], *Whead, *bhead;      // W*: tiled
+  const int32_t *sc_agent, *sc_local;
+  float ls_min, ls_max, scale, bias;
+  const float *state, *eps;
+  uint32_t seed, counter;
+  float *action, *mean;
+};
+
+__global__ void k_actor_tile_weights(int N, int K, int ntile, int ksteps, const float *__restrict__ src,
+                                     float *__restrict__ dst) {
+  // dst[a][n][s][lane][j] = src[a][16 n + (lane & 15)][16 s + 4 (lane >> 4) + j], zero outside N x K
+  const long long per = (long long)ntile * ksteps * 256;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per) return;
+  const int a = blockIdx.y;
+  const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const long long t = i >> 8;
+  const int sidx = (int)(t % ksteps), n = (int)(t / ksteps);
+  const int row = 16 * n + (lane & 15), col = 16 * sidx + 4 * (lane >> 4) + jj;
+  dst[(long long)a * per + i] = (row < N && col < K) ? src[((long long)a * N + row) * K + col] : 0.f;
+}
+
+// position of element (row, col) of a 16-row activation tile in its LDS image
+__device__ __forceinline__ int af_at(int row, int col) {
+  return (((col >> 4) * 64 + ((col >> 2) & 3) * 16 + row) << 2) + (col & 3);
+}
+
+#ifndef AF_D
+#define AF_D 2
+#endif
+// Out[16][N] = act(Xs[16][K] . W^T + b) on tiled images; ksteps = ceil(K / 16), W has ntile row tiles.
+__device__ __forceinline__ void af_layer(const float *__restrict__ Xs, int ksteps, const float *__restrict__ W,
+                                         const float *__restrict__ b, int N, bool relu, float *__restrict__ Out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kk = lane >> 4;
+  const int ntile = (N + 15) / 16, npairs = (ntile + 1) / 2;
+  constexpr int D = AF_D;
+  for (int pair = wave; pair < npairs; pair += 8) {
+    const float4 *wa = reinterpret_cast<const float4 *>(W) + (long long)(2 * pair) * ksteps * 64 + lane;
+    const float4 *wb = reinterpret_cast<const float4 *>(W) + (long long)min(2 * pair + 1, ntile - 1) * ksteps * 64 + lane;
+    const float4 *xs = reinterpret_cast<const float4 *>(Xs) + lane;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto fma8 = [&](const float4 x, const float4 a, const float4 c) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, a.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, c.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, a.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, c.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, a.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, c.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, a.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, c.w, acc1, 0, 0, 0);
+    };
+    // two register sets of D steps each, filled and drained in turn.  No branch around a load, no
+    // select on its result, no rotation of the sets: each of those makes the compiler wait for the data
+    // where it is loaded; and scheduling barriers, or it sinks every load to just before its use.
+    float4 ra[D], rb[D], qa[D], qb[D];
+    auto fill = [&](float4 (&a)[D], float4 (&c)[D], int s0) {
+#pragma unroll
+      for (int u = 0; u < D; u++) {
+        const int st = min(s0 + u, ksteps - 1) * 64;       // wave-uniform; beyond the end: any tile, unused
+        a[u] = wa[st]; c[u] = wb[st];
+      }
+    };
+    auto drain = [&](const float4 (&a)[D], const float4 (&c)[D], int s0) {
+#pragma unroll
+      for (int u = 0; u < D; u++) fma8(xs[(s0 + u) * 64], a[u], c[u]);
+    };
+    fill(ra, rb, 0);
+    int s = 0;
+    for (; s + 2 * D <= ksteps; s += 2 * D) {
+      fill(qa, qb, s + D);
+      __builtin_amdgcn_sched_barrier(0);
+      drain(ra, rb, s);
+      __builtin_amdgcn_sched_barrier(0);
+      fill(ra, rb, s + 2 * D);
+      __builtin_amdgcn_sched_barrier(0);
+      drain(qa, qb, s + D);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fill(qa, qb, s + D);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < D; u++)
+      if (s + u < ksteps) fma8(xs[(s + u) * 64], ra[u], rb[u]);
+#pragma unroll
+    for (int u = 0; u < D; u++)
+      if (s + D + u < ksteps) fma8(xs[(s + D + u) * 64], qa[u], qb[u]);
+    // C layout: register t of lane l = row 4 (l >> 4) + t, column l & 15
+    const int ca = 32 * pair + r, cb = ca + 16;
+    const float ba = (b && ca < N) ? b[ca] : 0.f, bb = (b && cb < N) ? b[cb] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      float va = acc0[t] + ba, vb = acc1[t] + bb;
+      if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+      if (ca < N) Out[af_at(4 * kk + t, ca)] = va;
+      if (cb < N) Out[af_at(4 * kk + t, cb)] = vb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_actor_fused(ActorArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float af_lds[];
+  const int tiles = (p.nenv + 15) / 16;
+  const int q = blockIdx.x & 7, idx = blockIdx.x >> 3;          // q: the XCD this workgroup lands on
+  const int a = q + 8 * (idx / tiles), e0 = (idx % tiles) * 16;
+  if (a >= p.A) return;
+  const int tid = threadIdx.x;
+  const int H = p.H, no = 2 * p.act_max;
+  const int ks1 = (p.in_max + 15) / 16, ksh = H / 16, nth = H / 16, nto = (no + 15) / 16;
+  const int img1 = 256 * max(ksh, nto), img0 = max(256 * ks1, img1);   // floats of the two activation images
+  float *R0 = af_lds, *R1 = af_lds + img0;
+  int *alist = reinterpret_cast<int *>(af_lds + img0 + img1);
+  if (tid == 0) alist[0] = 0;
+  __syncthreads();
+  // this agent's entries of the global action vector (any order; the loads of one thread are independent)
+  for (int g = tid; g < p.action_dim; g += 512)
+    if (p.sc_agent[g] == a) alist[1 + atomicAdd(&alist[0], 1)] = g;
+  // the gather index of a column does not depend on the row: one index load, 16 independent state loads
+  for (int k = tid; k < 16 * ks1; k += 512) {
+    const int g = k < p.in_max ? p.gather[a * p.in_max + k] : p.state_dim;
+    const bool col = g < p.state_dim;
+    const float *src = p.state + (col ? g : 0);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = src[(long long)min(e0 + r, p.nenv - 1) * p.state_dim];
+#pragma unroll
+    for (int r = 0; r < 16; r++) R0[af_at(r, k)] = (col && e0 + r < p.nenv) ? v[r] : 0.f;
+  }
+  __syncthreads();
+  af_layer(R0, ks1, p.W1 + (long long)a * nth * ks1 * 256, p.b1 + (long long)a * H, H, true, R1);
+  __syncthreads();
+  float *cur = R1, *nxt = R0;
+  for (int l = 0; l + 1 < p.n_hidden; l++) {
+    af_layer(cur, ksh, p.Wh[l] + (long long)a * nth * ksh * 256, p.bh[l] + (long long)a * H, H, true, nxt);
+    __syncthreads();
+    float *t = cur; cur = nxt; nxt = t;
+  }
+  af_layer(cur, ksh, p.Whead + (long long)a * nto * ksh * 256, p.bhead + (long long)a * no, no, false, nxt);
+  __syncthreads();
+  // k_policy_sample on the rows at hand: thread = (row, one in 32 of the agent's actions)
+  const int r = tid & 15, e = e0 + r;
+  if (e >= p.nenv) return;
+  const int nact = min(alist[0], p.act_max);
+  for (int i = tid >> 4; i < nact; i += 32) {
+    const int g = alist[1 + i];
+    const int l = p.sc_local[g];
+    const float m = nxt[af_at(r, l)];
+    const float ls = fminf(fmaxf(nxt[af_at(r, p.act_max + l)], p.ls_min), p.ls_max);
+    const float eps = p.eps ? p.eps[(long long)e * p.action_dim + g]
+                            : philox_normal(p.seed, 7u, p.counter, (uint32_t)e, (uint32_t)g);
+    const float x = m + expf(ls) * eps;
+    p.action[(long long)e * p.action_dim + g] = tanhf(x) * p.scale + p.bias;
+    p.mean[(long long)e * p.action_dim + g] = tanhf(m) * p.scale + p.bias;
+  }
+}
+
 struct StateBlocks {
   const float *src[8], *mean[8], *std[8];
   int ld[8], dim[8], off[8];
@@ -1483,11 +1654,58 @@ int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_mo
 // native launch already, but issuing them one by one from Python costs ~10 us each -- more than the
 // kernels themselves at small batch sizes.  These two entry points issue the same launches, in the
 // same order, from C.
+long long aomarl_actor_tiled_floats(int n_agents, int N, int K) {
+  return (long long)n_agents * ((N + 15) / 16) * ((K + 15) / 16) * 256;
+}
+
+int aomarl_actor_tile_weights(int n_agents, int N, int K, const float *src, float *dst, void *stream) {
+  if (!src || !dst) return fail("actor_tile_weights: null pointer");
+  if (n_agents <= 0 || N <= 0 || K <= 0) return fail("actor_tile_weights: bad sizes");
+  const int ntile = (N + 15) / 16, ksteps = (K + 15) / 16;
+  const long long per = (long long)ntile * ksteps * 256;
+  hipLaunchKernelGGL(k_actor_tile_weights, dim3((unsigned)((per + 255) / 256), n_agents), dim3(256), 0,
+                     (hipStream_t)stream, N, K, ntile, ksteps, src, dst);
+  LAUNCHCHK();
+  return 0;
+}
+
 int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const float *eps, uint32_t seed,
                          uint32_t counter, float *action, float *mean, void *stream) {
   if (!d || !state || !action || !mean) return fail("actor_forward: null argument");
   if (d->n_hidden < 1 || d->n_hidden > 8) return fail("actor_forward: 1..8 hidden layers");
   const int A = d->n_agents, n = d->nenv, H = d->hidden;
+  if (A <= 0 || n <= 0) return 0;
+  if (!(d->flags & AOMARL_ACTOR_LAYER_BY_LAYER) && d->W1_tiled && d->Whead_tiled && H % 16 == 0) {
+    // one launch: pre-tiled weights at hand and the activations of 16 environments fit in LDS
+    const int ks1 = (d->in_max + 15) / 16, nto = (2 * d->act_max + 15) / 16;
+    const size_t img1 = (size_t)256 * std::max(H / 16, nto), img0 = std::max((size_t)256 * ks1, img1);
+    const size_t lds = (img0 + img1 + d->act_max + 4) * sizeof(float);
+    static bool big_lds = false;
+    if (!big_lds && lds > 64 * 1024 && lds <= 128 * 1024) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_actor_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      big_lds = true;
+    }
+    if (lds <= 128 * 1024) {
+      ActorArgs p;
+      p.A = A; p.nenv = n; p.state_dim = d->state_dim; p.in_max = d->in_max; p.act_max = d->act_max; p.H = H;
+      p.n_hidden = d->n_hidden; p.action_dim = d->action_dim;
+      p.gather = d->gather; p.W1 = d->W1_tiled; p.b1 = d->b1;
+      for (int l = 0; l < 8; l++) {
+        p.Wh[l] = l + 1 < d->n_hidden ? d->Wh_tiled[l] : nullptr;
+        p.bh[l] = l + 1 < d->n_hidden ? d->bh[l] : nullptr;
+        if (l + 1 < d->n_hidden && !p.Wh[l]) return fail("actor_forward: tiled hidden weights missing");
+      }
+      if (((uintptr_t)p.W1 | (uintptr_t)d->Whead_tiled) & 15) return fail("actor_forward: tiled weights must be 16-byte aligned");
+      p.Whead = d->Whead_tiled; p.bhead = d->bhead; p.sc_agent = d->sc_agent; p.sc_local = d->sc_local;
+      p.ls_min = d->log_sig_min; p.ls_max = d->log_sig_max; p.scale = d->scale; p.bias = d->bias;
+      p.state = state; p.eps = eps; p.seed = seed; p.counter = counter; p.action = action; p.mean = mean;
+      const int tiles = (n + 15) / 16, groups = (A + 7) / 8;
+      hipLaunchKernelGGL(k_actor_fused, dim3(8 * tiles * groups), dim3(512), lds, (hipStream_t)stream, p);
+      LAUNCHCHK();
+      return 0;
+    }
+  }
+  if (!d->x || !d->h0 || !d->h1 || !d->head) return fail("actor_forward: the layer-by-layer path needs its scratch buffers");
   int rc = aomarl_split_states(n, d->state_dim, A, d->in_max, d->gather, state, d->x, stream);
   if (rc) return rc;
   rc = aomarl_gemm_nt_batched(A, n, H, d->in_max, d->x, d->in_max, (long long)n * d->in_max, d->W1, d->in_max,

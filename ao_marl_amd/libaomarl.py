@@ -118,6 +118,8 @@ SYMBOLS = [
     ("aomarl_assemble_state_cols", _i, [_i, _i, C.POINTER(C.c_void_p), _ip, _ip, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), _vp, _vp, _vp]),
     ("aomarl_agent_rewards", _i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _vp]),
+    ("aomarl_actor_tiled_floats", C.c_longlong, [_i, _i, _i]),
+    ("aomarl_actor_tile_weights", _i, [_i, _i, _i, _vp, _vp, _vp]),
     ("aomarl_actor_forward", _i, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     ("aomarl_env_step", _i, [_vp, C.POINTER(State), _vp, _vp, _f, _fp, _fp, _vp, _vp, _vp]),
     ("aomarl_frame_kernel_name", C.c_char_p, [_vp]),
@@ -175,7 +177,11 @@ class ActorDesc(C.Structure):
                 ("Whead", C.c_void_p), ("bhead", C.c_void_p), ("sc_agent", C.c_void_p),
                 ("sc_local", C.c_void_p)] + \
                [(n, C.c_float) for n in ("log_sig_min", "log_sig_max", "scale", "bias")] + \
-               [(n, C.c_void_p) for n in ("x", "h0", "h1", "head")]
+               [(n, C.c_void_p) for n in ("x", "h0", "h1", "head")] + [("flags", C.c_int32)] + \
+               [("W1_tiled", C.c_void_p), ("Wh_tiled", C.POINTER(C.c_void_p)), ("Whead_tiled", C.c_void_p)]
+
+
+ACTOR_LAYER_BY_LAYER = 1
 
 
 class EnvGlue(C.Structure):
@@ -321,6 +327,17 @@ def linear_batched(x, weight, bias=None, relu=False, out=None):
             weight.stride(0), bias.data_ptr() if bias is not None else None,
             bias.stride(0) if bias is not None else 0, out.data_ptr(), out.stride(1), out.stride(0),
             1 if relu else 0, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out
+
+
+def tile_weights(w):
+    """[A, N, K] (nn.Linear layout, stacked) -> the tile order of the one-kernel actor
+    (aomarl_actor_tile_weights)."""
+    import torch
+    A, N, K = w.shape
+    w = w.contiguous()
+    out = torch.empty(load().aomarl_actor_tiled_floats(A, N, K), dtype=torch.float32, device=w.device)
+    check(load().aomarl_actor_tile_weights(A, N, K, w.data_ptr(), out.data_ptr(), _stream_of(w)))
     return out
 
 

@@ -36,6 +36,7 @@ What the ONE JSON line (rank 0) says:
                    1 thread and all cores, bounded samples.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -343,7 +344,10 @@ def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None)
            "mean_strehl_le": float(w.sim.strehl[:, 1].mean())}
     if denoiser:
         w.env.supervisor.autoencoder.check_range()
+    import torch
     del w
+    gc.collect()                # the HIP context of this configuration goes NOW (hipFree synchronises the
+    torch.cuda.synchronize()    # device), not at some later collection inside the next timed region
     return out
 
 
@@ -481,6 +485,8 @@ def main():
             out["sac_update"] = {"error": str(e)[:200]}
         s_main = env.supervisor.s
         del w, env, sim
+        gc.collect()
+        torch.cuda.synchronize()
         torch.cuda.empty_cache()
         if not args.no_side_configs and main_is_headline:
             out["configs"] = {}

@@ -383,8 +383,23 @@ typedef struct {
   const float *Whead, *bhead;          /* device [A][2 act_max][H], [A][2 act_max]                    */
   const int32_t *sc_agent, *sc_local;  /* device [action_dim]                                         */
   float log_sig_min, log_sig_max, scale, bias;
-  float *x, *h0, *h1, *head;           /* device scratch [A][nenv][in_max], [A][nenv][H] x 2, [A][nenv][2 act_max] */
+  float *x, *h0, *h1, *head;           /* device scratch [A][nenv][in_max], [A][nenv][H] x 2, [A][nenv][2 act_max]
+                                          (only the layer-by-layer path uses them)                    */
+  int32_t flags;                       /* AOMARL_ACTOR_*                                              */
+  const float *W1_tiled;               /* device copies of W1 / Wh / Whead in the tile order of      */
+  const float *const *Wh_tiled;        /* aomarl_actor_tile_weights (HOST array for Wh), or NULL      */
+  const float *Whead_tiled;
 } aomarl_actor_desc;
+/* With the tiled copies at hand (and hidden % 16 == 0): ONE launch -- one workgroup per agent x 16
+ * environments, activations in LDS, fp32 matrix instructions.  Without them, or with this flag:
+ * split_states + one batched GEMM per layer + policy_sample.  Same arithmetic up to the order of the
+ * fp32 sums. */
+#define AOMARL_ACTOR_LAYER_BY_LAYER 1
+/* dst[a] = the [N][K] matrix src[a] (nn.Linear layout, stacked over agents) cut into 16 x 16 tiles in
+ * the operand order of the 16 x 16 x 4 matrix instruction, zero-padded: tile (n, s) holds 64 x float4,
+ * entry l = row 16 n + (l & 15), columns 16 s + 4 (l >> 4) .. + 3.  dst: aomarl_actor_tiled_floats(). */
+long long aomarl_actor_tiled_floats(int n_agents, int N, int K);
+int aomarl_actor_tile_weights(int n_agents, int N, int K, const float *src, float *dst, void *stream);
 int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const float *eps, uint32_t seed,
                          uint32_t counter, float *action, float *mean, void *stream);
 /* aomarl_env_step        TrainerRPC.env_step (train_rpc.py:633-648) for the default state layout

@@ -166,23 +166,51 @@ def test_one_call_step_is_the_call_by_call_step(denoise):
 
 
 def test_one_call_actor_is_the_layer_by_layer_actor():
+    """aomarl_actor_forward: with AOMARL_ACTOR_LAYER_BY_LAYER the very kernels of the call-by-call
+    path (bit for bit); by default ONE kernel (k_actor_fused) whose fp32 sums run in another order:
+    same draws, actions within fp32 round-off of the layered ones, and of a float64 evaluation."""
     lay = _layout()
-    a = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=5, device="cuda:0")
-    b = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=5, device="cuda:0")
+    mk = lambda: BatchedGaussianPolicy(lay, last_layer_zero=False, seed=5, device="cuda:0")   # noqa: E731
+    a, b, f = mk(), mk(), mk()
+    a.layer_by_layer = True
     b.native_forward = False
-    for nenv in (33, 256):
-        st = torch.randn(nenv, lay.state_dim, device="cuda:0")
+    for p in (a, b, f):
+        with torch.no_grad():
+            g = torch.Generator(device="cuda:0").manual_seed(3)
+            p.bm.copy_(torch.randn(p.bm.shape, device="cuda:0", generator=g) * 0.3)
+            p.bs.copy_(torch.randn(p.bs.shape, device="cuda:0", generator=g) * 0.3)
+            p.b1.copy_(torch.randn(p.b1.shape, device="cuda:0", generator=g) * 0.1)
+        p._native = None
+    for nenv in (33, 256, 7):
+        st = torch.randn(nenv, lay.state_dim, device="cuda:0") * 3
         for ev in (False, True):
             x, mx = a.select_action(st, eval_mode=ev)
             y, my = b.select_action(st, eval_mode=ev)
+            z, mz = f.select_action(st, eval_mode=ev)
             assert torch.equal(x, y) and torch.equal(mx, my)
-    eps = torch.randn(256, lay.action_dim, device="cuda:0")
+            assert (z - y).abs().max().item() < 2e-5 and (mz - my).abs().max().item() < 2e-5, nenv
+    eps = torch.randn(7, lay.action_dim, device="cuda:0")
     assert torch.equal(a.select_action(st, eps=eps)[0], b.select_action(st, eps=eps)[0])
+    zf, mf = f.select_action(st, eps=eps)
+    assert (zf - b.select_action(st, eps=eps)[0]).abs().max().item() < 2e-5
+    # float64 evaluation of the same network from the stacked weights
+    pad = torch.cat([st, st.new_zeros(st.shape[0], 1)], dim=1).double()
+    x = pad[:, f.gather].permute(1, 0, 2)
+    x = torch.relu(torch.baddbmm(f.b1.double(), x, f.W1.double()))
+    for W, bb in zip(f.Wh, f.bh):
+        x = torch.relu(torch.baddbmm(bb.double(), x, W.double()))
+    mu = torch.tanh(torch.baddbmm(f.bm.double(), x, f.Wm.double()))
+    want = mu[f.sc_agent, :, f.sc_local].T
+    assert (mf.double() - want).abs().max().item() < 5e-6
     # new weights are picked up (the update invalidates the inference copies)
-    with torch.no_grad():
-        a.W1.mul_(0.5); b.W1.mul_(0.5)
-    a._native = b._native = None
-    assert torch.equal(a.select_action(st)[0], b.select_action(st)[0])
+    for p in (a, b, f):
+        with torch.no_grad():
+            p.W1.mul_(0.5)
+        p._native = None
+    a._draws = b._draws = f._draws = 100
+    y = b.select_action(st)[0]
+    assert torch.equal(a.select_action(st)[0], y)
+    assert (f.select_action(st)[0] - y).abs().max().item() < 2e-5
 
 
 @pytest.mark.gpu
