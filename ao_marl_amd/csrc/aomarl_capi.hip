@@ -1758,14 +1758,16 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
     const bool defer = c->defer_dm_shape && aomarl_dm_from_voltage_available(c);
     rc = aomarl_frame_fused(c, st, 0, n, AOMARL_IMG_NOISE | AOMARL_IMG_WRITE_BINCUBE | (defer ? AOMARL_IMG_DM_FROM_VOLTAGE : 0), stream);
     if (rc) return rc;
-    if (c->prefetch_atmos && !c->premoved) {
-      rc = aomarl_prefetch_atmos(c, st, 0, n, accumx, accumy, stream);
-      if (rc) return rc;
-    }
     const long long nimg = (long long)n * c->sys.nvalid;
     rc = g->denoiser_f32 ? aomarl_denoiser_apply_f32((aomarl_denoiser *)g->denoiser, st->bincube, nimg, stream)
                          : aomarl_denoiser_apply((aomarl_denoiser *)g->denoiser, st->bincube, nimg, stream);
     if (rc) return rc;
+    // the next frame's extrusions go beside centroids / control / agents, not beside the denoiser: that
+    // kernel fills the GPU by itself and small kernels next to it only stretch both
+    if (c->prefetch_atmos && !c->premoved) {
+      rc = aomarl_prefetch_atmos(c, st, 0, n, accumx, accumy, stream);
+      if (rc) return rc;
+    }
     rc = aomarl_do_centroids(c, st, 0, n, stream);
     if (rc) return rc;
     rc = aomarl_do_control(c, st, 0, n, stream);

@@ -280,9 +280,9 @@ class VecRlSupervisor(object):
             # the bincube never leaves the device (the reference copies it to the host and back)
             self._move_or_keep(move_atmos)
             self._target_and_image(write_bincube=True, cog=False)
-            if self.prefetch_atmos and move_atmos:
-                self.sim.prefetch_atmos()
             self.autoencoder.denoise_bincube_(self.sim.t["bincube"])
+            if self.prefetch_atmos and move_atmos:      # beside centroids / control, not the denoiser
+                self.sim.prefetch_atmos()
             self.sim.do_centroids()
             if do_control:
                 self.sim.do_control()

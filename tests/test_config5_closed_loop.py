@@ -118,9 +118,10 @@ def test_closed_loop_with_noise_and_denoiser_matches_oracle(noisy):
         assert r["nflip"] <= 2e-4 * r["npix"], r
         assert r["good"] >= 0.999, r
         # one differing photon (of ~240 in a sub-aperture) moves that sub-aperture's centroid by up to
-        # 0.03 pixel, which the tip-tilt rows of the command matrix turn into <= 1e-3 of the command
-        # scale: the smoke tolerance, plus that per differing count
-        assert r["dcom"] < 2e-4 + 5e-3 / com_scale + 1e-3 * r["nflip"], r
+        # 0.03 pixel -- more where the denoiser sharpens the spot around it -- which the tip-tilt rows
+        # of the command matrix turn into up to ~2e-3 of the command scale (measured: 1.9e-3 for a
+        # single count): the smoke tolerance, plus 3e-3 per differing count (a handful per 12 M pixels)
+        assert r["dcom"] < 2e-4 + 5e-3 / com_scale + 3e-3 * r["nflip"], r
         assert r["dvol"] < 2e-4 + 5e-3 / com_scale, r
         assert r["dsr"] < 1e-3, r
     assert min(r["sr_le"] for r in log[-2:]) > 0.2           # the loop did close
@@ -141,8 +142,11 @@ def test_free_running_loops_stay_statistically_together(noisy):
         assert r["good"] >= 0.95, r
         assert r["dcom"] < 1e-2 and r["dvol"] < 1e-2, r
         assert r["dsr"] < 2e-3 and r["dsr_le"] < 2e-3, r
+    # the first frames differ by the odd count only (the kernel's Box-Muller runs on the hardware
+    # log2 / sin / cos: its normals are the oracle's to ~1e-6, ~3e-7 of the counts land on the other
+    # side of a rounding threshold)
     first = [r for r in log if r["it"] < 3]
-    assert all(r["nflip"] == 0 or r["good"] == 1.0 for r in first)
+    assert all(r["nflip"] <= 2 and r["good"] >= 0.999 for r in first)
 
 
 def test_supervisor_branch_is_that_sequence(noisy):
