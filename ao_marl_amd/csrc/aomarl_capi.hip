@@ -1232,6 +1232,37 @@ __global__ void k_modal_compose(int nm, const float *__restrict__ m0, const floa
   if (modes_out) modes_out[(long long)r * nm + m] = v;
 }
 
+// k_modal_compose and k_agent_rewards side by side in one launch (blocks beyond the compose range: one
+// per agent, first wave): both read the residual modes, neither reads what the other writes
+__global__ __launch_bounds__(256) void k_compose_rewards(int nm, const float *__restrict__ m0, const float *__restrict__ m1,
+                                                         float g, const float *__restrict__ action, int nact,
+                                                         const int32_t *__restrict__ amode_inv,
+                                                         const float *__restrict__ freedom, float *__restrict__ modes, int ldm,
+                                                         float *__restrict__ modes_out, int cx, int n_agents,
+                                                         const int32_t *__restrict__ lohi, float factor,
+                                                         float *__restrict__ rew) {
+  const int r = blockIdx.y;
+  if ((int)blockIdx.x >= cx) {
+    if (threadIdx.x >= 64) return;
+    const int a = blockIdx.x - cx, lane = threadIdx.x;
+    const int lo = lohi[2 * a], hi = lohi[2 * a + 1];
+    float s = 0.f;
+    for (int m = lo + lane; m < hi; m += 64) { const float v = m1[(long long)r * nm + m]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) rew[(long long)r * n_agents + a] = -factor * s / (float)(hi - lo);
+    return;
+  }
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nm) return;
+  float v = m0[(long long)r * nm + m] + g * m1[(long long)r * nm + m];
+  if (action) {
+    const int j = amode_inv[m];
+    if (j >= 0) v += action[(long long)r * nact + j] * freedom[m];
+  }
+  modes[(long long)r * ldm + m] = v;
+  if (modes_out) modes_out[(long long)r * nm + m] = v;
+}
+
 int aomarl_rl_control_modes(aomarl_ctx *c, aomarl_state *st, int b, int n, const float *m0,
                             const float *m1, float g, const float *action, float *modes_out,
                             void *stream) {
@@ -1548,16 +1579,29 @@ struct StateBlocks {
   int ld[8], dim[8], off[8];
   int nblocks, total;
   const int32_t *sel;           // optional: column sel[i] of the source instead of column i (every block)
+  // optional: the LAST block's source is still split-K partial tiles part[z][nenv][pn]: its value is
+  // alpha * sum_z part[z] (k_gemm_reduce's expression), also written in full to sum_out[nenv][pn]
+  const float *part; int nsplit, pn; float alpha; float *sum_out;
 };
 
 __global__ void k_assemble_state(int nenv, StateBlocks sb, float *__restrict__ out) {
   const int e = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= sb.total) return;
+  auto psum = [&](int col) {
+    float s = 0.f;
+    for (int z = 0; z < sb.nsplit; z++) s += sb.part[((long long)z * nenv + e) * sb.pn + col];
+    return sb.alpha * s;
+  };
+  if (j >= sb.total) {                       // extra threads: the reduced matrix itself
+    const int col = j - sb.total;
+    if (sb.part && col < sb.pn) sb.sum_out[(long long)e * sb.pn + col] = psum(col);
+    return;
+  }
   int b = 0;
 #pragma unroll
   for (int k = 1; k < 8; k++) if (k < sb.nblocks && j >= sb.off[k]) b = k;
   const int i = j - sb.off[b];
-  float v = sb.src[b][(long long)e * sb.ld[b] + (sb.sel ? sb.sel[i] : i)];
+  const int col = sb.sel ? sb.sel[i] : i;
+  float v = (sb.part && b == sb.nblocks - 1) ? psum(col) : sb.src[b][(long long)e * sb.ld[b] + col];
   if (sb.mean[b]) v = (v - sb.mean[b][i]) / sb.std[b][i];
   out[(long long)e * sb.total + j] = v;
 }
@@ -1596,9 +1640,10 @@ int aomarl_policy_sample(int nenv, int act_max, int action_dim, const float *hea
   return 0;
 }
 
+struct AssemblePart { const float *part; int nsplit, pn; float alpha; float *sum_out; };
 static int assemble_state_impl(int nenv, int nblocks, const float *const *src, const int32_t *ld,
                                const int32_t *dim, const float *const *mean, const float *const *std_,
-                               const int32_t *sel, float *out, void *stream);
+                               const int32_t *sel, float *out, void *stream, const AssemblePart *pt = nullptr);
 
 int aomarl_assemble_state(int nenv, int nblocks, const float *const *src, const int32_t *ld,
                           const int32_t *dim, const float *const *mean, const float *const *std_,
@@ -1614,7 +1659,7 @@ int aomarl_assemble_state_cols(int nenv, int nblocks, const float *const *src, c
 
 static int assemble_state_impl(int nenv, int nblocks, const float *const *src, const int32_t *ld,
                                const int32_t *dim, const float *const *mean, const float *const *std_,
-                               const int32_t *sel, float *out, void *stream) {
+                               const int32_t *sel, float *out, void *stream, const AssemblePart *pt) {
   if (!src || !ld || !dim || !out) return fail("assemble_state: null pointer");
   if (nblocks < 1 || nblocks > 8) return fail("assemble_state: 1..8 blocks");
   StateBlocks sb;
@@ -1631,8 +1676,14 @@ static int assemble_state_impl(int nenv, int nblocks, const float *const *src, c
     }
   }
   sb.nblocks = nblocks; sb.total = off; sb.sel = sel;
+  sb.part = nullptr; sb.nsplit = 0; sb.pn = 0; sb.alpha = 1.f; sb.sum_out = nullptr;
+  int extra = 0;
+  if (pt && pt->part && pt->nsplit > 0) {
+    sb.part = pt->part; sb.nsplit = pt->nsplit; sb.pn = pt->pn; sb.alpha = pt->alpha; sb.sum_out = pt->sum_out;
+    extra = pt->pn;
+  }
   if (nenv <= 0) return 0;
-  hipLaunchKernelGGL(k_assemble_state, dim3((off + 255) / 256, nenv), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_assemble_state, dim3((off + extra + 255) / 256, nenv), dim3(256), 0, (hipStream_t)stream,
                      nenv, sb, out);
   LAUNCHCHK();
   return 0;
@@ -1736,17 +1787,68 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   float *newest = g->modes_ring + (size_t)g->ring_pos * slot;
   const int nxt = (g->ring_pos + 1) % R;
   float *mnew = g->modes_ring + (size_t)nxt * slot;
-  // ---- AoEnv.rl_step: Btt correction from the coordinates at hand, delay line, Strehl
-  int rc = aomarl_rl_control_modes(c, st, 0, n, newest, g->res_modes, gain, action, mnew, stream);
+  int rc = check_range(c, st, 0, n);
   if (rc) return rc;
-  rc = aomarl_apply_control(c, st, 0, n, AOMARL_APPLY_COMP_VOLTAGE | (c->defer_dm_shape ? AOMARL_APPLY_DEFER_STACK_SHAPE : 0), stream);
-  if (rc) return rc;
-  rc = aomarl_comp_strehl(c, st, 0, n, stream);
-  if (rc) return rc;
-  // ---- per-agent rewards from the residual measured before this action reached the DM
-  if (reward_out) {
-    rc = aomarl_agent_rewards(n, nm, g->n_agents, g->res_modes, nm, g->lohi, g->reward_factor, reward_out, stream);
+  if (!c->v2m || !c->m2v) return fail("env_step: no modal basis (aomarl_set_modal)");
+  if (nm != c->nmodes) return fail("env_step: glue has %d modes, the basis %d", nm, c->nmodes);
+  if (action && c->nact <= 0) return fail("env_step: no action modes set");
+  hipStream_t s = (hipStream_t)stream;
+  Work w = work_layout(c, st->nenv);
+  DevState ds = dev_state(st);
+  const int na = c->sys.nactu;
+  // Fused form of the chain (same arithmetic, same order of every sum -- the results are bit for bit
+  // those of the entry points called one by one): every split-K reduction happens in the kernel that
+  // consumes the product, independent small kernels share a launch.  10 launches per step on the
+  // main stream instead of 14.
+  int ktt = -1, ntt = 0, nother = 0;
+  for (int k = 0; k < c->ndm; k++) {
+    if (c->sys.dms[k].type == AOMARL_DM_TT) { ktt = k; ntt++; } else nother++;
+  }
+  const bool defer = c->defer_dm_shape && aomarl_dm_from_voltage_available(c);
+  const bool fused = !(g->flags & AOMARL_ENV_STEP_UNFUSED) && ntt == 1 && (defer || nother == 0);
+  if (fused) {
+    // ---- AoEnv.rl_step: Btt correction from the coordinates at hand (+ the per-agent rewards of the
+    // residual measured before this action reaches the DM), delay line, tip-tilt shape, Strehl
+    float *modes = st->work + w.MODES;
+    const int cx = (nm + 255) / 256;
+    hipLaunchKernelGGL(k_compose_rewards, dim3(cx + (reward_out ? g->n_agents : 0), n), dim3(256), 0, s, nm, newest,
+                       g->res_modes, gain, action, c->nact, c->amode_inv, c->freedom, modes, w.ldm, mnew, cx,
+                       g->n_agents, g->lohi, g->reward_factor, reward_out);
+    LAUNCHCHK();
+    int nsp = 0;
+    float alpha = 1.f;
+    launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, st->com, st->ld_actu, s,
+                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, true, 16.f, c->m2v_scale, &alpha);
+    LAUNCHCHK();
+    const float d = c->delay;
+    float wa, wb, wc;
+    if (d <= 1.f) { wa = 1.f - d; wb = d; wc = 0.f; } else { wa = 0.f; wb = 2.f - d; wc = d - 1.f; }
+    if (nsp > 0)
+      hipLaunchKernelGGL(k_delay_sum, dim3((na + 255) / 256, n), dim3(256), 0, s, ds, na, st->ld_actu, wa, wb, wc, 0, 1,
+                         st->work + w.GEMM, nsp, alpha, n);
+    else
+      hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, s, ds, na, st->ld_actu, wa, wb, wc, 0, 1);
+    LAUNCHCHK();
+    rc = psf_wait_pending(c, stream);
     if (rc) return rc;
+    const int W = 2 * c->sys.hw;
+    hipLaunchKernelGGL(k_post_delay, dim3(2 * n), dim3(256), 0, s, c->sys, ds, 0, n, st->work + w.PEND, 1, ktt,
+                       st->voltage, st->ld_actu);
+    (void)W;
+    LAUNCHCHK();
+  } else {
+    // ---- AoEnv.rl_step: Btt correction from the coordinates at hand, delay line, Strehl
+    rc = aomarl_rl_control_modes(c, st, 0, n, newest, g->res_modes, gain, action, mnew, stream);
+    if (rc) return rc;
+    rc = aomarl_apply_control(c, st, 0, n, AOMARL_APPLY_COMP_VOLTAGE | (c->defer_dm_shape ? AOMARL_APPLY_DEFER_STACK_SHAPE : 0), stream);
+    if (rc) return rc;
+    rc = aomarl_comp_strehl(c, st, 0, n, stream);
+    if (rc) return rc;
+    // ---- per-agent rewards from the residual measured before this action reached the DM
+    if (reward_out) {
+      rc = aomarl_agent_rewards(n, nm, g->n_agents, g->res_modes, nm, g->lohi, g->reward_factor, reward_out, stream);
+      if (rc) return rc;
+    }
   }
   // ---- AoEnv.linear_step
   if (g->denoiser) {
@@ -1775,8 +1877,18 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
     rc = aomarl_next_part_one(c, st, 0, n, accumx, accumy, 0, stream);
   }
   if (rc) return rc;
-  rc = aomarl_volts2modes(c, st, n, st->err, st->ld_actu, g->res_modes, stream);
-  if (rc) return rc;
+  AssemblePart part = {nullptr, 0, 0, 1.f, nullptr};
+  if (fused) {
+    int nsp = 0;
+    float alpha = 1.f;
+    launch_gemm_nt(n, nm, na, 1.0f, st->err, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, g->res_modes, nm, s,
+                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, /* volts */ true, 1.f, c->v2m_scale, &alpha);
+    LAUNCHCHK();
+    if (nsp > 0) { part.part = st->work + w.GEMM; part.nsplit = nsp; part.pn = nm; part.alpha = alpha; part.sum_out = g->res_modes; }
+  } else {
+    rc = aomarl_volts2modes(c, st, n, st->err, st->ld_actu, g->res_modes, stream);
+    if (rc) return rc;
+  }
   const float *src[8], *mean[8], *sd[8];
   int32_t ld[8], dim[8];
   int nb = 0;
@@ -1787,7 +1899,8 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   src[nb] = mnew; mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
   src[nb] = g->res_modes; mean[nb] = g->mean_res; sd[nb] = g->std_res; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
   const bool norm = g->mean_dm && g->std_dm && g->mean_res && g->std_res;
-  rc = assemble_state_impl(n, nb, src, ld, dim, norm ? mean : nullptr, norm ? sd : nullptr, g->sel, state_out, stream);
+  rc = assemble_state_impl(n, nb, src, ld, dim, norm ? mean : nullptr, norm ? sd : nullptr, g->sel, state_out, stream,
+                           &part);
   if (rc) return rc;
   g->ring_pos = nxt;
   return 0;

@@ -954,6 +954,30 @@ __device__ __forceinline__ float dm_value(const DevSys &sys, const DevState &st,
   return slot[0] * f.x + slot[1] * f.y;
 }
 
+// tip-tilt mirror k of environment env_begin + row: its two coefficients, and (p == 2) the stack-array
+// DM's value at the centre of the pupil grid
+__device__ __forceinline__ void dm_shape_tt_body(const DevSys &sys, const DevState &st, int env_begin, int row, int k,
+                                                 const float *__restrict__ volts, int ldv, int p) {
+  const DevDm &D = sys.dms[k];
+  const float *com = volts + (long long)row * ldv + D.com_off;
+  float *shape = st.dm_shape + (long long)(env_begin + row) * sys.shape_stride + D.shape_off;
+  if (p < 2) shape[p] = com[p];
+  if (p == 2 && sys.fused_ok) {
+    // stack-array DM value at the centre of the pupil grid (pivot of the one-pass frame kernel's
+    // variance sums when the stack-array shape is evaluated from the commands on the fly)
+    const DevDm &Z = sys.dms[0];
+    const float *zc = volts + (long long)row * ldv + Z.com_off;
+    const int half = sys.pupdiam / 2, zp = (half + Z.toy) * Z.dim + half + Z.tox;
+    const int ss2 = Z.ss * Z.ss, s0 = Z.influstart[zp], cn = Z.ninflu[zp];
+    float acc = 0.f;
+    for (int t = 0; t < cn; t++) {
+      const int pos = Z.influpos[s0 + t];
+      acc += Z.influ[pos] * zc[pos / ss2];
+    }
+    shape[2] = acc;
+  }
+}
+
 // generic per-pixel gather over the reference's influpos / ninflu / influstart tables
 __global__ __launch_bounds__(256) void k_dm_shape(DevSys sys, DevState st, int env_begin, int k,
                                                   const float *__restrict__ volts, int ldv) {
@@ -963,21 +987,7 @@ __global__ __launch_bounds__(256) void k_dm_shape(DevSys sys, DevState st, int e
   float *shape = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (D.type == AOMARL_DM_TT) {
-    if (p < 2) shape[p] = com[p];
-    if (p == 2 && sys.fused_ok) {
-      // stack-array DM value at the centre of the pupil grid (pivot of the one-pass frame kernel's
-      // variance sums when the stack-array shape is evaluated from the commands on the fly)
-      const DevDm &Z = sys.dms[0];
-      const float *zc = volts + (long long)blockIdx.y * ldv + Z.com_off;
-      const int half = sys.pupdiam / 2, zp = (half + Z.toy) * Z.dim + half + Z.tox;
-      const int ss2 = Z.ss * Z.ss, s0 = Z.influstart[zp], cn = Z.ninflu[zp];
-      float acc = 0.f;
-      for (int t = 0; t < cn; t++) {
-        const int pos = Z.influpos[s0 + t];
-        acc += Z.influ[pos] * zc[pos / ss2];
-      }
-      shape[2] = acc;
-    }
+    dm_shape_tt_body(sys, st, env_begin, blockIdx.y, k, volts, ldv, p);
     return;
   }
   if (p >= D.dim * D.dim) return;
@@ -2356,6 +2366,28 @@ __global__ void k_delay(DevState st, int nactu, int ld, float a, float b, float 
   }
 }
 
+// k_delay whose newest command is still the split-K partial tiles P[z][n][nactu] of the m2v product:
+// com = alpha * sum_z P[z] (k_gemm_reduce's expression, same order), then the delay line
+__global__ void k_delay_sum(DevState st, int nactu, int ld, float a, float b, float c, int env_begin,
+                            int comp_voltage, const float *__restrict__ P, int nsplit, float alpha, int nrows) {
+  const int e = env_begin + blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nactu) return;
+  const long long o = (long long)e * ld + i;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; z++) s += P[((long long)z * nrows + blockIdx.y) * nactu + i];
+  const float c0 = alpha * s;
+  st.com[o] = c0;
+  if (comp_voltage) {
+    const float c1 = st.com1[o], c2 = st.com2[o];
+    st.voltage[o] = a * c0 + b * c1 + c * c2;
+    st.com2[o] = c1;
+    st.com1[o] = c0;
+  } else {
+    st.voltage[o] = c0;
+  }
+}
+
 __global__ void k_copy_rows(float *__restrict__ dst, int ldd, const float *__restrict__ src,
                             int lds, int ncols) {
   const int r = blockIdx.y;
@@ -2892,13 +2924,13 @@ __global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const fl
 }
 
 // publish the pending PSF: LE accumulation, Strehl SE / LE, variance bookkeeping
-__global__ __launch_bounds__(256) void k_strehl_commit(DevSys sys, DevState st, int env_begin,
-                                                       const float *__restrict__ PEND) {
+__device__ __forceinline__ void strehl_commit_body(const DevSys &sys, const DevState &st, int env_begin, int blk,
+                                                   const float *__restrict__ PEND) {
   __shared__ float r0[256], r1[256];
   __shared__ int ri[256];
   const int W = 2 * sys.hw;
-  const int e = env_begin + blockIdx.x;
-  const float *pend = PEND + (long long)blockIdx.x * (W * W + 4);
+  const int e = env_begin + blk;
+  const float *pend = PEND + (long long)blk * (W * W + 4);
   float *le = st.le_img + (long long)e * W * W;
   float mse = 0.f, mle = 0.f;
   int arg = 0;
@@ -2929,6 +2961,24 @@ __global__ __launch_bounds__(256) void k_strehl_commit(DevSys sys, DevState st, 
     s[3] = s[3] + var;
     s[4] = cnt;
     s[5] = (ay == 0 || ax == 0 || ay == W - 1 || ax == W - 1) ? 1.f : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_strehl_commit(DevSys sys, DevState st, int env_begin,
+                                                       const float *__restrict__ PEND) {
+  strehl_commit_body(sys, st, env_begin, blockIdx.x, PEND);
+}
+
+// What follows the delay line in one launch: blocks [0, n) commit the pending PSF window (k_strehl_commit),
+// blocks [n, 2n) refresh the tip-tilt mirror's coefficients and the frame kernel's pivot from the
+// new voltages (k_dm_shape's tip-tilt branch).  The two halves touch different data.
+__global__ __launch_bounds__(256) void k_post_delay(DevSys sys, DevState st, int env_begin, int n,
+                                                    const float *__restrict__ PEND, int do_strehl, int ktt,
+                                                    const float *__restrict__ volts, int ldv) {
+  if ((int)blockIdx.x < n) {
+    if (do_strehl) strehl_commit_body(sys, st, env_begin, blockIdx.x, PEND);
+  } else {
+    dm_shape_tt_body(sys, st, env_begin, blockIdx.x - n, ktt, volts, ldv, threadIdx.x);
   }
 }
 

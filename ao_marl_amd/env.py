@@ -433,6 +433,7 @@ class VecAoEnv(object):
         # one library call per environment step (aomarl_env_step) when the configuration is the one it
         # covers (see _native_step_ok); the same launches in the same order as the call-by-call path
         self.native_step = True
+        self.fused_tail = True       # ... with the reductions folded into their consumers (see include/aomarl.h)
         # Btt coordinates of the last number_of_previous_dm + 1 commands, newest in slot _ring_pos
         self._ring, self._ring_pos, self._ring_next_valid = None, 0, False
         self._res_modes, self._glue, self._glue_keep = None, None, None
@@ -627,6 +628,7 @@ class VecAoEnv(object):
             g.n_agents, g.lohi, g.reward_factor = self.layout.n_agents, self._lohi_i32.data_ptr(), \
                 self._reward_factor
         g.modes_ring, g.res_modes = self._ring.data_ptr(), self._res_modes.data_ptr()
+        g.flags = 0 if self.fused_tail else la.ENV_STEP_UNFUSED
         ae = sup.autoencoder
         if ae is not None:
             g.denoiser, g.denoiser_f32 = ae._native().value, int(bool(ae.wants_f32()))

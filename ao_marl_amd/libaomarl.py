@@ -189,7 +189,10 @@ class EnvGlue(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nmodes", "dm_dim", "n_agents", "nhist", "ring_pos")] + \
                [(n, C.c_void_p) for n in ("sel", "mean_dm", "std_dm", "mean_res", "std_res", "lohi")] + \
                [("reward_factor", C.c_float), ("modes_ring", C.c_void_p), ("res_modes", C.c_void_p),
-                ("denoiser", C.c_void_p), ("denoiser_f32", C.c_int32)]
+                ("denoiser", C.c_void_p), ("denoiser_f32", C.c_int32), ("flags", C.c_int32)]
+
+
+ENV_STEP_UNFUSED = 1
 
 
 class AomarlError(RuntimeError):

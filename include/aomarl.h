@@ -421,7 +421,12 @@ typedef struct {
   void *denoiser;                      /* aomarl_denoiser* or NULL: the autoencoder branch of
                                           next_part_one_integrator (rlSupervisor.py:975-984); needs st->bincube */
   int32_t denoiser_f32;                /* 1: aomarl_denoiser_apply_f32                                 */
+  int32_t flags;                       /* AOMARL_ENV_STEP_*                                            */
 } aomarl_env_glue;
+/* Default: the chain with every split-K reduction folded into the kernel that consumes the product and
+ * independent small kernels sharing a launch (10 launches per step on the main stream).  With this
+ * flag: the entry points above called one after the other (14).  Bit-identical results. */
+#define AOMARL_ENV_STEP_UNFUSED 1
 int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, const float *action_dev,
                     float gain, float *accumx, float *accumy, float *state_out, float *reward_out,
                     void *stream);

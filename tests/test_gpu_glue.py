@@ -120,9 +120,10 @@ def test_modal_shortcut_equals_full_projection_path():
     assert used == 10
 
 
-@pytest.mark.parametrize("denoise", [False, True])
-def test_one_call_step_is_the_call_by_call_step(denoise):
-    """aomarl_env_step issues the launches of rl_step + rewards + linear_step from C: states, rewards,
+@pytest.mark.parametrize("denoise,fused_tail", [(False, True), (False, False), (True, True)])
+def test_one_call_step_is_the_call_by_call_step(denoise, fused_tail):
+    """aomarl_env_step issues the work of rl_step + rewards + linear_step from C -- by default in fused
+    form (10 launches instead of 14, see include/aomarl.h): states, rewards,
     commands, Strehl of a rollout are those of the call-by-call path BIT FOR BIT, also when the two
     are mixed (integrator-only steps and dictionary states go call by call), with per-agent rewards
     for several agents, and through the denoiser branch."""
@@ -139,6 +140,7 @@ def test_one_call_step_is_the_call_by_call_step(denoise):
                           autoencoder=SubapDenoiser.load(device="cuda:0") if denoise else None, **kw)
     a, b = mk(), mk()
     b.native_step = False
+    a.fused_tail = fused_tail       # True: split-K sums folded into their consumers, kernels sharing launches
     sa, sb = a.reset(), b.reset()
     assert torch.equal(sa, sb)
     g = torch.Generator(device="cuda:0").manual_seed(11)
