@@ -66,7 +66,7 @@ struct aomarl_ctx {
   bool time_fw = false;
   std::vector<hipEvent_t> fw_ev;            // 2 per timed launch, created on demand
   size_t fw_ev_used = 0;
-  hipStream_t atm_stream = nullptr;
+  hipStream_t atm_stream = nullptr, psf_stream = nullptr;
   hipEvent_t ev_frame = nullptr, ev_moved = nullptr, ev_psf = nullptr;
   bool psf_side = false;                // a k_target_finish_mfma launched on the side stream may still run
   const float *pre_screens = nullptr;
@@ -489,6 +489,7 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (!c) return 0;
   for (void *p : c->owned) (void)hipFree(p);
   if (c->atm_stream) { (void)hipStreamSynchronize(c->atm_stream); (void)hipStreamDestroy(c->atm_stream); }
+  if (c->psf_stream) { (void)hipStreamSynchronize(c->psf_stream); (void)hipStreamDestroy(c->psf_stream); }
   if (c->ev_frame) (void)hipEventDestroy(c->ev_frame);
   if (c->ev_moved) (void)hipEventDestroy(c->ev_moved);
   if (c->ev_psf) (void)hipEventDestroy(c->ev_psf);
@@ -672,8 +673,8 @@ static DevState dev_state(const aomarl_state *st) {
 }
 
 // ---------------------------------------------------------------- side stream
-// One low-priority stream of the library carries what is off the control chain's critical path: the
-// next frame's extrusions (aomarl_prefetch_atmos) and the second axis of the PSF window
+// Two streams of the library run beside the control / agent chain: the next frame's extrusions
+// (aomarl_prefetch_atmos) and, at the lowest priority, the second axis of the PSF window
 // (k_target_finish_mfma, whose result nobody reads before the end-of-step Strehl commit).
 static int side_stream(aomarl_ctx *c) {
   if (!c->atm_stream) {
@@ -681,7 +682,12 @@ static int side_stream(aomarl_ctx *c) {
     // chain should not queue behind it
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->atm_stream, hipStreamNonBlocking, prio_lo));
+    // the extrusions: with the control / agent chain down to ten launches they are as long as that chain,
+    // i.e. on the critical path themselves (the next frame kernel waits for them) -- normal priority,
+    // and nothing in front of them; the PSF finish (needed at the end of the step) has its own stream
+    const char *pe = getenv("AOMARL_SIDE_PRIORITY");
+    HIPCHK(hipStreamCreateWithPriority(&c->atm_stream, hipStreamNonBlocking, pe ? atoi(pe) : 0));
+    HIPCHK(hipStreamCreateWithPriority(&c->psf_stream, hipStreamNonBlocking, prio_lo));
     HIPCHK(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_moved, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_psf, hipEventDisableTiming));
@@ -2134,10 +2140,10 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     rc = side_stream(c);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_frame, s));
-    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
-    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->atm_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
+    HIPCHK(hipStreamWaitEvent(c->psf_stream, c->ev_frame, 0));
+    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
     LAUNCHCHK();
-    HIPCHK(hipEventRecord(c->ev_psf, c->atm_stream));
+    HIPCHK(hipEventRecord(c->ev_psf, c->psf_stream));
     c->psf_side = true;
     return 0;
   }

@@ -393,7 +393,6 @@ def main():
                  prefetch=not args.no_prefetch)
     env, sim, layout = w.env, w.sim, w.layout
     env.residual_shortcut = bool(args.residual_shortcut)
-    env.supervisor.next_part_one_split = True      # stage-by-stage call order (same kernels)
     if args.unfused:
         sim.set_option("force_unfused_frame", 1)
     if args.no_defer:
@@ -529,9 +528,13 @@ def stage_split(w, steps):
             pairs.setdefault(_label, []).append((e0, e1))
             return r
         setattr(sim, name, timed)
+    sup = w.env.supervisor
+    native, split = w.env.native_step, sup.next_part_one_split
+    w.env.native_step, sup.next_part_one_split = False, True     # stage by stage (same kernels, unfused tail)
     for _ in range(steps):
         w.one_step()
     torch.cuda.synchronize()
+    w.env.native_step, sup.next_part_one_split = native, split
     for name in saved:
         delattr(sim, name)                  # back to the class methods
     return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in pairs.items()}

@@ -16,3 +16,4 @@ sim.set_option("fused_debug", dbg)
 for _ in range(6):
     sim.frame_fused(noise=False, cog=True, dm_from_voltage=True)
 torch.cuda.synchronize()
+open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fw_kernel_name.txt"), "w").write(sim.frame_kernel_name())

@@ -22,6 +22,17 @@ m={k:sum(v)/len(v) for k,v in tot.items()}
 print("$TAG dbg=$DBG")
 for k in sorted(m): print("  %-28s %.4g" % (k, m[k]))
 if "FETCH_SIZE" in m: print("  fetch GB (x2 corr) %.3f  write GB %.4f  L2 hit %.3f" % (m["FETCH_SIZE"]*2048/1e9, m.get("WRITE_SIZE",0)*1024/1e9, m.get("TCC_HIT_sum",0)/max(1,m.get("TCC_HIT_sum",0)+m.get("TCC_MISS_sum",0))))
+import json
+name=open("gpurun_out/fw_kernel_name.txt").read().strip()
+if "FETCH_SIZE" in m:
+    # MI355X_MICROARCH.md: FETCH_SIZE counts 64-B units but reports in KiB of 32-B requests on gfx950 (x2);
+    # WRITE_SIZE in KiB
+    fetch=m["FETCH_SIZE"]*2048.; write=m.get("WRITE_SIZE",0)*1024.
+    out={"_config":"production_sh_40x40_8m_3layers","_envs":256,"_how":"tools/fw_pmc.sh: rocprofv3 --kernel-trace --pmc, one pass per counter group, mean of the last 3 launches of the kernel; frame kernel alone (tools/fw_pmc.py)",
+         "frame_fused":{"kernel":name,"hbm_traffic_bytes_per_launch":fetch+write,"fetch_bytes":fetch,"write_bytes":write,
+                        "l2_hit":m.get("TCC_HIT_sum",0)/max(1,m.get("TCC_HIT_sum",0)+m.get("TCC_MISS_sum",0)),
+                        "counters":{k:m[k] for k in sorted(m)}}}
+    json.dump(out,open("gpurun_out/$TAG"+"_pmc_frame_kernel.json","w"),indent=1)
 if "SQ_WAVE_CYCLES" in m: print("  wait_any/wave_cycles %.3f  active_any %.3f  wait_inst %.3f  valu/tilewave %.1f mfma %.1f lds %.1f vmem %.1f" % (m["SQ_WAIT_ANY"]/m["SQ_WAVE_CYCLES"], m["SQ_ACTIVE_INST_ANY"]/m["SQ_WAVE_CYCLES"], m["SQ_WAIT_INST_ANY"]/m["SQ_WAVE_CYCLES"], m["SQ_INSTS_VALU"]/335872., m["SQ_INSTS_MFMA"]/335872., m["SQ_INSTS_LDS"]/335872., m["SQ_INSTS_VMEM_RD"]/335872.))
 PY
 rm -rf gpurun_out/pmc_$TAG

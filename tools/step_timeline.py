@@ -15,12 +15,15 @@ ap.add_argument("trace")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--marker", default="k_frame_wave")
 ap.add_argument("--skip-last", type=int, default=0)
+ap.add_argument("--from-index", type=int, default=None, help="window = marker launches [i, i + steps] counted from the first one")
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]]
 if a.skip_last:
     marks = marks[:-a.skip_last]
+if a.from_index is not None:
+    marks = marks[a.from_index:a.from_index + a.steps + 1]
 marks = marks[-a.steps - 1:]
 steps = [rows[marks[k]:marks[k + 1]] for k in range(len(marks) - 1)]
 common = collections.Counter(len(s) for s in steps).most_common(1)[0][0]

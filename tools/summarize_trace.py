@@ -6,6 +6,7 @@ import argparse, csv, collections, sys
 ap = argparse.ArgumentParser(); ap.add_argument("trace"); ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--marker", default="k_wfs_spot")
 ap.add_argument("--skip-last", type=int, default=0, help="marker launches to drop at the end (bench.py's diagnostic pass)")
+ap.add_argument("--from-index", type=int, default=None, help="window = marker launches [i, i + steps] counted from the first one (e.g. bench.py: 1 reset + 1 timed reset + W warm-up = 2 + W)")
 ap.add_argument("--before", default=None, help="ignore everything from the first launch of this kernel on")
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
@@ -17,6 +18,8 @@ if a.before:
 marks = [int(r["Start_Timestamp"]) for r in rows if a.marker in r["Kernel_Name"]]
 if a.skip_last:
     marks = marks[:-a.skip_last]
+if a.from_index is not None:
+    marks = marks[a.from_index:a.from_index + a.steps + 1]
 t0 = marks[-a.steps - 1]; t1 = marks[-1]
 sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 agg = collections.OrderedDict()
