@@ -374,7 +374,12 @@ __device__ __forceinline__ void gh_split(float4 v, const float scale, hx4 &hi, h
 
 // Three k-tiles of global loads are in flight per thread (register stages, loop unrolled by three):
 // with the 10-20 k-tiles a split-K block walks, one tile ahead left the loop waiting for L2 / HBM on
-// every iteration (measured: 20 us per call, the fp32 kernel's time; the matrix pipe was idle).
+// every iteration.  The loop body has NO branch around a load and no select on a load's result: the
+// loads are unconditional (addresses clamped into the row; a tile past the end of the chunk is masked
+// to zero as it is staged into LDS, so the loop simply runs whole groups of three tiles) -- with
+// either, the compiler waits for the data where it is loaded and the three stages collapse into one
+// (3 000 lines of branchy ISA and 20 us per call; measured).  Scheduling barriers keep the loads where
+// they are written.  Callers make the chunk a multiple of 96 so that only the last chunk has padding.
 __device__ __forceinline__ void gh_mainloop(const float *__restrict__ A, int lda,
                                             const float *__restrict__ B, int ldb, int M, int N,
                                             int m0, int n0, int kb, int ke, _Float16 *S, f32x16 &acc,
@@ -382,70 +387,70 @@ __device__ __forceinline__ void gh_mainloop(const float *__restrict__ A, int lda
   // S: [2 buffers][4 planes: A hi, A lo, B hi, B lo][64 rows][GH_LD]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const float *pa0 = A + (long long)min(m0 + lr, M - 1) * lda + lc;
-  const float *pa1 = A + (long long)min(m0 + lr + 32, M - 1) * lda + lc;
-  const float *pb0 = B + (long long)min(n0 + lr, N - 1) * ldb + lc;
-  const float *pb1 = B + (long long)min(n0 + lr + 32, N - 1) * ldb + lc;
+  const float *pa0 = A + (long long)min(m0 + lr, M - 1) * lda;
+  const float *pa1 = A + (long long)min(m0 + lr + 32, M - 1) * lda;
+  const float *pb0 = B + (long long)min(n0 + lr, N - 1) * ldb;
+  const float *pb1 = B + (long long)min(n0 + lr + 32, N - 1) * ldb;
+  const int klast = (ke - 1) & ~3;               // last 16-byte group that holds a valid element (lda, ldb >= its end)
   constexpr int ST = 3;                          // register stages
   float4 ra0[ST], ra1[ST], rb0[ST], rb1[ST];
   auto gload = [&](int k0, int st) {             // st: compile-time after unrolling
-    if (k0 >= ke) return;
-    if (k0 + 32 <= ke) {
-      ra0[st] = *reinterpret_cast<const float4 *>(pa0 + k0); ra1[st] = *reinterpret_cast<const float4 *>(pa1 + k0);
-      rb0[st] = *reinterpret_cast<const float4 *>(pb0 + k0); rb1[st] = *reinterpret_cast<const float4 *>(pb1 + k0);
-    } else {
-      ra0[st] = g2_load4(pa0 - lc, k0 + lc, ke, true); ra1[st] = g2_load4(pa1 - lc, k0 + lc, ke, true);
-      rb0[st] = g2_load4(pb0 - lc, k0 + lc, ke, true); rb1[st] = g2_load4(pb1 - lc, k0 + lc, ke, true);
-    }
+    const int k = min(k0 + lc, klast);
+    ra0[st] = *reinterpret_cast<const float4 *>(pa0 + k); ra1[st] = *reinterpret_cast<const float4 *>(pa1 + k);
+    rb0[st] = *reinterpret_cast<const float4 *>(pb0 + k); rb1[st] = *reinterpret_cast<const float4 *>(pb1 + k);
   };
   constexpr int PL = 64 * GH_LD;                 // halfs per plane
-  auto lstore = [&](int buf, int st) {
+  auto lstore = [&](int buf, int st, int k0) {
     _Float16 *s = S + buf * 4 * PL;
+    float4 a0 = ra0[st], a1 = ra1[st], b0 = rb0[st], b1 = rb1[st];
+    if (k0 + 32 > ke) {                          // wave-uniform: the tile crosses the end of the chunk
+      const int k = k0 + lc;
+      const bool m0_ = k < ke, m1_ = k + 1 < ke, m2_ = k + 2 < ke, m3_ = k + 3 < ke;
+      auto msk = [&](float4 &v) { v.x = m0_ ? v.x : 0.f; v.y = m1_ ? v.y : 0.f; v.z = m2_ ? v.z : 0.f; v.w = m3_ ? v.w : 0.f; };
+      msk(a0); msk(a1); msk(b0); msk(b1);
+    }
     hx4 h, l;
-    gh_split(ra0[st], sa, h, l);
+    gh_split(a0, sa, h, l);
     *reinterpret_cast<hx4 *>(s + lr * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + PL + lr * GH_LD + lc) = l;
-    gh_split(ra1[st], sa, h, l);
+    gh_split(a1, sa, h, l);
     *reinterpret_cast<hx4 *>(s + (lr + 32) * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + PL + (lr + 32) * GH_LD + lc) = l;
-    gh_split(rb0[st], sb, h, l);
+    gh_split(b0, sb, h, l);
     *reinterpret_cast<hx4 *>(s + 2 * PL + lr * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + 3 * PL + lr * GH_LD + lc) = l;
-    gh_split(rb1[st], sb, h, l);
+    gh_split(b1, sb, h, l);
     *reinterpret_cast<hx4 *>(s + 2 * PL + (lr + 32) * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + 3 * PL + (lr + 32) * GH_LD + lc) = l;
   };
   // operand of lane l for k-chunk c (16 k): row (l & 31) of the wave's 32, k = 16 c + 8 (l >> 5) .. + 7
   const int ro = (lane & 31) * GH_LD + 8 * (lane >> 5);
 #pragma unroll
   for (int st = 0; st < ST; st++) gload(kb + 32 * st, st);
-  lstore(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  lstore(0, 0, kb);
   gload(kb + 32 * ST, 0);
   __syncthreads();
   int buf = 0;
   for (int k0 = kb; k0 < ke; k0 += 32 * ST) {
 #pragma unroll
     for (int u = 0; u < ST; u++) {
-      const int kc = k0 + 32 * u;                // the tile in LDS buffer `buf`
-      if (kc < ke) {                             // wave-uniform
-        const _Float16 *s = S + buf * 4 * PL;
-        const _Float16 *ah = s + wm * 32 * GH_LD + ro, *al = ah + PL;
-        const _Float16 *bh = s + 2 * PL + wn * 32 * GH_LD + ro, *bl = bh + PL;
+      const int kc = k0 + 32 * u;                // the tile in LDS buffer `buf` (all zeros past the end)
+      // tile kc + 32 sits in register stage (u + 1) % ST: split it into the other LDS buffer, then
+      // reuse that stage for tile kc + 32 (ST + 1); only then the matrix instructions on this tile
+      lstore(buf ^ 1, (u + 1) % ST, kc + 32);
+      gload(kc + 32 * (ST + 1), (u + 1) % ST);
+      __builtin_amdgcn_sched_barrier(0);
+      const _Float16 *s = S + buf * 4 * PL;
+      const _Float16 *ah = s + wm * 32 * GH_LD + ro, *al = ah + PL;
+      const _Float16 *bh = s + 2 * PL + wn * 32 * GH_LD + ro, *bl = bh + PL;
 #pragma unroll
-        for (int cch = 0; cch < 2; cch++) {
-          const hx8 Ah = *reinterpret_cast<const hx8 *>(ah + 16 * cch), Al = *reinterpret_cast<const hx8 *>(al + 16 * cch);
-          const hx8 Bh = *reinterpret_cast<const hx8 *>(bh + 16 * cch), Bl = *reinterpret_cast<const hx8 *>(bl + 16 * cch);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
-        }
-        // tile kc + 32 sits in register stage (u + 1) % ST: split it into the other LDS buffer, then
-        // reuse that stage for tile kc + 32 (ST + 1)
-        constexpr int nx = 0;
-        (void)nx;
-        if (kc + 32 < ke) {
-          lstore(buf ^ 1, (u + 1) % ST);
-          gload(kc + 32 * (ST + 1), (u + 1) % ST);
-        }
-        __syncthreads();
-        buf ^= 1;
+      for (int cch = 0; cch < 2; cch++) {
+        const hx8 Ah = *reinterpret_cast<const hx8 *>(ah + 16 * cch), Al = *reinterpret_cast<const hx8 *>(al + 16 * cch);
+        const hx8 Bh = *reinterpret_cast<const hx8 *>(bh + 16 * cch), Bl = *reinterpret_cast<const hx8 *>(bl + 16 * cch);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      buf ^= 1;
     }
   }
 }
@@ -758,11 +763,13 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     if (nsplit > 8) nsplit = 8;
     while (nsplit > 1 && (K / nsplit < 128 || (size_t)nsplit * M * N > ws_floats)) nsplit--;
   }
-  int kchunk = ((K + nsplit - 1) / nsplit + 31) & ~31;
-  nsplit = (K + kchunk - 1) / kchunk;
-  dim3 grid(bx, by, nsplit);
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
+  int kchunk = ((K + nsplit - 1) / nsplit + 31) & ~31;
+  if (al && fast && g_gemm_split_f16)            // whole groups of three k-tiles (gh_mainloop)
+    kchunk = ((K + nsplit - 1) / nsplit + 95) / 96 * 96;
+  nsplit = (K + kchunk - 1) / kchunk;
+  dim3 grid(bx, by, nsplit);
   if (al && fast && g_gemm_split_f16) {
     alpha /= (sa * sb);                            // also what the split-K reduce below applies
     if (alpha_out) *alpha_out = alpha;
