@@ -279,6 +279,10 @@ class Workload(object):
         """W untimed + exactly K timed steps between barriers + synchronisations.  Returns (elapsed s
         -- MAX over ranks --, host enqueue s, frame-kernel ms per launch from the library's events)."""
         torch = self.torch
+        # no cyclic-garbage collection inside the timed region: a collection that frees an earlier
+        # configuration's device buffers (hipFree synchronises the device) would be charged to this one
+        gc.collect()
+        gc.disable()
         for _ in range(warmup):
             self.one_step()
         torch.cuda.synchronize()
@@ -296,6 +300,7 @@ class Workload(object):
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         fk_ms = None
         if time_frame:
             tot, n = self.sim.frame_kernel_time()
@@ -311,6 +316,7 @@ class Workload(object):
     def time_reset(self, dist=None, backend="nccl"):
         """One env.reset() (RlSupervisor.reset: 2n extrusions per layer + the first frame), MAX over ranks."""
         torch = self.torch
+        gc.collect()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
