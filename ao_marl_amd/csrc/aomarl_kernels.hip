@@ -1181,6 +1181,15 @@ __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
   if (lam < 30.f) {
     // hardware exp2 / reciprocal (1 ulp): the cumulative sums move in their last bit against the
     // oracle's libm, which flips a count where u sits within ~1e-7 of a threshold
+#ifdef AOMARL_LIBM_NOISE
+    float p = expf(-lam), c = p;
+    int k = 0;
+    while (u > c && k < 200) {
+      k++;
+      p *= lam / (float)k;
+      c += p;
+    }
+#else
     float p = __expf(-lam), c = p;
     int k = 0;
     while (u > c && k < 200) {
@@ -1188,6 +1197,7 @@ __device__ __forceinline__ float poisson_draw(float lam, float u, float zn) {
       p *= lam * __builtin_amdgcn_rcpf((float)k);
       c += p;
     }
+#endif
     return (float)k;
   }
   float v = floorf(lam + sqrtf(lam) * zn + 0.5f);
@@ -1203,11 +1213,19 @@ __device__ __forceinline__ float sh_noise(float lam, float sigma, uint32_t seed,
   // Box-Muller on the transcendental unit: log2, and sin / cos of an angle given in revolutions
   // (v_sin_f32 / v_cos_f32 take exactly that) -- ~6 instructions against ~150 for libm's logf, sinf,
   // cosf; the normals agree with the oracle's to ~1e-6
+#ifdef AOMARL_LIBM_NOISE
+  const float r = sqrtf(-2.0f * logf(u01(x[1])));
+  const float a = 6.28318530717958647692f * u01(x[2]);
+  float v = poisson_draw(lam, u01(x[0]), r * cosf(a));
+  if (sigma > 0.f) v += sigma * (r * sinf(a));
+  return v;
+#else
   const float r = sqrtf(-2.0f * __logf(u01(x[1])));
   const float t = u01(x[2]);
   float v = poisson_draw(lam, u01(x[0]), r * __builtin_amdgcn_cosf(t));
   if (sigma > 0.f) v += sigma * (r * __builtin_amdgcn_sinf(t));
   return v;
+#endif
 }
 
 // MFMA stages + binning + normalisation (+noise) + COG of one sub-aperture whose complex amplitude
