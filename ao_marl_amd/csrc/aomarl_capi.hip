@@ -52,6 +52,7 @@ struct aomarl_ctx {
   int spot_blocks_per_env = 0, spot_lds_pad = 0;
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
   bool force_f32_dft = false;          // frame kernel: fp32 MFMAs through LDS tiles instead of split-fp16
+  bool no_extrude_sg = false;          // "extrude_unfused": scatter and gather of consecutive rounds as separate launches
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
   int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
   // "prefetch_atmos": the composite moves the atmosphere of the NEXT frame on a side stream as soon
@@ -710,6 +711,70 @@ static int atmos_wait_pending(aomarl_ctx *c, void *stream) {
   return 0;
 }
 
+static bool same_round(const RoundOps &a, const RoundOps &b) {
+  if (a.nops != b.nops) return false;
+  for (int i = 0; i < a.nops; i++)
+    if (a.layer[i] != b.layer[i] || a.dir[i] != b.dir[i]) return false;
+  return true;
+}
+
+// A sequence of extrusion rounds (round = at most one operation per layer).  Per round: stencil gather +
+// normals -> Z, Z . [A|B]^T (split-K tiles), new line -> ring.  Two consecutive rounds with the same
+// operations share a launch for the scatter of the first and the gather of the second (k_extrude_sg):
+// 2 launches per round instead of 3 -- every round of a reset (1296 of them), most rounds of a frame.
+static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const RoundOps *rounds, int nrounds,
+                          void *stream) {
+  if (n == 0 || nrounds == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DevState ds = dev_state(st);
+  Work w = work_layout(c, st->nenv);
+  float *Z = st->work + w.Z, *NEWL = st->work + w.NEWL, *ZREF = st->work + w.ZREF;
+  bool gathered = false;                        // Z / ZREF of the coming round are already in place
+  for (int r = 0; r < nrounds; r++) {
+    // one sub-round per [A|B] class
+    int nsub = 0;
+    for (int cls = 0; cls < c->nclass; cls++) {
+      RoundOps ops;
+      ops.nops = 0;
+      int ref = -1;
+      for (int i = 0; i < rounds[r].nops; i++)
+        if (c->abclass[rounds[r].layer[i]] == cls) {
+          ops.layer[ops.nops] = rounds[r].layer[i]; ops.dir[ops.nops] = rounds[r].dir[i]; ops.nops++; ref = rounds[r].layer[i];
+        }
+      if (ops.nops == 0) continue;
+      nsub++;
+      const int dimc = c->dim[ref], nsc = c->ns[ref], K = dimc + nsc;
+      const int ncol = n * ops.nops;
+      // fusing across rounds only when the round is ONE sub-round (one class) and the next round repeats it
+      const bool single = ops.nops == rounds[r].nops;
+      const bool fuse_next = single && !c->no_extrude_sg && r + 1 < nrounds && same_round(rounds[r], rounds[r + 1]);
+      if (!(gathered && single)) {
+        hipLaunchKernelGGL(k_extrude_gather, dim3(ncol, (nsc + (dimc + 3) / 4 + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
+                           ops, Z, w.ldz, ZREF);
+        LAUNCHCHK();
+      }
+      int nsp = 0;
+      float pscale = 1.f;
+      launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
+                     0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp,
+                     /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
+      LAUNCHCHK();
+      if (fuse_next) {
+        hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(512), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
+                           st->work + w.GEMM_ATM, nsp, ncol, dimc, pscale, Z, w.ldz);
+        gathered = true;
+      } else {
+        hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
+                           ZREF, st->work + w.GEMM_ATM, nsp, ncol, dimc, pscale);
+        gathered = false;
+      }
+      LAUNCHCHK();
+    }
+    (void)nsub;
+  }
+  return 0;
+}
+
 int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, const int32_t *layer,
                    const int32_t *dir, void *stream) {
   int rc = check_range(c, st, b, n);
@@ -717,40 +782,16 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
   if (n == 0 || nops == 0) return 0;
   if (nops < 0 || nops > c->nlayers) return fail("nops out of range");
   if ((hipStream_t)stream != c->atm_stream || !c->atm_stream) { rc = atmos_wait_pending(c, stream); if (rc) return rc; }
+  RoundOps ops;
+  ops.nops = nops;
   for (int i = 0; i < nops; i++) {
     if (layer[i] < 0 || layer[i] >= c->nlayers) return fail("extrude: bad layer");
     if (!(dir[i] == 1 || dir[i] == -1 || dir[i] == 2 || dir[i] == -2)) return fail("extrude: bad direction");
     for (int j = 0; j < i; j++)
       if (layer[j] == layer[i]) return fail("extrude: a layer appears twice in one round");
+    ops.layer[i] = layer[i]; ops.dir[i] = dir[i];
   }
-  hipStream_t s = (hipStream_t)stream;
-  DevState ds = dev_state(st);
-  Work w = work_layout(c, st->nenv);
-  // one sub-round per [A|B] class
-  for (int cls = 0; cls < c->nclass; cls++) {
-    RoundOps ops;
-    ops.nops = 0;
-    int ref = -1;
-    for (int i = 0; i < nops; i++)
-      if (c->abclass[layer[i]] == cls) { ops.layer[ops.nops] = layer[i]; ops.dir[ops.nops] = dir[i]; ops.nops++; ref = layer[i]; }
-    if (ops.nops == 0) continue;
-    const int dimc = c->dim[ref], nsc = c->ns[ref], K = dimc + nsc;
-    const int ncol = n * ops.nops;
-    float *Z = st->work + w.Z, *NEWL = st->work + w.NEWL, *ZREF = st->work + w.ZREF;
-    hipLaunchKernelGGL(k_extrude_gather, dim3(ncol, (nsc + (dimc + 3) / 4 + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
-                       ops, Z, w.ldz, ZREF);
-    LAUNCHCHK();
-    int nsp = 0;
-    float pscale = 1.f;
-    launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
-                   0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp,
-                   /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
-    LAUNCHCHK();
-    hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
-                       ZREF, st->work + w.GEMM_ATM, nsp, ncol, dimc, pscale);
-    LAUNCHCHK();
-  }
-  return 0;
+  return extrude_rounds(c, st, b, n, &ops, 1, stream);
 }
 
 // plan of one env: signed pixel shifts per layer after adding the per-frame deltas
@@ -769,18 +810,19 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
     int len = abs(p.kx[l]) + abs(p.ky[l]);
     if (len > maxr) maxr = len;
   }
+  if (maxr == 0) return 0;
+  if ((hipStream_t)stream != c->atm_stream || !c->atm_stream) { int rc = atmos_wait_pending(c, stream); if (rc) return rc; }
+  std::vector<RoundOps> rounds((size_t)maxr);
   for (int r = 0; r < maxr; r++) {
-    int32_t layer[AOMARL_MAX_LAYERS], dir[AOMARL_MAX_LAYERS];
-    int nops = 0;
+    RoundOps &o = rounds[r];
+    o.nops = 0;
     for (int l = 0; l < c->nlayers; l++) {
       int ax = abs(p.kx[l]), ay = abs(p.ky[l]);
-      if (r < ax) { layer[nops] = l; dir[nops] = p.kx[l] > 0 ? 1 : -1; nops++; }
-      else if (r < ax + ay) { layer[nops] = l; dir[nops] = p.ky[l] > 0 ? 2 : -2; nops++; }
+      if (r < ax) { o.layer[o.nops] = l; o.dir[o.nops] = p.kx[l] > 0 ? 1 : -1; o.nops++; }
+      else if (r < ax + ay) { o.layer[o.nops] = l; o.dir[o.nops] = p.ky[l] > 0 ? 2 : -2; o.nops++; }
     }
-    int rc = aomarl_extrude(c, st, b, n, nops, layer, dir, stream);
-    if (rc) return rc;
   }
-  return 0;
+  return extrude_rounds(c, st, b, n, rounds.data(), maxr, stream);
 }
 
 static int move_atmos_now(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
@@ -903,14 +945,15 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
   // refresh_screen: 2*dim extrusions along x, sign of deltax (atmosCompass.py:141-145)
   int maxr = 0;
   for (int l = 0; l < c->nlayers; l++) if (2 * c->dim[l] > maxr) maxr = 2 * c->dim[l];
+  std::vector<RoundOps> rounds((size_t)maxr);
   for (int r = 0; r < maxr; r++) {
-    int32_t layer[AOMARL_MAX_LAYERS], dir[AOMARL_MAX_LAYERS];
-    int nops = 0;
+    RoundOps &o = rounds[r];
+    o.nops = 0;
     for (int l = 0; l < c->nlayers; l++)
-      if (r < 2 * c->dim[l]) { layer[nops] = l; dir[nops] = c->deltax[l] > 0.f ? 1 : -1; nops++; }
-    rc = aomarl_extrude(c, st, b, n, nops, layer, dir, stream);
-    if (rc) return rc;
+      if (r < 2 * c->dim[l]) { o.layer[o.nops] = l; o.dir[o.nops] = c->deltax[l] > 0.f ? 1 : -1; o.nops++; }
   }
+  rc = extrude_rounds(c, st, b, n, rounds.data(), maxr, stream);
+  if (rc) return rc;
   // pending PSF of the fresh atmosphere with flat DMs: comp_strehl before the first
   // next_part_one is well defined
   if (!c->sys.tar_all_int && !st->tar_phase) return 0;
@@ -1001,6 +1044,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
+  if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "gemm_split_f16")) { g_gemm_split_f16 = value != 0; return 0; }
   if (!strcmp(name, "time_frame_kernel")) {
     // value = number of launches to keep event pairs for (0: off)

@@ -806,23 +806,21 @@ struct RoundOps {
 };
 
 // Z[col][0..ns) = screen[stencil] - zref ; Z[col][ns..ns+n) = amplitude * N(0,1)
-__global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st, int env_begin,
-                                                        RoundOps ops, float *__restrict__ Z,
-                                                        int ldz, float *__restrict__ ZREF) {
-  const int col = blockIdx.x;
+// work item j of column col, for a ring origin (ox, oy) and an extrusion counter cnt given by the caller
+__device__ __forceinline__ void extrude_gather_item(const DevSys &sys, const DevState &st, int env_begin,
+                                                    const RoundOps &ops, float *__restrict__ Z, int ldz,
+                                                    float *__restrict__ ZREF, int col, int j, int ox, int oy,
+                                                    uint32_t cnt) {
   const int e = env_begin + col / ops.nops, op = col % ops.nops;
   const int li = ops.layer[op], dir = ops.dir[op];
   const DevLayer &L = sys.layers[li];
   const int n = L.dim, ns = L.ns;
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-  const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
   const bool top_right = (dir == 1 || dir == -2);
   const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, ox, oy, n)];
   const uint32_t *ist = (dir == 1 || dir == -1) ? L.istx : L.isty;
   const uint32_t seed = st.seeds[e] + (uint32_t)li;
-  const uint32_t cnt = st.ext_count[e * sys.nlayers + li];
-  // threads [0, ns): stencil values; threads [ns, ns + ceil(n / 4)): 4 normals each (one Philox block)
-  const int j = blockIdx.y * blockDim.x + threadIdx.x;
+  // items [0, ns): stencil values; items [ns, ns + ceil(n / 4)): 4 normals each (one Philox block)
   if (j < ns) {
     uint32_t xy = ist[j];
     Z[(long long)col * ldz + j] = base[ring_idx(xy & 0xFFFF, xy >> 16, ox, oy, n)] - zref;
@@ -837,24 +835,29 @@ __global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st,
   if (j == 0) ZREF[col] = zref;
 }
 
-// new line -> ring (+ mirror columns), then the ring origin / extrusion counter of this
-// (environment, layer) advance: one block per column, so nobody else reads that origin
-__global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st, int env_begin,
-                                                         RoundOps ops,
-                                                         const float *__restrict__ NEWL, int ldn,
-                                                         const float *__restrict__ ZREF,
-                                                         const float *__restrict__ P, int nsplit,
-                                                         int ncol, int pn, float pscale) {
+__global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st, int env_begin,
+                                                        RoundOps ops, float *__restrict__ Z,
+                                                        int ldz, float *__restrict__ ZREF) {
+  const int col = blockIdx.x;
+  const int e = env_begin + col / ops.nops, li = ops.layer[col % ops.nops];
+  const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
+  extrude_gather_item(sys, st, env_begin, ops, Z, ldz, ZREF, col, blockIdx.y * blockDim.x + threadIdx.x, ox, oy,
+                      st.ext_count[e * sys.nlayers + li]);
+}
+
+// new line -> ring (+ mirror columns) for a ring origin (ox, oy); returns the advanced origin
+__device__ __forceinline__ void extrude_scatter_col(const DevSys &sys, const DevState &st, int env_begin,
+                                                    const RoundOps &ops, const float *__restrict__ NEWL, int ldn,
+                                                    const float *__restrict__ ZREF, const float *__restrict__ P,
+                                                    int nsplit, int ncol, int pn, float pscale, int col, int ox,
+                                                    int oy, int &nox, int &noy) {
   // nsplit > 0: the new lines are still split-K partial tiles P[z][ncol][pn] of the extrusion GEMM
   // (times 1 / pscale when the split-f16 kernel produced them from scaled operands)
-  const int col = blockIdx.x;
   const int e = env_begin + col / ops.nops, op = col % ops.nops;
   const int li = ops.layer[op], dir = ops.dir[op];
   const DevLayer &L = sys.layers[li];
   const int n = L.dim;
   float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-  int *o = st.origin + (e * sys.nlayers + li) * 2;
-  const int ox = o[0], oy = o[1];
   const float zref = ZREF[col];
   const int stride = n + RING_PAD;
   for (int r = threadIdx.x; r < n; r += blockDim.x) {
@@ -883,14 +886,86 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
     base[py * stride + px] = v;
     if (px < RING_PAD) base[py * stride + n + px] = v;     // mirror columns
   }
+  nox = ox; noy = oy;
+  if (dir == 1) nox = (ox + 1 >= n) ? 0 : ox + 1;
+  else if (dir == -1) nox = (ox - 1 < 0) ? n - 1 : ox - 1;
+  else if (dir == 2) noy = (oy + 1 >= n) ? 0 : oy + 1;
+  else noy = (oy - 1 < 0) ? n - 1 : oy - 1;
+}
+
+// new line -> ring, then the ring origin / extrusion counter of this (environment, layer) advance:
+// one block per column, so nobody else reads that origin
+__global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st, int env_begin,
+                                                         RoundOps ops,
+                                                         const float *__restrict__ NEWL, int ldn,
+                                                         const float *__restrict__ ZREF,
+                                                         const float *__restrict__ P, int nsplit,
+                                                         int ncol, int pn, float pscale) {
+  const int col = blockIdx.x;
+  const int e = env_begin + col / ops.nops, li = ops.layer[col % ops.nops];
+  int *o = st.origin + (e * sys.nlayers + li) * 2;
+  const int ox = o[0], oy = o[1];
+  int nox, noy;
+  extrude_scatter_col(sys, st, env_begin, ops, NEWL, ldn, ZREF, P, nsplit, ncol, pn, pscale, col, ox, oy, nox, noy);
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (dir == 1) o[0] = (ox + 1 >= n) ? 0 : ox + 1;
-    else if (dir == -1) o[0] = (ox - 1 < 0) ? n - 1 : ox - 1;
-    else if (dir == 2) o[1] = (oy + 1 >= n) ? 0 : oy + 1;
-    else o[1] = (oy - 1 < 0) ? n - 1 : oy - 1;
+    o[0] = nox; o[1] = noy;
     st.ext_count[e * sys.nlayers + li] += 1u;
   }
+}
+
+// scatter of round r and gather of round r + 1 in one launch, for two consecutive rounds with the SAME
+// operations (every round of a reset; most rounds of a frame): the dependency is column-local -- a
+// column's next stencil reads only that column's screen, including the line just written -- so one
+// block does both, with the advanced origin and counter carried in registers (never re-read: a
+// uniform re-load could come from the scalar cache, which the block's own stores do not update).
+__global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int env_begin, RoundOps ops,
+                                                    const float *__restrict__ NEWL, int ldn,
+                                                    float *__restrict__ ZREF, const float *__restrict__ P,
+                                                    int nsplit, int ncol, int pn, float pscale,
+                                                    float *__restrict__ Z, int ldz) {
+  const int col = blockIdx.x;
+  const int e = env_begin + col / ops.nops, li = ops.layer[col % ops.nops];
+  int *o = st.origin + (e * sys.nlayers + li) * 2;
+  const int ox = o[0], oy = o[1];
+  const uint32_t cnt = st.ext_count[e * sys.nlayers + li];
+  int nox, noy;
+  extrude_scatter_col(sys, st, env_begin, ops, NEWL, ldn, ZREF, P, nsplit, ncol, pn, pscale, col, ox, oy, nox, noy);
+  __syncthreads();                               // the new line is in the ring (block-visible); ZREF[col] was read by everyone
+  if (threadIdx.x == 0) {
+    o[0] = nox; o[1] = noy;
+    st.ext_count[e * sys.nlayers + li] = cnt + 1u;
+  }
+  // the gather of extrude_gather_item, restated so that one thread's loads are independent of each
+  // other (index loads first, then the screen loads): with one block per column instead of six, a
+  // dependent pair of loads per item was the whole kernel
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim, ns = L.ns, dir = ops.dir[col % ops.nops];
+  const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  const bool top_right = (dir == 1 || dir == -2);
+  const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, nox, noy, n)];
+  const uint32_t *ist = (dir == 1 || dir == -1) ? L.istx : L.isty;
+  constexpr int U = 4;
+  for (int j0 = threadIdx.x; j0 < ns; j0 += U * blockDim.x) {
+    uint32_t xy[U];
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) xy[u] = ist[min(j0 + u * (int)blockDim.x, ns - 1)];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = base[ring_idx(xy[u] & 0xFFFF, xy[u] >> 16, nox, noy, n)];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (j0 + u * (int)blockDim.x < ns) Z[(long long)col * ldz + j0 + u * blockDim.x] = v[u] - zref;
+  }
+  const uint32_t seed = st.seeds[e] + (uint32_t)li;
+  for (int g = threadIdx.x; g < (n + 3) / 4; g += blockDim.x) {
+    float z4[4];
+    philox_normal4(seed, 0u, cnt + 1u, 0u, (uint32_t)g, z4);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (4 * g + u < n) Z[(long long)col * ldz + ns + 4 * g + u] = L.amp * z4[u];
+  }
+  if (threadIdx.x == 0) ZREF[col] = zref;
 }
 
 __global__ void k_fill_f32(float *p, long long n, float v) {

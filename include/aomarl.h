@@ -254,6 +254,8 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * aomarl_prefetch_atmos),
  * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
  * ctx may be NULL),
+ * "extrude_unfused" (1: scatter and gather of two consecutive extrusion rounds with the same operations
+ * as separate launches; default 0: one launch, k_extrude_sg -- same values),
  * "defer_dm_shape" (the composites
  * aomarl_next_part_two / aomarl_next_part_one use AOMARL_APPLY_DEFER_STACK_SHAPE /
  * AOMARL_IMG_DM_FROM_VOLTAGE when available: st->voltage is the DM state and the stack-array
