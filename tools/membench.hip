@@ -65,6 +65,80 @@ __global__ __launch_bounds__(256) void k_read(const float *__restrict__ scr, lon
   if (acc == 12345.678f) out[0] = acc + pad[lds_pad ? 0 : 0];
 }
 
+// WIDE pattern: one instruction = (16 / W) rows x (W x 64) contiguous bytes (the rows of W adjacent tiles);
+// W instructions per layer fetch a group of W tiles.  Same bytes as MAP 0 / 1, longer contiguous pieces.
+template <int W, int DEPTH>
+__global__ __launch_bounds__(256) void k_read_wide(const float *__restrict__ scr, long long env_stride,
+                                                   const int *__restrict__ org, float *__restrict__ out, int nenv) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = blockIdx.x, e = 4 * blockIdx.y + wv;
+  if (e >= nenv) return;
+  constexpr int CH = 4 * W, RPI = 64 / CH;                 // 16-byte chunks per row, rows per instruction
+  const int row = lane / CH, col = 4 * (lane % CH);
+  const float *lay[NL];
+  unsigned lpx[NL], lrow[NL][W];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    lay[l] = scr + (long long)e * env_stride + (long long)l * DIM * LD;
+    unsigned px = org[(e * NL + l) * 2] + 4;
+    px -= px >= DIM ? DIM : 0;
+    lpx[l] = px + col;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      unsigned py = org[(e * NL + l) * 2 + 1] + 4 + 16 * r + RPI * i + row;
+      py -= py >= DIM ? DIM : 0;
+      lrow[l][i] = py * LD;
+    }
+  }
+  float raw[DEPTH][NL][W][4];
+  auto fetch = [&](int g, int slot) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      unsigned px = 16u * W * g + lpx[l]; px = min(px, px - DIM);
+#pragma unroll
+      for (int i = 0; i < W; i++) {
+        const f4u v = *reinterpret_cast<const f4u *>(lay[l] + (lrow[l][i] + px));
+#pragma unroll
+        for (int j = 0; j < 4; j++) raw[slot][l][i][j] = v.v[j];
+      }
+    }
+  };
+  constexpr int NG = NT / W;
+  float acc = 0.f;
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) fetch(d, d);
+  for (int k = 0; k < NG; k += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+      if (k + d < NG) {
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+#pragma unroll
+          for (int i = 0; i < W; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += raw[d][l][i][j];
+        if (k + d + DEPTH < NG) fetch(k + d + DEPTH, d);
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int W, int DEPTH>
+float run_wide(const float *scr, long long es, const int *org, float *out, int nenv) {
+  dim3 grid(NT, (nenv + 3) / 4), blk(256);
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_read_wide<W, DEPTH>), grid, blk, 0, 0, scr, es, org, out, nenv);
+  CK(hipEventRecord(a));
+  const int reps = 10;
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_read_wide<W, DEPTH>), grid, blk, 0, 0, scr, es, org, out, nenv);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
 template <int MAP, int DEPTH, int MODE>
 float run(const float *scr, long long es, const int *org, float *out, int nenv, int lds) {
   dim3 grid(NT, MODE == 0 ? (nenv + 3) / 4 : nenv), blk(256);
@@ -104,5 +178,11 @@ int main() {
   R(0, 1, 1, 0); R(0, 2, 1, 0); R(0, 4, 1, 0);
   R(1, 1, 1, 0); R(1, 2, 1, 0);
   R(0, 2, 0, 40000); R(0, 2, 0, 60000); R(1, 2, 0, 40000);
+#define RW(W, DEPTH)                                                                          \
+  do {                                                                                        \
+    float ms = run_wide<W, DEPTH>(scr, es, org, out, nenv);                                    \
+    printf("wide %d tiles per group, depth %d groups : %.3f ms  %.2f TB/s\n", W, DEPTH, ms, bytes / ms * 1e-9); \
+  } while (0)
+  RW(2, 1); RW(2, 2); RW(4, 1); RW(4, 2); RW(8, 1);
   return 0;
 }
