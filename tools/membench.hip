@@ -184,5 +184,20 @@ int main() {
     printf("wide %d tiles per group, depth %d groups : %.3f ms  %.2f TB/s\n", W, DEPTH, ms, bytes / ms * 1e-9); \
   } while (0)
   RW(2, 1); RW(2, 2); RW(4, 1); RW(4, 2); RW(8, 1);
+  // every environment at the SAME ring origin (what a simulation has: one wind for all) -- do the
+  // environments' equal row offsets, one environment stride apart, fall on the same memory channels?
+  for (auto &v : h) v = 123;
+  CK(hipMemcpy(org, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+  printf("same origin in every environment, environment stride %lld B:\n", es * 4);
+  R(1, 2, 0, 0); R(1, 4, 0, 0);
+  for (long long padf : {64LL, 1024LL, 4160LL, 16448LL}) {
+    float *scr2;
+    const long long es2 = es + padf;
+    CK(hipMalloc(&scr2, sizeof(float) * es2 * nenv));
+    CK(hipMemset(scr2, 0, sizeof(float) * es2 * nenv));
+    float ms = run<1, 2, 0>(scr2, es2, org, out, nenv, 0);
+    printf("  stride + %lld B : map 1 depth 2 : %.3f ms  %.2f TB/s\n", padf * 4, ms, bytes / ms * 1e-9);
+    CK(hipFree(scr2));
+  }
   return 0;
 }
