@@ -35,16 +35,19 @@ def test_struct_sizes_match_the_header():
     import subprocess
     import tempfile
     from ao_marl_amd import libaomarl as la
-    src = ('#include <stdio.h>\n#include "aomarl.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
+    src = ('#include <stdio.h>\n#include "aomarl.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
            'sizeof(aomarl_desc),sizeof(aomarl_state),sizeof(aomarl_dm_desc),'
-           'sizeof(aomarl_layer_desc));return 0;}\n')
+           'sizeof(aomarl_layer_desc),sizeof(aomarl_actor_desc),sizeof(aomarl_env_glue),'
+           'sizeof(aomarl_sac_desc));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o",
                                os.path.join(d, "p"), os.path.join(d, "p.c")])
         out = subprocess.check_output([os.path.join(d, "p")]).decode().split()
     assert [int(x) for x in out] == [ctypes.sizeof(la.Desc), ctypes.sizeof(la.State),
-                                     ctypes.sizeof(la.DmDesc), ctypes.sizeof(la.LayerDesc)]
+                                     ctypes.sizeof(la.DmDesc), ctypes.sizeof(la.LayerDesc),
+                                     ctypes.sizeof(la.ActorDesc), ctypes.sizeof(la.EnvGlue),
+                                     ctypes.sizeof(la.SacDesc)]
 
 
 def test_product_fails_loudly_without_gpu():
