@@ -52,6 +52,7 @@ struct aomarl_ctx {
   int spot_blocks_per_env = 0, spot_lds_pad = 0;
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
   bool force_f32_dft = false;          // frame kernel: fp32 MFMAs through LDS tiles instead of split-fp16
+  bool reset_untransposed = false;     // "reset_untransposed": the reset's x extrusions on the row-major screen itself
   bool no_extrude_sg = false;          // "extrude_unfused": scatter and gather of consecutive rounds as separate launches
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
   int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
@@ -217,6 +218,11 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
     }
     UP(uint32_t, ix.data(), ix.size(), D.istx);
     UP(uint32_t, iy.data(), iy.size(), D.isty);
+    {
+      std::vector<uint32_t> it(ix.size());
+      for (size_t k = 0; k < ix.size(); k++) it[k] = (ix[k] >> 16) | (ix[k] << 16);
+      UP(uint32_t, it.data(), it.size(), D.istT);
+    }
     // [A | B] concatenated, shared between layers that were given the same host matrices
     int cls = -1;
     for (int m = 0; m < c->nclass; m++)
@@ -714,7 +720,7 @@ static int atmos_wait_pending(aomarl_ctx *c, void *stream) {
 static bool same_round(const RoundOps &a, const RoundOps &b) {
   if (a.nops != b.nops) return false;
   for (int i = 0; i < a.nops; i++)
-    if (a.layer[i] != b.layer[i] || a.dir[i] != b.dir[i]) return false;
+    if (a.layer[i] != b.layer[i] || a.dir[i] != b.dir[i] || a.tflag[i] != b.tflag[i]) return false;
   return true;
 }
 
@@ -739,7 +745,8 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
       int ref = -1;
       for (int i = 0; i < rounds[r].nops; i++)
         if (c->abclass[rounds[r].layer[i]] == cls) {
-          ops.layer[ops.nops] = rounds[r].layer[i]; ops.dir[ops.nops] = rounds[r].dir[i]; ops.nops++; ref = rounds[r].layer[i];
+          ops.layer[ops.nops] = rounds[r].layer[i]; ops.dir[ops.nops] = rounds[r].dir[i];
+          ops.tflag[ops.nops] = rounds[r].tflag[i]; ops.nops++; ref = rounds[r].layer[i];
         }
       if (ops.nops == 0) continue;
       nsub++;
@@ -789,7 +796,7 @@ int aomarl_extrude(aomarl_ctx *c, aomarl_state *st, int b, int n, int nops, cons
     if (!(dir[i] == 1 || dir[i] == -1 || dir[i] == 2 || dir[i] == -2)) return fail("extrude: bad direction");
     for (int j = 0; j < i; j++)
       if (layer[j] == layer[i]) return fail("extrude: a layer appears twice in one round");
-    ops.layer[i] = layer[i]; ops.dir[i] = dir[i];
+    ops.layer[i] = layer[i]; ops.dir[i] = dir[i]; ops.tflag[i] = 0;
   }
   return extrude_rounds(c, st, b, n, &ops, 1, stream);
 }
@@ -818,8 +825,8 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
     o.nops = 0;
     for (int l = 0; l < c->nlayers; l++) {
       int ax = abs(p.kx[l]), ay = abs(p.ky[l]);
-      if (r < ax) { o.layer[o.nops] = l; o.dir[o.nops] = p.kx[l] > 0 ? 1 : -1; o.nops++; }
-      else if (r < ax + ay) { o.layer[o.nops] = l; o.dir[o.nops] = p.ky[l] > 0 ? 2 : -2; o.nops++; }
+      if (r < ax) { o.layer[o.nops] = l; o.dir[o.nops] = p.kx[l] > 0 ? 1 : -1; o.tflag[o.nops] = 0; o.nops++; }
+      else if (r < ax + ay) { o.layer[o.nops] = l; o.dir[o.nops] = p.ky[l] > 0 ? 2 : -2; o.tflag[o.nops] = 0; o.nops++; }
     }
   }
   return extrude_rounds(c, st, b, n, rounds.data(), maxr, stream);
@@ -949,11 +956,29 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
   for (int r = 0; r < maxr; r++) {
     RoundOps &o = rounds[r];
     o.nops = 0;
+    // The 2 n extrusions of a reset all run along x: every new line is a COLUMN of the row-major ring
+    // (648 scattered 4-byte writes per environment and layer, and the stencil's full first column 648
+    // scattered reads: one 64-byte sector each).  Done on the TRANSPOSED screen they are row
+    // operations -- the x stencil with its coordinates exchanged, the zero screen is its own
+    // transpose -- and one in-place transposition at the end gives the same screen, bit for bit.
+    const bool tr = !c->reset_untransposed;
     for (int l = 0; l < c->nlayers; l++)
-      if (r < 2 * c->dim[l]) { o.layer[o.nops] = l; o.dir[o.nops] = c->deltax[l] > 0.f ? 1 : -1; o.nops++; }
+      if (r < 2 * c->dim[l]) {
+        const int dx = c->deltax[l] > 0.f ? 1 : -1;
+        o.layer[o.nops] = l; o.dir[o.nops] = tr ? 2 * dx : dx; o.tflag[o.nops] = tr ? 1 : 0; o.nops++;
+      }
   }
   rc = extrude_rounds(c, st, b, n, rounds.data(), maxr, stream);
   if (rc) return rc;
+  if (!c->reset_untransposed) {
+    for (int l = 0; l < c->nlayers; l++) {
+      const int T = (c->dim[l] + 31) / 32;
+      hipLaunchKernelGGL(k_transpose_ring, dim3(T * (T + 1) / 2, n), dim3(256), 0, s, c->sys, ds, b, l, T);
+      LAUNCHCHK();
+      hipLaunchKernelGGL(k_refresh_mirror, dim3((c->dim[l] * RING_PAD + 255) / 256, n), dim3(256), 0, s, c->sys, ds, b, l);
+      LAUNCHCHK();
+    }
+  }
   // pending PSF of the fresh atmosphere with flat DMs: comp_strehl before the first
   // next_part_one is well defined
   if (!c->sys.tar_all_int && !st->tar_phase) return 0;
@@ -1045,6 +1070,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
+  if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
   if (!strcmp(name, "gemm_split_f16")) { g_gemm_split_f16 = value != 0; return 0; }
   if (!strcmp(name, "time_frame_kernel")) {
     // value = number of launches to keep event pairs for (0: off)

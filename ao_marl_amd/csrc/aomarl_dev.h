@@ -12,6 +12,7 @@ struct DevLayer {
   int dim, ns;
   long long screen_off;          // floats from the env's screen base
   const uint32_t *istx, *isty;   // packed (x | y << 16) logical stencil coordinates
+  const uint32_t *istT;          // istx with x and y exchanged: the x stencil of the TRANSPOSED screen (reset)
   const float *AB;               // [dim][ldab]: row r = [A[r][0..ns) | B[r][0..dim)]
   int ldab;
   float amp;

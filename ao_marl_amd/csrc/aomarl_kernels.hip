@@ -803,6 +803,7 @@ struct RoundOps {
   int nops;
   int layer[AOMARL_MAX_LAYERS];
   int dir[AOMARL_MAX_LAYERS];
+  int tflag[AOMARL_MAX_LAYERS];     // 1: the screen holds the transpose (reset): dir is +-2, stencil istT
 };
 
 // Z[col][0..ns) = screen[stencil] - zref ; Z[col][ns..ns+n) = amplitude * N(0,1)
@@ -818,7 +819,7 @@ __device__ __forceinline__ void extrude_gather_item(const DevSys &sys, const Dev
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const bool top_right = (dir == 1 || dir == -2);
   const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, ox, oy, n)];
-  const uint32_t *ist = (dir == 1 || dir == -1) ? L.istx : L.isty;
+  const uint32_t *ist = ops.tflag[op] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
   const uint32_t seed = st.seeds[e] + (uint32_t)li;
   // items [0, ns): stencil values; items [ns, ns + ceil(n / 4)): 4 normals each (one Philox block)
   if (j < ns) {
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const bool top_right = (dir == 1 || dir == -2);
   const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, nox, noy, n)];
-  const uint32_t *ist = (dir == 1 || dir == -1) ? L.istx : L.isty;
+  const uint32_t *ist = ops.tflag[col % ops.nops] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
   constexpr int U = 4;
   for (int j0 = threadIdx.x; j0 < ns; j0 += U * blockDim.x) {
     uint32_t xy[U];
@@ -966,6 +967,51 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
       if (4 * g + u < n) Z[(long long)col * ldz + ns + 4 * g + u] = L.amp * z4[u];
   }
   if (threadIdx.x == 0) ZREF[col] = zref;
+}
+
+// in-place transposition of the n x n ring of (environment, layer li): 32 x 32 tiles, block = the tile
+// pair (i, j) / (j, i), i <= j; the ring origin is exchanged with it.  The mirror columns are rebuilt by
+// k_refresh_mirror afterwards.
+__global__ __launch_bounds__(256) void k_transpose_ring(DevSys sys, DevState st, int env_begin, int li, int T) {
+  __shared__ float A[32][33], B[32][33];
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim, stride = n + RING_PAD;
+  const int e = env_begin + blockIdx.y;
+  float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  // pair index -> (i, j), i <= j (row-major over the upper triangle)
+  int k = blockIdx.x, i = 0;
+  while (k >= T - i) { k -= T - i; i++; }
+  const int j = i + k;
+  const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
+  for (int ty = ty0; ty < 32; ty += 8) {
+    const int ya = 32 * i + ty, xa = 32 * j + tx;          // tile (i, j): rows of tile row i, columns of tile column j
+    const int yb = 32 * j + ty, xb = 32 * i + tx;
+    A[ty][tx] = (ya < n && xa < n) ? base[ya * stride + xa] : 0.f;
+    B[ty][tx] = (yb < n && xb < n) ? base[yb * stride + xb] : 0.f;
+  }
+  __syncthreads();
+  for (int ty = ty0; ty < 32; ty += 8) {
+    const int ya = 32 * i + ty, xa = 32 * j + tx;
+    const int yb = 32 * j + ty, xb = 32 * i + tx;
+    if (ya < n && xa < n) base[ya * stride + xa] = B[tx][ty];
+    if (i != j && yb < n && xb < n) base[yb * stride + xb] = A[tx][ty];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int *o = st.origin + (e * sys.nlayers + li) * 2;
+    const int ox = o[0], oy = o[1];
+    o[0] = oy; o[1] = ox;
+  }
+}
+
+__global__ void k_refresh_mirror(DevSys sys, DevState st, int env_begin, int li) {
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim, stride = n + RING_PAD;
+  const int e = env_begin + blockIdx.y;
+  float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n * RING_PAD) return;
+  const int y = p / RING_PAD, x = p - y * RING_PAD;
+  base[y * stride + n + x] = base[y * stride + x];
 }
 
 __global__ void k_fill_f32(float *p, long long n, float v) {

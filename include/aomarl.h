@@ -254,6 +254,9 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * aomarl_prefetch_atmos),
  * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
  * ctx may be NULL),
+ * "reset_untransposed" (1: aomarl_reset runs its 2 n x-extrusions on the row-major screen itself; default 0:
+ * on the transposed screen -- every new line a row instead of 648 scattered 4-byte writes -- followed by
+ * one in-place transposition: same screens, bit for bit, 46 instead of 60 ms per 256 environments),
  * "extrude_unfused" (1: scatter and gather of two consecutive extrusion rounds with the same operations
  * as separate launches; default 0: one launch, k_extrude_sg -- same values),
  * "defer_dm_shape" (the composites

@@ -64,6 +64,30 @@ def test_reset_screens_match_oracle(setup):
             assert np.std(o.screens[l]) > 0.05
 
 
+def test_reset_variants_give_the_same_screens(setup):
+    """The reset runs its 2 n x-extrusions on the TRANSPOSED screen (row operations) and transposes in
+    place at the end, with the scatter of one round and the gather of the next in one launch; both can be
+    switched off: the very same screens, ring origins and extrusion counters, bit for bit, also after
+    further moves in every direction."""
+    from ao_marl_amd.sim import HipSim
+    _, s, _, _, _ = setup
+    out = []
+    for opts in ((("reset_untransposed", 1), ("extrude_unfused", 1)), (("reset_untransposed", 0), ("extrude_unfused", 1)),
+                 (("reset_untransposed", 0), ("extrude_unfused", 0))):
+        sim = HipSim(s, nenv=len(SEEDS))
+        for k, v in opts:
+            sim.set_option(k, v)
+        sim.reset(SEEDS)
+        for _ in range(5):
+            sim.move_atmos()
+        for l in range(s.nscreens):
+            sim.extrude([l], [(-1, 2, -2, 1)[l % 4]])
+        out.append((sim.t["screens"].clone(), sim.t["origin"].clone(), sim.t["ext_count"].clone()))
+        del sim
+    for o in out[1:]:
+        assert torch.equal(o[0], out[0][0]) and torch.equal(o[1], out[0][1]) and torch.equal(o[2], out[0][2])
+
+
 def test_move_atmos_matches_oracle(setup):
     _, s, _, sim, oracles = setup
     _push_oracle_state(sim, oracles)

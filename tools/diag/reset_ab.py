@@ -10,7 +10,7 @@ s.cmat = np.zeros((s.nactu, s.nslope), dtype=np.float32)
 out = {}
 for unf in (1, 0):
     sim = HipSim(s, nenv=nenv)
-    sim.set_option("extrude_unfused", unf)
+    sim.set_option("reset_untransposed", unf)
     sim.reset(1234 + 16 * np.arange(nenv))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     sim.reset(1234 + 16 * np.arange(nenv))
@@ -19,6 +19,6 @@ for unf in (1, 0):
     for _ in range(7): sim.move_atmos()
     torch.cuda.synchronize()
     out[unf] = (sim.t["screens"].clone(), sim.t["origin"].clone(), sim.t["ext_count"].clone())
-    print("unfused" if unf else "fused  ", "reset %.1f ms (host %.1f ms)" % (t * 1e3, th * 1e3), flush=True)
+    print("row-major reset  " if unf else "transposed reset ", "reset %.1f ms (host %.1f ms)" % (t * 1e3, th * 1e3), flush=True)
     del sim
 print("screens equal:", torch.equal(out[0][0], out[1][0]), " origins:", torch.equal(out[0][1], out[1][1]), " counters:", torch.equal(out[0][2], out[1][2]))
