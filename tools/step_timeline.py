@@ -23,7 +23,12 @@ marks = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]]
 if a.skip_last:
     marks = marks[:-a.skip_last]
 if a.from_index is not None:
-    marks = marks[a.from_index:a.from_index + a.steps + 1]
+    if a.from_index < 0:          # the `steps` consecutive marker launches that took the least time
+        ts = [int(rows[i]["Start_Timestamp"]) for i in marks]
+        best = min(range(len(marks) - a.steps), key=lambda i: ts[i + a.steps] - ts[i])
+        marks = marks[best:best + a.steps + 1]
+    else:
+        marks = marks[a.from_index:a.from_index + a.steps + 1]
 marks = marks[-a.steps - 1:]
 steps = [rows[marks[k]:marks[k + 1]] for k in range(len(marks) - 1)]
 common = collections.Counter(len(s) for s in steps).most_common(1)[0][0]

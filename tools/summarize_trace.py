@@ -19,7 +19,11 @@ marks = [int(r["Start_Timestamp"]) for r in rows if a.marker in r["Kernel_Name"]
 if a.skip_last:
     marks = marks[:-a.skip_last]
 if a.from_index is not None:
-    marks = marks[a.from_index:a.from_index + a.steps + 1]
+    if a.from_index < 0:          # the `steps` consecutive marker launches that took the least time: the timed region
+        best = min(range(len(marks) - a.steps), key=lambda i: marks[i + a.steps] - marks[i])
+        marks = marks[best:best + a.steps + 1]
+    else:
+        marks = marks[a.from_index:a.from_index + a.steps + 1]
 t0 = marks[-a.steps - 1]; t1 = marks[-1]
 sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 agg = collections.OrderedDict()
