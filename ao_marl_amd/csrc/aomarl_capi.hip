@@ -60,6 +60,10 @@ struct aomarl_ctx {
   // as this frame's image kernels are done, so the extrusion chain runs beside do_control / the
   // agents / next_part_two instead of in front of the next image
   bool prefetch_atmos = false, premoved = false;
+  // prefetch: the side stream has not yet waited for the frame kernel that reads the screens (ev_frame): the
+  // first kernel that WRITES them does (extrude_rounds); gather and GEMM of the first round run beside it
+  bool frame_wait_pending = false;
+  bool screens_dirty_main = true;       // the screens / origins were last written on the caller's stream
   // power-of-two scales of the static matrices for the split-f16 GEMM (gemm_scale)
   float cmat_scale = 1.f, v2m_scale = 1.f, m2v_scale = 1.f, s2m_scale = 1.f, ab_scale[AOMARL_MAX_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   int fw_variant[6] = {0, 0, 0, 0, 0, 0};   // template arguments of the last k_frame_wave launch
@@ -766,6 +770,11 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
                      0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp,
                      /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
       LAUNCHCHK();
+      if (c->frame_wait_pending && s == c->atm_stream) {
+        HIPCHK(hipStreamWaitEvent(s, c->ev_frame, 0));
+        c->frame_wait_pending = false;
+      }
+      if (s != c->atm_stream) c->screens_dirty_main = true;
       if (fuse_next) {
         hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(512), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
                            st->work + w.GEMM_ATM, nsp, ncol, dimc, pscale, Z, w.ldz);
@@ -860,9 +869,24 @@ int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *
   rc = side_stream(c);
   if (rc) return rc;
   HIPCHK(hipEventRecord(c->ev_frame, (hipStream_t)stream));        // readers of the screens are done
-  HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
+  // The stencil gather and the GEMM of the first round only READ the screens (like the frame kernel the
+  // caller has just launched): they need not wait for it.  The first kernel that writes a ring line
+  // does (extrude_rounds).  Only in the steady state, though: if the screens were last written on the
+  // caller's stream (reset, set_screen, an un-prefetched move), those writes are ordered before this
+  // point of that stream only, so the side stream waits for it right away.
+  if (c->screens_dirty_main) {
+    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
+    c->frame_wait_pending = false;
+  } else {
+    c->frame_wait_pending = true;
+  }
   rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
   if (rc) return rc;
+  if (c->frame_wait_pending) {            // nothing was extruded this frame: still order the marker behind the readers
+    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
+    c->frame_wait_pending = false;
+  }
+  c->screens_dirty_main = false;
   HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
   c->premoved = true; c->pre_screens = st->screens; c->pre_b = b; c->pre_n = n;
   return 0;
@@ -934,6 +958,7 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
     c->seed_stage_n = st->nenv;
   }
   HIPCHK(hipMemcpyAsync(c->seed_stage, seeds, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+  c->screens_dirty_main = true;
   hipLaunchKernelGGL(k_reset_env, dim3(n), dim3(256), 0, s, c->sys, ds, b, n, c->seed_stage, st->ld_actu);
   LAUNCHCHK();
   hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, st->screens + (size_t)b * c->sys.screen_stride,
@@ -992,6 +1017,7 @@ int aomarl_set_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, 
   if (rc) return rc;
   if (layer < 0 || layer >= c->nlayers || !src) return fail("set_screen: bad argument");
   if (n == 0) return 0;
+  c->screens_dirty_main = true;
   hipLaunchKernelGGL(k_set_screen, dim3(256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, layer, src);
   LAUNCHCHK();
   return 0;
