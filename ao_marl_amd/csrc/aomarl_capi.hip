@@ -63,8 +63,6 @@ struct aomarl_ctx {
   // prefetch: the side stream has not yet waited for the frame kernel that reads the screens (ev_frame): the
   // first kernel that WRITES them does (extrude_rounds); gather and GEMM of the first round run beside it
   bool frame_wait_pending = false;
-  int32_t *origin_override = nullptr;   // extrude_rounds on the side stream: advance THESE origins (see aomarl_prefetch_atmos)
-  bool slack_ok = false;                // every layer moves fewer than RING_SLACK lines per frame and axis
   bool screens_dirty_main = true;       // the screens / origins were last written on the caller's stream
   // power-of-two scales of the static matrices for the split-f16 GEMM (gemm_scale)
   float cmat_scale = 1.f, v2m_scale = 1.f, m2v_scale = 1.f, s2m_scale = 1.f, ab_scale[AOMARL_MAX_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
@@ -212,11 +210,8 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
     const aomarl_layer_desc &L = d->layers[l];
     DevLayer &D = s.layers[l];
     if (L.dim <= 0 || L.dim > 65535 || L.nstencil <= 0) { aomarl_destroy(c); return fail("bad layer %d", l); }
-    D.dim = L.dim; D.ring = L.dim + RING_SLACK; D.ns = L.nstencil; D.screen_off = off;
-    off += (long long)D.ring * (D.ring + RING_PAD);
+    D.dim = L.dim; D.ns = L.nstencil; D.screen_off = off; off += (long long)L.dim * (L.dim + RING_PAD);
     c->dim[l] = L.dim; c->ns[l] = L.nstencil; c->deltax[l] = L.deltax; c->deltay[l] = L.deltay;
-    if (l == 0) c->slack_ok = true;
-    if (ceilf(fabsf(L.deltax)) + 1.f > (float)RING_SLACK || ceilf(fabsf(L.deltay)) + 1.f > (float)RING_SLACK) c->slack_ok = false;
     if (L.dim > c->maxdim) c->maxdim = L.dim;
     if (L.dim + L.nstencil > c->maxK) c->maxK = L.dim + L.nstencil;
     std::vector<uint32_t> ix(L.nstencil), iy(L.nstencil);
@@ -628,7 +623,7 @@ int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m
 
 // ---- workspace layout (floats)
 struct Work {
-  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, ORGP, GEMM, GEMM_ATM, gemm_floats, total;
+  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, GEMM, GEMM_ATM, gemm_floats, total;
   int ldz, ldn, ldm, nblk;
 };
 
@@ -650,7 +645,6 @@ static Work work_layout(const aomarl_ctx *c, int nenv) {
   w.TR = take((size_t)nenv * s.pupdiam * W * 2);
   w.TPART = take((size_t)nenv * w.nblk * 4);
   w.PEND = take((size_t)nenv * (W * W + 4));
-  w.ORGP = take(2 * ncol);                       // int32: ring origins while a prefetched move is in progress
   {
     size_t mn = std::max(ncol * (size_t)w.ldn, (size_t)nenv * (size_t)w.ldm);
     w.gemm_floats = 8 * mn;            // up to 8 partial tiles of the split-K GEMM
@@ -743,7 +737,6 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
   if (n == 0 || nrounds == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   DevState ds = dev_state(st);
-  if (c->origin_override && s == c->atm_stream) ds.origin = c->origin_override;
   Work w = work_layout(c, st->nenv);
   float *Z = st->work + w.Z, *NEWL = st->work + w.NEWL, *ZREF = st->work + w.ZREF;
   bool gathered = false;                        // Z / ZREF of the coming round are already in place
@@ -777,6 +770,10 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
                      0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp,
                      /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
       LAUNCHCHK();
+      if (c->frame_wait_pending && s == c->atm_stream) {
+        HIPCHK(hipStreamWaitEvent(s, c->ev_frame, 0));
+        c->frame_wait_pending = false;
+      }
       if (s != c->atm_stream) c->screens_dirty_main = true;
       if (fuse_next) {
         hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(512), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
@@ -872,29 +869,22 @@ int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *
   rc = side_stream(c);
   if (rc) return rc;
   HIPCHK(hipEventRecord(c->ev_frame, (hipStream_t)stream));        // readers of the screens are done
-  // The ring has RING_SLACK spare lines per axis: every extrusion of this move writes OUTSIDE the window
-  // the caller's frame kernel is reading, so the whole chain runs beside that kernel instead of behind it.
-  // What the readers must not see change is the ring ORIGIN: the chain advances a private copy
-  // (workspace) and the copy replaces st->origin only after the readers are done (ev_frame).
-  // Only in the steady state: if the screens were last written on the caller's stream (reset,
-  // set_screen, an un-prefetched move) those writes are ordered before this point of THAT stream only,
-  // and a wind of more than RING_SLACK - 1 lines per frame does not fit the slack -- then the side stream
-  // waits for the caller's stream first and moves in place, as before.
-  if (c->screens_dirty_main || !c->slack_ok) {
+  // The stencil gather and the GEMM of the first round only READ the screens (like the frame kernel the
+  // caller has just launched): they need not wait for it.  The first kernel that writes a ring line
+  // does (extrude_rounds).  Only in the steady state, though: if the screens were last written on the
+  // caller's stream (reset, set_screen, an un-prefetched move), those writes are ordered before this
+  // point of that stream only, so the side stream waits for it right away.
+  if (c->screens_dirty_main) {
     HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
-    rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
-    if (rc) return rc;
+    c->frame_wait_pending = false;
   } else {
-    Work w = work_layout(c, st->nenv);
-    int32_t *pend = reinterpret_cast<int32_t *>(st->work + w.ORGP);
-    const size_t o0 = (size_t)b * c->nlayers * 2, cnt = (size_t)n * c->nlayers * 2;
-    HIPCHK(hipMemcpyAsync(pend + o0, st->origin + o0, cnt * sizeof(int32_t), hipMemcpyDeviceToDevice, c->atm_stream));
-    c->origin_override = pend;
-    rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
-    c->origin_override = nullptr;
-    if (rc) return rc;
+    c->frame_wait_pending = true;
+  }
+  rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
+  if (rc) return rc;
+  if (c->frame_wait_pending) {            // nothing was extruded this frame: still order the marker behind the readers
     HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
-    HIPCHK(hipMemcpyAsync(st->origin + o0, pend + o0, cnt * sizeof(int32_t), hipMemcpyDeviceToDevice, c->atm_stream));
+    c->frame_wait_pending = false;
   }
   c->screens_dirty_main = false;
   HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
@@ -1007,10 +997,10 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
   if (rc) return rc;
   if (!c->reset_untransposed) {
     for (int l = 0; l < c->nlayers; l++) {
-      const int M = c->dim[l] + RING_SLACK, T = (M + 31) / 32;
+      const int T = (c->dim[l] + 31) / 32;
       hipLaunchKernelGGL(k_transpose_ring, dim3(T * (T + 1) / 2, n), dim3(256), 0, s, c->sys, ds, b, l, T);
       LAUNCHCHK();
-      hipLaunchKernelGGL(k_refresh_mirror, dim3((M * RING_PAD + 255) / 256, n), dim3(256), 0, s, c->sys, ds, b, l);
+      hipLaunchKernelGGL(k_refresh_mirror, dim3((c->dim[l] * RING_PAD + 255) / 256, n), dim3(256), 0, s, c->sys, ds, b, l);
       LAUNCHCHK();
     }
   }

@@ -10,7 +10,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct DevLayer {
   int dim, ns;
-  int ring;                      // ring modulus = dim + RING_SLACK (rows and columns of the physical buffer)
   long long screen_off;          // floats from the env's screen base
   const uint32_t *istx, *isty;   // packed (x | y << 16) logical stencil coordinates
   const uint32_t *istT;          // istx with x and y exchanged: the x stencil of the TRANSPOSED screen (reset)
@@ -151,12 +150,6 @@ __device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, 
 // frame kernel wraps once per tile, on the scalar unit); the extrusion scatter keeps the mirror
 // up to date.
 #define RING_PAD 16
-// The ring is RING_SLACK lines larger than the screen in both directions: an extrusion writes its new
-// line OUTSIDE the window [origin, origin + dim) that is current when a frame starts (at origin + dim
-// going forward, origin - 1 going backward), so up to RING_SLACK extrusions per axis can run while a
-// kernel still reads that window -- the next frame's atmosphere is moved beside the frame kernel, not
-// behind it.  ring_idx takes the ring modulus (DevLayer.ring), not the screen size.
-#define RING_SLACK 8
 __device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
   int px = x + ox;
   px -= (px >= n) ? n : 0;

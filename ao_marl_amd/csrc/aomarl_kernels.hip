@@ -815,16 +815,16 @@ __device__ __forceinline__ void extrude_gather_item(const DevSys &sys, const Dev
   const int e = env_begin + col / ops.nops, op = col % ops.nops;
   const int li = ops.layer[op], dir = ops.dir[op];
   const DevLayer &L = sys.layers[li];
-  const int n = L.dim, ns = L.ns, M = L.ring;
+  const int n = L.dim, ns = L.ns;
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const bool top_right = (dir == 1 || dir == -2);
-  const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, ox, oy, M)];
+  const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, ox, oy, n)];
   const uint32_t *ist = ops.tflag[op] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
   const uint32_t seed = st.seeds[e] + (uint32_t)li;
   // items [0, ns): stencil values; items [ns, ns + ceil(n / 4)): 4 normals each (one Philox block)
   if (j < ns) {
     uint32_t xy = ist[j];
-    Z[(long long)col * ldz + j] = base[ring_idx(xy & 0xFFFF, xy >> 16, ox, oy, M)] - zref;
+    Z[(long long)col * ldz + j] = base[ring_idx(xy & 0xFFFF, xy >> 16, ox, oy, n)] - zref;
   } else if (j < ns + (n + 3) / 4) {
     const int g = j - ns;
     float z4[4];
@@ -857,10 +857,10 @@ __device__ __forceinline__ void extrude_scatter_col(const DevSys &sys, const Dev
   const int e = env_begin + col / ops.nops, op = col % ops.nops;
   const int li = ops.layer[op], dir = ops.dir[op];
   const DevLayer &L = sys.layers[li];
-  const int n = L.dim, M = L.ring;
+  const int n = L.dim;
   float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const float zref = ZREF[col];
-  const int stride = M + RING_PAD;
+  const int stride = n + RING_PAD;
   for (int r = threadIdx.x; r < n; r += blockDim.x) {
     float v = zref;
     if (nsplit > 0) {
@@ -870,30 +870,28 @@ __device__ __forceinline__ void extrude_scatter_col(const DevSys &sys, const Dev
     } else {
       v += NEWL[(long long)col * ldn + r];
     }
-    // going forward the new line becomes logical n - 1 of the advanced window: physical origin + n;
-    // going backward logical 0: physical origin - 1.  Both lie outside the window [origin, origin + n).
     int px, py;
     if (dir == 1) {
-      px = ox + n; px -= (px >= M) ? M : 0;
-      py = r + oy; py -= (py >= M) ? M : 0;
+      px = ox;
+      py = r + oy; py -= (py >= n) ? n : 0;
     } else if (dir == -1) {
-      px = ox - 1; px += (px < 0) ? M : 0;
-      py = n - 1 - r + oy; py -= (py >= M) ? M : 0;
+      px = ox - 1; px += (px < 0) ? n : 0;
+      py = n - 1 - r + oy; py -= (py >= n) ? n : 0;
     } else if (dir == 2) {
-      py = oy + n; py -= (py >= M) ? M : 0;
-      px = r + ox; px -= (px >= M) ? M : 0;
+      py = oy;
+      px = r + ox; px -= (px >= n) ? n : 0;
     } else {
-      py = oy - 1; py += (py < 0) ? M : 0;
-      px = n - 1 - r + ox; px -= (px >= M) ? M : 0;
+      py = oy - 1; py += (py < 0) ? n : 0;
+      px = n - 1 - r + ox; px -= (px >= n) ? n : 0;
     }
     base[py * stride + px] = v;
-    if (px < RING_PAD) base[py * stride + M + px] = v;     // mirror columns
+    if (px < RING_PAD) base[py * stride + n + px] = v;     // mirror columns
   }
   nox = ox; noy = oy;
-  if (dir == 1) nox = (ox + 1 >= M) ? 0 : ox + 1;
-  else if (dir == -1) nox = (ox - 1 < 0) ? M - 1 : ox - 1;
-  else if (dir == 2) noy = (oy + 1 >= M) ? 0 : oy + 1;
-  else noy = (oy - 1 < 0) ? M - 1 : oy - 1;
+  if (dir == 1) nox = (ox + 1 >= n) ? 0 : ox + 1;
+  else if (dir == -1) nox = (ox - 1 < 0) ? n - 1 : ox - 1;
+  else if (dir == 2) noy = (oy + 1 >= n) ? 0 : oy + 1;
+  else noy = (oy - 1 < 0) ? n - 1 : oy - 1;
 }
 
 // new line -> ring, then the ring origin / extrusion counter of this (environment, layer) advance:
@@ -943,10 +941,10 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   // other (index loads first, then the screen loads): with one block per column instead of six, a
   // dependent pair of loads per item was the whole kernel
   const DevLayer &L = sys.layers[li];
-  const int n = L.dim, ns = L.ns, M = L.ring, dir = ops.dir[col % ops.nops];
+  const int n = L.dim, ns = L.ns, dir = ops.dir[col % ops.nops];
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const bool top_right = (dir == 1 || dir == -2);
-  const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, nox, noy, M)];
+  const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, nox, noy, n)];
   const uint32_t *ist = ops.tflag[col % ops.nops] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
   constexpr int U = 4;
   for (int j0 = threadIdx.x; j0 < ns; j0 += U * blockDim.x) {
@@ -955,7 +953,7 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
 #pragma unroll
     for (int u = 0; u < U; u++) xy[u] = ist[min(j0 + u * (int)blockDim.x, ns - 1)];
 #pragma unroll
-    for (int u = 0; u < U; u++) v[u] = base[ring_idx(xy[u] & 0xFFFF, xy[u] >> 16, nox, noy, M)];
+    for (int u = 0; u < U; u++) v[u] = base[ring_idx(xy[u] & 0xFFFF, xy[u] >> 16, nox, noy, n)];
 #pragma unroll
     for (int u = 0; u < U; u++)
       if (j0 + u * (int)blockDim.x < ns) Z[(long long)col * ldz + j0 + u * blockDim.x] = v[u] - zref;
@@ -977,7 +975,7 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
 __global__ __launch_bounds__(256) void k_transpose_ring(DevSys sys, DevState st, int env_begin, int li, int T) {
   __shared__ float A[32][33], B[32][33];
   const DevLayer &L = sys.layers[li];
-  const int n = L.ring, stride = n + RING_PAD;               // the whole physical ring, slack lines included
+  const int n = L.dim, stride = n + RING_PAD;
   const int e = env_begin + blockIdx.y;
   float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   // pair index -> (i, j), i <= j (row-major over the upper triangle)
@@ -1007,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_transpose_ring(DevSys sys, DevState st,
 
 __global__ void k_refresh_mirror(DevSys sys, DevState st, int env_begin, int li) {
   const DevLayer &L = sys.layers[li];
-  const int n = L.ring, stride = n + RING_PAD;
+  const int n = L.dim, stride = n + RING_PAD;
   const int e = env_begin + blockIdx.y;
   float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1044,13 +1042,12 @@ __global__ void k_reset_env(DevSys sys, DevState st, int env_begin, int env_coun
 // upload logical screens src [env_count][n*n] (origin reset to 0, mirror columns filled)
 __global__ void k_set_screen(DevSys sys, DevState st, int env_begin, int li, const float *src) {
   const DevLayer &L = sys.layers[li];
-  const int n = L.dim, M = L.ring, stride = M + RING_PAD;
+  const int n = L.dim, stride = n + RING_PAD;
   const int e = env_begin + blockIdx.y;
   float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < M * stride; p += gridDim.x * blockDim.x) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n * stride; p += gridDim.x * blockDim.x) {
     int y = p / stride, x = p - y * stride;
-    if (x >= M) x -= M;                                      // mirror columns
-    base[p] = (y < n && x < n) ? src[(long long)blockIdx.y * n * n + y * n + x] : 0.f;   // slack lines: zero
+    base[p] = src[(long long)blockIdx.y * n * n + y * n + (x >= n ? x - n : x)];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st.origin[(e * sys.nlayers + li) * 2] = 0;
@@ -1066,7 +1063,7 @@ __global__ void k_get_screen(DevSys sys, DevState st, int env_begin, int li, flo
   const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n * n; p += gridDim.x * blockDim.x) {
     int y = p / n, x = p - y * n;
-    dst[(long long)blockIdx.y * n * n + p] = base[ring_idx(x, y, ox, oy, L.ring)];
+    dst[(long long)blockIdx.y * n * n + p] = base[ring_idx(x, y, ox, oy, n)];
   }
 }
 
@@ -1221,14 +1218,14 @@ __device__ __forceinline__ float bilinear_plain(const float *in, int N, float fx
   return (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
 }
 
-__device__ __forceinline__ float bilinear_ring(const float *in, int N, int M, int ox, int oy, float fx,
+__device__ __forceinline__ float bilinear_ring(const float *in, int N, int ox, int oy, float fx,
                                                float fy) {
   int ix = (int)floorf(fx), iy = (int)floorf(fy);
   float wx = fx - (float)ix, wy = fy - (float)iy;
   if (ix < 0 || iy < 0 || ix >= N || iy >= N) return 0.f;
   int ix1 = ix + 1 < N ? ix + 1 : ix, iy1 = iy + 1 < N ? iy + 1 : iy;
-  float v00 = in[ring_idx(ix, iy, ox, oy, M)], v01 = in[ring_idx(ix1, iy, ox, oy, M)];
-  float v10 = in[ring_idx(ix, iy1, ox, oy, M)], v11 = in[ring_idx(ix1, iy1, ox, oy, M)];
+  float v00 = in[ring_idx(ix, iy, ox, oy, N)], v01 = in[ring_idx(ix1, iy, ox, oy, N)];
+  float v10 = in[ring_idx(ix, iy1, ox, oy, N)], v11 = in[ring_idx(ix1, iy1, ox, oy, N)];
   return (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
 }
 
@@ -1247,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_raytrace(DevSys sys, DevState st, int e
       const DevLayer &L = sys.layers[l];
       const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
       const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
-      v += bilinear_ring(base, L.dim, L.ring, ox, oy, (float)x + (TARGET ? L.txo : L.wxo),
+      v += bilinear_ring(base, L.dim, ox, oy, (float)x + (TARGET ? L.txo : L.wxo),
                          (float)y + (TARGET ? L.tyo : L.wyo));
     }
   }
@@ -1663,9 +1660,9 @@ __device__ __forceinline__ void spot_load(const DevSys &sys, const DevState &st,
         const DevLayer &L = sys.layers[l];
         const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
         const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
-        int py = gy + L.woy + oy; py -= (py >= L.ring) ? L.ring : 0;
-        int px = gx0 + tx0 + L.wox + ox; px -= (px >= L.ring) ? L.ring : 0;
-        add4_ring(ph, base + py * (L.ring + RING_PAD), px, L.ring);
+        int py = gy + L.woy + oy; py -= (py >= L.dim) ? L.dim : 0;
+        int px = gx0 + tx0 + L.wox + ox; px -= (px >= L.dim) ? L.dim : 0;
+        add4_ring(ph, base + py * (L.dim + RING_PAD), px, L.dim);
       }
     }
     if (!no_dms) {
@@ -1869,9 +1866,9 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
   for (int l = 0; l < NL; l++) {
     const DevLayer &L = sys.layers[l];
     E.lay[l] = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-    E.dim[l] = L.ring;                                       // ring modulus (and row pitch - RING_PAD)
-    int px = L.wox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.ring) ? L.ring : 0;
-    int py = L.woy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.ring) ? L.ring : 0;
+    E.dim[l] = L.dim;
+    int px = L.wox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
+    int py = L.woy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
     E.px0[l] = px; E.py0[l] = py;
   }
   {
@@ -2150,10 +2147,10 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     const DevLayer &L = sys.layers[l];
     layb[l] = reinterpret_cast<const char *>(st.screens + (long long)e * sys.screen_stride + L.screen_off);
     lrs[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(layb[l]), 0,
-                                               4 * L.ring * (L.ring + RING_PAD), 0x00020000);
-    ldim[l] = (unsigned)L.ring;                              // ring modulus
-    int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.ring) ? L.ring : 0;
-    int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.ring) ? L.ring : 0;
+                                               4 * L.dim * (L.dim + RING_PAD), 0x00020000);
+    ldim[l] = (unsigned)L.dim;
+    int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
+    int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
     lpxs[l] = (unsigned)px;
     unsigned pr = (unsigned)y + (unsigned)py; pr = min(pr, pr - ldim[l]);
     lvo[l] = 4u * (pr * (ldim[l] + RING_PAD) + 4u * (unsigned)q);
@@ -2187,7 +2184,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       const DevLayer &L = sys.layers[l];
-      int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.ring) ? L.ring : 0;
+      int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
       unsigned pyc = (unsigned)(half + py); pyc = min(pyc, pyc - ldim[l]);
       unsigned pxc = (unsigned)half + lpxs[l]; pxc = min(pxc, pxc - ldim[l]);
       v += reinterpret_cast<const float *>(layb[l])[pyc * (ldim[l] + RING_PAD) + pxc];
@@ -2591,7 +2588,7 @@ __global__ __launch_bounds__(256) void k_target_rows(DevSys sys, DevState st, in
         const DevLayer &L = sys.layers[l];
         const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
         const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
-        v += base[ring_idx(cx + L.tox, cy + L.toy, ox, oy, L.ring)];
+        v += base[ring_idx(cx + L.tox, cy + L.toy, ox, oy, L.dim)];
       }
       for (int k = 0; k < sys.ndm; k++)
         v += dm_value(sys, st, e, k, cx + sys.dms[k].tox, cy + sys.dms[k].toy);
@@ -2620,7 +2617,7 @@ __global__ __launch_bounds__(256) void k_target_rows(DevSys sys, DevState st, in
               const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
               const int ox = st.origin[(e * sys.nlayers + l) * 2];
               const int oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
-              v += base[ring_idx(x + L.tox, y + L.toy, ox, oy, L.ring)];
+              v += base[ring_idx(x + L.tox, y + L.toy, ox, oy, L.dim)];
             }
             for (int k = 0; k < sys.ndm; k++)
               v += dm_value(sys, st, e, k, x + sys.dms[k].tox, y + sys.dms[k].toy);
@@ -2736,7 +2733,7 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
         const DevLayer &L = sys.layers[l];
         const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
         const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
-        v += base[ring_idx(cx + L.tox, cy + L.toy, ox, oy, L.ring)];
+        v += base[ring_idx(cx + L.tox, cy + L.toy, ox, oy, L.dim)];
       }
       for (int k = 0; k < sys.ndm; k++)
         v += dm_value(sys, st, e, k, cx + sys.dms[k].tox, cy + sys.dms[k].toy);
@@ -2765,9 +2762,9 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
             const DevLayer &L = sys.layers[l];
             const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
             const int ox = st.origin[(e * sys.nlayers + l) * 2], oy = st.origin[(e * sys.nlayers + l) * 2 + 1];
-            int py = y + L.toy + oy; py -= (py >= L.ring) ? L.ring : 0;
-            int px = xb + L.tox + ox; px -= (px >= L.ring) ? L.ring : 0;
-            add4_ring(ph, base + py * (L.ring + RING_PAD), px, L.ring);
+            int py = y + L.toy + oy; py -= (py >= L.dim) ? L.dim : 0;
+            int px = xb + L.tox + ox; px -= (px >= L.dim) ? L.dim : 0;
+            add4_ring(ph, base + py * (L.dim + RING_PAD), px, L.dim);
           }
           for (int k = 0; k < sys.ndm; k++) {
             const DevDm &D = sys.dms[k];
@@ -2874,9 +2871,9 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
   for (int l = 0; l < NL; l++) {
     const DevLayer &L = sys.layers[l];
     lay[l] = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-    ldim[l] = L.ring;                                        // ring modulus
-    int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.ring) ? L.ring : 0;
-    int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.ring) ? L.ring : 0;
+    ldim[l] = L.dim;
+    int px = L.tox + st.origin[(e * sys.nlayers + l) * 2]; px -= (px >= L.dim) ? L.dim : 0;
+    int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
     lpx[l] = px; lpy[l] = py;
   }
   const DevDm &D0 = sys.dms[0], &D1 = sys.dms[1];
