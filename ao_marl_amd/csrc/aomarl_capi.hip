@@ -1088,12 +1088,12 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
     g_gemm_kgroups = value;
     return 0;
   }
+  if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }   // process-wide
   if (!c) return fail("set_option: null context");
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
   if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
-  if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
@@ -1239,7 +1239,7 @@ int aomarl_do_control(aomarl_ctx *c, aomarl_state *st, int b, int n, void *strea
   ep.gain_row = c->env_gain ? c->env_gain + b : nullptr;
   const bool fused = launch_gemm_nt(n, na, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->cmat, c->ld_cmat, 0.0f,
                                     st->err + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM,
-                                    w.gemm_floats, &ep, nullptr, /* slopes (arcsec): unscaled, saturation only beyond 65504" */ true, 1.f, c->cmat_scale);
+                                    w.gemm_floats, &ep, nullptr, /* slopes (arcsec): unscaled, saturation only beyond 65504" */ true, 1.f, c->cmat_scale, nullptr, 288);
   LAUNCHCHK();
   if (!fused) {
     hipLaunchKernelGGL(k_integrate, dim3((na + 255) / 256, n), dim3(256), 0, s, st->com, st->err, na, st->ld_actu, c->gain, b, c->env_gain);
@@ -1269,7 +1269,7 @@ int aomarl_volts2modes(aomarl_ctx *c, aomarl_state *st, int nrows, const float *
   size_t wsn = 0;
   if (st && st->work) { Work w = work_layout(c, st->nenv); ws = st->work + w.GEMM; wsn = w.gemm_floats; }
   launch_gemm_nt(nrows, c->nmodes, c->sys.nactu, 1.0f, vec, ldvec, c->v2m, c->ld_v2m, 0.0f,
-                 modes, c->nmodes, (hipStream_t)stream, ws, wsn, nullptr, nullptr, /* volts */ true, 1.f, c->v2m_scale);
+                 modes, c->nmodes, (hipStream_t)stream, ws, wsn, nullptr, nullptr, /* volts */ true, 1.f, c->v2m_scale, nullptr, 288);
   LAUNCHCHK();
   return 0;
 }
@@ -1285,7 +1285,7 @@ int aomarl_slopes2modes(aomarl_ctx *c, aomarl_state *st, int b, int n, float *mo
   // residual modes = v2m . err = -(v2m . cmat) . slopes
   launch_gemm_nt(n, c->s2m_nmodes, nsl, -1.0f, st->slopes + (size_t)b * nsl, nsl, c->s2m, ld, 0.0f, modes,
                  c->s2m_nmodes, (hipStream_t)stream, st->work + w.GEMM, w.gemm_floats, nullptr, nullptr,
-                 /* slopes (arcsec), unscaled */ true, 1.f, c->s2m_scale);
+                 /* slopes (arcsec), unscaled */ true, 1.f, c->s2m_scale, nullptr, 288);
   LAUNCHCHK();
   return 0;
 }
@@ -1305,14 +1305,14 @@ int aomarl_rl_control(aomarl_ctx *c, aomarl_state *st, int b, int n, const float
   GemmEpi ep = {};
   ep.mode = 2; ep.action = action; ep.nact = c->nact; ep.amode_inv = c->amode_inv; ep.freedom = c->freedom;
   const bool fused = launch_gemm_nt(n, nm, na, 1.0f, com, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, modes, w.ldm, s,
-                                    st->work + w.GEMM, w.gemm_floats, &ep, nullptr, true, 1.f, c->v2m_scale);
+                                    st->work + w.GEMM, w.gemm_floats, &ep, nullptr, true, 1.f, c->v2m_scale, nullptr, 288);
   LAUNCHCHK();
   if (!fused) {
     hipLaunchKernelGGL(k_modal_add, dim3((c->nact + 255) / 256, n), dim3(256), 0, s, modes, w.ldm, action, c->nact, c->amodes, c->freedom);
     LAUNCHCHK();
   }
   launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, com, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats,
-                 nullptr, nullptr, /* Btt coordinates x 2^4 */ true, 16.f, c->m2v_scale);
+                 nullptr, nullptr, /* Btt coordinates x 2^4 */ true, 16.f, c->m2v_scale, nullptr, 288);
   LAUNCHCHK();
   return 0;
 }
@@ -1383,7 +1383,7 @@ int aomarl_rl_control_modes(aomarl_ctx *c, aomarl_state *st, int b, int n, const
   LAUNCHCHK();
   launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f,
                  st->com + (size_t)b * st->ld_actu, st->ld_actu, s, st->work + w.GEMM, w.gemm_floats,
-                 nullptr, nullptr, /* Btt coordinates x 2^4 */ true, 16.f, c->m2v_scale);
+                 nullptr, nullptr, /* Btt coordinates x 2^4 */ true, 16.f, c->m2v_scale, nullptr, 288);
   LAUNCHCHK();
   return 0;
 }
@@ -1920,7 +1920,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
     int nsp = 0;
     float alpha = 1.f;
     launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, st->com, st->ld_actu, s,
-                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, true, 16.f, c->m2v_scale, &alpha);
+                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, true, 16.f, c->m2v_scale, &alpha, 288);
     LAUNCHCHK();
     const float d = c->delay;
     float wa, wb, wc;
@@ -1984,7 +1984,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
     int nsp = 0;
     float alpha = 1.f;
     launch_gemm_nt(n, nm, na, 1.0f, st->err, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, g->res_modes, nm, s,
-                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, /* volts */ true, 1.f, c->v2m_scale, &alpha);
+                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, /* volts */ true, 1.f, c->v2m_scale, &alpha, 288);
     LAUNCHCHK();
     if (nsp > 0) { part.part = st->work + w.GEMM; part.nsplit = nsp; part.pn = nm; part.alpha = alpha; part.sum_out = g->res_modes; }
   } else {

@@ -751,7 +751,8 @@ static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 
 bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, const float *B,
                     int ldb, float beta, float *C, int ldc, hipStream_t s, float *ws = nullptr,
                     size_t ws_floats = 0, const GemmEpi *epi = nullptr, int *nsplit_out = nullptr,
-                    bool fast = false, float sa = 1.f, float sb = 1.f, float *alpha_out = nullptr) {
+                    bool fast = false, float sa = 1.f, float sb = 1.f, float *alpha_out = nullptr,
+                    int min_chunk = 128) {
   // alpha_out: the factor the caller must apply to the partial tiles when it sums them itself
   if (nsplit_out) *nsplit_out = 0;
   if (alpha_out) *alpha_out = alpha;
@@ -761,7 +762,12 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   if (ws && bx * by < 384) {
     nsplit = (g_gemm_target_blocks + bx * by - 1) / (bx * by);
     if (nsplit > 8) nsplit = 8;
-    while (nsplit > 1 && (K / nsplit < 128 || (size_t)nsplit * M * N > ws_floats)) nsplit--;
+    // min_chunk: the control chain's products ask for at least three groups of three k-tiles per block
+    // (288): below that the fill / drain of the load pipeline and the wider reduce cost more than the
+    // extra blocks bring (256 x 1283 x 1288: 15.9 us with 4 chunks of 322, 18.8 us with 7 of 184;
+    // tools/diag/gemm_split_time.py).  The extrusion keeps 128: its chunking is part of the bit pattern
+    // of the screens (a 2 n-step fp32 recursion) the parity tests were calibrated on.
+    while (nsplit > 1 && (K / nsplit < min_chunk || (size_t)nsplit * M * N > ws_floats)) nsplit--;
   }
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
