@@ -1088,6 +1088,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
     g_gemm_kgroups = value;
     return 0;
   }
+  if (!strcmp(name, "gemm_xcd_map")) { g_gemm_xcd = value != 0; return 0; }   // process-wide
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }   // process-wide
   if (!c) return fail("set_option: null context");
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }

@@ -459,11 +459,27 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h(int M, int N, int K, float al
                                                    const float *__restrict__ A, int lda,
                                                    const float *__restrict__ B, int ldb, float beta,
                                                    float *__restrict__ C, int ldc, int kchunk,
-                                                   float *__restrict__ P, float sa, float sb) {
+                                                   float *__restrict__ P, float sa, float sb, int xcd) {
   __shared__ __attribute__((aligned(16))) _Float16 S[2 * 4 * 64 * GH_LD];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
+  // Workgroups go to the 8 XCDs round-robin in launch order, each XCD with its own 4 MB L2.  With the
+  // plain (x, y, z) order every XCD sees tiles of every k-chunk, i.e. streams BOTH operands whole
+  // (5 + 6 MB for an extrusion round) through its L2; remapped, XCD q owns a contiguous range of the
+  // z-major order -- about one k-chunk, 1.6 MB of operands.  Worth 2.5 % of a reset (45.8 -> 44.6 ms),
+  // no more: the kernel is not bound by where its operands come from (the GEMM notes).
+  int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  if (xcd) {
+    const int T = gridDim.x * gridDim.y * gridDim.z;
+    const int L = bxi + gridDim.x * (byi + gridDim.y * bzi);
+    const int q = L & 7, i = L >> 3;
+    const int lg = q * (T >> 3) + min(q, T & 7) + i;
+    const int xy = gridDim.x * gridDim.y;
+    bzi = lg / xy;
+    const int r = lg - bzi * xy;
+    byi = r / gridDim.x; bxi = r - byi * gridDim.x;
+  }
+  const int m0 = byi * 64, n0 = bxi * 64;
+  const int kb = bzi * kchunk, ke = min(K, kb + kchunk);
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h(int M, int N, int K, float al
     int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (row < M && col < N) {
       if (split) {
-        P[((long long)blockIdx.z * M + row) * N + col] = acc[r];
+        P[((long long)bzi * M + row) * N + col] = acc[r];
       } else {
         float *c = C + (long long)row * ldc + col;
         float v = alpha * acc[r];
@@ -736,6 +752,7 @@ static float gemm_scale(const float *h, size_t n) {
   return ldexpf(1.f, e);
 }
 static bool g_gemm_split_f16 = true;  // "gemm_split_f16": the internal GEMMs (extrusion, command matrix, Btt projections) on k_gemm_nt_h
+static int g_gemm_xcd = 1;            // "gemm_xcd_map": k_gemm_nt_h's blocks grouped by k-chunk per XCD
 static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
 // Retired after their A/B runs (profiles/r01g_*): the un-pipelined aligned kernel (30 us vs 22 us per
 // call) and an in-kernel split-K reduction through ticket counters (4x slower: every block pays an
@@ -780,7 +797,7 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     alpha /= (sa * sb);                            // also what the split-K reduce below applies
     if (alpha_out) *alpha_out = alpha;
     hipLaunchKernelGGL(k_gemm_nt_h, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                       ldc, kchunk, ws, sa, sb);
+                       ldc, kchunk, ws, sa, sb, g_gemm_xcd);
   }
   else if (al)
     hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,

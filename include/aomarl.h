@@ -248,6 +248,8 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
  * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
  * "gemm_target_blocks" (split-K target of the fp32 GEMM),
+ * "gemm_xcd_map" (default 1: the split-f16 GEMM's blocks are renumbered so that one XCD works on one k-chunk and
+ * its L2 holds that slice of both operands; 0: plain grid order; same values; process-wide, ctx may be NULL),
  * "time_frame_kernel" (see aomarl_frame_kernel_time),
  * "gemm_split_f16" (default 1: see aomarl_gemm_nt_split; 0: every product on fp32 matrix instructions),
  * "prefetch_atmos" (aomarl_next_part_one moves the next frame's atmosphere on a side stream, see

@@ -1,0 +1,13 @@
+"""The extrusion round's GEMM (768 x 648 x 1960, split-K) a few times, for rocprofv3 --pmc (development aid)."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from ao_marl_amd import libaomarl as la
+lib = la.load()
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+M, N, K = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (768, 648, 1960)))
+A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); Cd = torch.zeros(M, N, device="cuda")
+ws = torch.zeros(8 * M * N + 4096, device="cuda")
+for _ in range(12):
+    la.check(lib.aomarl_gemm_nt_split(M, N, K, 1.0, A.data_ptr(), K, B.data_ptr(), K, 0.0, Cd.data_ptr(), N, 1.0, 1.0, ws.data_ptr(), ws.numel(), stream))
+torch.cuda.synchronize()
