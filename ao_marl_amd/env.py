@@ -229,10 +229,19 @@ class VecRlSupervisor(object):
         (rlSupervisor.py:215-234 -> basis.compute_cmat_with_Btt)."""
         self.n_reverse_filtered_from_cmat = int(modes_filtered)
         cmat = modal.cmat_with_btt(self.cal.imat, self.cal.Btt, max(int(modes_filtered), 0))
+        self._proj_w2m = None
         self.cal.cmat = cmat
         self.s.cmat = np.ascontiguousarray(cmat)
         self.sim.set_cmat(self.s.cmat)
         self._s2m_ok = False
+
+    @property
+    def projector_wfs2modes(self):
+        """rlSupervisor.py:191-194 (built when a reward type asks for it)."""
+        if getattr(self, "_proj_w2m", None) is None:
+            self._proj_w2m = modal.projector_wfs2modes(
+                self.cal.imat, self.cal.Btt, max(int(getattr(self, "n_reverse_filtered_from_cmat", 0)), 0)).astype(np.float32)
+        return self._proj_w2m
 
     def next_part_two(self, action, linear_control=False, apply_control=True,
                       compute_tar_psf=True, modes_pair=None, modes_out=None):
@@ -664,21 +673,53 @@ class VecAoEnv(object):
         sup.iter += 1
         return state, r, False, ""
 
-    def calculate_reward(self):
-        """ao_env.py:585-860, the branches the shipped configurations use."""
-        st = self.supervisor.get_strehl()
-        rt = self.reward_type
-        if rt == "wavefront_phase_error":
-            return -st[:, 2]
-        if rt == "strehl_ratio_le":
-            return st[:, 1]
-        if rt == "strehl_ratio_se":
-            return st[:, 0]
-        if "avg_squared_modes_" in rt:
-            factor = float(rt.split("_")[-1])
-            m = self.transform_state_to_zernike(self.supervisor.get_err(), return_reward=True)
-            return -factor * (m * m).mean(dim=1)
+    def calculate_reward(self, reward_type=None):
+        """ao_env.py:585-860, every branch that reads slopes, err, residual modes or the Strehl tuple
+        (formulas: ao_marl_amd/rewards.py); [nenv].  The four branches that need the full-frame target
+        image or the phase projector raise NotImplementedError with the reason."""
+        from . import rewards as R
+        sup = self.supervisor
+        rt = self.reward_type if reward_type is None else reward_type
+        if rt in R.STREHL:
+            return R.strehl_reward(rt, sup.get_strehl())
+        if rt in R.SLOPES:
+            return R.slopes_reward(rt, sup.get_slopes())
+        if rt == "residual_dm":                                                  # :603-605
+            return -torch.linalg.vector_norm(sup.get_err(), dim=1)
+        if rt == "avg_squared_modes_from_measurements":                          # :773-776
+            proj = self._dev_matrix("projector_wfs2modes")                        # rows: the KEPT modes only
+            rng = np.asarray(sup.obtain_action_range_modal())
+            if rng.size and int(rng.max()) >= proj.shape[0]:                     # what NumPy raises in the reference
+                raise IndexError("index %d is out of bounds for axis 0 with size %d" % (int(rng.max()), proj.shape[0]))
+            m = sup.get_slopes() @ proj.T
+            return -(m[:, self._action_range_t()] ** 2).sum(dim=1)
+        if rt == "variance_actuators_filtered_from_modes":                       # :834-844
+            m = sup.get_err() @ self._dev_matrix("volts2modes").T
+            keep = torch.zeros(m.shape[1], dtype=torch.bool, device=m.device)
+            keep[self._action_range_t()] = True
+            c = (m * keep) @ self._dev_matrix("modes2volts").T
+            return -c.var(dim=1, unbiased=False)
+        if R.is_modes_reward(rt):
+            return R.modes_reward(rt, self.transform_state_to_zernike(sup.get_err(), return_reward=True))
+        if "counterfactual_rpc" in rt:                                           # :855-856: r = None
+            return None
+        if rt in R.UNSUPPORTED:
+            raise NotImplementedError("reward type %r: %s" % (rt, R.UNSUPPORTED[rt]))
         raise NotImplementedError("This reward type not implemented")
+
+    def _dev_matrix(self, name):
+        """A host matrix of the supervisor (volts2modes, modes2volts, projector_wfs2modes) as a device
+        tensor, uploaded on first use (only the non-default reward types read them)."""
+        cache = self.__dict__.setdefault("_dev_mats", {})
+        src = getattr(self.supervisor, name)
+        if src is None:
+            raise RuntimeError("%s is not available (obtain_and_set_cmat_filtered has not run)" % name)
+        if name not in cache or cache[name][0] is not src:
+            cache[name] = (src, torch.as_tensor(np.asarray(src, dtype=np.float32), device=self.device))
+        return cache[name][1]
+
+    def _action_range_t(self):
+        return torch.as_tensor(np.asarray(self.supervisor.obtain_action_range_modal()), device=self.device)
 
     def rl_step(self, action, linear_control=False, apply_control=True, compute_tar_psf=True,
                 compute_env_reward=False):

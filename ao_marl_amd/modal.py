@@ -145,16 +145,25 @@ def compute_btt(IFpzt, IFtt):
     return Btt.astype(np.float32), P.astype(np.float32)
 
 
-def cmat_with_btt(D, Btt, nfilt):
-    """Command matrix filtering the `nfilt` highest-order Btt modes, TT kept
-    (basis.py:229-256)."""
+def _btt_filtered(Btt, nfilt):
     nm = Btt.shape[1]
     Bf = np.zeros((Btt.shape[0], nm - nfilt))
     Bf[:, :nm - nfilt - 2] = Btt[:, :nm - (nfilt + 2)]
     Bf[:, nm - nfilt - 2:] = Btt[:, nm - 2:]
-    Dm = D.astype(np.float64) @ Bf
-    Dmp = np.linalg.solve(Dm.T @ Dm, Dm.T)
-    return (Bf @ Dmp).astype(np.float32)
+    return Bf
+
+
+def projector_wfs2modes(D, Btt, nfilt):
+    """Least-squares projector from slopes onto the kept Btt modes (first nm - nfilt - 2, then tip-tilt):
+    [nm - nfilt, nslope], float64 (helper_functions/utils/utils_projectors.py:3-21)."""
+    Dm = D.astype(np.float64) @ _btt_filtered(Btt, nfilt)
+    return np.linalg.solve(Dm.T @ Dm, Dm.T)
+
+
+def cmat_with_btt(D, Btt, nfilt):
+    """Command matrix filtering the `nfilt` highest-order Btt modes, TT kept
+    (basis.py:229-256)."""
+    return (_btt_filtered(Btt, nfilt) @ projector_wfs2modes(D, Btt, nfilt)).astype(np.float32)
 
 
 def geo_projector(IF):

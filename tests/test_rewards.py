@@ -1,0 +1,126 @@
+"""Environment-level reward types (ao_env.py:585-860): the batched formulas of ao_marl_amd/rewards.py
+against per-environment NumPy evaluations written from the reference's definitions (np.var =
+population variance, halves = s[: n // 2], s[n // 2 :]); then, on the GPU, VecAoEnv.calculate_reward
+for every supported name against the same NumPy on the tensors the environment exposes."""
+import numpy as np
+import pytest
+import torch
+
+from ao_marl_amd import rewards as R
+
+
+def _np_slopes(name, s):
+    n = len(s); x, y = s[: n // 2], s[n // 2:]
+    v, a, q = np.var(s), np.average(s), np.average(np.square(s))
+    base = name[:-5] if name.endswith("_norm") else name
+    f = {
+        "residual_wfs": lambda: -np.linalg.norm(s), "var_wfs": lambda: -v,
+        "averages_wfs": lambda: -(np.average(x) + np.average(y)),
+        "average_var_wfs": lambda: -v - (np.average(x) + np.average(y)),
+        "average_residual_wfs": lambda: -v - (np.average(x) + np.average(y)),
+        "r_modes_1": lambda: np.exp(-v), "r_modes_2": lambda: -v, "r_modes_3": lambda: np.exp(-v) - 1,
+        "r_modes_4": lambda: np.exp(-np.var(np.square(s))), "r_modes_5": lambda: -np.var(np.square(s)),
+        "r_modes_6": lambda: np.exp(-np.var(np.square(s))) - 1,
+        "r_tt_1": lambda: -np.square(a), "r_tt_2": lambda: -np.abs(a), "r_tt_3": lambda: -q,
+        "r_tt_5": lambda: np.exp(-q), "r_tt_6": lambda: np.exp(-q) - 1,
+        "r_tt_7": lambda: -(np.square(np.average(x)) + np.square(np.average(y))),
+        "r_modes_7": lambda: -(np.square(np.var(x)) + np.square(np.var(y))),
+        "r_1_and_2": lambda: -v - np.abs(a), "single_agent_1": lambda: -q, "avg_square_m": lambda: -q,
+        "sum_measurements_squared": lambda: -np.sum(np.square(s)), "single_agent_2": lambda: np.exp(-v) - 1,
+        "single_agent_3": lambda: (-q) / (-q + np.exp(-v) - 1) + (np.exp(-v) - 1) / (-q + np.exp(-v) - 1),
+        "single_agent_4": lambda: 0.4479 * (np.exp(-v) - 1) / (np.exp(-v) - 1 - q) + 0.5485 * (-q) / (np.exp(-v) - 1 - q),
+        "new_single_agent": lambda: np.exp(-q), "log_avg_m": lambda: -np.log(1 + q),
+    }
+    return f[base]()
+
+
+def _np_strehl(name, st):
+    se, le, va = st[0], st[1], st[2]
+    if name == "wavefront_phase_error": return -va
+    if name == "strehl_ratio_le": return le
+    if name == "strehl_ratio_se": return se
+    if name == "r_le": return 0.0
+    if name == "log_var": return -np.log(1 + va)
+    k = int(name[-1]); off = 2.60 if k <= 4 else 3.50; mult = (1.0, 5.0, 10.0, 0.5)[(k - 1) % 4]
+    return -(np.log(1 + va) - off) * mult
+
+
+def _np_modes(name, m):
+    if name == "avg_squared_modes": return -np.sum(np.square(m))
+    if name == "true_avg_squared_modes": return -np.average(np.square(m))
+    if name.startswith("avg_squared_modes_scaled_"): return -np.sum(np.square(m)) * 10.0 ** int(name[-1])
+    return -float(name.split("_")[-1]) * np.average(np.square(m))
+
+
+def test_reward_formulas_against_numpy():
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(7, 128, generator=g, dtype=torch.float64) * 0.3 + 0.05
+    for name in R.SLOPES:
+        got = R.slopes_reward(name, s).numpy()
+        want = np.array([_np_slopes(name, row) for row in s.numpy()])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14, err_msg=name)
+    st = torch.rand(7, 6, generator=g, dtype=torch.float64)
+    for name in R.STREHL:
+        got = R.strehl_reward(name, st).numpy()
+        want = np.array([_np_strehl(name, row) for row in st.numpy()])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=0, err_msg=name)
+    m = torch.randn(7, 82, generator=g, dtype=torch.float64)
+    for name in ("avg_squared_modes", "true_avg_squared_modes", "avg_squared_modes_scaled_1",
+                 "avg_squared_modes_scaled_2", "avg_squared_modes_scaled_3", "avg_squared_modes_1000", "avg_squared_modes_2.5"):
+        assert R.is_modes_reward(name)
+        got = R.modes_reward(name, m).numpy()
+        want = np.array([_np_modes(name, row) for row in m.numpy()])
+        np.testing.assert_allclose(got, want, rtol=1e-12, err_msg=name)
+    assert not R.is_modes_reward("avg_squared_modes_from_measurements")
+    # the reference's chain has 61 named branches + the generic "avg_squared_modes_<factor>" + counterfactual
+    assert len(R.SLOPES) == 39 and len(R.STREHL) == 13 and len(R.UNSUPPORTED) == 5
+
+
+@pytest.mark.gpu
+def test_env_reward_types_on_the_device():
+    from ao_marl_amd.env import VecAoEnv
+    env = VecAoEnv("production_sh_10x10_2m", 4, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5),
+                   n_agents_modal=1)
+    env.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for _ in range(3):
+        env.step(torch.rand(4, env.layout.action_dim, device="cuda:0", generator=g) * 2 - 1)
+    sup = env.supervisor
+    s, e, st = sup.get_slopes().cpu().numpy(), sup.get_err().cpu().numpy(), sup.get_strehl().cpu().numpy()
+    for name in list(R.SLOPES) + list(R.STREHL):
+        got = env.calculate_reward(name).cpu().numpy()
+        want = np.array([_np_slopes(name, s[i]) if name in R.SLOPES else _np_strehl(name, st[i]) for i in range(4)])
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-6, err_msg=name)
+    np.testing.assert_allclose(env.calculate_reward("residual_dm").cpu().numpy(), -np.linalg.norm(e, axis=1), rtol=1e-5)
+    v2m, m2v = sup.volts2modes.astype(np.float64), sup.modes2volts.astype(np.float64)
+    rng = np.asarray(sup.obtain_action_range_modal())
+    m = e.astype(np.float64) @ v2m.T
+    mk = np.zeros_like(m); mk[:, rng] = m[:, rng]
+    np.testing.assert_allclose(env.calculate_reward("variance_actuators_filtered_from_modes").cpu().numpy(),
+                               -np.var(mk @ m2v.T, axis=1), rtol=1e-3)
+    # the projector has one row per KEPT mode: with modes filtered and tip-tilt in the action range the reference's
+    # own indexing runs off its end (ao_env.py:776) -- same exception here; inside the range, same numbers
+    pm = s.astype(np.float64) @ sup.projector_wfs2modes.astype(np.float64).T
+    assert pm.shape[1] == sup.nmodes - 5
+    if rng.max() >= pm.shape[1]:
+        with pytest.raises(IndexError):
+            env.calculate_reward("avg_squared_modes_from_measurements")
+        sup.n_modes_start_end, keep_tt = (0, 60), sup.include_tip_tilt
+        sup.include_tip_tilt = False
+        rng2 = np.asarray(sup.obtain_action_range_modal())
+        np.testing.assert_allclose(env.calculate_reward("avg_squared_modes_from_measurements").cpu().numpy(),
+                                   -np.sum(np.square(pm[:, rng2]), axis=1), rtol=1e-3)
+        sup.n_modes_start_end, sup.include_tip_tilt = (0, 80), keep_tt
+    else:
+        np.testing.assert_allclose(env.calculate_reward("avg_squared_modes_from_measurements").cpu().numpy(),
+                                   -np.sum(np.square(pm[:, rng]), axis=1), rtol=1e-3)
+    msel = env.transform_state_to_zernike(sup.get_err(), return_reward=True).cpu().numpy()
+    for name in ("avg_squared_modes", "true_avg_squared_modes", "avg_squared_modes_scaled_2", "avg_squared_modes_1000"):
+        want = np.array([_np_modes(name, msel[i]) for i in range(4)])
+        np.testing.assert_allclose(env.calculate_reward(name).cpu().numpy(), want, rtol=1e-4, err_msg=name)
+    assert env.calculate_reward("counterfactual_rpc") is None
+    for name in R.UNSUPPORTED:
+        with pytest.raises(NotImplementedError):
+            env.calculate_reward(name)
+    with pytest.raises(NotImplementedError):
+        env.calculate_reward("no_such_reward")
