@@ -74,6 +74,12 @@ struct aomarl_ctx {
   size_t fw_ev_used = 0;
   hipStream_t atm_stream = nullptr, psf_stream = nullptr;
   hipEvent_t ev_frame = nullptr, ev_moved = nullptr, ev_psf = nullptr;
+  // the event the screens' readers were last marked with on the caller's stream (ev_frame, or the closing
+  // event of a timed frame launch: an event record is a barrier packet of its own on the queue, 3-5 us of
+  // the step each -- one per frame, not three); frame_marked: recorded by aomarl_frame_fused and nothing
+  // launched on that stream since (the composites' prefetch reuses it)
+  hipEvent_t ev_frame_cur = nullptr;
+  bool frame_marked = false;
   bool psf_side = false;                // a k_target_finish_mfma launched on the side stream may still run
   const float *pre_screens = nullptr;
   int pre_b = 0, pre_n = 0;
@@ -700,6 +706,7 @@ static int side_stream(aomarl_ctx *c) {
     HIPCHK(hipStreamCreateWithPriority(&c->atm_stream, hipStreamNonBlocking, 0));
     HIPCHK(hipStreamCreateWithPriority(&c->psf_stream, hipStreamNonBlocking, prio_lo));
     HIPCHK(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming));
+    c->ev_frame_cur = c->ev_frame;
     HIPCHK(hipEventCreateWithFlags(&c->ev_moved, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_psf, hipEventDisableTiming));
   }
@@ -771,7 +778,7 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
                      /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
       LAUNCHCHK();
       if (c->frame_wait_pending && s == c->atm_stream) {
-        HIPCHK(hipStreamWaitEvent(s, c->ev_frame, 0));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_frame_cur, 0));
         c->frame_wait_pending = false;
       }
       if (s != c->atm_stream) c->screens_dirty_main = true;
@@ -860,22 +867,25 @@ int aomarl_move_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accu
   return move_atmos_now(c, st, b, n, accumx, accumy, stream);
 }
 
-int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
-                          void *stream) {
+static int prefetch_atmos_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
+                               void *stream, bool frame_marked) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
   if (!accumx || !accumy) return fail("prefetch_atmos: null accumulators");
   if (c->premoved) return fail("prefetch_atmos: a prefetched frame is already pending");
   rc = side_stream(c);
   if (rc) return rc;
-  HIPCHK(hipEventRecord(c->ev_frame, (hipStream_t)stream));        // readers of the screens are done
+  if (!frame_marked) {                           // readers of the screens are done
+    HIPCHK(hipEventRecord(c->ev_frame, (hipStream_t)stream));
+    c->ev_frame_cur = c->ev_frame;
+  }
   // The stencil gather and the GEMM of the first round only READ the screens (like the frame kernel the
   // caller has just launched): they need not wait for it.  The first kernel that writes a ring line
   // does (extrude_rounds).  Only in the steady state, though: if the screens were last written on the
   // caller's stream (reset, set_screen, an un-prefetched move), those writes are ordered before this
   // point of that stream only, so the side stream waits for it right away.
   if (c->screens_dirty_main) {
-    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
+    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame_cur, 0));
     c->frame_wait_pending = false;
   } else {
     c->frame_wait_pending = true;
@@ -883,13 +893,18 @@ int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *
   rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
   if (rc) return rc;
   if (c->frame_wait_pending) {            // nothing was extruded this frame: still order the marker behind the readers
-    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame, 0));
+    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame_cur, 0));
     c->frame_wait_pending = false;
   }
   c->screens_dirty_main = false;
   HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
   c->premoved = true; c->pre_screens = st->screens; c->pre_b = b; c->pre_n = n;
   return 0;
+}
+
+int aomarl_prefetch_atmos(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
+                          void *stream) {
+  return prefetch_atmos_impl(c, st, b, n, accumx, accumy, stream, false);
 }
 
 static int move_atmos_now(aomarl_ctx *c, aomarl_state *st, int b, int n, float *accumx, float *accumy,
@@ -2223,7 +2238,9 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   const bool timed = c->time_fw && c->fw_ev_used + 2 <= c->fw_ev.size();
   if (timed) HIPCHK(hipEventRecord(c->fw_ev[c->fw_ev_used], s));
   if (c->nlayers == 1) FW_L(1); else FW_L(3);
-  if (timed) { HIPCHK(hipEventRecord(c->fw_ev[c->fw_ev_used + 1], s)); c->fw_ev_used += 2; }
+  c->frame_marked = false;
+  hipEvent_t ev_done = nullptr;                  // closing event of a timed launch: also the "readers are done" mark
+  if (timed) { ev_done = c->fw_ev[c->fw_ev_used + 1]; HIPCHK(hipEventRecord(ev_done, s)); c->fw_ev_used += 2; }
   c->fw_variant[0] = c->nlayers == 1 ? 1 : 3; c->fw_variant[1] = otf ? nb : 1; c->fw_variant[2] = otf;
   c->fw_variant[3] = noise; c->fw_variant[4] = cube; c->fw_variant[5] = hp;
 #undef FW_L
@@ -2236,8 +2253,9 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     // the step), so it goes to the side stream, in front of the next frame's extrusions
     rc = side_stream(c);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_frame, s));
-    HIPCHK(hipStreamWaitEvent(c->psf_stream, c->ev_frame, 0));
+    if (!ev_done) { ev_done = c->ev_frame; HIPCHK(hipEventRecord(ev_done, s)); }
+    c->ev_frame_cur = ev_done; c->frame_marked = true;
+    HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
     hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
     LAUNCHCHK();
     HIPCHK(hipEventRecord(c->ev_psf, c->psf_stream));
@@ -2267,7 +2285,8 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
     rc = aomarl_frame_fused(c, st, b, n, fl | (defer ? AOMARL_IMG_DM_FROM_VOLTAGE : 0), stream);
     if (rc) return rc;
     if (c->prefetch_atmos && !c->premoved) {     // one frame ahead for ONE range at a time
-      rc = aomarl_prefetch_atmos(c, st, b, n, accumx, accumy, stream);
+      // nothing was launched on `stream` since the frame kernel: its mark stands for the screens' readers
+      rc = prefetch_atmos_impl(c, st, b, n, accumx, accumy, stream, c->frame_marked);
       if (rc) return rc;
     }
     return aomarl_do_control(c, st, b, n, stream);
