@@ -1523,25 +1523,17 @@ __global__ void k_policy_sample(int nenv, int act_max, int action_dim, const flo
 
 // ---- the whole actor in one launch -----------------------------------------------------------
 // One workgroup = one agent x 16 environments: gather the agent's state columns into LDS, run the
-// Linear + ReLU stack and the merged head with the activations staying in LDS, then clamp / exp /
-// sample / tanh / scatter.  Replaces k_split_states + (n_hidden + 1) k_gemm_nt_batched2 +
-// k_policy_sample: launch-latency-bound kernels of ~0.3-1 GFLOP.
+// Linear + ReLU stack and the merged head with the activations staying in LDS (fp32 matrix
+// instructions, 16 x 16 x 4), then clamp / exp / sample / tanh / scatter.  Replaces k_split_states +
+// (n_hidden + 1) k_gemm_nt_batched2 + k_policy_sample: launch-latency-bound kernels of ~0.3-1 GFLOP.
 //
 // Every workgroup streams its agent's ~1 MB of weights from L2 (each agent's workgroups sit on one
 // XCD, so HBM sees them once); what bounds the kernel is the number of cache lines a load instruction
 // touches, so the weights come PRE-TILED in the operand order of the matrix instruction
-// (aomarl_actor_tile_weights): one 1 KB contiguous read per wave, operand and k step.  Read row-major,
-// the same loads touch 64 lines instead of 8 and the kernel runs at half the speed.
-//
-// Arithmetic: split fp16 on v_mfma_f32_16x16x32_f16 (like k_gemm_nt_h): a value v is carried as
-// hi = f16(s v), lo = f16(s v - hi), a product as hi.hi + lo.hi + hi.lo with fp32 accumulation -- three
-// 16-cycle instructions per 32 k against eight 32-cycle fp32 ones (the fp32 kernel spent 14 of its 33 us
-// in the matrix pipe, beside 14 us of weight streaming).  The weights are split when they are tiled
-// (s = 2^10: |w| < 64, lo exact to 3e-11), the activations when a layer writes them to LDS (s = 2^4:
-// |x| < 4094, saturating; lo exact to 2e-9); both factors are undone on the accumulator.
-// Tile (n, s) of a weight matrix = rows 16 n .. + 15, columns 32 s .. + 31, stored as 64 x 16 bytes of hi
-// followed by 64 x 16 bytes of lo, lane l = (row l & 15, columns 8 (l >> 4) .. + 7); the activation
-// images in LDS use the same tiling (conflict-free 128-bit reads).
+// (aomarl_actor_tile_weights): tile (n, s) = rows 16 n .. 16 n + 15, columns 16 s .. 16 s + 15, stored as
+// 64 x float4 with lane l = (row l & 15, columns 4 (l >> 4) .. + 3) -- one 1 KB contiguous read per
+// wave and k step.  Read row-major, the same loads touch 64 lines instead of 8 and the kernel runs at
+// half the speed.  The activations use the same tiling in LDS (conflict-free 128-bit reads).
 struct ActorArgs {
   int A, nenv, state_dim, in_max, act_max, H, n_hidden, action_dim;
   const int32_t *gather;
@@ -1552,123 +1544,94 @@ struct ActorArgs {
   uint32_t seed, counter;
   float *action, *mean;
 };
-#define AF_SW 1024.f                 // weights x 2^10
-#define AF_SX 16.f                   // activations x 2^4
-__device__ __forceinline__ void af_split1(float v, const float scale, _Float16 &hi, _Float16 &lo) {
-  v = __builtin_amdgcn_fmed3f(v * scale, -65504.f, 65504.f);
-  hi = (_Float16)v;                  // round to nearest even
-  lo = (_Float16)(v - (float)hi);
-}
 
 __global__ void k_actor_tile_weights(int N, int K, int ntile, int ksteps, const float *__restrict__ src,
                                      float *__restrict__ dst) {
-  // thread = (agent, tile n, k step s, lane): 8 elements src[a][16 n + (lane & 15)][32 s + 8 (lane >> 4) + j]
-  const long long lanes = (long long)ntile * ksteps * 64;
+  // dst[a][n][s][lane][j] = src[a][16 n + (lane & 15)][16 s + 4 (lane >> 4) + j], zero outside N x K
+  const long long per = (long long)ntile * ksteps * 256;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= lanes) return;
+  if (i >= per) return;
   const int a = blockIdx.y;
-  const int lane = (int)(i & 63);
-  const long long t = i >> 6;                    // n * ksteps + s
+  const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const long long t = i >> 8;
   const int sidx = (int)(t % ksteps), n = (int)(t / ksteps);
-  const int row = 16 * n + (lane & 15), col0 = 32 * sidx + 8 * (lane >> 4);
-  hx8 h, l;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int col = col0 + j;
-    const float v = (row < N && col < K) ? src[((long long)a * N + row) * K + col] : 0.f;
-    _Float16 hh, ll;
-    af_split1(v, AF_SW, hh, ll);
-    h[j] = hh; l[j] = ll;
-  }
-  hx8 *d = reinterpret_cast<hx8 *>(dst + (long long)a * lanes * 8) + t * 128 + lane;
-  d[0] = h; d[64] = l;
+  const int row = 16 * n + (lane & 15), col = 16 * sidx + 4 * (lane >> 4) + jj;
+  dst[(long long)a * per + i] = (row < N && col < K) ? src[((long long)a * N + row) * K + col] : 0.f;
 }
 
-// half index of the hi part of element (row, col) of a 16-row activation tile in its LDS image (lo: + 512)
+// position of element (row, col) of a 16-row activation tile in its LDS image
 __device__ __forceinline__ int af_at(int row, int col) {
-  return (((col >> 5) * 128 + ((col >> 3) & 3) * 16 + row) << 3) + (col & 7);
-}
-__device__ __forceinline__ void af_put(_Float16 *img, int row, int col, float v) {
-  _Float16 h, l;
-  af_split1(v, AF_SX, h, l);
-  const int i = af_at(row, col);
-  img[i] = h; img[i + 512] = l;
+  return (((col >> 4) * 64 + ((col >> 2) & 3) * 16 + row) << 2) + (col & 3);
 }
 
 #ifndef AF_D
 #define AF_D 2
 #endif
-// Out[16][N] = act(Xs[16][K] . W^T + b) on tiled images; ksteps = ceil(K / 32), W has ntile row tiles.
-// Out32 != null: the result as plain fp32, Out32[row * ld32 + col] (the head), instead of a split image.
-__device__ __forceinline__ void af_layer(const _Float16 *__restrict__ Xs, int ksteps, const float *__restrict__ W,
-                                         const float *__restrict__ b, int N, bool relu, _Float16 *__restrict__ Out,
-                                         float *__restrict__ Out32, int ld32) {
+// Out[16][N] = act(Xs[16][K] . W^T + b) on tiled images; ksteps = ceil(K / 16), W has ntile row tiles.
+__device__ __forceinline__ void af_layer(const float *__restrict__ Xs, int ksteps, const float *__restrict__ W,
+                                         const float *__restrict__ b, int N, bool relu, float *__restrict__ Out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kk = lane >> 4;
   const int ntile = (N + 15) / 16, npairs = (ntile + 1) / 2;
   constexpr int D = AF_D;
   for (int pair = wave; pair < npairs; pair += 8) {
-    const hx8 *wa = reinterpret_cast<const hx8 *>(W) + (long long)(2 * pair) * ksteps * 128 + lane;
-    const hx8 *wb = reinterpret_cast<const hx8 *>(W) + (long long)min(2 * pair + 1, ntile - 1) * ksteps * 128 + lane;
-    const hx8 *xs = reinterpret_cast<const hx8 *>(Xs) + lane;
+    const float4 *wa = reinterpret_cast<const float4 *>(W) + (long long)(2 * pair) * ksteps * 64 + lane;
+    const float4 *wb = reinterpret_cast<const float4 *>(W) + (long long)min(2 * pair + 1, ntile - 1) * ksteps * 64 + lane;
+    const float4 *xs = reinterpret_cast<const float4 *>(Xs) + lane;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto fma6 = [&](const hx8 xh, const hx8 xl, const hx8 ah, const hx8 al, const hx8 ch, const hx8 cl) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, ah, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, ch, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ah, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ch, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, al, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, cl, acc1, 0, 0, 0);
+    auto fma8 = [&](const float4 x, const float4 a, const float4 c) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, a.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, c.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, a.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, c.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, a.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, c.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, a.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, c.w, acc1, 0, 0, 0);
     };
     // two register sets of D steps each, filled and drained in turn.  No branch around a load, no
     // select on its result, no rotation of the sets: each of those makes the compiler wait for the data
     // where it is loaded; and scheduling barriers, or it sinks every load to just before its use.
-    hx8 rah[D], ral[D], rbh[D], rbl[D], qah[D], qal[D], qbh[D], qbl[D];
-    auto fill = [&](hx8 (&ah)[D], hx8 (&al)[D], hx8 (&ch)[D], hx8 (&cl)[D], int s0) {
+    float4 ra[D], rb[D], qa[D], qb[D];
+    auto fill = [&](float4 (&a)[D], float4 (&c)[D], int s0) {
 #pragma unroll
       for (int u = 0; u < D; u++) {
-        const int st = min(s0 + u, ksteps - 1) * 128;      // wave-uniform; beyond the end: any tile, unused
-        ah[u] = wa[st]; al[u] = wa[st + 64]; ch[u] = wb[st]; cl[u] = wb[st + 64];
+        const int st = min(s0 + u, ksteps - 1) * 64;       // wave-uniform; beyond the end: any tile, unused
+        a[u] = wa[st]; c[u] = wb[st];
       }
     };
-    auto drain = [&](const hx8 (&ah)[D], const hx8 (&al)[D], const hx8 (&ch)[D], const hx8 (&cl)[D], int s0) {
+    auto drain = [&](const float4 (&a)[D], const float4 (&c)[D], int s0) {
 #pragma unroll
-      for (int u = 0; u < D; u++) fma6(xs[(s0 + u) * 128], xs[(s0 + u) * 128 + 64], ah[u], al[u], ch[u], cl[u]);
+      for (int u = 0; u < D; u++) fma8(xs[(s0 + u) * 64], a[u], c[u]);
     };
-    fill(rah, ral, rbh, rbl, 0);
+    fill(ra, rb, 0);
     int s = 0;
     for (; s + 2 * D <= ksteps; s += 2 * D) {
-      fill(qah, qal, qbh, qbl, s + D);
+      fill(qa, qb, s + D);
       __builtin_amdgcn_sched_barrier(0);
-      drain(rah, ral, rbh, rbl, s);
+      drain(ra, rb, s);
       __builtin_amdgcn_sched_barrier(0);
-      fill(rah, ral, rbh, rbl, s + 2 * D);
+      fill(ra, rb, s + 2 * D);
       __builtin_amdgcn_sched_barrier(0);
-      drain(qah, qal, qbh, qbl, s + D);
+      drain(qa, qb, s + D);
       __builtin_amdgcn_sched_barrier(0);
     }
-    fill(qah, qal, qbh, qbl, s + D);
+    fill(qa, qb, s + D);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < D; u++)
-      if (s + u < ksteps) fma6(xs[(s + u) * 128], xs[(s + u) * 128 + 64], rah[u], ral[u], rbh[u], rbl[u]);
+      if (s + u < ksteps) fma8(xs[(s + u) * 64], ra[u], rb[u]);
 #pragma unroll
     for (int u = 0; u < D; u++)
-      if (s + D + u < ksteps) fma6(xs[(s + D + u) * 128], xs[(s + D + u) * 128 + 64], qah[u], qal[u], qbh[u], qbl[u]);
+      if (s + D + u < ksteps) fma8(xs[(s + D + u) * 64], qa[u], qb[u]);
     // C layout: register t of lane l = row 4 (l >> 4) + t, column l & 15
     const int ca = 32 * pair + r, cb = ca + 16;
     const float ba = (b && ca < N) ? b[ca] : 0.f, bb = (b && cb < N) ? b[cb] : 0.f;
-    constexpr float unscale = 1.f / (AF_SW * AF_SX);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      float va = acc0[t] * unscale + ba, vb = acc1[t] * unscale + bb;
+      float va = acc0[t] + ba, vb = acc1[t] + bb;
       if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
-      if (Out32) {
-        if (ca < N) Out32[(4 * kk + t) * ld32 + ca] = va;
-        if (cb < N) Out32[(4 * kk + t) * ld32 + cb] = vb;
-      } else {
-        if (ca < N) af_put(Out, 4 * kk + t, ca, va);
-        if (cb < N) af_put(Out, 4 * kk + t, cb, vb);
-      }
+      if (ca < N) Out[af_at(4 * kk + t, ca)] = va;
+      if (cb < N) Out[af_at(4 * kk + t, cb)] = vb;
     }
   }
 }
@@ -1681,13 +1644,9 @@ __global__ __launch_bounds__(512) void k_actor_fused(ActorArgs p) {
   if (a >= p.A) return;
   const int tid = threadIdx.x;
   const int H = p.H, no = 2 * p.act_max;
-  const int ks1 = (p.in_max + 31) / 32, ksh = H / 32, nth = H / 16, nto = (no + 15) / 16;
-  const int ld32 = no + 1;
-  // floats of the two regions: a 16 x 32 k-step of a split image takes 2 KB = 512 floats; the head's
-  // fp32 output [16][no + 1] goes where the first hidden image was
-  const int img1 = max(512 * ksh, 16 * ld32), img0 = max(512 * ks1, img1);
-  float *R0f = af_lds, *R1f = af_lds + img0;
-  _Float16 *R0 = reinterpret_cast<_Float16 *>(R0f), *R1 = reinterpret_cast<_Float16 *>(R1f);
+  const int ks1 = (p.in_max + 15) / 16, ksh = H / 16, nth = H / 16, nto = (no + 15) / 16;
+  const int img1 = 256 * max(ksh, nto), img0 = max(256 * ks1, img1);   // floats of the two activation images
+  float *R0 = af_lds, *R1 = af_lds + img0;
   int *alist = reinterpret_cast<int *>(af_lds + img0 + img1);
   if (tid == 0) alist[0] = 0;
   __syncthreads();
@@ -1695,7 +1654,7 @@ __global__ __launch_bounds__(512) void k_actor_fused(ActorArgs p) {
   for (int g = tid; g < p.action_dim; g += 512)
     if (p.sc_agent[g] == a) alist[1 + atomicAdd(&alist[0], 1)] = g;
   // the gather index of a column does not depend on the row: one index load, 16 independent state loads
-  for (int k = tid; k < 32 * ks1; k += 512) {
+  for (int k = tid; k < 16 * ks1; k += 512) {
     const int g = k < p.in_max ? p.gather[a * p.in_max + k] : p.state_dim;
     const bool col = g < p.state_dim;
     const float *src = p.state + (col ? g : 0);
@@ -1703,19 +1662,18 @@ __global__ __launch_bounds__(512) void k_actor_fused(ActorArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = src[(long long)min(e0 + r, p.nenv - 1) * p.state_dim];
 #pragma unroll
-    for (int r = 0; r < 16; r++) af_put(R0, r, k, (col && e0 + r < p.nenv) ? v[r] : 0.f);
+    for (int r = 0; r < 16; r++) R0[af_at(r, k)] = (col && e0 + r < p.nenv) ? v[r] : 0.f;
   }
   __syncthreads();
-  af_layer(R0, ks1, p.W1 + (long long)a * nth * ks1 * 512, p.b1 + (long long)a * H, H, true, R1, nullptr, 0);
+  af_layer(R0, ks1, p.W1 + (long long)a * nth * ks1 * 256, p.b1 + (long long)a * H, H, true, R1);
   __syncthreads();
-  _Float16 *cur = R1, *nxt = R0;
+  float *cur = R1, *nxt = R0;
   for (int l = 0; l + 1 < p.n_hidden; l++) {
-    af_layer(cur, ksh, p.Wh[l] + (long long)a * nth * ksh * 512, p.bh[l] + (long long)a * H, H, true, nxt, nullptr, 0);
+    af_layer(cur, ksh, p.Wh[l] + (long long)a * nth * ksh * 256, p.bh[l] + (long long)a * H, H, true, nxt);
     __syncthreads();
-    _Float16 *t = cur; cur = nxt; nxt = t;
+    float *t = cur; cur = nxt; nxt = t;
   }
-  float *head = reinterpret_cast<float *>(nxt);
-  af_layer(cur, ksh, p.Whead + (long long)a * nto * ksh * 512, p.bhead + (long long)a * no, no, false, nullptr, head, ld32);
+  af_layer(cur, ksh, p.Whead + (long long)a * nto * ksh * 256, p.bhead + (long long)a * no, no, false, nxt);
   __syncthreads();
   // k_policy_sample on the rows at hand: thread = (row, one in 32 of the agent's actions)
   const int r = tid & 15, e = e0 + r;
@@ -1724,8 +1682,8 @@ __global__ __launch_bounds__(512) void k_actor_fused(ActorArgs p) {
   for (int i = tid >> 4; i < nact; i += 32) {
     const int g = alist[1 + i];
     const int l = p.sc_local[g];
-    const float m = head[r * ld32 + l];
-    const float ls = fminf(fmaxf(head[r * ld32 + p.act_max + l], p.ls_min), p.ls_max);
+    const float m = nxt[af_at(r, l)];
+    const float ls = fminf(fmaxf(nxt[af_at(r, p.act_max + l)], p.ls_min), p.ls_max);
     const float eps = p.eps ? p.eps[(long long)e * p.action_dim + g]
                             : philox_normal(p.seed, 7u, p.counter, (uint32_t)e, (uint32_t)g);
     const float x = m + expf(ls) * eps;
@@ -1866,15 +1824,15 @@ int aomarl_agent_rewards(int nenv, int nmodes, int n_agents, const float *res_mo
 // kernels themselves at small batch sizes.  These two entry points issue the same launches, in the
 // same order, from C.
 long long aomarl_actor_tiled_floats(int n_agents, int N, int K) {
-  return (long long)n_agents * ((N + 15) / 16) * ((K + 31) / 32) * 512;
+  return (long long)n_agents * ((N + 15) / 16) * ((K + 15) / 16) * 256;
 }
 
 int aomarl_actor_tile_weights(int n_agents, int N, int K, const float *src, float *dst, void *stream) {
   if (!src || !dst) return fail("actor_tile_weights: null pointer");
   if (n_agents <= 0 || N <= 0 || K <= 0) return fail("actor_tile_weights: bad sizes");
-  const int ntile = (N + 15) / 16, ksteps = (K + 31) / 32;
-  const long long lanes = (long long)ntile * ksteps * 64;
-  hipLaunchKernelGGL(k_actor_tile_weights, dim3((unsigned)((lanes + 255) / 256), n_agents), dim3(256), 0,
+  const int ntile = (N + 15) / 16, ksteps = (K + 15) / 16;
+  const long long per = (long long)ntile * ksteps * 256;
+  hipLaunchKernelGGL(k_actor_tile_weights, dim3((unsigned)((per + 255) / 256), n_agents), dim3(256), 0,
                      (hipStream_t)stream, N, K, ntile, ksteps, src, dst);
   LAUNCHCHK();
   return 0;
@@ -1886,10 +1844,10 @@ int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const f
   if (d->n_hidden < 1 || d->n_hidden > 8) return fail("actor_forward: 1..8 hidden layers");
   const int A = d->n_agents, n = d->nenv, H = d->hidden;
   if (A <= 0 || n <= 0) return 0;
-  if (!(d->flags & AOMARL_ACTOR_LAYER_BY_LAYER) && d->W1_tiled && d->Whead_tiled && H % 32 == 0) {
+  if (!(d->flags & AOMARL_ACTOR_LAYER_BY_LAYER) && d->W1_tiled && d->Whead_tiled && H % 16 == 0) {
     // one launch: pre-tiled weights at hand and the activations of 16 environments fit in LDS
-    const int ks1 = (d->in_max + 31) / 32;
-    const size_t img1 = std::max((size_t)512 * (H / 32), (size_t)16 * (2 * d->act_max + 1)), img0 = std::max((size_t)512 * ks1, img1);
+    const int ks1 = (d->in_max + 15) / 16, nto = (2 * d->act_max + 15) / 16;
+    const size_t img1 = (size_t)256 * std::max(H / 16, nto), img0 = std::max((size_t)256 * ks1, img1);
     const size_t lds = (img0 + img1 + d->act_max + 4) * sizeof(float);
     static bool big_lds = false;
     if (!big_lds && lds > 64 * 1024 && lds <= 128 * 1024) {

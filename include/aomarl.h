@@ -397,16 +397,14 @@ typedef struct {
   const float *const *Wh_tiled;        /* aomarl_actor_tile_weights (HOST array for Wh), or NULL      */
   const float *Whead_tiled;
 } aomarl_actor_desc;
-/* With the tiled copies at hand (and hidden % 32 == 0): ONE launch -- one workgroup per agent x 16
- * environments, activations in LDS, split-fp16 matrix instructions (every operand as an fp16 pair hi + lo,
- * products hi.hi + lo.hi + hi.lo accumulated in fp32: 22 significant bits; |weight| < 64 and
- * |activation| < 4094, saturating beyond).  Without them, or with this flag: split_states + one batched
- * fp32 GEMM per layer + policy_sample.  Actions agree to 2e-5 (test). */
+/* With the tiled copies at hand (and hidden % 16 == 0): ONE launch -- one workgroup per agent x 16
+ * environments, activations in LDS, fp32 matrix instructions.  Without them, or with this flag:
+ * split_states + one batched GEMM per layer + policy_sample.  Same arithmetic up to the order of the
+ * fp32 sums. */
 #define AOMARL_ACTOR_LAYER_BY_LAYER 1
-/* dst[a] = the [N][K] matrix src[a] (nn.Linear layout, stacked over agents) cut into 16 x 32 tiles in
- * the operand order of the 16 x 16 x 32 fp16 matrix instruction, zero-padded and split: tile (n, s) holds
- * 64 x 16 bytes of hi = f16(2^10 w) followed by 64 x 16 bytes of lo = f16(2^10 w - hi), entry l = row
- * 16 n + (l & 15), columns 32 s + 8 (l >> 4) .. + 7.  dst: aomarl_actor_tiled_floats() floats. */
+/* dst[a] = the [N][K] matrix src[a] (nn.Linear layout, stacked over agents) cut into 16 x 16 tiles in
+ * the operand order of the 16 x 16 x 4 matrix instruction, zero-padded: tile (n, s) holds 64 x float4,
+ * entry l = row 16 n + (l & 15), columns 16 s + 4 (l >> 4) .. + 3.  dst: aomarl_actor_tiled_floats(). */
 long long aomarl_actor_tiled_floats(int n_agents, int N, int K);
 int aomarl_actor_tile_weights(int n_agents, int N, int K, const float *src, float *dst, void *stream);
 int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const float *eps, uint32_t seed,

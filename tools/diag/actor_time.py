@@ -12,7 +12,6 @@ def run(lay, nenv, tag):
         for _ in range(20):
             p.select_action(st)
         torch.cuda.synchronize()
-        import gc; gc.collect(); gc.disable()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
@@ -20,7 +19,7 @@ def run(lay, nenv, tag):
             p.select_action(st)
         e1.record()
         th = time.perf_counter() - t0
-        torch.cuda.synchronize(); gc.enable()
+        torch.cuda.synchronize()
         print("%s nenv %d %s: %.1f us per call on the GPU, host %.1f us" %
               (tag, nenv, "layered" if lbl else "fused", e0.elapsed_time(e1) / 300 * 1e3, th / 300 * 1e6),
               "in_max", p.in_max, "act_max", p.act_max, flush=True)
