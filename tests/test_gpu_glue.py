@@ -297,6 +297,29 @@ def test_prefetched_atmosphere_gives_the_same_frames():
 
 
 @pytest.mark.gpu
+def test_two_live_environments_share_the_side_streams():
+    """Every context of the process prefetches on the SAME pair of side streams (one pair per device): two
+    supervisors alive and stepped in turn, each one frame ahead on those streams, give what each gives
+    alone in plain call order, bit for bit."""
+    import torch
+    from ao_marl_amd.env import VecRlSupervisor
+    mk = lambda seed, p: VecRlSupervisor("production_sh_10x10_2m", {}, 4, initial_seed=seed, prefetch_atmos=p)  # noqa: E731
+    a, b = mk(11, True), mk(500, True)
+    ra, rb = mk(11, False), mk(500, False)
+    for s in (a, b, ra, rb):
+        s.reset()
+    for it in range(9):
+        for s, r in ((a, ra), (b, rb)):
+            s.next_part_one(); r.next_part_one()
+            s.next_part_two(None, linear_control=True); r.next_part_two(None, linear_control=True)
+        assert a.sim.pending_atmos and b.sim.pending_atmos
+        for s, r in ((a, ra), (b, rb)):
+            assert torch.equal(s.get_slopes(), r.get_slopes()) and torch.equal(s.get_command(), r.get_command()), it
+            assert torch.equal(s.get_strehl(), r.get_strehl()), it
+    assert not torch.equal(a.get_slopes(), b.get_slopes())
+
+
+@pytest.mark.gpu
 def test_prefetch_with_partial_ranges_equals_batch_stepping():
     """prefetch_atmos on, the batch stepped as two halves through the composite: the first half runs
     one frame ahead, the second in plain order -- same bits as stepping the whole batch."""
