@@ -2233,7 +2233,9 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   const size_t smm = sizeof(float) * (2 * 128 + (hp ? 0 : 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD) +
                                       (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + (hp ? 8192 + 128 : 0);
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
-#define FW(NL, NB, OTF, NZ, WC, HP) hipLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm, s, c->sys, ds, b, n, cog, TR, TP, w.nblk)
+// the events ride on the dispatch itself (its start / completion signal): no marker packets of their own
+// on the queue in front of and behind the kernel
+#define FW(NL, NB, OTF, NZ, WC, HP) hipExtLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm, s, ev_start, ev_done, 0, c->sys, ds, b, n, cog, TR, TP, w.nblk)
 #define FW_H(NL, NB, OTF, NZ, WC) do { if (hp) FW(NL, NB, OTF, NZ, WC, true); else FW(NL, NB, OTF, NZ, WC, false); } while (0)
 #define FW_NC(NL, NB, OTF)                                                                     \
   do {                                                                                          \
@@ -2247,11 +2249,17 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     else FW_NC(NL, 2, true);                                              \
   } while (0)
   const bool timed = c->time_fw && c->fw_ev_used + 2 <= c->fw_ev.size();
-  if (timed) HIPCHK(hipEventRecord(c->fw_ev[c->fw_ev_used], s));
+  // closing event: the "readers of the screens are done" mark the side streams wait for (the closing
+  // event of a timed launch doubles as it); only with the prefetch on, which is what creates ev_frame
+  hipEvent_t ev_start = nullptr, ev_done = nullptr;
+  if (c->prefetch_atmos) {
+    rc = side_stream(c);
+    if (rc) return rc;
+    ev_done = c->ev_frame;
+  }
+  if (timed) { ev_start = c->fw_ev[c->fw_ev_used]; ev_done = c->fw_ev[c->fw_ev_used + 1]; c->fw_ev_used += 2; }
   if (c->nlayers == 1) FW_L(1); else FW_L(3);
   c->frame_marked = false;
-  hipEvent_t ev_done = nullptr;                  // closing event of a timed launch: also the "readers are done" mark
-  if (timed) { ev_done = c->fw_ev[c->fw_ev_used + 1]; HIPCHK(hipEventRecord(ev_done, s)); c->fw_ev_used += 2; }
   c->fw_variant[0] = c->nlayers == 1 ? 1 : 3; c->fw_variant[1] = otf ? nb : 1; c->fw_variant[2] = otf;
   c->fw_variant[3] = noise; c->fw_variant[4] = cube; c->fw_variant[5] = hp;
 #undef FW_L
@@ -2262,9 +2270,6 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   if (c->prefetch_atmos) {
     // second axis of the PSF window: off the critical path (read by aomarl_comp_strehl at the end of
     // the step), so it goes to the side stream, in front of the next frame's extrusions
-    rc = side_stream(c);
-    if (rc) return rc;
-    if (!ev_done) { ev_done = c->ev_frame; HIPCHK(hipEventRecord(ev_done, s)); }
     c->ev_frame_cur = ev_done; c->frame_marked = true;
     HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
     hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);

@@ -1,6 +1,7 @@
 // aomarl_dev.h -- device-side description shared by the kernels of libaomarl_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/aomarl.h"

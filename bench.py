@@ -439,7 +439,7 @@ def main():
                     "traffic": pmc_traffic(args.pmc, kernel_name, args.envs, args.config),
                     "avg_launch_ms": fk_ms, "algorithmic_bytes_per_launch": model["bytes"],
                     "algorithmic_tflops": model["flops"] / (fk_ms * 1e-3) * 1e-12,
-                    "timing": "HIP event pair around each k_frame_wave launch on its stream, inside the timed region"}
+                    "timing": "HIP event pair attached to each k_frame_wave dispatch (start / stop events of hipExtLaunchKernelGGL) on its stream, inside the timed region"}
         hp = kernel_name.endswith("true>")
         out = {
             "metric": "env steps/sec (AO frames/sec)", "value": value, "unit": "env steps/s",

@@ -284,9 +284,10 @@ int aomarl_frame_fused_available(aomarl_ctx *ctx);
  * DM from voltage, noise, bincube, split-fp16 DFT); "" before the first launch.  bench.py matches
  * it against the kernel name recorded in the profiles/ file it takes the HBM traffic from. */
 const char *aomarl_frame_kernel_name(aomarl_ctx *ctx);
-/* Under aomarl_set_option(ctx, "time_frame_kernel", nlaunches) every k_frame_wave launch is bracketed
- * by a HIP event pair on its own stream (the first `nlaunches` launches after the option is set or the
- * times were last read).  This reads them: sum of the launch durations and their count; waits for the
+/* Under aomarl_set_option(ctx, "time_frame_kernel", nlaunches) every k_frame_wave launch carries a HIP
+ * event pair on its own stream, attached to the dispatch as its start / stop events
+ * (hipExtLaunchKernelGGL: no marker packets of their own on the queue; the first `nlaunches` launches
+ * after the option is set or the times were last read).  This reads them: sum of the launch durations and their count; waits for the
  * recorded launches, then starts over.  bench.py's roofline.achieved comes from here. */
 int aomarl_frame_kernel_time(aomarl_ctx *ctx, double *total_ms, int *launches);
 int aomarl_frame_fused(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int flags,
