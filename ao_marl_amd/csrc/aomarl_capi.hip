@@ -51,7 +51,7 @@ struct aomarl_ctx {
   bool force_generic_dm = false, force_valu_target = false;
   int spot_blocks_per_env = 0, spot_lds_pad = 0;
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
-  bool force_f32_dft = false;          // frame kernel: fp32 MFMAs through LDS tiles instead of split-fp16
+  int dft_mode = -1;                   // frame kernel DFTs: -1 follow the library's precision mode, 0 fp32 MFMAs, 1 split-fp16 ("force_f32_dft")
   bool reset_untransposed = false;     // "reset_untransposed": the reset's x extrusions on the row-major screen itself
   bool no_extrude_sg = false;          // "extrude_unfused": scatter and gather of consecutive rounds as separate launches
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
@@ -66,6 +66,8 @@ struct aomarl_ctx {
   bool screens_dirty_main = true;       // the screens / origins were last written on the caller's stream
   // power-of-two scales of the static matrices for the split-f16 GEMM (gemm_scale)
   float cmat_scale = 1.f, v2m_scale = 1.f, m2v_scale = 1.f, s2m_scale = 1.f, ab_scale[AOMARL_MAX_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  const int32_t *sel_checked = nullptr;     // aomarl_env_step: the column selection last validated
+  int sel_checked_n = 0, sel_checked_nm = 0;
   int fw_variant[6] = {0, 0, 0, 0, 0, 0};   // template arguments of the last k_frame_wave launch
   char fw_name[96] = {0};
   // "time_frame_kernel": a HIP event pair around every k_frame_wave launch (aomarl_frame_kernel_time)
@@ -106,6 +108,30 @@ struct aomarl_ctx {
 
 const char *aomarl_last_error(void) { return g_err; }
 int aomarl_abi_version(void) { return AOMARL_ABI_VERSION; }
+
+int aomarl_set_precision(int mode) {
+  if (mode != AOMARL_PRECISION_F32 && mode != AOMARL_PRECISION_SPLIT_F16) return fail("set_precision: unknown mode %d", mode);
+  g_precision = mode;
+  g_gemm_split_f16 = mode == AOMARL_PRECISION_SPLIT_F16;
+  return 0;
+}
+int aomarl_get_precision(void) { return g_precision; }
+int aomarl_gemm_saturated(unsigned *count, void *stream) {
+  if (!count) return fail("gemm_saturated: null argument");
+  *count = 0;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !g_gemm_sat[dev]) return 0;       // no split-fp16 GEMM ever ran on this device
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(count, g_gemm_sat[dev], sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (*count) HIPCHK(hipMemsetAsync(g_gemm_sat[dev], 0, sizeof(unsigned), s));
+  return 0;
+}
+int aomarl_arith_families(void) { return AR_N; }
+const char *aomarl_arith_family_name(int i) { return (i >= 0 && i < AR_N) ? g_arith_name[i] : ""; }
+unsigned long long aomarl_arith_launches(int i) { return (i >= 0 && i < AR_N) ? g_arith[i] : 0ULL; }
+void aomarl_arith_reset(void) { for (int i = 0; i < AR_N; i++) g_arith[i] = 0ULL; }
 
 template <typename T>
 static int upload(aomarl_ctx *c, const T *host, size_t n, T **dev) {
@@ -1116,6 +1142,8 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "gemm_xcd_map")) { g_gemm_xcd = value != 0; return 0; }   // process-wide
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 512; return 0; }   // process-wide
+  if (!strcmp(name, "gemm_split_f16")) { g_gemm_split_f16 = value != 0; return 0; }          // process-wide
+  if (!strcmp(name, "precision")) return aomarl_set_precision(value);                        // process-wide
   if (!c) return fail("set_option: null context");
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
@@ -1124,7 +1152,6 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
-  if (!strcmp(name, "gemm_split_f16")) { g_gemm_split_f16 = value != 0; return 0; }
   if (!strcmp(name, "time_frame_kernel")) {
     // value = number of launches to keep event pairs for (0: off)
     c->time_fw = value > 0;
@@ -1138,7 +1165,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "prefetch_atmos")) { c->prefetch_atmos = value != 0; return 0; }
   if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
-  if (!strcmp(name, "force_f32_dft")) { c->force_f32_dft = value != 0; return 0; }
+  if (!strcmp(name, "force_f32_dft")) { c->dft_mode = value < 0 ? -1 : (value != 0 ? 0 : 1); return 0; }
   if (!strcmp(name, "force_unfused_frame")) { c->force_unfused_frame = value != 0; return 0; }
   if (!strcmp(name, "force_generic_spot")) { c->force_generic_spot = value != 0; return 0; }
   if (!strcmp(name, "force_generic_target")) { c->force_generic_target = value != 0; return 0; }
@@ -1881,6 +1908,7 @@ int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const f
       p.state = state; p.eps = eps; p.seed = seed; p.counter = counter; p.action = action; p.mean = mean;
       const int tiles = (n + 15) / 16, groups = (A + 7) / 8;
       hipLaunchKernelGGL(k_actor_fused, dim3(8 * tiles * groups), dim3(512), lds, (hipStream_t)stream, p);
+      g_arith[AR_ACTOR_F32]++;
       LAUNCHCHK();
       return 0;
     }
@@ -1921,6 +1949,24 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   if (!c->v2m || !c->m2v) return fail("env_step: no modal basis (aomarl_set_modal)");
   if (nm != c->nmodes) return fail("env_step: glue has %d modes, the basis %d", nm, c->nmodes);
   if (action && c->nact <= 0) return fail("env_step: no action modes set");
+  if (!g->modes_ring || !g->res_modes) return fail("env_step: glue->modes_ring / glue->res_modes are null");
+  if (reward_out && (g->n_agents <= 0 || !g->lohi)) return fail("env_step: reward_out needs glue->n_agents > 0 and glue->lohi");
+  if (g->dm_dim <= 0 || g->dm_dim > nm || (!g->sel && g->dm_dim != nm))
+    return fail("env_step: glue->dm_dim = %d does not fit %d modes%s", g->dm_dim, nm, g->sel ? "" : " (no column selection given)");
+  if ((g->mean_dm || g->std_dm || g->mean_res || g->std_res) && !(g->mean_dm && g->std_dm && g->mean_res && g->std_res))
+    return fail("env_step: standardisation needs all of mean_dm, std_dm, mean_res, std_res (or none)");
+  if (c->env_gain)
+    return fail("env_step: per-environment integrator gains are set on this context (aomarl_set_env_gains); env_step "
+                "takes ONE scalar gain -- clear them (aomarl_set_env_gains(ctx, NULL, 0)) or step call by call");
+  if (g->sel && (c->sel_checked != g->sel || c->sel_checked_n != g->dm_dim || c->sel_checked_nm != nm)) {
+    // column selection of the state blocks: validated once per (pointer, size) -- a synchronous copy of
+    // dm_dim indices, never again in the steady state
+    std::vector<int32_t> h((size_t)g->dm_dim);
+    HIPCHK(hipMemcpy(h.data(), g->sel, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); i++)
+      if (h[i] < 0 || h[i] >= nm) return fail("env_step: glue->sel[%zu] = %d is outside the %d modes", i, h[i], nm);
+    c->sel_checked = g->sel; c->sel_checked_n = g->dm_dim; c->sel_checked_nm = nm;
+  }
   hipStream_t s = (hipStream_t)stream;
   Work w = work_layout(c, st->nenv);
   DevState ds = dev_state(st);
@@ -1991,7 +2037,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
     if (rc) return rc;
     const long long nimg = (long long)n * c->sys.nvalid;
     rc = g->denoiser_f32 ? aomarl_denoiser_apply_f32((aomarl_denoiser *)g->denoiser, st->bincube, nimg, stream)
-                         : aomarl_denoiser_apply((aomarl_denoiser *)g->denoiser, st->bincube, nimg, stream);
+                         : aomarl_denoiser_apply_split_f16((aomarl_denoiser *)g->denoiser, st->bincube, nimg, stream);
     if (rc) return rc;
     // the next frame's extrusions go beside centroids / control / agents, not beside the denoiser: that
     // kernel fills the GPU by itself and small kernels next to it only stretch both
@@ -2229,7 +2275,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   DevState ds = dev_state(st);
   if (w.nblk != c->sys.ntiles) return fail("frame_fused: internal stripe count mismatch");
   const int nb = otf ? c->sys.otf_nb : 1;
-  const bool hp = !c->force_f32_dft;
+  const bool hp = c->dft_mode < 0 ? g_precision != 0 : c->dft_mode == 1;
   const size_t smm = sizeof(float) * (2 * 128 + (hp ? 0 : 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD) +
                                       (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + (hp ? 8192 + 128 : 0);
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
@@ -2262,6 +2308,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   c->frame_marked = false;
   c->fw_variant[0] = c->nlayers == 1 ? 1 : 3; c->fw_variant[1] = otf ? nb : 1; c->fw_variant[2] = otf;
   c->fw_variant[3] = noise; c->fw_variant[4] = cube; c->fw_variant[5] = hp;
+  g_arith[hp ? AR_FRAME_SPLIT : AR_FRAME_F32]++;
 #undef FW_L
 #undef FW_NC
 #undef FW_H

@@ -889,15 +889,21 @@ static int denoiser_launch(aomarl_denoiser *d, float *cube, long long nimg, bool
     // split-fp16 operands in 32-channel chunks, four waves per image
     const size_t smc = sizeof(float) * (DN_X + DC_Y + 144);
     hipLaunchKernelGGL(k_denoise4c, dim3(blocks), dim3(256), smc, (hipStream_t)stream, d->w, cube, (int)nimg);
+    g_arith[AR_DENOISE_SPLIT]++;
   } else {
     const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
     hipLaunchKernelGGL(k_denoise4<false>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+    g_arith[AR_DENOISE_F32]++;
   }
   LAUNCHCHK();
   return 0;
 }
 
 int aomarl_denoiser_apply(aomarl_denoiser *d, float *cube, long long nimg, void *stream) {
+  return denoiser_launch(d, cube, nimg, g_precision == 0, stream);      // the library's precision mode
+}
+
+int aomarl_denoiser_apply_split_f16(aomarl_denoiser *d, float *cube, long long nimg, void *stream) {
   return denoiser_launch(d, cube, nimg, false, stream);
 }
 

@@ -360,11 +360,14 @@ __device__ __forceinline__ hx2 cvt_rn2(float a, float b) {
   const fx2 v = {a, b};
   return __builtin_convertvector(v, hx2);
 }
-__device__ __forceinline__ void gh_split(float4 v, const float scale, hx4 &hi, hx4 &lo) {
+__device__ __forceinline__ void gh_split(float4 v, const float scale, hx4 &hi, hx4 &lo, float &amax) {
   // power of two: exact; clamped to the f16 range (a value beyond it -- a centroid whose total flux
-  // came out ~0 -- saturates instead of turning into inf - inf = NaN)
-  v.x = __builtin_amdgcn_fmed3f(v.x * scale, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y * scale, -65504.f, 65504.f);
-  v.z = __builtin_amdgcn_fmed3f(v.z * scale, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w * scale, -65504.f, 65504.f);
+  // came out ~0 -- saturates instead of turning into inf - inf = NaN).  amax: largest scaled magnitude this
+  // thread staged; the kernel counts the threads that saw one above the range (aomarl_gemm_saturated)
+  v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+  amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  v.x = __builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f);
+  v.z = __builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f);
   const hx2 h01 = cvt_rn2(v.x, v.y), h23 = cvt_rn2(v.z, v.w);
   const hx2 l01 = cvt_rn2(sub_lo(h01, v.x), sub_hi(h01, v.y));   // |v - hi| <= 2^-12 |v|, lo keeps 11 bits of it
   const hx2 l23 = cvt_rn2(sub_lo(h23, v.z), sub_hi(h23, v.w));
@@ -383,7 +386,7 @@ __device__ __forceinline__ void gh_split(float4 v, const float scale, hx4 &hi, h
 __device__ __forceinline__ void gh_mainloop(const float *__restrict__ A, int lda,
                                             const float *__restrict__ B, int ldb, int M, int N,
                                             int m0, int n0, int kb, int ke, _Float16 *S, f32x16 &acc,
-                                            const float sa, const float sb) {
+                                            const float sa, const float sb, float &amax) {
   // S: [2 buffers][4 planes: A hi, A lo, B hi, B lo][64 rows][GH_LD]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int lr = tid >> 3, lc = (tid & 7) * 4;
@@ -410,13 +413,13 @@ __device__ __forceinline__ void gh_mainloop(const float *__restrict__ A, int lda
       msk(a0); msk(a1); msk(b0); msk(b1);
     }
     hx4 h, l;
-    gh_split(a0, sa, h, l);
+    gh_split(a0, sa, h, l, amax);
     *reinterpret_cast<hx4 *>(s + lr * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + PL + lr * GH_LD + lc) = l;
-    gh_split(a1, sa, h, l);
+    gh_split(a1, sa, h, l, amax);
     *reinterpret_cast<hx4 *>(s + (lr + 32) * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + PL + (lr + 32) * GH_LD + lc) = l;
-    gh_split(b0, sb, h, l);
+    gh_split(b0, sb, h, l, amax);
     *reinterpret_cast<hx4 *>(s + 2 * PL + lr * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + 3 * PL + lr * GH_LD + lc) = l;
-    gh_split(b1, sb, h, l);
+    gh_split(b1, sb, h, l, amax);
     *reinterpret_cast<hx4 *>(s + 2 * PL + (lr + 32) * GH_LD + lc) = h; *reinterpret_cast<hx4 *>(s + 3 * PL + (lr + 32) * GH_LD + lc) = l;
   };
   // operand of lane l for k-chunk c (16 k): row (l & 31) of the wave's 32, k = 16 c + 8 (l >> 5) .. + 7
@@ -459,7 +462,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h(int M, int N, int K, float al
                                                    const float *__restrict__ A, int lda,
                                                    const float *__restrict__ B, int ldb, float beta,
                                                    float *__restrict__ C, int ldc, int kchunk,
-                                                   float *__restrict__ P, float sa, float sb, int xcd) {
+                                                   float *__restrict__ P, float sa, float sb, int xcd,
+                                                   unsigned *__restrict__ sat) {
   __shared__ __attribute__((aligned(16))) _Float16 S[2 * 4 * 64 * GH_LD];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
   // Workgroups go to the 8 XCDs round-robin in launch order, each XCD with its own 4 MB L2.  With the
@@ -483,7 +487,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h(int M, int N, int K, float al
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  gh_mainloop(A, lda, B, ldb, M, N, m0, n0, kb, ke, S, acc, sa, sb);
+  float amax = 0.f;
+  gh_mainloop(A, lda, B, ldb, M, N, m0, n0, kb, ke, S, acc, sa, sb, amax);
+  if (amax > 65504.f) atomicAdd(sat, 1u);        // a scaled operand left the fp16 range and was clipped (rare: one atomic per such thread)
   const int col = n0 + wn * 32 + (lane & 31);
   const bool split = gridDim.z > 1;
 #pragma unroll
@@ -751,13 +757,41 @@ static float gemm_scale(const float *h, size_t n) {
   e = std::max(-10, std::min(24, e));
   return ldexpf(1.f, e);
 }
-static bool g_gemm_split_f16 = true;  // "gemm_split_f16": the internal GEMMs (extrusion, command matrix, Btt projections) on k_gemm_nt_h
+// Arithmetic of the library.  The reference computes in fp32 throughout (Rtc_FFF, shesha/sutra_wrap.py:49; every
+// array cast to np.float32, shesha/init/wfs_init.py:76-101), and so does the DEFAULT here: fp32 operands on fp32
+// matrix instructions (v_mfma_f32_*_f32), fp32 vector arithmetic.  "precision" = 1 (aomarl_set_precision) is the
+// opt-in fast mode: split-fp16 operand pairs (hi + lo, 22-bit mantissa, fp32 accumulation) in the three kernel
+// families that have such a form -- the frame kernel's DFTs, the internal GEMMs, the denoiser.
+static bool g_gemm_split_f16 = false; // "gemm_split_f16": the internal GEMMs (extrusion, command matrix, Btt projections) on k_gemm_nt_h
+static int g_precision = 0;           // process-wide default of every family (aomarl_set_precision)
+// launches per arithmetic family since aomarl_arith_reset (bench.py builds its `dtype` from them)
+enum { AR_FRAME_F32 = 0, AR_FRAME_SPLIT, AR_GEMM_F32, AR_GEMM_SPLIT, AR_DENOISE_F32, AR_DENOISE_SPLIT, AR_ACTOR_F32, AR_N };
+static unsigned long long g_arith[AR_N] = {0, 0, 0, 0, 0, 0, 0};
+static const char *const g_arith_name[AR_N] = {
+    "frame_kernel_dft:f32_mfma", "frame_kernel_dft:split_f16_mfma", "gemm:f32_mfma", "gemm:split_f16_mfma",
+    "denoiser:f32_mfma", "denoiser:split_f16_mfma", "actor:f32_mfma"};
 static int g_gemm_xcd = 1;            // "gemm_xcd_map": k_gemm_nt_h's blocks grouped by k-chunk per XCD
 static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
 // Retired after their A/B runs (profiles/r01g_*): the un-pipelined aligned kernel (30 us vs 22 us per
 // call) and an in-kernel split-K reduction through ticket counters (4x slower: every block pays an
 // L2 write-back for its __threadfence).  k_gemm_nt<false> / k_gemm_nt_batched stay as the fallback
 // for operands that are not 16-byte aligned.
+
+// Threads of k_gemm_nt_h launches that staged an operand beyond the fp16 range (clipped to +-65504): one
+// counter per device, read and cleared by aomarl_gemm_saturated.  The internal call sites scale their
+// operands with margins of 10^2 .. 10^4 over what a closed loop produces (stencil differences x 2^8 up to
+// 255 um, modes x 2^4 up to 4094, slopes x 1); a diverging policy or a runaway loop can leave them.
+static unsigned *g_gemm_sat[64] = {nullptr};
+static unsigned *gemm_sat_counter() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!g_gemm_sat[dev]) {
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned)) != hipSuccess) return nullptr;
+    g_gemm_sat[dev] = (unsigned *)p;
+  }
+  return g_gemm_sat[dev];
+}
 
 // ws / ws_floats: optional split-K workspace (NULL: never split)
 // epi: applied by the split-K reduce when there is one (returns true), else left to the caller
@@ -793,18 +827,23 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     kchunk = ((K + nsplit - 1) / nsplit + 95) / 96 * 96;
   nsplit = (K + kchunk - 1) / kchunk;
   dim3 grid(bx, by, nsplit);
-  if (al && fast && g_gemm_split_f16) {
+  unsigned *sat = (al && fast && g_gemm_split_f16) ? gemm_sat_counter() : nullptr;
+  if (al && fast && g_gemm_split_f16 && sat) {
     alpha /= (sa * sb);                            // also what the split-K reduce below applies
     if (alpha_out) *alpha_out = alpha;
     hipLaunchKernelGGL(k_gemm_nt_h, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                       ldc, kchunk, ws, sa, sb, g_gemm_xcd);
+                       ldc, kchunk, ws, sa, sb, g_gemm_xcd, sat);
+    g_arith[AR_GEMM_SPLIT]++;
   }
-  else if (al)
+  else if (al) {
     hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
                        ldc, kchunk, ws);
-  else
+    g_arith[AR_GEMM_F32]++;
+  } else {
     hipLaunchKernelGGL(k_gemm_nt<false>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb,
                        beta, C, ldc, kchunk, ws);
+    g_arith[AR_GEMM_F32]++;
+  }
   if (nsplit > 1) {
     const long long tot = (long long)M * N;
     if (nsplit_out) { *nsplit_out = nsplit; return false; }

@@ -91,8 +91,12 @@ class SubapDenoiser(object):
         self.input_bound = float(bound)
 
     def wants_f32(self, bincube=None):
-        """True when the images may leave the range the split-fp16 kernel is exact in.  Without a
-        declared bound the cube itself is measured (one device reduction + sync)."""
+        """True in the library's default precision (f32); in the fast mode (libaomarl.set_precision
+        ("split_f16")) only when the images may leave the range the split-fp16 kernel is exact in.
+        Without a declared bound the cube itself is measured (one device reduction + sync)."""
+        from . import libaomarl as la
+        if la.get_precision() == "f32":         # the library's default: the reference's arithmetic
+            return True
         if self.input_bound is None:
             if bincube is None:
                 return False
@@ -136,14 +140,15 @@ class SubapDenoiser(object):
     def denoise_bincube_(self, bincube, f32=None):
         """In place on a [nenv, nvalid, 256] bincube of [y][x] tiles.  f32 = True: every product on
         fp32 matrix instructions (aomarl_denoiser_apply_f32); False: fp16 pairs; None (default):
-        fp16 pairs unless the declared / measured input range says otherwise (wants_f32)."""
+        what the library's precision mode says (wants_f32: fp32 unless the fast mode is on and the
+        declared / measured input range fits fp16 pairs)."""
         n, nv, np2 = bincube.shape
         if self.use_native and bincube.is_contiguous() and bincube.dtype == torch.float32:
             from . import libaomarl as la
             if f32 is None:
                 f32 = self.wants_f32(bincube)
             self._used_fp16 = self._used_fp16 or not f32
-            fn = la.load().aomarl_denoiser_apply_f32 if f32 else la.load().aomarl_denoiser_apply
+            fn = la.load().aomarl_denoiser_apply_f32 if f32 else la.load().aomarl_denoiser_apply_split_f16
             la.check(fn(
                     self._native(), bincube.data_ptr(), n * nv,
                     C.c_void_p(torch.cuda.current_stream(bincube.device).cuda_stream)))

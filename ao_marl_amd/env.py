@@ -193,11 +193,27 @@ class VecRlSupervisor(object):
         """rlSupervisor.py:236-246 for every environment (seed e: current_seed + stride*e)."""
         if self.autoencoder is not None and hasattr(self.autoencoder, "check_range"):
             self.autoencoder.check_range()      # a saturated fp16 launch of the last episode is an error
+        self.check_range()
         self.sim.reset(self.env_seeds())
         if self.geo is not None:
             self.geo.reset()
         self._control_pending, self._err_stale = False, False
         self.iter = 0
+
+    def check_range(self):
+        """Fast mode (libaomarl.set_precision("split_f16")): raise if a split-fp16 GEMM of the finished
+        episode clipped an operand at the fp16 range (aomarl_gemm_saturated) -- screens, commands or
+        states of that episode are wrong.  Synchronises; called at episode boundaries."""
+        if not hasattr(self.sim, "lib"):
+            return
+        from . import libaomarl as la
+        import ctypes as C
+        n = la.gemm_saturated(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if n:
+            raise FloatingPointError(
+                    "split-fp16 GEMM: operands left the fp16 range in %d kernel threads since the last check "
+                    "(a diverging loop or policy?); results of that episode are wrong.  Run in the default "
+                    "precision (libaomarl.set_precision('f32'))" % n)
 
     def rl_control(self, action):
         """rlSupervisor.py:713-733 (+ correction_modal_basis :784-818) on the device."""
@@ -573,6 +589,10 @@ class VecAoEnv(object):
         if cfg["state_dm_residual"]:
             out["dm_residual"] = self._standardise(s_res, "dm_residual")
         if return_dict:
+            if not self.normalization_bool:
+                # without standardisation the blocks are views of the command ring / the residual buffer,
+                # which later steps overwrite in place: hand out copies
+                out = OrderedDict((k, v.clone()) for k, v in out.items())
             return out
         return torch.cat(list(out.values()), dim=1)
 

@@ -13,7 +13,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AOMARL_LIB: another build of the same library (A/B measurements of kernel variants, csrc/Makefile `variant`)
 LIB_PATH = os.environ.get("AOMARL_LIB") or os.path.join(HERE, "libaomarl_hip.so")
-MAX_LAYERS, MAX_DMS, ABI_VERSION = 8, 4, 1
+MAX_LAYERS, MAX_DMS, ABI_VERSION = 8, 4, 2
+PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
 
 DM_PZT, DM_TT = 0, 1
 TRACE_ATMOS, TRACE_DMS, TRACE_RESET, TRACE_MASK = 1, 2, 4, 8
@@ -74,6 +75,13 @@ _range = [_vp, C.POINTER(State), _i, _i]
 SYMBOLS = [
     ("aomarl_last_error", C.c_char_p, []),
     ("aomarl_abi_version", _i, []),
+    ("aomarl_set_precision", _i, [_i]),
+    ("aomarl_get_precision", _i, []),
+    ("aomarl_gemm_saturated", _i, [C.POINTER(C.c_uint), _vp]),
+    ("aomarl_arith_families", _i, []),
+    ("aomarl_arith_family_name", C.c_char_p, [_i]),
+    ("aomarl_arith_launches", C.c_ulonglong, [_i]),
+    ("aomarl_arith_reset", None, []),
     ("aomarl_create", _i, [C.POINTER(Desc), C.POINTER(_vp)]),
     ("aomarl_destroy", _i, [_vp]),
     ("aomarl_set_cmat", _i, [_vp, _fp]),
@@ -127,6 +135,7 @@ SYMBOLS = [
     ("aomarl_denoiser_create", _i, [C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_void_p)]),
     ("aomarl_denoiser_apply", _i, [_vp, _vp, C.c_longlong, _vp]),
     ("aomarl_denoiser_apply_f32", _i, [_vp, _vp, C.c_longlong, _vp]),
+    ("aomarl_denoiser_apply_split_f16", _i, [_vp, _vp, C.c_longlong, _vp]),
     ("aomarl_denoiser_overflow", _i, [_vp, C.POINTER(C.c_uint), _vp]),
     ("aomarl_denoiser_destroy", _i, [_vp]),
     ("aomarl_target_psf_buffer", _i, _range + [_vp]),
@@ -230,7 +239,63 @@ def load():
         raise AomarlError("libaomarl_hip.so ABI %d != binding %d" %
                           (L.aomarl_abi_version(), ABI_VERSION))
     _lib = L
+    # AOMARL_PRECISION=split_f16 selects the fast mode for the whole process (e.g. to run the test suite
+    # in it); the default is the reference's arithmetic, fp32
+    mode = os.environ.get("AOMARL_PRECISION", "").strip().lower()
+    if mode:
+        set_precision(mode)
     return L
+
+
+_PRECISIONS = {"f32": PRECISION_F32, "fp32": PRECISION_F32, "split_f16": PRECISION_SPLIT_F16,
+               "split-f16": PRECISION_SPLIT_F16, "fast": PRECISION_SPLIT_F16}
+
+
+def set_precision(mode):
+    """Arithmetic of the whole library (aomarl_set_precision): "f32" (default, the reference's) or
+    "split_f16" (fast mode: fp16 operand pairs with 22-bit mantissa, fp32 accumulation, in the frame
+    kernel's DFTs, the internal GEMMs and the denoiser)."""
+    if isinstance(mode, str):
+        if mode.lower() not in _PRECISIONS:
+            raise ValueError("unknown precision %r (f32 | split_f16)" % mode)
+        mode = _PRECISIONS[mode.lower()]
+    check(load().aomarl_set_precision(int(mode)))
+
+
+def get_precision():
+    return "split_f16" if load().aomarl_get_precision() == PRECISION_SPLIT_F16 else "f32"
+
+
+def gemm_saturated(stream=None):
+    """Threads of split-fp16 GEMM launches since the last call that clipped an operand at the fp16 range
+    (aomarl_gemm_saturated); 0 in the default precision."""
+    n = C.c_uint(0)
+    check(load().aomarl_gemm_saturated(C.byref(n), stream))
+    return int(n.value)
+
+
+def arith_launches(reset=False):
+    """{family: launches since the last reset} for the kernel families that exist in more than one
+    arithmetic (aomarl_arith_*), e.g. {"gemm:f32_mfma": 12, "gemm:split_f16_mfma": 0, ...}."""
+    L = load()
+    out = {L.aomarl_arith_family_name(i).decode(): int(L.aomarl_arith_launches(i))
+           for i in range(L.aomarl_arith_families())}
+    if reset:
+        L.aomarl_arith_reset()
+    return out
+
+
+def dtype_string(launches):
+    """The `dtype` of a bench line from what was launched: "f32" when no split-fp16 family ran, otherwise
+    every split-fp16 family by name."""
+    split = sorted(k.split(":")[0] for k, v in launches.items() if v and k.endswith(":split_f16_mfma"))
+    f32 = sorted(k.split(":")[0] for k, v in launches.items() if v and k.endswith(":f32_mfma"))
+    if not split:
+        return "f32"
+    s = "f16x2-split operands (hi+lo, 22-bit mantissa), f32 accumulate in: " + ", ".join(split)
+    if f32:
+        s += "; f32 in: " + ", ".join(f32)
+    return s + "; f32 vector arithmetic elsewhere"
 
 
 def check(rc):

@@ -21,15 +21,21 @@ What the ONE JSON line (rank 0) says:
   value            env steps/s with the metric's episode structure: one env.reset() per
                    `--episode-len` (1000) frames, timed in this run, amortised into the K timed steps:
                    N_env * K / (T_K + K / 1000 * T_reset).  `value_no_reset` is N_env * K / T_K.
-  dtype            arithmetic of the dominant kernel.  Default build: both DFTs of the frame kernel on
-                   split-fp16 operand pairs (hi + lo, 22-bit mantissa) with fp32 accumulation;
-                   `f32_pass` times the same loop with the fp32-MFMA variant ("force_f32_dft").
-  roofline         the one-pass frame kernel: algorithmic bytes / the kernel's
-                   launch duration from HIP event pairs recorded by the library around that launch
-                   on its own stream (aomarl_frame_kernel_time) inside the timed region, against the
-                   8 TB/s HBM peak; `traffic` = HBM bytes per launch from rocprofv3 --pmc passes kept
-                   under profiles/ -- refused (null) unless that file names the kernel instantiation
-                   this run launched.
+  dtype            built from what the timed region LAUNCHED (aomarl_arith_launches): "f32" when every
+                   kernel family ran its fp32 form -- the library's default and the reference's
+                   arithmetic (Rtc_FFF, shesha/sutra_wrap.py:49) -- otherwise every split-fp16 family by
+                   name.  `value` is the all-fp32 pass.  `fast_mode` repeats the loop under
+                   aomarl_set_precision(SPLIT_F16) (fp16 operand pairs, 22-bit mantissa, fp32 accumulation
+                   in the frame kernel's DFTs and the internal GEMMs) with its own dtype / roofline.
+  roofline         the one-pass frame kernel, from its launch duration measured inside the timed region by
+                   HIP event pairs the library attaches to that dispatch on its own stream
+                   (aomarl_frame_kernel_time).  fp32 instantiation: bound = "mfma" -- algorithmic flops
+                    against the 157.3 TFLOP/s dense fp32 matrix peak (it is
+                   compute-bound: fp32 matrix and vector instructions share the issue slots); `hbm_frac`
+                   is the same launch against the 8 TB/s HBM peak.  split-fp16 instantiation
+                   (`fast_mode.roofline`): bound = "hbm", algorithmic bytes / duration.  `traffic` =
+                   HBM bytes per launch from rocprofv3 --pmc passes kept under profiles/ -- refused
+                   (null) unless that file names the kernel instantiation this run launched.
   configs          side figures of BASELINE configs[1] (10x10, 64 envs, 2 agents) and configs[4]
                    (noise + denoiser) from the same process (not `value`).
   cpu_baseline     the CPU oracle (C restatement of the COMPASS frame, oracle/aoref.c) on this host:
@@ -52,7 +58,7 @@ SMALL = "production_sh_10x10_2m"
 NOISY = "production_sh_40x40_8m_3layers_d0_noise"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
-PMC_FILE = "r02_pmc_frame_kernel.json"
+PMC_FILE = "r03_pmc_frame_kernel.json"
 
 
 def parse_args():
@@ -80,8 +86,8 @@ def parse_args():
     ap.add_argument("--no-defer", action="store_true",
                     help="materialise the stack-array DM shapes instead of evaluating them from the "
                          "voltages inside the frame kernel")
-    ap.add_argument("--f32-dft", action="store_true",
-                    help="fp32-MFMA DFTs in the frame kernel for the MAIN timed pass")
+    ap.add_argument("--precision", default="f32", choices=("f32", "split_f16"),
+                    help="arithmetic of the MAIN timed pass (libaomarl.set_precision); f32 is the reference's")
     ap.add_argument("--pmc", default=PMC_FILE,
                     help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes")
     return ap.parse_args()
@@ -91,22 +97,54 @@ def parse_args():
 def spawn_ranks(args):
     """`--gpus N` without a launcher: start N ranks of this script, one per GPU, and pass rank 0's
     line through.  Runs before this process has touched a GPU (no HIP call, no torch.cuda query);
-    children are fresh processes -- nothing is re-exec'd."""
+    children are fresh processes -- nothing is re-exec'd.  All children are polled together: the
+    first one that fails takes its siblings down (they would otherwise sit in a barrier until the
+    process-group timeout) and its stderr tail is shown."""
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+        ef = tempfile.TemporaryFile(mode="w+")
+        errs.append(ef)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stderr=ef))
+    rc, failed = 0, None
+    live = set(range(len(procs)))
+    while live and failed is None:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc, failed = code, r
+                break
+        if live and failed is None:
+            time.sleep(0.05)
+    if failed is not None:
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    for r, ef in enumerate(errs):                # children's stderr: everything of a failed rank, else as is
+        ef.seek(0)
+        txt = ef.read()
+        if txt:
+            sys.stderr.write(("[rank %d stderr]\n" % r if failed is not None else "") + txt[-8000:])
+        ef.close()
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were stopped\n" % (failed, rc))
     sys.exit(rc)
 
 
@@ -267,6 +305,9 @@ class Workload(object):
         self.sim = self.env.supervisor.sim
         self.state = None
         self.torch = torch
+        from ao_marl_amd import libaomarl
+        self.lib = libaomarl
+        self.launched, self.local_elapsed = {}, None
 
     def one_step(self):
         a, _ = self.policy.select_action(self.state)
@@ -283,24 +324,29 @@ class Workload(object):
         # configuration's device buffers (hipFree synchronises the device) would be charged to this one
         gc.collect()
         gc.disable()
-        for _ in range(warmup):
-            self.one_step()
-        torch.cuda.synchronize()
-        if time_frame:
-            self.sim.set_option("time_frame_kernel", steps)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.one_step()
-        t_enq = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        gc.enable()
+        try:
+            for _ in range(warmup):
+                self.one_step()
+            torch.cuda.synchronize()
+            if time_frame:
+                self.sim.set_option("time_frame_kernel", steps)
+            self.lib.arith_launches(reset=True)     # `dtype` = what the timed steps launch
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.one_step()
+            t_enq = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        self.launched = self.lib.arith_launches()
+        self.local_elapsed = elapsed
         fk_ms = None
         if time_frame:
             tot, n = self.sim.frame_kernel_time()
@@ -335,21 +381,57 @@ def amortised(envs_total, steps, elapsed, reset_s, episode_len):
     return envs_total * steps / (elapsed + steps / float(episode_len) * reset_s)
 
 
+def roofline_block(model, fk_ms, kernel_name, args_pmc, envs, config):
+    """The frame kernel against the roof that bounds the instantiation launched: the split-fp16 one is
+    HBM-bound (algorithmic bytes / duration against 8 TB/s), the fp32 one compute-bound on the fp32
+    matrix pipe (algorithmic flops / duration against 157.3 TFLOP/s; its HBM fraction rides along)."""
+    if not fk_ms:
+        return None
+    gbs = model["bytes"] / (fk_ms * 1e-3) * 1e-9
+    tfl = model["flops"] / (fk_ms * 1e-3) * 1e-12
+    split = kernel_name.endswith("true>")
+    common = {"kernel": kernel_name, "traffic": pmc_traffic(args_pmc, kernel_name, envs, config),
+              "avg_launch_ms": fk_ms, "algorithmic_bytes_per_launch": model["bytes"],
+              "algorithmic_flops_per_launch": model["flops"],
+              "timing": "HIP event pair attached to each k_frame_wave dispatch (start / stop events of "
+                        "hipExtLaunchKernelGGL) on its stream, inside the timed region"}
+    if split:
+        r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+             "algorithmic_tflops": tfl}
+    else:
+        r = {"bound": "mfma", "achieved": tfl, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+             "frac": tfl / FP32_MFMA_PEAK_TF, "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+    r.update(common)
+    return r
+
+
 def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None):
-    """A BASELINE configuration other than the headline one, same loop, same accounting (1 GPU)."""
+    """A BASELINE configuration other than the headline one, same loop, same accounting (1 GPU): the
+    all-fp32 pass is the figure, the split-fp16 pass rides along as `fast_mode`."""
+    from ao_marl_amd import libaomarl
     w = Workload(config, envs, 0, 1, device, denoiser=denoiser)
-    w.reset()
-    reset_s = w.time_reset()
-    elapsed, _, fk = w.timed(steps, warmup, time_frame=True)
     out = {"workload": config + (" + shipped denoiser" if denoiser else ""), "envs": envs,
-           "agents": w.layout.n_agents, "steps": steps,
-           "value": amortised(envs, steps, elapsed, reset_s, episode_len),
-           "value_no_reset": envs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
-           "reset_ms": reset_s * 1e3, "frame_kernel_ms": fk,
-           "frame_kernel": w.sim.frame_kernel_name(),
-           "mean_strehl_le": float(w.sim.strehl[:, 1].mean())}
-    if denoiser:
-        w.env.supervisor.autoencoder.check_range()
+           "agents": w.layout.n_agents, "steps": steps}
+    for mode in ("f32", "split_f16"):
+        libaomarl.set_precision(mode)
+        try:
+            w.reset()
+            reset_s = w.time_reset()
+            elapsed, _, fk = w.timed(steps, warmup, time_frame=True)
+            rec = {"dtype": libaomarl.dtype_string(w.launched),
+                   "value": amortised(envs, steps, elapsed, reset_s, episode_len),
+                   "value_no_reset": envs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+                   "reset_ms": reset_s * 1e3, "frame_kernel_ms": fk,
+                   "frame_kernel": w.sim.frame_kernel_name(),
+                   "mean_strehl_le": float(w.sim.strehl[:, 1].mean())}
+            if denoiser:
+                w.env.supervisor.autoencoder.check_range()
+        finally:
+            libaomarl.set_precision("f32")
+        if mode == "f32":
+            out.update(rec)
+        else:
+            out["fast_mode"] = rec
     import torch
     del w
     gc.collect()                # the HIP context of this configuration goes NOW (hipFree synchronises the
@@ -363,6 +445,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)                   # does not return
 
+    import datetime
     import numpy as np  # noqa: F401
     import torch
 
@@ -385,16 +468,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=int(os.environ.get("AOMARL_DIST_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,
                                     device_id=torch.device("cuda", dev_index))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
+    from ao_marl_amd import libaomarl
     from ao_marl_amd.dist import gather_episode_returns
     denoiser = args.denoiser
     if denoiser == "golden":                # the old spelling
         denoiser = "shipped"
+    libaomarl.set_precision(args.precision)
     w = Workload(args.config, args.envs, rank, world, device, denoiser=denoiser,
                  prefetch=not args.no_prefetch)
     env, sim, layout = w.env, w.sim, w.layout
@@ -403,8 +489,6 @@ def main():
         sim.set_option("force_unfused_frame", 1)
     if args.no_defer:
         sim.defer_shape = False
-    if args.f32_dft:
-        sim.set_option("force_f32_dft", 1)
 
     w.reset()
     reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
@@ -412,13 +496,16 @@ def main():
     envs_total = args.envs * world
     value = amortised(envs_total, args.steps, elapsed, reset_s, args.episode_len)
     kernel_name = sim.frame_kernel_name()
+    launched = dict(w.launched)
     sr = float(sim.strehl[:, 1].mean())
 
     # epilogue collective of the path: per-environment returns of every rank, in global seed order
     # (here: the reward of the last step summed over agents, and the long-exposure Strehl)
     ret_all = gather_episode_returns(w.last_r.sum(dim=1))
     sr_all = gather_episode_returns(sim.strehl[:, 1].contiguous())
-    shards = [dict(rank=rank, first_seed=int(w.first_seed), envs=args.envs)]
+    shards = [dict(rank=rank, first_seed=int(w.first_seed), envs=args.envs,
+                   ms_per_step=w.local_elapsed / args.steps * 1e3, frame_kernel_ms=fk_ms,
+                   device=torch.cuda.get_device_name(dev_index))]
     if dist is not None:
         got = [None] * world
         dist.all_gather_object(got, shards[0])
@@ -431,23 +518,12 @@ def main():
     if rank == 0:
         s = env.supervisor.s
         model = frame_kernel_model(s, args.envs)
-        roof = None
-        if fk_ms:
-            achieved = model["bytes"] / (fk_ms * 1e-3) * 1e-9
-            roof = {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(args.pmc, kernel_name, args.envs, args.config),
-                    "avg_launch_ms": fk_ms, "algorithmic_bytes_per_launch": model["bytes"],
-                    "algorithmic_tflops": model["flops"] / (fk_ms * 1e-3) * 1e-12,
-                    "timing": "HIP event pair attached to each k_frame_wave dispatch (start / stop events of hipExtLaunchKernelGGL) on its stream, inside the timed region"}
-        hp = kernel_name.endswith("true>")
         out = {
             "metric": "env steps/sec (AO frames/sec)", "value": value, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": args.envs * world / value * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f16x2-split operands (hi+lo, 22-bit mantissa), f32 accumulate" if hp
-                      else "f32") + "; control / projection / actor GEMMs f32",
+            "dtype": libaomarl.dtype_string(launched),
             "data": "synthetic",
             "config": {"workload": args.config + (" + denoiser" if denoiser else ""),
                        "envs_per_gpu": args.envs, "agents": layout.n_agents,
@@ -458,7 +534,8 @@ def main():
             "value_no_reset": envs_total * args.steps / elapsed,
             "ms_per_step_no_reset": elapsed / args.steps * 1e3,
             "reset_ms": reset_s * 1e3,
-            "roofline": roof,
+            "roofline": roofline_block(model, fk_ms, kernel_name, args.pmc, args.envs, args.config),
+            "launched": {k: v for k, v in launched.items() if v},
             "stage_ms": stage_diag, "atmos_prefetch": bool(env.supervisor.prefetch_atmos),
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "mean_strehl_le": sr,
@@ -472,18 +549,23 @@ def main():
     # ---- everything below is single-GPU side information (rank 0 of an N = 1 run)
     if rank == 0 and world == 1:
         main_is_headline = args.config == WORKLOAD and not denoiser
-        if not args.no_side_configs and main_is_headline and not args.f32_dft:
-            try:        # the same loop on the fp32-MFMA frame kernel (exact fp32 operands)
-                sim.set_option("force_f32_dft", 1)
+        if not args.no_side_configs and main_is_headline and args.precision == "f32":
+            try:        # the same loop in the fast mode: split-fp16 operand pairs in the DFTs and the GEMMs
+                libaomarl.set_precision("split_f16")
                 w.reset()
-                e32, _, fk32 = w.timed(args.steps, args.warmup)
-                out["f32_pass"] = {"dtype": "f32", "kernel": sim.frame_kernel_name(),
-                                   "value": amortised(args.envs, args.steps, e32, reset_s, args.episode_len),
-                                   "value_no_reset": args.envs * args.steps / e32,
-                                   "ms_per_step_no_reset": e32 / args.steps * 1e3, "frame_kernel_ms": fk32}
-                sim.set_option("force_f32_dft", 0)
+                rs16 = w.time_reset()
+                e16, _, fk16 = w.timed(args.steps, args.warmup)
+                out["fast_mode"] = {"dtype": libaomarl.dtype_string(w.launched),
+                                    "value": amortised(args.envs, args.steps, e16, rs16, args.episode_len),
+                                    "value_no_reset": args.envs * args.steps / e16,
+                                    "ms_per_step_no_reset": e16 / args.steps * 1e3, "reset_ms": rs16 * 1e3,
+                                    "launched": {k: v for k, v in w.launched.items() if v},
+                                    "roofline": roofline_block(model, fk16, sim.frame_kernel_name(), args.pmc,
+                                                               args.envs, args.config)}
             except Exception as e:
-                out["f32_pass"] = {"error": str(e)[:200]}
+                out["fast_mode"] = {"error": str(e)[:200]}
+            finally:
+                libaomarl.set_precision("f32")
         try:
             out["sac_update"] = sac_update_rate(layout, device) if main_is_headline else None
         except Exception as e:                      # secondary figure: never fail the bench line
@@ -549,7 +631,7 @@ def stage_split(w, steps):
 def pmc_traffic(fname, kernel_name, envs, config):
     """HBM bytes per launch of the frame kernel from the rocprofv3 --pmc passes summarised in
     profiles/<fname> (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md; collected by
-    tools/pmc_collect.py).  None unless the file was measured on the kernel instantiation and the
+    tools/fw_pmc.sh + tools/fw_pmc.py).  None unless the file was measured on the kernel instantiation and the
     configuration this run launched."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))

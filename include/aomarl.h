@@ -26,7 +26,7 @@ extern "C" {
 
 #define AOMARL_MAX_LAYERS 8
 #define AOMARL_MAX_DMS 4
-#define AOMARL_ABI_VERSION 1
+#define AOMARL_ABI_VERSION 2
 
 enum { AOMARL_DM_PZT = 0, AOMARL_DM_TT = 1 };
 
@@ -137,6 +137,31 @@ typedef struct aomarl_ctx aomarl_ctx;
 const char *aomarl_last_error(void);
 int aomarl_abi_version(void);
 
+/* Arithmetic of the library (process-wide).  The reference computes in fp32 throughout (Rtc_FFF,
+ * shesha/sutra_wrap.py:49; np.float32 arrays, shesha/init/wfs_init.py:76-101), and AOMARL_PRECISION_F32 --
+ * fp32 operands on fp32 matrix instructions, fp32 vector arithmetic in every kernel -- is the default.
+ * AOMARL_PRECISION_SPLIT_F16 is the opt-in fast mode: operands carried as fp16 pairs (hi + lo, 22-bit
+ * mantissa, fp32 accumulation) in the three kernel families that have such a form: the DFTs of the
+ * one-pass frame kernel, the internal GEMMs (extrusion, command matrix, Btt projections; see
+ * aomarl_gemm_nt_split) and the denoiser (aomarl_denoiser_apply).  The per-family switches of
+ * aomarl_set_option ("force_f32_dft", "gemm_split_f16") override it for one family.
+ * aomarl_arith_*: launches per arithmetic family since aomarl_arith_reset, e.g.
+ * "gemm:split_f16_mfma" -- bench.py builds its `dtype` from what was actually launched. */
+enum { AOMARL_PRECISION_F32 = 0, AOMARL_PRECISION_SPLIT_F16 = 1 };
+int aomarl_set_precision(int mode);
+int aomarl_get_precision(void);
+/* Fast mode only: number of kernel threads of split-fp16 GEMM launches on the current device since the
+ * last query that staged an operand whose scaled value left the fp16 range (|v| > 65504: it is clipped
+ * there, the product is wrong).  Synchronises `stream`, clears the counter.  The internal call sites keep
+ * margins of 10^2 .. 10^4 over what a closed loop produces (stencil differences up to 255 um, Btt
+ * coordinates up to 4094, slopes up to 65504 arcsec); a diverging policy can leave them.  ao_marl_amd.env
+ * checks it at every episode boundary, like aomarl_denoiser_overflow. */
+int aomarl_gemm_saturated(unsigned *count, void *stream);
+int aomarl_arith_families(void);
+const char *aomarl_arith_family_name(int family);
+unsigned long long aomarl_arith_launches(int family);
+void aomarl_arith_reset(void);
+
 /* Build the static device-side description (replaces the Telescope/Atmos/Sensors/Dms/Target/
  * Rtc constructors + load_arrays calls of shesha/init/xxx_init.py). Host pointers are copied. */
 int aomarl_create(const aomarl_desc *desc, aomarl_ctx **out);
@@ -246,12 +271,14 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * tables instead of the separable-lattice kernel), "force_valu_target" (VALU PSF rows kernel),
  * "force_generic_spot" / "force_generic_target" (layout-agnostic kernels), "force_unfused_frame"
  * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
- * kernel: fp32 MFMAs through LDS tiles instead of split-fp16 MFMAs from registers),
+ * kernel: 1 = fp32 MFMAs through LDS tiles, 0 = split-fp16 MFMAs from registers, -1 = follow
+ * aomarl_set_precision, the default), "precision" (= aomarl_set_precision; process-wide, ctx may be NULL),
  * "gemm_target_blocks" (split-K target of the fp32 GEMM),
  * "gemm_xcd_map" (default 1: the split-f16 GEMM's blocks are renumbered so that one XCD works on one k-chunk and
  * its L2 holds that slice of both operands; 0: plain grid order; same values; process-wide, ctx may be NULL),
  * "time_frame_kernel" (see aomarl_frame_kernel_time),
- * "gemm_split_f16" (default 1: see aomarl_gemm_nt_split; 0: every product on fp32 matrix instructions),
+ * "gemm_split_f16" (1: the internal products on split-fp16 operands, see aomarl_gemm_nt_split; 0: on fp32
+ * matrix instructions; follows aomarl_set_precision, i.e. 0, until set; process-wide),
  * "prefetch_atmos" (aomarl_next_part_one moves the next frame's atmosphere on a side stream, see
  * aomarl_prefetch_atmos),
  * "gemm_kgroups" (k-groups per tile of aomarl_gemm_batched: 0 = heuristic, 1 / 2 / 4; process-wide,
@@ -449,13 +476,16 @@ int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, co
 typedef struct aomarl_denoiser aomarl_denoiser;
 int aomarl_denoiser_create(const float *const *weights, const float *const *biases,
                            aomarl_denoiser **out);
+/* In the library's precision mode (aomarl_set_precision): fp32 by default. */
 int aomarl_denoiser_apply(aomarl_denoiser *dn, float *cube, long long nimg, void *stream);
-/* The same network with every product on fp32 matrix instructions (4x the matrix-pipe time).  The
- * default entry point carries each operand as an fp16 pair (hi + lo, 22 mantissa bits, fp32
- * accumulation): same results to fp32 rounding as long as inputs and activations stay inside the
- * fp16 range (|v| < 65504); use this one for data that does not. */
+/* Every product on fp32 matrix instructions (the reference's arithmetic; 4x the matrix-pipe time of the
+ * split form). */
 int aomarl_denoiser_apply_f32(aomarl_denoiser *dn, float *cube, long long nimg, void *stream);
-/* Number of kernel threads of aomarl_denoiser_apply calls since the last query that saw an activation
+/* Fast mode: each operand carried as an fp16 pair (hi + lo, 22 mantissa bits, fp32 accumulation): same
+ * results to fp32 rounding as long as inputs and activations stay inside the fp16 range (|v| < 65504);
+ * what leaves it is counted (aomarl_denoiser_overflow). */
+int aomarl_denoiser_apply_split_f16(aomarl_denoiser *dn, float *cube, long long nimg, void *stream);
+/* Number of kernel threads of split-fp16 denoiser launches since the last query that saw an activation
  * outside the fp16 range (the split-fp16 operands saturate there instead of overflowing loudly);
  * synchronises `stream`, clears the counter.  Non-zero: those results are wrong -- rerun on
  * aomarl_denoiser_apply_f32.  ao_marl_amd.denoiser checks it at every episode boundary. */

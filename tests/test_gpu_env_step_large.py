@@ -1,0 +1,130 @@
+"""The composition bench.py times, with an assert: VecAoEnv("production_sh_40x40_8m_3layers", 13 windowed
+modal agents + the windowed tip-tilt agent) stepping through ONE library call per step
+(aomarl_env_step: rl_step -> per-agent rewards -> linear_step -> state assembly, Btt coordinates carried by
+linearity, fused tail) against the same VecAoEnv host logic over the CPU oracle (tests/oracle_vecsim.py:
+every native stage restated in C, explicit v2m / m2v projections, call-by-call order).  State layout =
+helper_states.py:202-283 (windowed), rewards = helper_rewards.py:14-22."""
+import copy
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from ao_marl_amd import geometry as G, modal, system  # noqa: E402
+from tests.oracle_vecsim import OracleVecSim  # noqa: E402
+
+NAME = "production_sh_40x40_8m_3layers"
+RL = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5, window_n_zernike=20,
+          include_tip_tilt_windowed=True)
+NENV, NSTEP = 4, 6
+
+
+def _pushed_sim_class():
+    from ao_marl_amd.sim import HipSim
+
+    class PushedSim(HipSim):
+        """HipSim whose full reset ends on the ORACLE's screens: the two sides generate theirs with
+        differently ordered fp32 sums over a 1296-step recursion; the step is what is compared here (the
+        reset itself: tests/test_gpu_large.py)."""
+        source = None
+
+        def reset(self, seeds, env_begin=0, env_count=None):
+            HipSim.reset(self, seeds, env_begin, env_count)
+            src = type(self).source
+            if src is not None and env_begin == 0 and env_count in (None, self.nenv):
+                for l in range(self.s.nscreens):
+                    self.set_screen(l, np.stack([o.screens[l] for o in src.sims]))
+                    self.t["ext_count"][:, l] = torch.tensor([o.ext_count[l] for o in src.sims], dtype=torch.int32)
+                self.target_psf()           # the pending PSF of the pushed screens
+    return PushedSim
+
+
+@pytest.mark.parametrize("precision", ["f32", "split_f16"])
+def test_env_step_40x40_windowed_agents_match_the_oracle_env(monkeypatch, precision):
+    from ao_marl_amd import libaomarl as la
+    from ao_marl_amd.env import VecAoEnv
+    keep = la.get_precision()
+    la.set_precision(precision)
+    try:
+        _run(monkeypatch, precision)
+    finally:
+        la.set_precision(keep)
+
+
+def _run(monkeypatch, precision):
+    from ao_marl_amd import libaomarl as la
+    from ao_marl_amd.env import VecAoEnv
+    PushedSim = _pushed_sim_class()
+    env = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cuda:0",
+                   sim_factory=PushedSim)
+    lay = env.layout
+    assert lay.n_agents == 14 and lay.state_shapes()[0] == 552 and lay.state_shapes()[-1] == 168
+    assert env._native_glue and env._default_state_layout
+    cal = env.supervisor.cal
+
+    # the oracle-backed twin takes the GPU side's calibration (an interaction matrix of 1286 actuators
+    # through the CPU oracle would take minutes; the calibration itself is compared in test_gpu_parity)
+    def calibrate(s, sysm, backend, nfilt=0, verbose=False):
+        for k, d in enumerate(s.dms):
+            if d.type == "pzt":
+                G.pzt_select(d, sysm.geom, cal.kept[k])
+        system.refresh_dms(s)
+        backend.reload_dms()
+        s.cmat = np.ascontiguousarray(cal.cmat)
+        return copy.copy(cal)
+    monkeypatch.setattr(modal, "calibrate", calibrate)
+    oenv = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cpu",
+                    sim_factory=OracleVecSim)
+    monkeypatch.undo()
+    assert oenv.supervisor.s.nactu == env.supervisor.s.nactu == 1286
+    assert [tuple(v) for v in oenv.layout.agents.values()] == [tuple(v) for v in lay.agents.values()]
+
+    so = oenv.reset().numpy()                       # full 40x40 reset in the oracle (3 x 1296 extrusions per env)
+    PushedSim.source = oenv.supervisor.sim
+    sg = env.reset()
+    PushedSim.source = None
+    assert sg.shape == (NENV, env.state_dim) == so.shape
+    rng = np.random.default_rng(5)
+    worst = dict(state=0.0, reward=0.0, slopes=0.0, com=0.0)
+    la.arith_launches(reset=True)
+    used_native = 0
+    for it in range(NSTEP):
+        scale = np.maximum(1.0, np.abs(so).max())
+        d = np.abs(sg.cpu().numpy() - so).max() / scale
+        worst["state"] = max(worst["state"], d)
+        # standardised Btt coordinates: O(1) columns; fp32 round-off of two differently ordered chains
+        assert d < 2e-3, ("state", it, d)
+        a = rng.uniform(-1, 1, size=(NENV, env.action_dim)).astype(np.float32)
+        ok = env._native_step_ok(False)
+        sg, rg, done, _ = env.step(torch.from_numpy(a).cuda())
+        used_native += int(ok)
+        so_t, ro, _, _ = oenv.step(torch.from_numpy(a))
+        so, ro = so_t.numpy(), ro.numpy()
+        rg = rg.cpu().numpy()
+        assert rg.shape == ro.shape == (NENV, 14) and done is False
+        dr = np.abs(rg - ro).max() / np.maximum(np.abs(ro).max(), 1e-12)
+        worst["reward"] = max(worst["reward"], dr)
+        assert dr < 2e-3, ("reward", it, dr)
+        sl = env.supervisor.get_slopes().cpu().numpy()
+        slo = oenv.supervisor.get_slopes().numpy()
+        worst["slopes"] = max(worst["slopes"], np.abs(sl - slo).max())
+        assert np.abs(sl - slo).max() < 1e-4, ("slopes", it)            # arcsec, the north-star tolerance
+        cm = env.supervisor.get_command().cpu().numpy()
+        cmo = oenv.supervisor.get_command().numpy()
+        dc = np.abs(cm - cmo).max() / np.abs(cmo).max()
+        worst["com"] = max(worst["com"], dc)
+        assert dc < 5e-4, ("com", it, dc)
+    assert used_native == NSTEP                      # every step went through aomarl_env_step
+    launched = {k: v for k, v in la.arith_launches().items() if v}
+    if precision == "f32":
+        assert not any("split" in k for k in launched), launched
+        assert env.supervisor.sim.frame_kernel_name() == "k_frame_wave<3, 1, true, false, false, false>"
+    else:
+        assert env.supervisor.sim.frame_kernel_name() == "k_frame_wave<3, 1, true, false, false, true>"
+        assert "gemm:f32_mfma" not in launched, launched
+    st = env.supervisor.get_strehl().cpu().numpy()
+    sto = oenv.supervisor.get_strehl().numpy()
+    assert np.abs(st[:, :2] - sto[:, :2]).max() < 2e-4
+    print("worst deviations over %d steps (%s): %s" % (NSTEP, precision, worst))

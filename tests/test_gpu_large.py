@@ -53,10 +53,28 @@ def _push(sim, oracles):
             sim.t["ext_count"][e, l] = o.ext_count[l]
 
 
-@pytest.mark.parametrize("unfused", [0, 1, 2])
-def test_large_frames_match_oracle(large, unfused):
-    """0: one-pass frame kernel (science + WFS from the same tiles, stack-array DM from the
-    commands); 1: separate passes; 2: one-pass kernel reading materialised DM shapes."""
+# (unfused, write_bincube, precision).  unfused 0: one-pass frame kernel (science + WFS from the same
+# tiles, stack-array DM from the commands); 1: separate passes; 2: one-pass kernel reading materialised
+# DM shapes.  write_bincube False is what bench.py and VecAoEnv.step launch: the COG-only instantiations
+# k_frame_wave<3, 1, true, false, false, false> (f32, the default) and <..., true> (fast mode), with
+# the GEMMs of the control chain in the same arithmetic.
+LARGE_CASES = [(0, True, "f32"), (1, True, "f32"), (2, True, "f32"), (0, False, "f32"),
+               (0, False, "split_f16"), (0, True, "split_f16")]
+
+
+@pytest.mark.parametrize("unfused,cube,precision", LARGE_CASES)
+def test_large_frames_match_oracle(large, unfused, cube, precision):
+    from ao_marl_amd import libaomarl as la
+    keep = la.get_precision()
+    la.set_precision(precision)
+    try:
+        _large_frames(large, unfused, cube, precision)
+    finally:
+        la.set_precision(keep)
+
+
+def _large_frames(large, unfused, write_cube, precision):
+    from ao_marl_amd import libaomarl as la
     from ao_marl_amd.sim import HipSim
     _, s, cal = large
     seeds = [1234, 4321]
@@ -73,21 +91,23 @@ def test_large_frames_match_oracle(large, unfused):
     sim.accumx[:] = 0
     sim.accumy[:] = 0
     sim.target_psf()                        # pending PSF of the pushed screens, like the oracle's reset
+    la.arith_launches(reset=True)
     for it in range(3):
         sim.next_part_two(None)
-        sim.next_part_one(write_bincube=True)
+        sim.next_part_one(write_bincube=write_cube)
         sl, cm, st = sim.slopes.cpu().numpy(), sim.com.cpu().numpy(), sim.strehl.cpu().numpy()
         cube = sim.t["bincube"].cpu().numpy()
         for e, o in enumerate(oracles):
             o.next_part_two(None)
             o.next_part_one()
             assert np.abs(sl[e] - o.slopes).max() < 1e-4, it          # arcsec
-            # brightest pixel exact wherever it is unambiguous (an almost flat phase puts the
-            # spot on the corner of 4 pixels: a 4-way tie up to round-off)
-            top2 = np.sort(o.bincube, axis=1)[:, -2:]
-            clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 1]
-            assert np.array_equal(cube[e].argmax(axis=1)[clear], o.bincube.argmax(axis=1)[clear])
-            assert np.abs(cube[e] - o.bincube).max() < 2e-5 * o.bincube.max()
+            if write_cube:
+                # brightest pixel exact wherever it is unambiguous (an almost flat phase puts the
+                # spot on the corner of 4 pixels: a 4-way tie up to round-off)
+                top2 = np.sort(o.bincube, axis=1)[:, -2:]
+                clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 1]
+                assert np.array_equal(cube[e].argmax(axis=1)[clear], o.bincube.argmax(axis=1)[clear])
+                assert np.abs(cube[e] - o.bincube).max() < 2e-5 * o.bincube.max()
             # tip-tilt rows of cmat are O(10): 1e-5 arcsec of slope round-off shows up as ~1e-3 V
             assert np.abs(cm[e] - o.com).max() < 2e-4 * np.abs(o.com).max() + 5e-3
             assert abs(st[e, 0] - o.strehl_se) < 2e-4
@@ -96,6 +116,18 @@ def test_large_frames_match_oracle(large, unfused):
         scr = sim.screen(l).cpu().numpy()
         for e, o in enumerate(oracles):
             assert np.abs(scr[e] - o.screens[l]).max() < 5e-5
+    # what ran: the instantiation and the arithmetic the case names
+    launched = {k: v for k, v in la.arith_launches().items() if v}
+    if unfused != 1:
+        name = sim.frame_kernel_name()
+        want = "k_frame_wave<3, 1, %s, false, %s, %s>" % ("true" if unfused == 0 else "false",
+                                                          "true" if write_cube else "false",
+                                                          "true" if precision == "split_f16" else "false")
+        assert name == want, name
+    if precision == "f32":
+        assert not any("split" in k for k in launched), launched
+    else:
+        assert launched.get("gemm:split_f16_mfma", 0) > 0 and "gemm:f32_mfma" not in launched, launched
 
 
 def test_noisy_wfs_matches_oracle():

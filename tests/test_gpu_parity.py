@@ -310,7 +310,7 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
         sim.comp_strehl()
         out[mode] = (sim.slopes.cpu().numpy().copy(), sim.strehl.cpu().numpy().copy(),
                      sim.t["bincube"].cpu().numpy().copy())
-    sim.set_option("force_f32_dft", 0)
+    sim.set_option("force_f32_dft", -1)         # back to the library's precision mode
     # materialising afterwards restores the stored planes from the same voltages
     shp = sim.dm_shape(0).cpu().numpy()
     assert not sim._stale
@@ -338,12 +338,17 @@ def test_fused_frame_matches_oracle_and_unfused(setup):
 @pytest.mark.parametrize("unfused", [0, 1, 2, 3])
 def test_closed_loop_trace_matches_oracle(setup, unfused):
     """40 frames of the integrator loop (next_part_two + next_part_one) from a common state: the
-    one-pass frame kernel with the stack-array DM evaluated from the commands and the DFTs on
-    split-fp16 MFMAs (0), separate target / WFS passes (1), the one-pass kernel reading
-    materialised DM shapes (2), the one-pass kernel with fp32 MFMAs through LDS tiles (3)."""
+    one-pass frame kernel with the stack-array DM evaluated from the commands in the library's FAST mode
+    -- DFTs and internal GEMMs on split-fp16 MFMAs -- (0), separate target / WFS passes (1), the
+    one-pass kernel reading materialised DM shapes (2), the one-pass kernel as the product runs it by
+    default: everything fp32 (3).  1 - 3 in the default precision (f32)."""
+    from ao_marl_amd import libaomarl as la
     _, s, _, sim, oracles = setup
+    keep_precision = la.get_precision()
+    la.set_precision("split_f16" if unfused == 0 else "f32")
+    la.arith_launches(reset=True)
     sim.set_option("force_unfused_frame", 1 if unfused == 1 else 0)
-    sim.set_option("force_f32_dft", 1 if unfused == 3 else 0)
+    sim.set_option("force_f32_dft", -1)
     sim.defer_shape = unfused in (0, 3)
     sim.reset(SEEDS)
     for o, sd in zip(oracles, SEEDS):
@@ -368,8 +373,13 @@ def test_closed_loop_trace_matches_oracle(setup, unfused):
             assert abs(st[e, 0] - o.strehl_se) < 1e-4, it
             assert abs(st[e, 1] - o.strehl_le) < 1e-4, it
     sim.set_option("force_unfused_frame", 0)
-    sim.set_option("force_f32_dft", 0)
     sim.defer_shape = True
+    launched = {k: v for k, v in la.arith_launches().items() if v}
+    la.set_precision(keep_precision)
+    if unfused == 0:
+        assert launched.get("frame_kernel_dft:split_f16_mfma") == 40 and launched.get("gemm:split_f16_mfma", 0) > 0
+    else:
+        assert not any("split" in k for k in launched), launched
     assert sim.strehl[:, 0].min().item() > 0.3   # the loop closed
     print("worst slope deviation over the trace: %.3g arcsec" % worst)
 
