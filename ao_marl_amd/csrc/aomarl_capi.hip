@@ -66,6 +66,11 @@ struct aomarl_ctx {
   bool screens_dirty_main = true;       // the screens / origins were last written on the caller's stream
   // power-of-two scales of the static matrices for the split-f16 GEMM (gemm_scale)
   float cmat_scale = 1.f, v2m_scale = 1.f, m2v_scale = 1.f, s2m_scale = 1.f, ab_scale[AOMARL_MAX_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  // "subpixel_flow" (experiment, profiles/r03_subpixel_flow.txt): the fractional remainder of the wind
+  // accumulators as a sub-pixel shift of the layer windows in the generic bilinear raytrace
+  // (aomarl_raytrace_wfs / _target); 0 (default): integer-pixel frozen flow
+  bool subpixel_flow = false;
+  float frac_x[AOMARL_MAX_LAYERS] = {0, 0, 0, 0, 0, 0, 0, 0}, frac_y[AOMARL_MAX_LAYERS] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int32_t *sel_checked = nullptr;     // aomarl_env_step: the column selection last validated
   int sel_checked_n = 0, sel_checked_nm = 0;
   int fw_variant[6] = {0, 0, 0, 0, 0, 0};   // template arguments of the last k_frame_wave launch
@@ -482,26 +487,30 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[a] > work[b]; });
         UP(int32_t, order.data(), order.size(), s.stripe_order);
       }
-      // split-fp16 PSF twiddles for lane (q, c) of tile t: x = 16 t + 4 q + j, kx = c - 8;
-      // [hi(j = 0..3) | lo(j = 0..3)] of cos, sin (2 pi kx x / npsf)
+      // PSF operand of the frame kernel for lane (q, c) of tile t: X = 16 t + 4 q + j (j = 0..3), column c of
+      // [cos 2 pi k X / npsf (k = 1..8) | sin 2 pi k X / npsf (k = 1..8)]; fp32 and [hi | lo] split-fp16 form
       {
-        std::vector<_Float16> tw((size_t)nt * 2 * 64 * 8);
+        std::vector<_Float16> tw((size_t)nt * 64 * 8);
+        std::vector<float> twf((size_t)nt * 64 * 4);
         for (int t = 0; t < nt; t++)
           for (int lane = 0; lane < 64; lane++)
             for (int j = 0; j < 4; j++) {
-              const int x = 16 * t + 4 * (lane >> 4) + j, kx = (lane & 15) - 8;
-              const double th = 2.0 * M_PI * (double)(((long long)kx * x) % d->npsf) / (double)d->npsf;
-              const float v[2] = {(float)cos(th), (float)sin(th)};
-              for (int u = 0; u < 2; u++) {
-                const _Float16 hi = (_Float16)v[u];
-                const _Float16 lo = (_Float16)(v[u] - (float)hi);
-                _Float16 *o = &tw[(((size_t)t * 2 + u) * 64 + lane) * 8];
-                o[j] = hi; o[4 + j] = lo;
-              }
+              const int x = 16 * t + 4 * (lane >> 4) + j, cc = lane & 15;
+              const int k = cc < 8 ? cc + 1 : cc - 7;
+              const double th = 2.0 * M_PI * (double)(((long long)k * x) % d->npsf) / (double)d->npsf;
+              const float v = (float)(cc < 8 ? cos(th) : sin(th));
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)(v - (float)hi);
+              _Float16 *o = &tw[((size_t)t * 64 + lane) * 8];
+              o[j] = hi; o[4 + j] = lo;
+              twf[((size_t)t * 64 + lane) * 4 + j] = v;
             }
         const _Float16 *dev = nullptr;
         UP(_Float16, tw.data(), tw.size(), dev);
         s.psf_tw_h = dev;
+        const float *devf = nullptr;
+        UP(float, twf.data(), twf.size(), devf);
+        s.psf_tw_f = devf;
       }
       UP(uint16_t, tmask.data(), tmask.size(), s.tile_mask);
       s.fused_ok = 1; s.ntiles = nt;
@@ -960,6 +969,7 @@ static int move_atmos_now(aomarl_ctx *c, aomarl_state *st, int b, int n, float *
         p.kx[l] = kx; p.ky[l] = ky;
         accumx[(size_t)e * nl + l] = ax - (float)kx;
         accumy[(size_t)e * nl + l] = ay - (float)ky;
+        if (e == b) { c->frac_x[l] = ax - (float)kx; c->frac_y[l] = ay - (float)ky; }   // "subpixel_flow": one remainder for the range
       }
     }
     if (e == b) { cur = p; continue; }
@@ -1164,6 +1174,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
     return 0;
   }
   if (!strcmp(name, "prefetch_atmos")) { c->prefetch_atmos = value != 0; return 0; }
+  if (!strcmp(name, "subpixel_flow")) { c->subpixel_flow = value != 0; return 0; }
   if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
   if (!strcmp(name, "force_f32_dft")) { c->dft_mode = value < 0 ? -1 : (value != 0 ? 0 : 1); return 0; }
   if (!strcmp(name, "force_unfused_frame")) { c->force_unfused_frame = value != 0; return 0; }
@@ -1173,6 +1184,17 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
 }
 
 // ---------------------------------------------------------------- raytrace (unfused API)
+// the static description with the layer windows moved by the wind accumulators' remainder ("subpixel_flow")
+static DevSys traced_sys(const aomarl_ctx *c) {
+  DevSys sy = c->sys;
+  if (c->subpixel_flow)
+    for (int l = 0; l < c->nlayers; l++) {
+      sy.layers[l].wxo += c->frac_x[l]; sy.layers[l].txo += c->frac_x[l];
+      sy.layers[l].wyo += c->frac_y[l]; sy.layers[l].tyo += c->frac_y[l];
+    }
+  return sy;
+}
+
 int aomarl_raytrace_wfs(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
@@ -1181,7 +1203,7 @@ int aomarl_raytrace_wfs(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags
   if (!st->wfs_phase) return fail("raytrace_wfs needs st->wfs_phase");
   if (n == 0) return 0;
   const int np = c->sys.n * c->sys.n;
-  hipLaunchKernelGGL(k_raytrace<false>, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, flags);
+  hipLaunchKernelGGL(k_raytrace<false>, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, traced_sys(c), dev_state(st), b, flags);
   LAUNCHCHK();
   return 0;
 }
@@ -1194,7 +1216,7 @@ int aomarl_raytrace_target(aomarl_ctx *c, aomarl_state *st, int b, int n, int fl
   if (!st->tar_phase) return fail("raytrace_target needs st->tar_phase");
   if (n == 0) return 0;
   const int np = c->sys.pupdiam * c->sys.pupdiam;
-  hipLaunchKernelGGL(k_raytrace<true>, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, c->sys, dev_state(st), b, flags);
+  hipLaunchKernelGGL(k_raytrace<true>, dim3((np + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, traced_sys(c), dev_state(st), b, flags);
   LAUNCHCHK();
   return 0;
 }
@@ -2276,8 +2298,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   if (w.nblk != c->sys.ntiles) return fail("frame_fused: internal stripe count mismatch");
   const int nb = otf ? c->sys.otf_nb : 1;
   const bool hp = c->dft_mode < 0 ? g_precision != 0 : c->dft_mode == 1;
-  const size_t smm = sizeof(float) * (2 * 128 + (hp ? 0 : 2 * c->sys.npsf + 4 * 4 * 16 * FW_LD) +
-                                      (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + (hp ? 8192 + 128 : 0);
+  const size_t smm = sizeof(float) * (2 * 128 + (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + 8192 + 128;
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
 // the events ride on the dispatch itself (its start / completion signal): no marker packets of their own
 // on the queue in front of and behind the kernel

@@ -74,7 +74,10 @@ struct DevSys {
   int otf_gx0, otf_gy0;          // first node column / row that reaches tile 0 / stripe 0
   int otf_xoff, otf_yoff;        // DM pixel of the tile origin minus the position of that node
   int otf_latw;                  // lattice columns a stripe can touch
-  const void *psf_tw_h;          // [ntiles][2][64] x 16 B: split-fp16 PSF twiddles (cos, sin)
+  // PSF operand of the frame kernel for lane (q, c) of tile t, 16 B each: column c of [cos k X (k = 1..8) |
+  // sin k X (k = 1..8)], X = 16 t + 4 q + j, j = 0..3
+  const void *psf_tw_h;          // [ntiles][64] x 8 halfs: [hi(j = 0..3) | lo(j = 0..3)]  (split-fp16 form)
+  const void *psf_tw_f;          // [ntiles][64] x 4 floats                                  (fp32 form)
 };
 
 struct DevState {

@@ -2132,20 +2132,39 @@ __global__ __launch_bounds__(256) void k_wfs_spot_fast(DevSys sys, DevState st, 
 // rounding, which the 2e-5 image tolerance needs) is dropped here.
 __device__ __forceinline__ float sci_rev(float ph, float inv_lambda) { return ph * inv_lambda; }
 
-template <int NL, bool OTF, bool HP>
+// Uniform tables that nothing writes during a launch, read through the CONSTANT address space: the compiler
+// then uses scalar loads (s_load, counted by lgkmcnt) instead of a vector load + v_readfirstlane.  It matters
+// for the per-tile walk of the lit-tile list: vector loads return in order, so waiting for the list entry --
+// the newest load in flight -- made every wave wait for ALL its prefetched tile loads at the top of each
+// iteration (s_waitcnt vmcnt(0)): the software pipeline of the frame kernel collapsed to one stage.
+typedef const int __attribute__((address_space(4))) *const_int_p;
+typedef const float __attribute__((address_space(4))) *const_float_p;
+
+template <int NL, bool OTF>
 struct FrameRaw {
   float L[NL][4];
   float P[OTF ? 1 : 4], T[8];
   unsigned mrow;      // 16-bit mask row of the tile (this lane's row)
   float F;
-  f4u SH;             // HP: this wave's quarter of the tile's environment-independent data
+  f4u SH;             // this wave's quarter of the tile's environment-independent data
 };
 
-// HP = true: both DFTs (spot, PSF rows) on split-fp16 MFMAs fed straight from registers (no LDS
-// amplitude tiles); the data of a tile that does not depend on the environment (tip-tilt planes,
-// PSF twiddles: 4 x 16 bytes per lane) is fetched once per block -- each of the 4 waves loads one
-// quarter a tile ahead, parks it in a double-buffered LDS slot, one barrier per lit tile -- instead
-// of once per wave from L2.  HP = false: fp32 MFMAs through transposed LDS tiles.
+// Both arithmetics share one skeleton.  The data of a tile that does not depend on the environment
+// (tip-tilt planes: 2 x 16 bytes per lane; PSF twiddle operand: 16 bytes per lane) is fetched once per
+// BLOCK -- each of the 4 waves loads one quarter a tile ahead, parks it in a double-buffered LDS slot, one
+// barrier per lit tile -- instead of once per wave from L2, and two tiles of loads are in flight per wave.
+// HP = false (default, the reference's arithmetic): fp32 operands on v_mfma_f32_16x16x4_f32.  Lane (q, c)
+// owns the pixels (y = c, x = 4q + s): with K step s of an MFMA taking x = 4q + s from K lane q, the lane's
+// own four amplitudes ARE the A operands of the first DFT stage and of the PSF rows, and the accumulator
+// registers of stage 1 the B operands of stage 2: no amplitude tile ever goes through LDS.
+// HP = true (fast mode): the same products on split-fp16 MFMAs (hi + lo operand pairs).
+//
+// Science path: R[y][kx] = sum_x a(y, x) exp(-2 pi i kx X / Npsf), X = 16 t + x, kx in [-8, 8).  cos is
+// even and sin odd in kx, so the 16 columns of ONE real operand  [cos k X (k = 1..8) | sin k X (k = 1..8)]
+// serve every kx != 0:  PA = a_r . [C|S],  PB = a_i . [C|S]  (8 fp32 MFMAs per tile instead of 16 for the
+// plain complex product; 4 instead of 8 split-fp16 ones), accumulated over the whole stripe and combined
+// once at its end:  kx = +k: (PA_C + PB_S, PB_C - PA_S);  kx = -k: (PA_C - PB_S, PB_C + PA_S).  The
+// kx = 0 column is the plain row sum of the amplitudes: 8 vector adds per tile.
 template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))  // 3 waves per SIMD: <= 168 VGPRs
 void k_frame_wave(DevSys sys, DevState st, int env_begin,
@@ -2153,17 +2172,14 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     float *__restrict__ TR,
                                                     float *__restrict__ TPART, int nblk) {
   extern __shared__ float smem[];
-  const int pd = sys.pupdiam, np = sys.npsf, ntl = sys.ntiles;
+  const int pd = sys.pupdiam, ntl = sys.ntiles;
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2 *sTw = reinterpret_cast<float2 *>(smem);            // [128] WFS twiddles
-  float2 *stw = sTw + 128;                                   // [npsf] PSF twiddles (npsf <= 4096)
-  float *tiles = reinterpret_cast<float *>(stw + (HP ? 0 : np));       // [4 waves][4][16 * FW_LD]
-  float *lat_all = tiles + (HP ? 0 : 4 * 4 * 16 * FW_LD);    // [4 waves][4 NB][latw]
-  float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // HP: [2][4][64]
+  float *lat_all = reinterpret_cast<float *>(sTw + 128);     // [4 waves][4 NB][latw]
+  float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // [2][4][64]
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
-  constexpr int PD = HP ? 2 : 1;                   // tiles of loads in flight per wave
   // blocks are dispatched x-fastest: x = group of 4 environments, y = rank of the stripe by
   // decreasing number of lit tiles -- the longest stripes start first and the launch ends on the
   // shortest ones (longest-processing-time order: smaller tail)
@@ -2174,12 +2190,8 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     sincospif((float)tid * (1.0f / 64.0f), &sn, &cs);
     sTw[tid] = make_float2(cs, sn);
   }
-  const float2 *gtw = reinterpret_cast<const float2 *>(sys.psf_tw);
-  if (!HP)
-    for (int j = tid; j < np; j += 256) stw[j] = gtw[j];
-  __syncthreads();                                           // the only block-wide barrier
-  const bool active = el < env_count;          // HP: idle waves still serve the block's shared loads
-  if (!HP && !active) return;
+  __syncthreads();
+  const bool active = el < env_count;          // idle waves still serve the block's shared loads
   const int e = env_begin + (active ? el : env_count - 1);
   float Cc[4], Ss[4];
 #pragma unroll
@@ -2189,11 +2201,9 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   }
   SpotTwH twh;
   if (HP) twh = spot_tw_h(Cc, Ss);
-  // shared loads: wave 0 / 1: the two 16-byte halves of the lane's tip-tilt pairs, wave 2 / 3: the
-  // split-fp16 PSF cos / sin vectors [t][2][64] x 16 B
+  // shared loads: wave 0 / 1: the two 16-byte halves of the lane's tip-tilt pairs, wave 2 (and 3, a
+  // duplicate that hits in the L1): the PSF operand of the lane, [t][64] x 16 B
   unsigned shstep;
-  float *Twr = tiles + wv * 4 * 16 * FW_LD, *Twi = Twr + 16 * FW_LD;   // WFS amplitude [x][y]
-  float *Tar = Twi + 16 * FW_LD, *Tai = Tar + 16 * FW_LD;              // target amplitude [x][y]
   const int y = 16 * r + c;                                  // pupil row of this lane
   // ---- per-environment constants (target-path offsets; the WFS sees the same pixels).
   // Every load address is  scalar base (advances with the tile)  +  per-lane byte offset (fixed
@@ -2234,8 +2244,8 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ttb), 0, 8 * D1.dim * D1.dim, 0x00020000);
     shvo = tvo + 16u * (unsigned)wv; shstep = 128u;
   } else {
-    shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(sys.psf_tw_h), 0, ntl * 2048, 0x00020000);
-    shvo = 16u * (unsigned)lane + 1024u * (unsigned)(wv - 2); shstep = 2048u;
+    shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(HP ? sys.psf_tw_h : sys.psf_tw_f), 0, ntl * 1024, 0x00020000);
+    shvo = 16u * (unsigned)lane; shstep = 1024u;
   }
   // pivot of the variance sums: phase at the grid centre (ttslot[2]: stack-array value there)
   float pivot;
@@ -2283,16 +2293,16 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   const float *latq = lat + (jm_ok ? jm : 0);
   const float wfs_il = sys.wfs_inv_lambda, tar_il = sys.tar_inv_lambda;
   const f32x4 Z4 = opaque_zero4();
-  f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
-  f32x4 Ri2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 PA = {0.f, 0.f, 0.f, 0.f}, PB = {0.f, 0.f, 0.f, 0.f};     // a_r . [C|S], a_i . [C|S] of the stripe
+  float R0r = 0.f, R0i = 0.f;                                     // kx = 0: row sums of this lane's 4 columns
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
-  const int kxf = c - 8;
   int nlit = 0;
 
+  const const_float_p cflux = (const_float_p)(unsigned long long)sys.flux;
   // Loads of one lit tile.  UNCONDITIONAL: the loops below walk the compact list of this stripe's
   // lit tiles (sys.lit_info), so no load sits under a branch and the prefetch registers need no
   // copies where control flow joins (those copies were 9 % of the vector instructions).
-  auto fetch = [&](int info, FrameRaw<NL, OTF, HP> &raw) {
+  auto fetch = [&](int info, FrameRaw<NL, OTF> &raw) {
     const int t = (info >> 24) & 0x7F;
 #pragma unroll
     for (int l = 0; l < NL; l++) {
@@ -2308,23 +2318,17 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
 #pragma unroll
       for (int j = 0; j < 4; j++) raw.P[OTF ? 0 : j] = p4.v[j];
     }
-    if (HP) {
+    {
       const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, shstep * (unsigned)t, 0));
 #pragma unroll
       for (int j = 0; j < 4; j++) raw.SH.v[j] = v4[j];
-    } else {
-      const char *tb = ttb + 128u * (unsigned)t;
-      const f4u t0 = *reinterpret_cast<const f4u *>(tb + tvo);
-      const f4u t1 = *reinterpret_cast<const f4u *>(tb + 16 + tvo);
-#pragma unroll
-      for (int j = 0; j < 4; j++) { raw.T[j] = t0.v[j]; raw.T[4 + j] = t1.v[j]; }
     }
     raw.mrow = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)t + mvo);
-    raw.F = sys.flux[info & 0xFFFF];                         // no sub-aperture: index 0, unused
+    raw.F = cflux[info & 0xFFFF];                            // scalar load; no sub-aperture: index 0, unused
   };
 
   // one lit tile: consume `cur`, then issue the loads of the tile `infon` describes into `nxt`
-  auto tile = [&](int info, int infon, FrameRaw<NL, OTF, HP> &cur, FrameRaw<NL, OTF, HP> &nxt) {
+  auto tile = [&](int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt) {
     const int t = (info >> 24) & 0x7F;
     // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
     f32x4 S = Z4;
@@ -2340,20 +2344,16 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     }
     const float flux_i = cur.F;
     // environment-independent data of the tile through the block's LDS slot
-    hx8 cosP, sinP;
-    if (HP) {
-      float4 *slot = shb + (nlit & 1) * 256;
-      nlit++;
-      slot[wv * 64 + lane] = make_float4(cur.SH.v[0], cur.SH.v[1], cur.SH.v[2], cur.SH.v[3]);
-      __syncthreads();
-      const float4 t0 = slot[lane], t1 = slot[64 + lane];
-      cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
-      cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
-      cosP = __builtin_bit_cast(hx8, slot[128 + lane]);
-      sinP = __builtin_bit_cast(hx8, slot[192 + lane]);
-      if (!active) { fetch(infon, nxt); return; }
-    }
-    // ---- phase of the 4 pixels, both complex amplitudes (registers; LDS tiles for the fp32 path)
+    float4 *slot = shb + (nlit & 1) * 256;
+    nlit++;
+    slot[wv * 64 + lane] = make_float4(cur.SH.v[0], cur.SH.v[1], cur.SH.v[2], cur.SH.v[3]);
+    __syncthreads();
+    const float4 t0 = slot[lane], t1 = slot[64 + lane];
+    cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
+    cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
+    const float4 csP = slot[128 + lane];          // HP: [hi | lo] halfs; fp32: the 4 K steps
+    if (!active) { fetch(infon, nxt); return; }
+    // ---- phase of the 4 pixels, both complex amplitudes (registers)
     float wr[4], wi[4], ar[4], ai[4];
     if (info & FW_FULL) {
 #pragma unroll
@@ -2384,64 +2384,45 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
       }
     }
-    if (HP) {
-      fetch(infon, nxt);                                     // these loads fly during the MFMAs
-      // ---- science path: R[y][kx] += sum_x a(y, x) exp(-2 pi i kx x / Npsf), split-fp16
-      if (!(dbg & 2)) {
+    fetch(infon, nxt);                                       // these loads fly during the MFMAs
+    // ---- science path (see the kernel's header)
+    if (!(dbg & 2)) {
+      R0r += (ar[0] + ar[1]) + (ar[2] + ar[3]);
+      R0i += (ai[0] + ai[1]) + (ai[2] + ai[3]);
+      if (HP) {
+        const hx8 csH = __builtin_bit_cast(hx8, csP);
         hx8 arH, arL, aiH, aiL;
         dup_hl(ar[0], ar[1], ar[2], ar[3], arH, arL);
         dup_hl(ai[0], ai[1], ai[2], ai[3], aiH, aiL);
-        Rr = mfma_h(arH, cosP, Rr); Rr = mfma_h(arL, cosP, Rr);
-        Rr = mfma_h(aiH, sinP, Rr); Rr = mfma_h(aiL, sinP, Rr);
-        Ri = mfma_h(aiH, cosP, Ri); Ri = mfma_h(aiL, cosP, Ri);
-        Ri2 = mfma_h(arH, sinP, Ri2); Ri2 = mfma_h(arL, sinP, Ri2);     // R_i = Ri - Ri2 at the end
-      }
-      // ---- WFS path (valid sub-apertures only; wave-uniform branch)
-      if ((info & FW_SUB) && !(dbg & 1)) {
-        float v[2][2][2];
-        spot_dft_h_v(twh, wr, wi, Z4, v);
-        spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, v, do_cog, flux_i);
-      }
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int o = (4 * q + j) * FW_LD + c;
-      Twr[o] = wr[j]; Twi[o] = wi[j]; Tar[o] = ar[j]; Tai[o] = ai[j];
-    }
-    fetch(infon, nxt);                                       // these loads fly during the MFMAs
-    __builtin_amdgcn_wave_barrier();
-    // ---- science path: R[y][kx] += sum_{x in tile} a(y, x) exp(-2 pi i kx x / Npsf)
-    if (!(dbg & 2)) {
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const int xl = 4 * q + s;
-        const float ar = Tar[xl * FW_LD + c], ai = Tai[xl * FW_LD + c];
-        const float2 w = stw[(kxf * (16 * t + xl)) & (np - 1)];
-        Rr = mfma16(ar, w.x, Rr);
-        Ri = mfma16(ai, w.x, Ri);
-        Rr = mfma16(ai, w.y, Rr);
-        Ri = mfma16(ar, -w.y, Ri);
+        PA = mfma_h(arH, csH, PA); PA = mfma_h(arL, csH, PA);
+        PB = mfma_h(aiH, csH, PB); PB = mfma_h(aiL, csH, PB);
+      } else {
+        PA = mfma16(ar[0], csP.x, PA); PB = mfma16(ai[0], csP.x, PB);
+        PA = mfma16(ar[1], csP.y, PA); PB = mfma16(ai[1], csP.y, PB);
+        PA = mfma16(ar[2], csP.z, PA); PB = mfma16(ai[2], csP.z, PB);
+        PA = mfma16(ar[3], csP.w, PA); PB = mfma16(ai[3], csP.w, PB);
       }
     }
     // ---- WFS path (valid sub-apertures only; wave-uniform branch)
     if ((info & FW_SUB) && !(dbg & 1)) {
-      float br[4], bi[4];
-#pragma unroll
-      for (int s = 0; s < 4; s++) { br[s] = Twr[(4 * q + s) * FW_LD + c]; bi[s] = Twi[(4 * q + s) * FW_LD + c]; }
-      spot_core<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Cc, Ss, br, bi, do_cog, flux_i, Z4);
+      if (HP) {
+        float v[2][2][2];
+        spot_dft_h_v(twh, wr, wi, Z4, v);
+        spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, v, do_cog, flux_i);
+      } else {
+        spot_core<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, flux_i, Z4);
+      }
     }
-    __builtin_amdgcn_wave_barrier();
   };
 
   // The stripe's lit tiles, compact (sys.lit_info[r][k], tile index in bits 24..30; the entries past
   // the last one repeat it, so the prefetch at the end of the list needs no test: the last tile is
-  // loaded again, from L2, and dropped).  Prefetch distance PD: the HP path keeps TWO tiles of loads
-  // in flight (two register sets, list walked in pairs; an odd first tile goes on its own).
+  // loaded again, from L2, and dropped).  TWO tiles of loads are in flight (two register sets, list
+  // walked in pairs; an odd first tile goes on its own).  The list is read with scalar loads.
   const int nl = sys.lit_count[r];
-  const int *linfo = sys.lit_info + r * (ntl + 4);
-  if (PD == 2) {
-    FrameRaw<NL, OTF, HP> raw0, raw1;
+  const const_int_p linfo = (const_int_p)(unsigned long long)(sys.lit_info + r * (ntl + 4));
+  {
+    FrameRaw<NL, OTF> raw0, raw1;
     int k = 0;
     if (nl & 1) {
       const int i0 = linfo[0];
@@ -2460,23 +2441,25 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         i0 = i2; i1 = i3;
       }
     }
-  } else if (nl > 0) {
-    FrameRaw<NL, OTF, HP> raw;
-    int info = linfo[0];
-    fetch(info, raw);
-    for (int k = 0; k < nl; k++) {
-      const int infon = linfo[k + 1];
-      tile(info, infon, raw, raw);
-      info = infon;
-    }
   }
-  if (HP && !active) return;
-  if (HP) Ri = Ri - Ri2;
-  // ---- PSF rows of this stripe: acc reg j of lane (q, c): y = 4q + j, kx = c
+  if (!active) return;
+  // ---- PSF rows of this stripe.  Register j of lane (q, c): row y = 4q + j, column c of the merged operand
+  // (c < 8: cos of k = c + 1; c >= 8: sin of k = c - 7); the other half of a +-k pair sits in lane c ^ 8 of
+  // the same 16-lane row (row_ror:8).  Lanes c < 8 write kx = -(c + 1), lanes 8 .. 14 kx = +(c - 7), lane 15
+  // (k = 8 has no +8 in the window [-8, 8)) writes kx = 0 from the row sums.
+  R0r += __shfl_xor(R0r, 16); R0r += __shfl_xor(R0r, 32);          // -> every lane: full sum of row y = c
+  R0i += __shfl_xor(R0i, 16); R0i += __shfl_xor(R0i, 32);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    float2 *o = reinterpret_cast<float2 *>(TR) + ((long long)el * pd + (16 * r + 4 * q + j)) * 16 + c;
-    *o = make_float2(Rr[j], Ri[j]);
+    const float oa = dpp_f<0x128>(PA[j]), ob = dpp_f<0x128>(PB[j]);
+    const float z0r = __shfl(R0r, 4 * q + j), z0i = __shfl(R0i, 4 * q + j);
+    float rr, ri;
+    int kxi;
+    if (c < 8) { rr = PA[j] - ob; ri = PB[j] + oa; kxi = 7 - c; }
+    else if (c < 15) { rr = oa + PB[j]; ri = ob - PA[j]; kxi = c + 1; }
+    else { rr = z0r; ri = z0i; kxi = 8; }
+    float2 *o = reinterpret_cast<float2 *>(TR) + ((long long)el * pd + (16 * r + 4 * q + j)) * 16 + kxi;
+    *o = make_float2(rr, ri);
   }
   sd = wave_sum(sd); sd2 = wave_sum(sd2); sm = wave_sum(sm);
   if (lane == 0) {

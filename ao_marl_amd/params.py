@@ -190,6 +190,39 @@ def _normalise(ps):
 BUILTIN_NAMES = ("production_sh_10x10_2m", "production_sh_40x40_8m_3layers",
                  "production_sh_40x40_8m_3layers_d0_noise",
                  "production_sh_40x40_8m_3layers_d1_noise")
+# The wind variants of the 40x40 file the reference ships (data/par/par4rl/production/
+# production_sh_40x40_8m_3layers_<variant>.py), each with recorded COMPASS statistics
+# (state_normalization/*.pickle).  They differ from the base file in exactly three numbers:
+#   _dir_0_15_30 / _same_dir      winddir [0, 15, 30] / [0, 0, 0]        (base: [0, 45, 90])
+#   _v_10_5_15 / _v_20_15_25      windspeed [10, 5, 15] / [20, 15, 25]   (base: [15, 10, 20])
+#   gain                          0.6 in the three _v_10_5_15 files, 0.7 otherwise
+# plus two statistics files recorded on _same_dir with the integrator gain changed on the command line
+# (--gain_change, train_rpc.py:80-82); their gains are the `g` of the geo/ parameter files of the same
+# name: _same_dir_gain_change_high = 0.9, _same_dir_gain_change_low = 0.2.  _same_dir_roket is
+# _same_dir without the geometric twin (identical statistics).
+_BASE_L = "production_sh_40x40_8m_3layers"
+WIND_VARIANTS = tuple(_BASE_L + sfx for sfx in (
+        "_dir_0_15_30", "_dir_0_15_30_v_10_5_15", "_dir_0_15_30_v_20_15_25", "_same_dir",
+        "_same_dir_v_10_5_15", "_same_dir_v_20_15_25", "_v_10_5_15", "_v_20_15_25", "_same_dir_roket",
+        "_same_dir_gain_change_high", "_same_dir_gain_change_low"))
+
+
+def _wind_variant(name):
+    """(winddir, windspeed, gain) of a WIND_VARIANTS name, or None."""
+    if name not in WIND_VARIANTS:
+        return None
+    sfx = name[len(_BASE_L):]
+    wdir = [0, 15, 30] if "_dir_0_15_30" in sfx else ([0, 0, 0] if "_same_dir" in sfx else [0, 45, 90])
+    speed, gain = [15, 10, 20], 0.7
+    if "_v_10_5_15" in sfx:
+        speed, gain = [10, 5, 15], 0.6
+    elif "_v_20_15_25" in sfx:
+        speed = [20, 15, 25]
+    if sfx.endswith("_gain_change_high"):
+        gain = 0.9
+    elif sfx.endswith("_gain_change_low"):
+        gain = 0.2
+    return wdir, speed, gain
 
 
 def _wfs(nxsub, gsmag, noise, dms_seen):
@@ -216,6 +249,15 @@ def builtin(name):
     reference's `parameters_telescope` option carries one, ao_env.py:290)."""
     if name.endswith(".py"):
         name = name[:-3]
+    variant = _wind_variant(name)
+    if variant is not None:
+        ps = builtin(_BASE_L)
+        ps.simul_name = name
+        ps.p_atmos.winddir = np.asarray(variant[0], dtype=np.float32)
+        ps.p_atmos.windspeed = np.asarray(variant[1], dtype=np.float32)
+        for c in ps.p_controllers:
+            c.gain = variant[2]
+        return ps.validate()
     if name not in BUILTIN_NAMES:
         raise NotImplementedError("unknown built-in parameter set %r" % name)
     small = name == "production_sh_10x10_2m"

@@ -32,7 +32,18 @@ def noisy():
     return sysm, s, cal
 
 
-def _run_loop(noisy, resync):
+@pytest.fixture(params=["f32", "split_f16"])
+def precision(request):
+    """Every test of this file in both arithmetics of the library: the default (fp32 operands on fp32 matrix
+    instructions: frame kernel, denoiser, GEMMs) and the fast mode (split-fp16 operand pairs)."""
+    from ao_marl_amd import libaomarl as la
+    keep = la.get_precision()
+    la.set_precision(request.param)
+    yield request.param
+    la.set_precision(keep)
+
+
+def _run_loop(noisy, resync, precision):
     """20 closed-loop frames on the HIP path and on the oracle.  resync: after every frame the
     oracle's integrator state is set to the HIP side's (see the test docstrings)."""
     from ao_marl_amd.sim import HipSim
@@ -51,7 +62,7 @@ def _run_loop(noisy, resync):
     dn_gpu = SubapDenoiser.load(device="cuda:0")
     dn_cpu = SubapDenoiser.load(device="cpu")
     dn_gpu.set_input_bound(float(s.nphot) * float(s.flux.max()) * 2 + 50)
-    assert not dn_gpu.wants_f32()                     # the split-fp16 kernel is the one under test
+    assert dn_gpu.wants_f32() == (precision == "f32")   # the kernel under test: all-fp32 / split-fp16
     log = []
     for it in range(FRAMES):
         # ---- HIP: next_part_two (delay 0) + the supervisor's denoiser branch of next_part_one
@@ -96,7 +107,7 @@ def _run_loop(noisy, resync):
     return log
 
 
-def test_closed_loop_with_noise_and_denoiser_matches_oracle(noisy):
+def test_closed_loop_with_noise_and_denoiser_matches_oracle(noisy, precision):
     """Frame-by-frame parity inside the closed loop.  The HIP loop runs free for 20 frames (its
     commands are the loop's own); the oracle runs the same frames and, after each comparison, takes
     over the HIP side's integrator state (com, com1, com2), so that every frame is compared from
@@ -105,7 +116,7 @@ def test_closed_loop_with_noise_and_denoiser_matches_oracle(noisy):
     Bars: photon counts exact on all but <= 2e-4 of the pixels, slopes within 1e-3 arcsec on
     >= 99.9 % of the sub-apertures, commands to the smoke tolerance (2e-4 of the command scale
     + 5e-3 V), every frame."""
-    log = _run_loop(noisy, resync=True)
+    log = _run_loop(noisy, True, precision)
     flips, pixels = sum(r["nflip"] for r in log), sum(r["npix"] for r in log)
     print("closed loop (state handed over each frame): %d of %d photon counts differ (%.2e)" %
           (flips, pixels, flips / float(pixels)))
@@ -127,7 +138,7 @@ def test_closed_loop_with_noise_and_denoiser_matches_oracle(noisy):
     assert min(r["sr_le"] for r in log[-2:]) > 0.2           # the loop did close
 
 
-def test_free_running_loops_stay_statistically_together(noisy):
+def test_free_running_loops_stay_statistically_together(noisy, precision):
     """The same two loops WITHOUT the hand-over.  A photon count is a threshold decision on the
     expected flux, so 1e-5 differences of two fp32 algorithms flip a few counts, a flipped count
     moves a slope by ~0.01 arcsec, the integrator feeds that into every later frame's phase, which
@@ -136,7 +147,7 @@ def test_free_running_loops_stay_statistically_together(noisy):
     loops stay the same loop: after 20 frames >= 95 % of the slopes still agree to 1e-3 arcsec, < 1e-3
     of the counts differ in any frame, commands within 1 % of their scale, Strehl (short and long
     exposure) within 2e-3."""
-    log = _run_loop(noisy, resync=False)
+    log = _run_loop(noisy, False, precision)
     for r in log:
         assert r["nflip"] < 1e-3 * r["npix"], r
         assert r["good"] >= 0.95, r
@@ -149,7 +160,7 @@ def test_free_running_loops_stay_statistically_together(noisy):
     assert all(r["nflip"] <= 2 and r["good"] >= 0.999 for r in first)
 
 
-def test_supervisor_branch_is_that_sequence(noisy):
+def test_supervisor_branch_is_that_sequence(noisy, precision):
     """VecRlSupervisor with the denoiser runs exactly the call sequence compared above."""
     from ao_marl_amd.env import VecRlSupervisor
     from ao_marl_amd.sim import HipSim
@@ -157,7 +168,7 @@ def test_supervisor_branch_is_that_sequence(noisy):
     dn = SubapDenoiser.load(device="cuda:0")
     sup = VecRlSupervisor(NAME, dict(n_reverse_filtered_from_cmat=5), 2, initial_seed=5, seed_stride=16,
                           autoencoder=dn, prefetch_atmos=False)
-    assert dn.input_bound is not None and not dn.wants_f32()
+    assert dn.input_bound is not None and dn.wants_f32() == (precision == "f32")
     sim = HipSim(sup.s, nenv=2, keep_bincube=True)
     dn2 = SubapDenoiser.load(device="cuda:0")
     sup.reset()

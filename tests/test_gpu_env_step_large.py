@@ -35,10 +35,19 @@ def _pushed_sim_class():
             src = type(self).source
             if src is not None and env_begin == 0 and env_count in (None, self.nenv):
                 for l in range(self.s.nscreens):
-                    self.set_screen(l, np.stack([o.screens[l] for o in src.sims]))
-                    self.t["ext_count"][:, l] = torch.tensor([o.ext_count[l] for o in src.sims], dtype=torch.int32)
+                    self.set_screen(l, np.stack([scr[l] for scr, _ in src.snap]))
+                    self.t["ext_count"][:, l] = torch.tensor([cnt[l] for _, cnt in src.snap], dtype=torch.int32)
                 self.target_psf()           # the pending PSF of the pushed screens
     return PushedSim
+
+
+class SnapOracleVecSim(OracleVecSim):
+    """Keeps the screens as the oracle's reset left them (VecAoEnv.reset goes straight on to the first
+    linear_step, which moves them)."""
+
+    def reset(self, seeds):
+        OracleVecSim.reset(self, seeds)
+        self.snap = [([scr.copy() for scr in o.screens], list(o.ext_count)) for o in self.sims]
 
 
 @pytest.mark.parametrize("precision", ["f32", "split_f16"])
@@ -76,7 +85,7 @@ def _run(monkeypatch, precision):
         return copy.copy(cal)
     monkeypatch.setattr(modal, "calibrate", calibrate)
     oenv = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cpu",
-                    sim_factory=OracleVecSim)
+                    sim_factory=SnapOracleVecSim)
     monkeypatch.undo()
     assert oenv.supervisor.s.nactu == env.supervisor.s.nactu == 1286
     assert [tuple(v) for v in oenv.layout.agents.values()] == [tuple(v) for v in lay.agents.values()]
@@ -88,11 +97,18 @@ def _run(monkeypatch, precision):
     assert sg.shape == (NENV, env.state_dim) == so.shape
     rng = np.random.default_rng(5)
     worst = dict(state=0.0, reward=0.0, slopes=0.0, com=0.0)
+    # Columns that carry signal.  The 5 Btt modes filtered out of the command matrix (and never commanded)
+    # have recorded standard deviations of ~1e-10 in the reference's statistics: their standardised values
+    # are round-off divided by 1e-10 on both sides (the reference feeds its agents the same noise) -- not
+    # comparable, and excluded here.
+    sd_dm, sd_res = env.norm["dm"][1].cpu().numpy(), env.norm["dm_residual"][1].cpu().numpy()
+    live = np.concatenate([sd_dm > 1e-3 * np.median(sd_dm)] * 3 + [sd_res > 1e-3 * np.median(sd_res)])
+    assert live.shape == (env.state_dim,) and (~live).sum() == 4 * 5
     la.arith_launches(reset=True)
     used_native = 0
     for it in range(NSTEP):
-        scale = np.maximum(1.0, np.abs(so).max())
-        d = np.abs(sg.cpu().numpy() - so).max() / scale
+        scale = np.maximum(1.0, np.abs(so[:, live]).max())
+        d = np.abs(sg.cpu().numpy() - so)[:, live].max() / scale
         worst["state"] = max(worst["state"], d)
         # standardised Btt coordinates: O(1) columns; fp32 round-off of two differently ordered chains
         assert d < 2e-3, ("state", it, d)

@@ -106,3 +106,30 @@ def test_delayed_mdp_matches_reference(golden_dir):
                 got.append((delay, int(modif), t, s, a, sn))
             m.save(10 * t, 100 * t, 10 * (t + 1))
     assert np.array_equal(np.asarray(got), rec)
+
+
+def test_wind_variant_parameter_sets_are_the_references():
+    """The 11 wind / gain variants of the 40x40 file (ao_marl_amd/params.py) against the numbers of the
+    reference's parameter files (data/par/par4rl/production/*.py; the two _gain_change files: the `g` of the
+    geo/ files of the same name) -- and every one of them has its recorded COMPASS statistics on board."""
+    from ao_marl_amd import params
+    from ao_marl_amd.env import load_norm
+    want = {"_dir_0_15_30": ([0, 15, 30], [15, 10, 20], 0.7), "_dir_0_15_30_v_10_5_15": ([0, 15, 30], [10, 5, 15], 0.6),
+            "_dir_0_15_30_v_20_15_25": ([0, 15, 30], [20, 15, 25], 0.7), "_same_dir": ([0, 0, 0], [15, 10, 20], 0.7),
+            "_same_dir_v_10_5_15": ([0, 0, 0], [10, 5, 15], 0.6), "_same_dir_v_20_15_25": ([0, 0, 0], [20, 15, 25], 0.7),
+            "_v_10_5_15": ([0, 45, 90], [10, 5, 15], 0.6), "_v_20_15_25": ([0, 45, 90], [20, 15, 25], 0.7),
+            "_same_dir_roket": ([0, 0, 0], [15, 10, 20], 0.7), "_same_dir_gain_change_high": ([0, 0, 0], [15, 10, 20], 0.9),
+            "_same_dir_gain_change_low": ([0, 0, 0], [15, 10, 20], 0.2)}
+    base = params.builtin("production_sh_40x40_8m_3layers")
+    assert len(params.WIND_VARIANTS) == len(want)
+    for sfx, (wd, ws, g) in want.items():
+        name = "production_sh_40x40_8m_3layers" + sfx
+        ps = params.builtin(name + ".py")
+        assert ps.simul_name == name
+        assert list(ps.p_atmos.winddir) == wd and list(ps.p_atmos.windspeed) == ws
+        assert all(abs(c.gain - g) < 1e-7 for c in ps.p_controllers)
+        assert list(ps.p_atmos.frac) == list(base.p_atmos.frac) and ps.p_tel.diam == base.p_tel.diam
+        norm, zn = load_norm(name)
+        assert norm["wfs"]["std"].shape == (2400,) and zn.shape == (1283,)
+    # a variant changes nothing of the base set it was derived from
+    assert list(base.p_atmos.winddir) == [0, 45, 90] and base.p_controllers[0].gain == 0.7

@@ -59,8 +59,20 @@ def test_save_norm_round_trips_through_load_norm(tmp_path, monkeypatch):
             assert np.array_equal(got[k][st], norm[k][st])
 
 
+L40 = "production_sh_40x40_8m_3layers"
+# every noise-free statistics file the reference holds with a parameter file whose settings are known:
+# the base files, the oblique-wind files (15 / 30 degrees: x AND y extrusions on one layer, fractional
+# accumulation on both axes -- the only pins of that part of move_atmos / raytrace), all layers along x,
+# slower / faster winds (gain 0.6 in the _v_10_5_15 files), and the two files recorded on _same_dir with
+# the integrator gain changed on the command line (0.9 / 0.2: ao_marl_amd/params.py)
+COMPASS_RUNS = ["production_sh_10x10_2m", L40, L40 + "_dir_0_15_30", L40 + "_same_dir", L40 + "_v_20_15_25",
+                L40 + "_v_10_5_15", L40 + "_dir_0_15_30_v_10_5_15", L40 + "_dir_0_15_30_v_20_15_25",
+                L40 + "_same_dir_v_10_5_15", L40 + "_same_dir_v_20_15_25",
+                L40 + "_same_dir_gain_change_high", L40 + "_same_dir_gain_change_low"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["production_sh_10x10_2m", "production_sh_40x40_8m_3layers"])
+@pytest.mark.parametrize("name", COMPASS_RUNS)
 def test_statistics_match_the_references_recorded_compass_runs(name):
     """Acceptance of SURVEY section 8c: median ratio of the per-slope and per-mode standard
     deviations within +-10 %, action bounds (extreme-value statistics) within +-20 %."""
