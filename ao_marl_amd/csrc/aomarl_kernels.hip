@@ -2191,7 +2191,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     sTw[tid] = make_float2(cs, sn);
   }
   __syncthreads();
-  const bool active = el < env_count;          // idle waves still serve the block's shared loads
+  const bool active = el < env_count;          // a wave past the last environment repeats it (see the tile)
   const int e = env_begin + (active ? el : env_count - 1);
   float Cc[4], Ss[4];
 #pragma unroll
@@ -2238,15 +2238,15 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   const char *pztb = reinterpret_cast<const char *>(pzt);
   const char *ttb = reinterpret_cast<const char *>(D1.influ);
   const char *mkb = reinterpret_cast<const char *>(sys.tile_mask);
-  __amdgpu_buffer_rsrc_t shrs;
-  unsigned shvo;
-  if (wv < 2) {
-    shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ttb), 0, 8 * D1.dim * D1.dim, 0x00020000);
-    shvo = tvo + 16u * (unsigned)wv; shstep = 128u;
-  } else {
-    shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(HP ? sys.psf_tw_h : sys.psf_tw_f), 0, ntl * 1024, 0x00020000);
-    shvo = 16u * (unsigned)lane; shstep = 1024u;
-  }
+  // (selected with scalar selects, not in two branches: the descriptor must stay provably wave-uniform, or
+  // every load through it is wrapped in a waterfall loop)
+  const bool sh_tt = wv < 2;
+  const void *shbase = sh_tt ? static_cast<const void *>(ttb) : (HP ? sys.psf_tw_h : sys.psf_tw_f);
+  const __amdgpu_buffer_rsrc_t shrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(shbase), 0, sh_tt ? 8 * D1.dim * D1.dim : ntl * 1024, 0x00020000);
+  const unsigned shvo = sh_tt ? tvo + 16u * (unsigned)wv : 16u * (unsigned)lane;
+  shstep = sh_tt ? 7u : 10u;          // log2 of the bytes per tile (a shift stays on the scalar unit; the
+                                      // compiler turns a multiplication into a VECTOR mul24 + waterfall loop)
   // pivot of the variance sums: phase at the grid centre (ttslot[2]: stack-array value there)
   float pivot;
   {
@@ -2304,6 +2304,13 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   // copies where control flow joins (those copies were 9 % of the vector instructions).
   auto fetch = [&](int info, FrameRaw<NL, OTF> &raw) {
     const int t = (info >> 24) & 0x7F;
+    {   // consumed first (slot write at the top of the tile): issued first, so that waiting for it never
+        // waits for the layer loads behind it (vector loads return in order)
+      const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, (unsigned)t << shstep, 0));
+#pragma unroll
+      for (int j = 0; j < 4; j++) raw.SH.v[j] = v4[j];
+    }
+    raw.mrow = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)t + mvo);
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       unsigned sx = 16u * (unsigned)t + lpxs[l]; sx -= (sx >= ldim[l]) ? ldim[l] : 0u;   // scalar
@@ -2318,12 +2325,6 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
 #pragma unroll
       for (int j = 0; j < 4; j++) raw.P[OTF ? 0 : j] = p4.v[j];
     }
-    {
-      const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, shstep * (unsigned)t, 0));
-#pragma unroll
-      for (int j = 0; j < 4; j++) raw.SH.v[j] = v4[j];
-    }
-    raw.mrow = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)t + mvo);
     raw.F = cflux[info & 0xFFFF];                            // scalar load; no sub-aperture: index 0, unused
   };
 
@@ -2352,7 +2353,9 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
     cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
     const float4 csP = slot[128 + lane];          // HP: [hi | lo] halfs; fp32: the 4 K steps
-    if (!active) { fetch(infon, nxt); return; }
+    // (a wave without an environment of its own -- env_count not a multiple of 4 -- repeats the block's last
+    // one: same loads, same arithmetic, same values stored twice.  No branch on `active` in here: a join behind
+    // a branch that issues loads makes the compiler wait for ALL loads in flight, vmcnt(0), on both sides)
     // ---- phase of the 4 pixels, both complex amplitudes (registers)
     float wr[4], wi[4], ar[4], ai[4];
     if (info & FW_FULL) {

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Learning acceptance: does an agent trained HERE beat the integrator?
+
+The reference's loop (TrainerRPC.train_agent, train_rpc.py:452-501): training episodes of 1000 steps followed
+by 1000 SAC updates per agent; every `test_every` episodes one evaluation with the policy's MEAN action and one
+with the integrator alone, on the same fresh atmosphere seeds (train_rpc.py:484-490, 555-631), reporting the
+summed per-agent reward and the long-exposure Strehl.  Same loop here on BASELINE configs[1]:
+production_sh_10x10_2m, 64 environments, 2 agents (80 Btt modes + tip-tilt), everything on the device --
+VecAoEnv.step through aomarl_env_step, actors through aomarl_actor_forward, updates through aomarl_sac_update.
+
+    python tools/learning_acceptance.py [--episodes 60] [--test-every 10] [--envs 64] [--precision f32]
+Prints one line per evaluation and a verdict line; exit code 1 when the last evaluation's RL reward or LE
+Strehl is not above the integrator's.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--episodes", type=int, default=60)
+    ap.add_argument("--test-every", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--updates", type=int, default=1000)
+    ap.add_argument("--precision", default="f32")
+    ap.add_argument("--seed", type=int, default=1234)
+    a = ap.parse_args()
+    import torch
+    from ao_marl_amd import libaomarl as la
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.sac import BatchedSAC, train_agent
+    la.set_precision(a.precision)
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, max_steps_per_episode=a.steps)
+    env = VecAoEnv("production_sh_10x10_2m", a.envs, rl, initial_seed=a.seed, seed_stride=16, n_agents_modal=1)
+    sac = BatchedSAC(env.layout, dict(updates_per_episode_rpc=a.updates, memory_size=1000000), seed=a.seed)
+    print("config production_sh_10x10_2m  envs %d  agents %d (state dims %s, action dims %s)  %d steps + %d updates per "
+          "episode  precision %s" % (a.envs, env.layout.n_agents, env.layout.state_shapes(), env.layout.action_shapes(),
+                                     a.steps, a.updates, la.get_precision()), flush=True)
+    t0 = time.time()
+    evals = []
+
+    def on_episode(rec):
+        if "test_r_rl" in rec:
+            evals.append(rec)
+            print("episode %3d (%.0f s): train reward %9.2f SR_LE %.4f | eval on seed %d: RL reward %9.2f SR_LE %.4f | "
+                  "integrator reward %9.2f SR_LE %.4f | RL - integrator: reward %+8.2f  SR_LE %+.4f" %
+                  (rec["episode"], time.time() - t0, rec["r_total"], rec["sr_le"], rec["test_seed"], rec["test_r_rl"],
+                   rec["test_sr_le_rl"], rec["test_r_integrator"], rec["test_sr_le_integrator"],
+                   rec["test_r_rl"] - rec["test_r_integrator"], rec["test_sr_le_rl"] - rec["test_sr_le_integrator"]),
+                  flush=True)
+    train_agent(env, sac, a.episodes, max_steps=a.steps, test_every=a.test_every, n_updates=a.updates, on_episode=on_episode)
+    torch.cuda.synchronize()
+    last = evals[-1]
+    ok = last["test_r_rl"] > last["test_r_integrator"] and last["test_sr_le_rl"] > last["test_sr_le_integrator"]
+    print("verdict after %d training episodes (%.0f s): RL %s the integrator (reward %.2f vs %.2f, LE Strehl %.4f vs %.4f)" %
+          (a.episodes, time.time() - t0, "BEATS" if ok else "does NOT beat", last["test_r_rl"], last["test_r_integrator"],
+           last["test_sr_le_rl"], last["test_sr_le_integrator"]))
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
