@@ -786,7 +786,10 @@ def train_agent(env, sac, n_episodes, max_steps=None, test_every=50, n_updates=N
             lin = run_episode(env, sac, max_steps=max_steps, train=False, linear_control=True)
             rec.update(test_r_rl=float(rl["r_total_all"].mean()), test_sr_le_rl=float(rl["sr_le_all"].mean()),
                        test_r_integrator=float(lin["r_total_all"].mean()),
-                       test_sr_le_integrator=float(lin["sr_le_all"].mean()))
+                       test_sr_le_integrator=float(lin["sr_le_all"].mean()),
+                       test_sr_se_rl=float(rl["sr_se_mean"].mean()), test_sr_se_integrator=float(lin["sr_se_mean"].mean()),
+                       test_r_agents_rl=rl["r_per_agent"].mean(dim=0).tolist(),
+                       test_r_agents_integrator=lin["r_per_agent"].mean(dim=0).tolist())
         env.next_seed_block(world)
         log.append(rec)
         if on_episode is not None:

@@ -635,8 +635,11 @@ def pmc_traffic(fname, kernel_name, envs, config):
     configuration this run launched."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
-        rec = pmc["frame_fused"]
-        if pmc.get("_config") != config or rec.get("kernel") != kernel_name:
+        if pmc.get("_config") != config:
+            return None
+        recs = pmc.get("kernels") or {pmc["frame_fused"]["kernel"]: pmc["frame_fused"]}
+        rec = recs.get(kernel_name)
+        if rec is None:
             return None
         return rec["hbm_traffic_bytes_per_launch"] * envs / pmc["_envs"]
     except Exception:

@@ -98,36 +98,34 @@ def test_statistics_match_the_references_recorded_compass_runs(name):
 
 @pytest.mark.gpu
 def test_noisy_configuration_against_the_references_d1_noise_statistics():
-    """The only reference-held fixture of the noisy configuration family: the normalisation the
-    reference recorded from real COMPASS for production_sh_40x40_8m_3layers_d1_noise (magnitude 9,
-    3 e- read-out noise, delay 1).  It is the independent check of the photon / read-out noise model
-    (the oracle shares the kernel's noise rule, so only COMPASS's own numbers can vouch for it).
+    """The only reference-held fixture of the noisy configuration family: the normalisation the reference
+    recorded from real COMPASS under the name production_sh_40x40_8m_3layers_d1_noise (magnitude 9, 3 e-
+    read-out noise; byte for byte the `_noise_M9` file, whose parameter file is not in the tree).  It is the
+    independent check of the photon / read-out noise model and of the centroid rule (the oracle shares the
+    kernel's, so only COMPASS's own numbers can vouch for them).  What round 3 established
+    (profiles/r03_d1_noise_centroid_rules.txt, profiles/r03_d1_noise_seed_blocks.txt; tools/d1_noise_cog_rules.py):
 
-    What the recorded file pins, and what it does not (measured, gpurun_out/r02d_diag.log):
-      * slopes and residual modes (v2m . cmat . s) are set by the sensor noise -- 5x the noise-free
-        configuration's.  At the shipped parameter file's settings (gain 0.65) this build gives
-        1.000 (p10 0.98, p90 1.02 over the 2400 slopes) of the recorded slope statistics: asserted,
-        +-10 %.  The residual modes come out at 1.06 - 1.31 of the recorded ones
-        depending on the LAST BITS of the arithmetic (three numerically equivalent builds of this
-        library gave 1.057, 1.204, 1.312): every mode is a dense combination of all slopes, so the
-        37-sigma outliers described below dominate each mode's standard deviation, and how many of
-        them a run of 20 x 1000 frames meets is decided by count-level differences that the closed
-        loop amplifies.  Asserted inside that band (0.9 .. 1.4), i.e. "set by the sensor noise, not
-        by the loop" -- it is the slopes that pin the noise model;
-      * the recorded run did NOT use the denoiser (with the shipped network the slopes' standard
-        deviation is 0.23 of the recorded one; next_integrator_normalization, rlSupervisor.py:506-590,
-        never calls it);
-      * the command modes / action bounds of the recorded run are NOT reproduced at the file's gain
-        (2.9x), nor together with the slopes at any other single gain (gain 0.4: commands 1.13,
-        action bounds 0.91, but slopes 0.87): at gain 0.65 the un-denoised loop is in a poor regime
-        here (Strehl 0.35; 37-sigma outliers of the residual from centroids whose total flux comes
-        close to zero kick the integrator, the commands of each environment wander: temporal std is
-        0.43 of the pooled one), and the reference's README says the file's gain is the one tuned
-        for the DENOISED loop.  Reported, bracketed by the gain scan below (the recorded command
-        statistics lie inside the family of loops this build produces), not asserted at +-10 %:
-        this part of the fixture stays unpinned.
-    The denoiser variant (k_frame_wave<noise> -> k_denoise4c -> k_cog) is run too and must show the
-    noise reduction it exists for."""
+      * SLOPES: 1.000 +- 0.004 of the recorded per-slope standard deviations on every one of 16 disjoint
+        blocks of 20 seeds at the parameter file's gain 0.65 -- asserted (+-2 %).  Any other gain or delay of
+        the family (0.3 / delay 0: 0.82; 0.3 / delay 1: 0.85) misses it: the recorded run WAS at 0.65, delay 1;
+      * CENTROID RULE: the recorded run has heavy-tailed centroids -- (max - min) / std per slope: median 13.6,
+        99th percentile 70 (a Gaussian gives 8) -- i.e. COMPASS divides by the measured flux whatever it is,
+        like the plain centre of gravity here: this build gives 13.4 .. 13.7 and 46 .. 100 on the 16 blocks.
+        A floor on the denominator, zeroing faint spots, clipping negative pixels or a threshold all destroy
+        that tail (99th percentile 10 .. 19) and / or the slope statistics (0.24 .. 0.30).  Asserted: the
+        median of that ratio within +-10 % of the recorded one;
+      * RESIDUAL MODES (v2m . cmat . s): 0.99 .. 1.04 on the blocks without a mega-outlier, up to 1.5 with
+        one -- asserted 0.95 .. 1.6;
+      * COMMAND MODES / action bounds are NOT a reproducible statistic of this loop in any implementation:
+        one centroid of a spot whose total flux came out near zero kicks the integrator of its environment by
+        10^2 .. 10^4 sigma, and the pooled standard deviation over 20 x 1000 frames is whatever the few such
+        events of the run make it: 0.97, 0.99, 1.29, 1.36, 1.47, 1.58, 2.2, 2.7, 2.7, 3.6, 3.8, 3.9, 4.0, 8.2,
+        13.6, 32.9 of the recorded value on 16 blocks of seeds of ONE rule (and the same spread between two
+        numerically equivalent forms of it on the SAME seeds).  The recorded run is one draw from that
+        distribution, at its quiet end; what can be asserted is the quiet floor: never below 0.9.
+    The denoiser variant (k_frame_wave<noise> -> denoiser -> k_cog) is run too and must show the noise
+    reduction it exists for (the recorded run did not use it: with the shipped network the slopes' standard
+    deviation is 0.23 of the recorded one)."""
     from ao_marl_amd.denoiser import SubapDenoiser
     from ao_marl_amd.env import VecRlSupervisor
     name = "production_sh_40x40_8m_3layers_d1_noise"
@@ -135,37 +133,42 @@ def test_noisy_configuration_against_the_references_d1_noise_statistics():
     nm = zn_ref.shape[0]
     live = np.arange(nm) < nm - 5 - 2
     live[-2:] = True
+    tail_ref = float(np.median((ref["wfs"]["max"] - ref["wfs"]["min"]) / ref["wfs"]["std"]))
+    assert 13.0 < tail_ref < 14.5
 
     def ratios(norm, zn, sr):
         return dict(wfs=float(np.median(norm["wfs"]["std"] / ref["wfs"]["std"])),
                     dm=float(np.median(norm["dm"]["std"][live] / ref["dm"]["std"][live])),
                     res=float(np.median(norm["dm_residual"]["std"][live] / ref["dm_residual"]["std"][live])),
-                    zn=float(np.median(zn[live] / zn_ref[live])), sr=float(sr.mean()))
+                    zn=float(np.median(zn[live] / zn_ref[live])), sr=float(sr.mean()),
+                    tail=float(np.median((norm["wfs"]["max"] - norm["wfs"]["min"]) / norm["wfs"]["std"])))
 
     def show(label, r):
-        print("%s [%s]: median std ratio  slopes %.3f  command modes %.3f  residual modes %.3f  "
-              "zn_norm %.3f  LE Strehl %.3f" % (name, label, r["wfs"], r["dm"], r["res"], r["zn"], r["sr"]))
+        print("%s [%s]: median std ratio  slopes %.3f  command modes %.3f  residual modes %.3f  zn_norm %.3f  "
+              "LE Strehl %.3f  slope (max - min) / std %.1f (recorded %.1f)" %
+              (name, label, r["wfs"], r["dm"], r["res"], r["zn"], r["sr"], r["tail"], tail_ref))
 
     sup = VecRlSupervisor(name, dict(n_reverse_filtered_from_cmat=5), 20, initial_seed=1, seed_stride=1)
     assert abs(sup.gain - 0.65) < 1e-6 and sup.s.delay == 1.0 and sup.s.noise == 3.0
-    at_file_gain = ratios(*N.normalization_loop(sup, frames=1000))
-    show("plain sensor, file gain 0.65", at_file_gain)
-    # the noise model: measured slopes and the residual they produce
-    assert abs(at_file_gain["wfs"] - 1) < 0.10, at_file_gain
-    assert 0.9 < at_file_gain["res"] < 1.4, at_file_gain
-    scan = {0.65: at_file_gain}
-    for g in (0.4, 0.3):
-        sup.set_gain(g)
-        scan[g] = ratios(*N.normalization_loop(sup, frames=1000))
-        show("plain sensor, gain %.2f" % g, scan[g])
-    # the recorded command statistics are bracketed by this build's loops
-    assert scan[0.65]["dm"] > 1.0 > scan[0.3]["dm"] and scan[0.65]["zn"] > 1.0 > scan[0.3]["zn"], scan
-    # less gain -> less propagated noise, everywhere
-    assert scan[0.65]["wfs"] > scan[0.4]["wfs"] > scan[0.3]["wfs"] - 0.02
-    assert scan[0.3]["sr"] > scan[0.65]["sr"]
+    blocks = []
+    for b in range(2):
+        sup.set_sim_seed(1 + 20 * b)
+        r = ratios(*N.normalization_loop(sup, frames=1000))
+        show("plain sensor, file gain 0.65, seeds %d..%d" % (1 + 20 * b, 20 + 20 * b), r)
+        assert abs(r["wfs"] - 1) < 0.02, r                  # the noise model, at the file's gain
+        assert abs(r["tail"] / tail_ref - 1) < 0.10, r      # the centroid rule: COMPASS's heavy tail
+        assert 0.95 < r["res"] < 1.6, r
+        assert r["dm"] > 0.9 and r["zn"] > 0.7, r           # the quiet floor; no upper bar (see the docstring)
+        blocks.append(r)
+    # less gain -> less propagated noise in the slopes: the recorded slopes pin the gain
+    sup.set_sim_seed(1)
+    sup.set_gain(0.3)
+    low = ratios(*N.normalization_loop(sup, frames=1000))
+    show("plain sensor, gain 0.30", low)
+    assert low["wfs"] < 0.92 and low["sr"] > blocks[0]["sr"]
     del sup
     dn = SubapDenoiser.load(device="cuda:0")
     den = ratios(*N.obtain_normalization(name, modes_filtered=5, episodes=20, frames=1000, autoencoder=dn))
     dn.check_range()
     show("shipped denoiser, file gain 0.65", den)
-    assert den["wfs"] < 0.5 and den["sr"] > at_file_gain["sr"] + 0.2      # what the denoiser is for
+    assert den["wfs"] < 0.5 and den["sr"] > blocks[0]["sr"] + 0.2      # what the denoiser is for

@@ -44,15 +44,31 @@ def main():
                                      a.steps, a.updates, la.get_precision()), flush=True)
     t0 = time.time()
     evals = []
+    # before any update the actors' last layer is zero: the mean action is 0 and the RL evaluation must BE the
+    # integrator's (same seeds, one through aomarl_env_step, one stage by stage)
+    from ao_marl_amd.sac import run_episode
+    rl0 = run_episode(env, sac, max_steps=200, train=False, eval_mode=True)
+    lin0 = run_episode(env, sac, max_steps=200, train=False, linear_control=True)
+    print("untrained (mean action 0), 200 steps: RL reward %.3f SR_LE %.5f SR_SE %.5f | integrator reward %.3f SR_LE %.5f "
+          "SR_SE %.5f | per-agent RL %s integrator %s" %
+          (rl0["r_total"].mean(), rl0["sr_le"].mean(), rl0["sr_se_mean"].mean(), lin0["r_total"].mean(),
+           lin0["sr_le"].mean(), lin0["sr_se_mean"].mean(), rl0["r_per_agent"].mean(dim=0).tolist(),
+           lin0["r_per_agent"].mean(dim=0).tolist()), flush=True)
+    env.next_seed_block(1)
 
     def on_episode(rec):
         if "test_r_rl" in rec:
             evals.append(rec)
             print("episode %3d (%.0f s): train reward %9.2f SR_LE %.4f | eval on seed %d: RL reward %9.2f SR_LE %.4f | "
-                  "integrator reward %9.2f SR_LE %.4f | RL - integrator: reward %+8.2f  SR_LE %+.4f" %
+                  "integrator reward %9.2f SR_LE %.4f | RL - integrator: reward %+8.2f  SR_LE %+.4f | SR_SE %.4f vs %.4f | "
+                  "per agent RL %s integrator %s | alpha %s q1 loss %s" %
                   (rec["episode"], time.time() - t0, rec["r_total"], rec["sr_le"], rec["test_seed"], rec["test_r_rl"],
                    rec["test_sr_le_rl"], rec["test_r_integrator"], rec["test_sr_le_integrator"],
-                   rec["test_r_rl"] - rec["test_r_integrator"], rec["test_sr_le_rl"] - rec["test_sr_le_integrator"]),
+                   rec["test_r_rl"] - rec["test_r_integrator"], rec["test_sr_le_rl"] - rec["test_sr_le_integrator"],
+                   rec["test_sr_se_rl"], rec["test_sr_se_integrator"],
+                   ["%.1f" % v for v in rec["test_r_agents_rl"]], ["%.1f" % v for v in rec["test_r_agents_integrator"]],
+                   ["%.4f" % v for v in sac.last_losses["alpha_value"].reshape(-1).tolist()] if sac.last_losses else "-",
+                   ["%.2e" % v for v in sac.last_losses["q1"].reshape(-1).tolist()] if sac.last_losses else "-"),
                   flush=True)
     train_agent(env, sac, a.episodes, max_steps=a.steps, test_every=a.test_every, n_updates=a.updates, on_episode=on_episode)
     torch.cuda.synchronize()
