@@ -305,6 +305,80 @@ __device__ __forceinline__ void g2_mainloop(const float *__restrict__ A, int lda
   }
 }
 
+// Three k-tiles of global loads in flight per thread (register stages, loop unrolled by three), the same
+// software pipeline as the split-fp16 kernel below (see the notes there: no branch around a load, no select on
+// a load's result, scheduling barriers): with the 10-20 k-tiles a split-K block walks and two blocks per CU,
+// one tile ahead (g2_mainloop) left the matrix pipe waiting for L2 on every iteration.  The loop runs whole
+// groups of three tiles; a tile past the end of the chunk is masked to zero as it is staged into LDS.
+__device__ __forceinline__ void g3_mainloop(const float *__restrict__ A, int lda,
+                                            const float *__restrict__ B, int ldb, int M, int N,
+                                            int m0, int n0, int kb, int ke, float *As, float *Bs,
+                                            f32x16 &acc) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;
+  const float *pa0 = A + (long long)min(m0 + lr, M - 1) * lda;
+  const float *pa1 = A + (long long)min(m0 + lr + 32, M - 1) * lda;
+  const float *pb0 = B + (long long)min(n0 + lr, N - 1) * ldb;
+  const float *pb1 = B + (long long)min(n0 + lr + 32, N - 1) * ldb;
+  const int klast = (ke - 1) & ~3;               // last 16-byte group that holds a valid element (lda, ldb >= its end)
+  constexpr int ST = 3;
+  float4 ra0[ST], ra1[ST], rb0[ST], rb1[ST];
+  auto gload = [&](int k0, int st) {
+    const int k = min(k0 + lc, klast);
+    ra0[st] = *reinterpret_cast<const float4 *>(pa0 + k); ra1[st] = *reinterpret_cast<const float4 *>(pa1 + k);
+    rb0[st] = *reinterpret_cast<const float4 *>(pb0 + k); rb1[st] = *reinterpret_cast<const float4 *>(pb1 + k);
+  };
+  auto lstore = [&](int buf, int st, int k0) {
+    float *as = As + buf * 64 * G2_LD, *bs = Bs + buf * 64 * G2_LD;
+    float4 a0 = ra0[st], a1 = ra1[st], b0 = rb0[st], b1 = rb1[st];
+    if (k0 + 32 > ke) {                          // wave-uniform: the tile crosses the end of the chunk
+      const int k = k0 + lc;
+      const bool m0_ = k < ke, m1_ = k + 1 < ke, m2_ = k + 2 < ke, m3_ = k + 3 < ke;
+      auto msk = [&](float4 &v) { v.x = m0_ ? v.x : 0.f; v.y = m1_ ? v.y : 0.f; v.z = m2_ ? v.z : 0.f; v.w = m3_ ? v.w : 0.f; };
+      msk(a0); msk(a1); msk(b0); msk(b1);
+    }
+    *reinterpret_cast<float4 *>(as + lr * G2_LD + lc) = a0;
+    *reinterpret_cast<float4 *>(as + (lr + 32) * G2_LD + lc) = a1;
+    *reinterpret_cast<float4 *>(bs + lr * G2_LD + lc) = b0;
+    *reinterpret_cast<float4 *>(bs + (lr + 32) * G2_LD + lc) = b1;
+  };
+  const int ro = (lane & 31) * G2_LD + 16 * (lane >> 5);
+#pragma unroll
+  for (int st = 0; st < ST; st++) gload(kb + 32 * st, st);
+  __builtin_amdgcn_sched_barrier(0);
+  lstore(0, 0, kb);
+  gload(kb + 32 * ST, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += 32 * ST) {
+#pragma unroll
+    for (int u = 0; u < ST; u++) {
+      const int kc = k0 + 32 * u;                // the tile in LDS buffer `buf` (all zeros past the end)
+      lstore(buf ^ 1, (u + 1) % ST, kc + 32);
+      gload(kc + 32 * (ST + 1), (u + 1) % ST);
+      __builtin_amdgcn_sched_barrier(0);
+      const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
+      const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
+      float4 a4[4], b4[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        a4[j] = *reinterpret_cast<const float4 *>(as + 4 * j);
+        b4[j] = *reinterpret_cast<const float4 *>(bs + 4 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alpha,
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb, float beta,
@@ -318,7 +392,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alp
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  g2_mainloop(A, lda, B, ldb, M, N, m0, n0, kb, ke, As, Bs, acc);
+  g3_mainloop(A, lda, B, ldb, M, N, m0, n0, kb, ke, As, Bs, acc);
   const int col = n0 + wn * 32 + (lane & 31);
   const bool split = gridDim.z > 1;
 #pragma unroll
@@ -823,7 +897,7 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
   int kchunk = ((K + nsplit - 1) / nsplit + 31) & ~31;
-  if (al && fast && g_gemm_split_f16)            // whole groups of three k-tiles (gh_mainloop)
+  if (al)                                        // whole groups of three k-tiles (g3_mainloop / gh_mainloop)
     kchunk = ((K + nsplit - 1) / nsplit + 95) / 96 * 96;
   nsplit = (K + kchunk - 1) / kchunk;
   dim3 grid(bx, by, nsplit);

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--episodes", type=int, default=60)
     ap.add_argument("--test-every", type=int, default=10)
@@ -30,15 +30,31 @@ def main():
     ap.add_argument("--updates", type=int, default=1000)
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--seed", type=int, default=1234)
-    a = ap.parse_args()
+    ap.add_argument("--recorded-normalisation", action="store_true",
+                    help="standardise the states with the reference's recorded 10x10 file instead of statistics generated "
+                         "here.  That file was recorded with TEN filtered modes (modes 75..84 have std 1e-8), so with the "
+                         "README's `--n_reverse_filtered_from_cmat 5 --n_zernike_start_end 0 80` the controlled modes "
+                         "75..79 enter the state divided by 1e-8: inputs of 1e6..1e8, the critic's loss starts at 1e12 and "
+                         "the 80-mode agent never learns (profiles/r03_learning_acceptance.txt)")
+    ap.add_argument("--torch-update", action="store_true",
+                    help="the torch-autograd statement of the SAC update instead of aomarl_sac_update (slow; A/B)")
+    a = ap.parse_args(argv)
     import torch
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     from ao_marl_amd.sac import BatchedSAC, train_agent
     la.set_precision(a.precision)
     rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, max_steps_per_episode=a.steps)
-    env = VecAoEnv("production_sh_10x10_2m", a.envs, rl, initial_seed=a.seed, seed_stride=16, n_agents_modal=1)
-    sac = BatchedSAC(env.layout, dict(updates_per_episode_rpc=a.updates, memory_size=1000000), seed=a.seed)
+    norm_kw = {}
+    if not a.recorded_normalisation:
+        # the reference's own workflow for a (parameter file, filtered modes) pair: run the normalisation recipe
+        # first (obtain_normalization.py:246-300) -- here on the device, 20 seeds x 1000 integrator frames
+        from ao_marl_amd.normalization import obtain_normalization
+        norm, zn, _ = obtain_normalization("production_sh_10x10_2m", modes_filtered=5)
+        norm_kw = dict(norm=norm, zn_norm=zn)
+    env = VecAoEnv("production_sh_10x10_2m", a.envs, rl, initial_seed=a.seed, seed_stride=16, n_agents_modal=1, **norm_kw)
+    sac = BatchedSAC(env.layout, dict(updates_per_episode_rpc=a.updates, memory_size=1000000), seed=a.seed,
+                     native=not a.torch_update)
     print("config production_sh_10x10_2m  envs %d  agents %d (state dims %s, action dims %s)  %d steps + %d updates per "
           "episode  precision %s" % (a.envs, env.layout.n_agents, env.layout.state_shapes(), env.layout.action_shapes(),
                                      a.steps, a.updates, la.get_precision()), flush=True)
@@ -77,6 +93,7 @@ def main():
     print("verdict after %d training episodes (%.0f s): RL %s the integrator (reward %.2f vs %.2f, LE Strehl %.4f vs %.4f)" %
           (a.episodes, time.time() - t0, "BEATS" if ok else "does NOT beat", last["test_r_rl"], last["test_r_integrator"],
            last["test_sr_le_rl"], last["test_sr_le_integrator"]))
+    main.evals = evals
     return 0 if ok else 1
 
 
