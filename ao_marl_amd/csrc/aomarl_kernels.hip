@@ -821,7 +821,7 @@ __global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const f
   *c = v;
 }
 
-static int g_gemm_target_blocks = 512;
+static int g_gemm_target_blocks = 0;     // 0: split-K by the blocks-per-CU cost model (launch_gemm_nt); > 0: about that many blocks
 // power-of-two scale that brings the largest magnitude of a matrix to ~4096 (f16: 11 bits, max 65504)
 static float gemm_scale(const float *h, size_t n) {
   float m = 0.f;
@@ -884,18 +884,33 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
   if (M <= 0 || N <= 0) return false;
   const int bx = (N + 63) / 64, by = (M + 63) / 64;
   int nsplit = 1;
-  if (ws && bx * by < 384) {
-    nsplit = (g_gemm_target_blocks + bx * by - 1) / (bx * by);
-    if (nsplit > 8) nsplit = 8;
-    // min_chunk: the control chain's products ask for at least three groups of three k-tiles per block
-    // (288): below that the fill / drain of the load pipeline and the wider reduce cost more than the
-    // extra blocks bring (256 x 1283 x 1288: 15.9 us with 4 chunks of 322, 18.8 us with 7 of 184;
-    // tools/diag/gemm_split_time.py).  The extrusion keeps 128: its chunking is part of the bit pattern
-    // of the screens (a 2 n-step fp32 recursion) the parity tests were calibrated on.
-    while (nsplit > 1 && (K / nsplit < min_chunk || (size_t)nsplit * M * N > ws_floats)) nsplit--;
-  }
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
+  if (ws && bx * by < 384) {
+    // Split K so that the launch is as short as its slowest CU: blocks go round-robin over the 256 CUs, a CU
+    // that gets one block more than the others sets the duration (528 blocks = 2.06 per CU took as long as 768
+    // would: 132 tiles x 4 chunks lost to 132 x 3 = 396).  Cost model per candidate: blocks per CU (rounded
+    // up) x k-tiles per block (whole groups of three for the pipelined kernels, + 2 tiles of fill / drain).
+    // min_chunk: the control chain's products ask for at least three groups of three k-tiles per block
+    // (288): below that the fill / drain of the load pipeline and the wider reduce cost more than the
+    // extra blocks bring (tools/diag/gemm_split_time.py).
+    const int ncu = 256, tiles = bx * by;
+    if (g_gemm_target_blocks > 0) {              // "gemm_target_blocks" > 0: the plain rule (about that many blocks)
+      nsplit = (g_gemm_target_blocks + tiles - 1) / tiles;
+      if (nsplit > 8) nsplit = 8;
+      while (nsplit > 1 && (K / nsplit < min_chunk || (size_t)nsplit * M * N > ws_floats)) nsplit--;
+    } else {
+      long long best = -1;
+      for (int ns = 1; ns <= 8; ns++) {
+        if (ns > 1 && (K / ns < min_chunk || (size_t)ns * M * N > ws_floats)) break;
+        const int chunk = al ? ((K + ns - 1) / ns + 95) / 96 * 96 : (((K + ns - 1) / ns + 31) & ~31);
+        const int nz = (K + chunk - 1) / chunk;
+        const long long per_cu = ((long long)tiles * nz + ncu - 1) / ncu;
+        const long long cost = per_cu * (chunk / 32 + 3);
+        if (best < 0 || cost < best) { best = cost; nsplit = ns; }
+      }
+    }
+  }
   int kchunk = ((K + nsplit - 1) / nsplit + 31) & ~31;
   if (al)                                        // whole groups of three k-tiles (g3_mainloop / gh_mainloop)
     kchunk = ((K + nsplit - 1) / nsplit + 95) / 96 * 96;

@@ -41,8 +41,10 @@ def timeit(fn, n=50):
 
 vec = torch.randn(nenv, sim.ld_actu, device="cuda")[:, :s.nactu]
 out = torch.empty(nenv, nm, device="cuda")
-for mode in ("f32", "split_f16"):
+for mode, tb in (("f32", 0), ("f32", 512), ("split_f16", 0), ("split_f16", 512)):
     la.set_precision(mode)
+    sim.set_option("gemm_target_blocks", tb)
+    print("---- %s, split-K rule: %s" % (mode, "cost model" if tb == 0 else "about %d blocks" % tb))
     sim.reset(1234 + 16 * np.arange(nenv))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -57,9 +59,12 @@ for mode in ("f32", "split_f16"):
     print("%-9s do_control (256 x %d x %d + integrate)   %6.1f us  %5.1f TFLOP/s" % (mode, s.nactu, s.nslope, us, gf_ctrl / us * 1e3))
     us = timeit(lambda: sim.volts2modes(vec, out=out))
     print("%-9s volts2modes (256 x %d x %d)               %6.1f us  %5.1f TFLOP/s" % (mode, nm, s.nactu, us, gf_v2m / us * 1e3))
+    us1 = timeit(lambda: sim.extrude([2], [-1]))
+    print("%-9s extrusion round, 1 layer  (256 x %d x %d) %6.1f us" % (mode, s.screen_dim[0], K, us1))
     us = timeit(lambda: sim.extrude([0, 1, 2], [-2, -1, -1]))
     print("%-9s extrusion round, 3 layers (768 x %d x %d) %6.1f us  %5.1f TFLOP/s (GEMM flops / whole round)" %
           (mode, s.screen_dim[0], K, us, gf_ext / us * 1e3))
     print("%-9s reset (2 x %d rounds)                      %6.1f ms  %5.1f TFLOP/s" %
           (mode, s.screen_dim[0], t_reset, gf_ext * 2 * s.screen_dim[0] / t_reset))
 la.set_precision("f32")
+sim.set_option("gemm_target_blocks", 0)
