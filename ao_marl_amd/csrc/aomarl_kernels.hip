@@ -1656,6 +1656,76 @@ __device__ __forceinline__ void spot_dft_h_v(const SpotTwH &tw, const float (&br
   }
 }
 
+// Slopes only (no noise, no image wanted), fp32: the centre of gravity straight from the stage-2 products.
+// With X(+-ky) = (QCr +- QSi, QCi -+ QSr):  |X(+-ky)|^2 = P +- 2 D,  P = QCr^2 + QSi^2 + QCi^2 + QSr^2,
+// D = QCr QSi - QCi QSr.  The image is never formed: the 2 x 2 binning only gives pairs of frequencies the same
+// pixel coordinate, so the three moments are weighted sums of P and D with per-lane constants --
+//   pixel row of +ky: 8 + 2q + (r >> 1), of -ky: 7 - 2q - (r >> 1): their sum is 15, their difference
+//   1 + 4q + 2 (r >> 1); pixel column of +kx: Xp = 8 + (c >> 1), of -kx: Xm = 7 - (c >> 1) --
+//   sum I   = 2 (P0 + P1)                    (Pm: P summed over the lane's 4 registers of half m)
+//   sum x I = 2 (Xp P0 + Xm P1)
+//   sum y I = 15 (P0 + P1) + 2 [(1 + 4q) (D over r = 0, 1) + (3 + 4q) (D over r = 2, 3)]
+// (the common factor 2 drops out of the ratios): 48 multiply-adds + 8 for the moments, against 125 vector
+// instructions for combine / square / bin / weight -- on fp32 matrix instructions vector and matrix work
+// share the issue slots, so every one of them is kernel time.
+__device__ __forceinline__ void spot_cog_f32(const DevSys &sys, const DevState &st, int e, int i, int lane,
+                                             const float (&Cc)[4], const float (&Ss)[4], const float (&br)[4],
+                                             const float (&bi)[4], int do_cog, const f32x4 z4) {
+  const int q = lane >> 4, c = lane & 15;
+  // ---- stage 1 (y = c on M, x = 4q + s on K, k = c on N)
+  f32x4 PCr = z4, PCi = z4, PSr = z4, PSi = z4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    PCr = mfma16(br[s], Cc[s], PCr);
+    PCi = mfma16(bi[s], Cc[s], PCi);
+    PSr = mfma16(br[s], Ss[s], PSr);
+    PSi = mfma16(bi[s], Ss[s], PSi);
+  }
+  float Pm[2], Da = 0.f, Db = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; m++) {                  // [0]: kx = +(k+1/2)   [1]: kx = -(k+1/2)
+    const f32x4 Tr = m == 0 ? PCr + PSi : PCr - PSi;
+    const f32x4 Ti = m == 0 ? PCi - PSr : PCi + PSr;
+    f32x4 QCr = z4, QCi = z4, QSr = z4, QSi = z4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      QCr = mfma16(Cc[s], Tr[s], QCr);
+      QCi = mfma16(Cc[s], Ti[s], QCi);
+      QSr = mfma16(Ss[s], Tr[s], QSr);
+      QSi = mfma16(Ss[s], Ti[s], QSi);
+    }
+    float P = QCr[0] * QCr[0];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (r) P = fmaf(QCr[r], QCr[r], P);
+      P = fmaf(QSi[r], QSi[r], P); P = fmaf(QCi[r], QCi[r], P); P = fmaf(QSr[r], QSr[r], P);
+    }
+    Pm[m] = P;
+    Da = fmaf(QCr[0], QSi[0], Da); Da = fmaf(-QCi[0], QSr[0], Da);
+    Da = fmaf(QCr[1], QSi[1], Da); Da = fmaf(-QCi[1], QSr[1], Da);
+    Db = fmaf(QCr[2], QSi[2], Db); Db = fmaf(-QCi[2], QSr[2], Db);
+    Db = fmaf(QCr[3], QSi[3], Db); Db = fmaf(-QCi[3], QSr[3], Db);
+  }
+  const float Xp = (float)(8 + (c >> 1)), Xm = (float)(7 - (c >> 1));
+  float s0 = Pm[0] + Pm[1];
+  float sx = fmaf(Xm, Pm[1], Xp * Pm[0]);
+  float sy = fmaf((float)(3 + 4 * q), Db, fmaf((float)(1 + 4 * q), Da, 7.5f * s0));
+  s0 = wave_sum_last(s0);
+  sx = wave_sum_last(sx);
+  sy = wave_sum_last(sy);
+  if (do_cog && lane == 63) {
+    float *sl = st.slopes + (long long)e * sys.nslope;
+    if (s0 > 0.f) {
+      const float inv = __builtin_amdgcn_rcpf(s0);       // 1 ulp; slopes are compared at 1e-4"
+      sl[i] = (sx * inv - sys.cog_offset) * sys.cog_scale;
+      sl[sys.nvalid + i] = (sy * inv - sys.cog_offset) * sys.cog_scale;
+    } else {
+      sl[i] = 0.f;
+      sl[sys.nvalid + i] = 0.f;
+    }
+  }
+}
+
 // flux normalisation (+noise), COG on the binned quadrant values v[sy][sx][h]
 template <bool NOISE, bool WRITE_CUBE>
 __device__ __forceinline__ void spot_finish_v(const DevSys &sys, const DevState &st, int e, int i,
@@ -2255,7 +2325,9 @@ struct FrameRaw {
 // once at its end:  kx = +k: (PA_C + PB_S, PB_C - PA_S);  kx = -k: (PA_C - PB_S, PB_C + PA_S).  The
 // kx = 0 column is the plain row sum of the amplitudes: 8 vector adds per tile.
 template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))  // 3 waves per SIMD: <= 168 VGPRs
+// 3 waves per SIMD (<= 168 VGPRs).  Forcing the fp32 slopes-only instantiation (140 VGPRs) into four (<= 128, 8
+// registers spilled) measured 0.466 against 0.459 ms: the kernel is bound by issue slots, not by latency
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     int env_count, int do_cog,
                                                     float *__restrict__ TR,
@@ -2501,6 +2573,8 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         float v[2][2][2];
         spot_dft_h_v(twh, wr, wi, Z4, v);
         spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, v, do_cog, flux_i);
+      } else if (!NOISE && !WRITE_CUBE) {
+        spot_cog_f32(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
       } else {
         spot_core<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, flux_i, Z4);
       }
