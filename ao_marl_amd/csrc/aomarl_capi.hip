@@ -49,7 +49,6 @@ struct aomarl_ctx {
   float gain = 0.f, delay = 0.f;
   bool spot_fast = false;
   bool force_generic_dm = false, force_valu_target = false;
-  int spot_blocks_per_env = 0, spot_lds_pad = 0;
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
   int dft_mode = -1;                   // frame kernel DFTs: -1 follow the library's precision mode, 0 fp32 MFMAs, 1 split-fp16 ("force_f32_dft")
   bool reset_untransposed = false;     // "reset_untransposed": the reset's x extrusions on the row-major screen itself
@@ -1157,8 +1156,6 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!c) return fail("set_option: null context");
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
-  if (!strcmp(name, "spot_blocks_per_env")) { c->spot_blocks_per_env = value; return 0; }
-  if (!strcmp(name, "spot_lds_pad")) { c->spot_lds_pad = value; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
@@ -1248,10 +1245,9 @@ int aomarl_comp_image(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, 
   // persistent waves: enough blocks per environment to fill the chip ~2x (256 CUs x 32 waves)
   int gx = (16384 + 4 * n - 1) / (4 * n);
   gx = std::max(1, std::min(gx, (c->sys.nvalid + 3) / 4));
-  if (c->spot_blocks_per_env > 0) gx = std::min(c->spot_blocks_per_env, (c->sys.nvalid + 3) / 4);
   dim3 grid(gx, n), blk(256);
 #define SPOT(FB, NZ, WC) hipLaunchKernelGGL((k_wfs_spot<FB, NZ, WC>), grid, blk, 0, s, c->sys, ds, b, na, nd, cog)
-#define FAST(NL, NZ, WC) hipLaunchKernelGGL((k_wfs_spot_fast<NL, NZ, WC>), grid, blk, (size_t)c->spot_lds_pad, s, c->sys, ds, b, cog)
+#define FAST(NL, NZ, WC) hipLaunchKernelGGL((k_wfs_spot_fast<NL, NZ, WC>), grid, blk, 0, s, c->sys, ds, b, cog)
   const bool fast_ok = !from_buf && !na && !nd && !c->force_generic_spot && c->ndm == 2 &&
                        c->sys.dms[0].type == AOMARL_DM_PZT && c->sys.dms[1].type == AOMARL_DM_TT &&
                        (c->nlayers == 1 || c->nlayers == 3);

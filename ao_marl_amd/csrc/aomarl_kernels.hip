@@ -1583,31 +1583,6 @@ __device__ __forceinline__ void spot_dft_f32(const float (&Cc)[4], const float (
   }
 }
 
-// the same two stages on split-fp16 MFMAs (24 instructions)
-__device__ __forceinline__ void spot_dft_h(const SpotTwH &tw, const float (&br)[4],
-                                           const float (&bi)[4], const f32x4 z4,
-                                           f32x4 (&Xr)[2][2], f32x4 (&Xi)[2][2]) {
-  const hx8 ar = pack_hl(br[0], br[1], br[2], br[3]), ai = pack_hl(bi[0], bi[1], bi[2], bi[3]);
-  f32x4 PCr = mfma_h(ar, tw.CL, mfma_h(ar, tw.CH, z4));
-  f32x4 PCi = mfma_h(ai, tw.CL, mfma_h(ai, tw.CH, z4));
-  f32x4 PSr = mfma_h(ar, tw.SL, mfma_h(ar, tw.SH, z4));
-  f32x4 PSi = mfma_h(ai, tw.SL, mfma_h(ai, tw.SH, z4));
-  f32x4 Tr[2], Ti[2];
-  Tr[0] = PCr + PSi; Ti[0] = PCi - PSr;
-  Tr[1] = PCr - PSi; Ti[1] = PCi + PSr;
-#pragma unroll
-  for (int m = 0; m < 2; m++) {
-    const hx8 tr = pack_hl(Tr[m][0], Tr[m][1], Tr[m][2], Tr[m][3]);
-    const hx8 ti = pack_hl(Ti[m][0], Ti[m][1], Ti[m][2], Ti[m][3]);
-    const f32x4 QCr = mfma_h(tw.CL, tr, mfma_h(tw.CH, tr, z4));
-    const f32x4 QCi = mfma_h(tw.CL, ti, mfma_h(tw.CH, ti, z4));
-    const f32x4 QSr = mfma_h(tw.SL, tr, mfma_h(tw.SH, tr, z4));
-    const f32x4 QSi = mfma_h(tw.SL, ti, mfma_h(tw.SH, ti, z4));
-    Xr[0][m] = QCr + QSi; Xi[0][m] = QCi - QSr;
-    Xr[1][m] = QCr - QSi; Xi[1][m] = QCi + QSr;
-  }
-}
-
 // |X|^2 and 2x2 binning of one quadrant tile.  Reg r, lane (q, c): ky' = 4q + r, kx' = c;
 // + tiles: k = k' -> LR index 8 + (k' >> 1);  - tiles: k = -(k'+1) -> LR index 7 - (k' >> 1)
 __device__ __forceinline__ void spot_bin(const f32x4 Xr, const f32x4 Xi, float (&v)[2]) {
@@ -2952,7 +2927,6 @@ __global__ __launch_bounds__(256) void k_target_rows_mfma(DevSys sys, DevState s
     pivot = v;
   }
   f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
-  f32x4 Ri2 = {0.f, 0.f, 0.f, 0.f};
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int fy = tid >> 4, fx0 = (tid & 15) * 4;     // fill: row fy, 4 consecutive columns
   const int y = y0 + fy;
@@ -3144,7 +3118,6 @@ __global__ __launch_bounds__(256) void k_target_rows_fast(DevSys sys, DevState s
   };
 
   f32x4 Rr = {0.f, 0.f, 0.f, 0.f}, Ri = {0.f, 0.f, 0.f, 0.f};
-  f32x4 Ri2 = {0.f, 0.f, 0.f, 0.f};
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   const int kxf = c - 8;
   fetch(0);

@@ -1,6 +1,6 @@
 """The `sutraWrap`-shaped facades against the call sequence the reference's own Python makes.
 
-tests/golden/calls_10x10_stock.pkl.xz is the complete Appendix-B call log of the reference's
+tests/golden/calls_10x10_stock.npz is the complete Appendix-B call log of the reference's
 UNMODIFIED RlSupervisor + AoEnv on its stock production_sh_10x10_2m.py (2 WFS, 4 DMs, 2 targets,
 LS + GEO controllers; init, calibration, reset, 30 closed-loop frames with RL actions), recorded
 over the oracle facade by tools/gen_golden_trace.py --record-calls: inputs of every call and the
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import record_calls as rc  # noqa: E402
 
-LOG = os.path.join(ROOT, "tests", "golden", "calls_10x10_stock.pkl.xz")
+LOG = os.path.join(ROOT, "tests", "golden", "calls_10x10_stock.npz")
 
 
 class Tally(object):

@@ -13,7 +13,7 @@ The parameter file is staged, with the reference's normalisation DATA, in a scra
 out like the reference expects (nothing of the reference is written into this repository).
 With --record-calls the whole Appendix-B call sequence the reference makes (constructors, array
 loads, per-frame calls, reads) is logged through tools/record_calls.py ->
-tests/golden/calls_10x10_<run>.pkl.xz: the input of the facade replay tests.
+tests/golden/calls_10x10_<run>.npz: the input of the facade replay tests.
 
 Usage: python tools/gen_golden_trace.py [single|stock] [--record-calls]
 """
@@ -122,7 +122,7 @@ def main(run="single", nframes=30, seed=1234, record=False):
     dst = os.path.join(ROOT, "tests", "golden", "trace_10x10_%s.npz" % run)
     np.savez_compressed(dst, **out)
     if rec_ is not None:
-        rec_.save(os.path.join(ROOT, "tests", "golden", "calls_10x10_%s.pkl.xz" % run))
+        rec_.save(os.path.join(ROOT, "tests", "golden", "calls_10x10_%s.npz" % run))
     print("wrote", dst, {k: v.shape for k, v in out.items()})
     print("SR se/le last:", out["strehl"][-1][:2], "state absmax", np.abs(out["state"]).max())
     os.chdir(ROOT)

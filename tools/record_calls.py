@@ -17,8 +17,6 @@ Objects inside arguments are stored as {"__ref__": path}; the carma context as {
 (ao_marl_amd.sutra_facade over libaomarl_hip.so on the GPU box) and hands every recorded read to
 `compare(entry, got)`: no reference code is needed at replay time, only this data.
 """
-import lzma
-import pickle
 
 import numpy as np
 
@@ -178,17 +176,66 @@ class Recorder(object):
             for k in ("args", "kwargs", "value"):
                 if k in e:
                     e[k] = intern(e[k])
-        with lzma.open(path, "wb", preset=9 | lzma.PRESET_EXTREME) as fh:
-            pickle.dump(self.log, fh, protocol=4)
+        save_log(self.log, path)
         n = {}
         for e in self.log:
             n[e["op"]] = n.get(e["op"], 0) + 1
         print("wrote", path, n)
 
 
+def save_log(log, path):
+    """The call log as ONE .npz without pickled objects: the structure as JSON (key "_log", utf-8 bytes), every
+    array as its own entry ("a<i>", referenced from the JSON as {"__nd__": i}; equal arrays stored once)."""
+    import json
+    arrays, index = [], {}
+
+    def enc(v):
+        if isinstance(v, np.ndarray):
+            if id(v) not in index:
+                index[id(v)] = len(arrays)
+                arrays.append(v)
+            return {"__nd__": index[id(v)]}
+        if isinstance(v, (np.integer,)):
+            return int(v)
+        if isinstance(v, (np.floating,)):
+            return {"__f__": float(v), "dtype": str(v.dtype)}
+        if isinstance(v, (np.bool_,)):
+            return bool(v)
+        if isinstance(v, tuple):
+            return {"__t__": [enc(x) for x in v]}
+        if isinstance(v, list):
+            return [enc(x) for x in v]
+        if isinstance(v, dict):
+            return {str(k): enc(x) for k, x in v.items()}
+        if v is None or isinstance(v, (str, int, float, bool)):
+            return v
+        raise TypeError("cannot store %r in the call log" % type(v))
+    doc = json.dumps(enc(log)).encode("utf-8")
+    np.savez_compressed(path, _log=np.frombuffer(doc, dtype=np.uint8), **{"a%d" % i: a for i, a in enumerate(arrays)})
+
+
 def load(path):
-    with lzma.open(path, "rb") as fh:
-        return pickle.load(fh)
+    """Inverse of save_log (np.load with allow_pickle=False: data only)."""
+    import json
+    z = np.load(path, allow_pickle=False)
+    cache = {}
+
+    def dec(v):
+        if isinstance(v, dict):
+            if "__nd__" in v:
+                i = v["__nd__"]
+                if i not in cache:
+                    cache[i] = z["a%d" % i]
+                return cache[i]
+            if "__t__" in v:
+                return tuple(dec(x) for x in v["__t__"])
+            if "__f__" in v:
+                return np.dtype(v["dtype"]).type(v["__f__"])
+            return {k: dec(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [dec(x) for x in v]
+        return v
+    return dec(json.loads(bytes(z["_log"]).decode("utf-8")))
 
 
 # ------------------------------------------------------------------------------------ replay
