@@ -285,6 +285,11 @@ class BatchedGaussianPolicy(object):
         self._desc = (d, scratch, Wh, bh, n, tiled)        # keeps every pointer alive
         return d
 
+    out_ring, _ring, _ring_i = 0, None, 0       # set out_ring = 6 for graph-replayed environment steps
+
+    def reset_output_ring(self):
+        self._ring_i = 0
+
     def _select_action_one_call(self, state, eval_mode, eps):
         """TrainerRPC.choose_action for all agents in ONE library call (aomarl_actor_forward): the
         same kernels as _native_head + policy_sample, issued from C."""
@@ -293,8 +298,19 @@ class BatchedGaussianPolicy(object):
         nenv = state.shape[0]
         d = self._actor_desc(nenv)
         self._draws += 1
-        a = torch.empty(nenv, self.layout.action_dim, dtype=torch.float32, device=self.device)
-        m = torch.empty_like(a)
+        if self.out_ring:
+            # fixed output buffers, cycled: an action tensor stays valid for out_ring - 1 further calls (graph
+            # replay of the environment step needs stable addresses, see VecAoEnv.OUT_RING)
+            if self._ring is None or self._ring[0][0].shape[0] != nenv:
+                self._ring = [(torch.empty(nenv, self.layout.action_dim, dtype=torch.float32, device=self.device),
+                               torch.empty(nenv, self.layout.action_dim, dtype=torch.float32, device=self.device))
+                              for _ in range(self.out_ring)]
+                self._ring_i = 0
+            a, m = self._ring[self._ring_i]
+            self._ring_i = (self._ring_i + 1) % self.out_ring
+        else:
+            a = torch.empty(nenv, self.layout.action_dim, dtype=torch.float32, device=self.device)
+            m = torch.empty_like(a)
         if eps is not None:
             eps = eps.to(torch.float32).contiguous()
         la.check(la.load().aomarl_actor_forward(

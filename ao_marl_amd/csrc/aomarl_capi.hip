@@ -70,6 +70,16 @@ struct aomarl_ctx {
   // (aomarl_raytrace_wfs / _target); 0 (default): integer-pixel frozen flow
   bool subpixel_flow = false;
   float frac_x[AOMARL_MAX_LAYERS] = {0, 0, 0, 0, 0, 0, 0, 0}, frac_y[AOMARL_MAX_LAYERS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // "graph_step": aomarl_env_step as a HIP graph (captured once per distinct launch sequence -- extrusion plan,
+  // ring position, buffer addresses --, replayed afterwards: one hipGraphLaunch instead of ~25 launches and ~8
+  // event operations per step).  capturing: the body is being recorded (no timed / event-carrying dispatch, the
+  // side streams fork from and join the caller's stream inside the graph).  side_joined: the caller's stream
+  // has already waited for everything issued on the side streams (the waits for ev_moved / ev_psf are skipped)
+  bool graph_step = false, capturing = false, side_joined = false, fork_recorded = false;
+  hipEvent_t ev_fork = nullptr;
+  struct StepGraph { std::vector<long long> key; hipGraphExec_t exec; hipGraph_t graph; unsigned long long arith[AR_N]; int fw_variant[6]; };
+  std::vector<StepGraph> graphs;
+  unsigned long long graph_hits = 0, graph_captures = 0;
   const int32_t *sel_checked = nullptr;     // aomarl_env_step: the column selection last validated
   int sel_checked_n = 0, sel_checked_nm = 0;
   int fw_variant[6] = {0, 0, 0, 0, 0, 0};   // template arguments of the last k_frame_wave launch
@@ -537,6 +547,9 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
 }
 
 int aomarl_destroy(aomarl_ctx *c) {
+  if (c)
+    for (auto &sg : c->graphs) { (void)hipGraphExecDestroy(sg.exec); (void)hipGraphDestroy(sg.graph); }
+  if (c) c->graphs.clear();
   if (!c) return 0;
   for (void *p : c->owned) (void)hipFree(p);
   // the side streams belong to the process (side_stream): drained here, never destroyed
@@ -754,13 +767,14 @@ static int side_stream(aomarl_ctx *c) {
     c->ev_frame_cur = c->ev_frame;
     HIPCHK(hipEventCreateWithFlags(&c->ev_moved, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_psf, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   }
   return 0;
 }
 // everything that reads (or overwrites) the pending PSF window on `stream` waits for a finish kernel
 // that may still be running on the side stream
 static int psf_wait_pending(aomarl_ctx *c, void *stream) {
-  if (c->psf_side) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_psf, 0));
+  if (c->psf_side && !c->side_joined) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_psf, 0));
   c->psf_side = false;
   return 0;
 }
@@ -769,7 +783,7 @@ static int psf_wait_pending(aomarl_ctx *c, void *stream) {
 // A prefetched move_atmos may still be running on the side stream: everything that touches the
 // screens on `stream` waits for it first.
 static int atmos_wait_pending(aomarl_ctx *c, void *stream) {
-  if (c->premoved) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_moved, 0));
+  if (c->premoved && !c->side_joined) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_moved, 0));
   return 0;
 }
 
@@ -929,6 +943,11 @@ static int prefetch_atmos_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, fl
   // does (extrude_rounds).  Only in the steady state, though: if the screens were last written on the
   // caller's stream (reset, set_screen, an un-prefetched move), those writes are ordered before this
   // point of that stream only, so the side stream waits for it right away.
+  c->side_joined = false;
+  if (c->capturing) {      // the side stream enters the capture at the fork recorded in front of the frame kernel
+    if (!c->fork_recorded) { HIPCHK(hipEventRecord(c->ev_fork, (hipStream_t)stream)); c->fork_recorded = true; }
+    HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_fork, 0));
+  }
   if (c->screens_dirty_main) {
     HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame_cur, 0));
     c->frame_wait_pending = false;
@@ -1172,6 +1191,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "prefetch_atmos")) { c->prefetch_atmos = value != 0; return 0; }
   if (!strcmp(name, "subpixel_flow")) { c->subpixel_flow = value != 0; return 0; }
+  if (!strcmp(name, "graph_step")) { c->graph_step = value != 0; return 0; }
   if (!strcmp(name, "fused_debug")) { c->fused_debug = value; return 0; }
   if (!strcmp(name, "force_f32_dft")) { c->dft_mode = value < 0 ? -1 : (value != 0 ? 0 : 1); return 0; }
   if (!strcmp(name, "force_unfused_frame")) { c->force_unfused_frame = value != 0; return 0; }
@@ -1952,8 +1972,8 @@ int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const f
                               d->bias, d->sc_agent, d->sc_local, eps, seed, counter, action, mean, stream);
 }
 
-int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
-                    float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
+static int env_step_body(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
+                         float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
   if (!c || !st || !g || !state_out) return fail("env_step: null argument");
   if (g->nhist < 0 || g->nhist > 5) return fail("env_step: 0..5 command histories");
   const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1;
@@ -2096,6 +2116,127 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
                            &part);
   if (rc) return rc;
   g->ring_pos = nxt;
+  return 0;
+}
+
+
+// ---------------------------------------------------------------- aomarl_env_step as a HIP graph ("graph_step")
+// The launch sequence of one step depends on three things the host decides: the extrusion plan of the prefetched
+// move (how many lines each layer moves this frame: 2 values per layer and axis), the position of the command ring,
+// and the addresses of the caller's buffers.  One graph per distinct combination, captured from the very code path
+// the plain call takes (env_step_body) the first time it occurs, replayed afterwards.  Inside a graph the side
+// streams fork from the caller's stream in front of the frame kernel and join it again at the end: the next step's
+// head (compose .. Strehl commit) therefore starts after this step's extrusions -- a dependency the plain path
+// does not have (there the extrusion chain runs on beside the next step's head), which is why this mode is for
+// the launch-bound regime (small batches: 10x10 / 64 environments is host-bound at ~0.16 ms per step) and off by
+// default.  Results are identical: same kernels, same arguments, same order per stream.
+static bool step_plan_uniform(const aomarl_ctx *c, int n, const float *accumx, const float *accumy, Plan &p) {
+  const int nl = c->nlayers;
+  for (int e = 0; e < n; e++)
+    for (int l = 0; l < nl; l++) {
+      const int kx = (int)(accumx[(size_t)e * nl + l] + c->deltax[l]), ky = (int)(accumy[(size_t)e * nl + l] + c->deltay[l]);
+      if (e == 0) { p.kx[l] = kx; p.ky[l] = ky; }
+      else if (p.kx[l] != kx || p.ky[l] != ky) return false;
+    }
+  return true;
+}
+
+int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
+                    float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
+  if (!c || !st || !g || !state_out) return fail("env_step: null argument");
+  if (!c->graph_step || c->capturing) return env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
+  const int n = st->nenv, nl = c->nlayers;
+  // the steady state only: a prefetched move of exactly this batch is pending, the glue has been validated by a
+  // plain call, every environment moves by the same plan
+  Plan plan;
+  // (the null stream cannot be captured: a caller on it gets the plain path)
+  const bool steady = stream && c->prefetch_atmos && aomarl_frame_fused_available(c) && accumx && accumy && c->premoved &&
+                      c->pre_screens == st->screens && c->pre_b == 0 && c->pre_n == n &&
+                      (!g->sel || (c->sel_checked == g->sel && c->sel_checked_n == g->dm_dim && c->sel_checked_nm == g->nmodes)) &&
+                      g->nhist >= 0 && g->nhist <= 5 && g->ring_pos >= 0 && g->ring_pos <= g->nhist &&
+                      step_plan_uniform(c, n, accumx, accumy, plan);
+  if (!steady) return env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = side_stream(c);
+  if (rc) return rc;
+  if (!c->side_joined) {        // work issued on the side streams by plain calls: wait for it OUTSIDE the graph
+    HIPCHK(hipStreamWaitEvent(s, c->ev_moved, 0));
+    if (c->psf_side) HIPCHK(hipStreamWaitEvent(s, c->ev_psf, 0));
+    c->side_joined = true;
+  }
+  std::vector<long long> key;
+  auto kp = [&](const void *p) { key.push_back((long long)(uintptr_t)p); };
+  for (int l = 0; l < nl; l++) { key.push_back(plan.kx[l]); key.push_back(plan.ky[l]); }
+  key.push_back(g->ring_pos); key.push_back(g->nhist); key.push_back(g->nmodes); key.push_back(g->dm_dim);
+  key.push_back(g->n_agents); key.push_back(g->flags); key.push_back(g->denoiser_f32);
+  { int gi; memcpy(&gi, &gain, sizeof(gi)); key.push_back(gi); memcpy(&gi, &g->reward_factor, sizeof(gi)); key.push_back(gi); }
+  kp(st); kp(st->screens); kp(st->com); kp(st->voltage); kp(st->slopes); kp(st->work); kp(st->bincube); kp(st->strehl);
+  kp(action); kp(state_out); kp(reward_out); kp(stream);
+  kp(g->sel); kp(g->mean_dm); kp(g->std_dm); kp(g->mean_res); kp(g->std_res); kp(g->lohi); kp(g->modes_ring); kp(g->res_modes);
+  kp(g->denoiser); kp(c->cmat); kp(c->v2m); kp(c->m2v); kp(c->freedom); kp(c->amode_inv);
+  key.push_back(n); key.push_back(g_precision); key.push_back(g_gemm_split_f16 ? 1 : 0); key.push_back(c->dft_mode);
+  key.push_back(c->defer_dm_shape ? 1 : 0); key.push_back(g_gemm_target_blocks); key.push_back(c->fused_debug);
+  { int gi; memcpy(&gi, &c->gain, sizeof(gi)); key.push_back(gi); }
+  aomarl_ctx::StepGraph *hit = nullptr;
+  for (auto &sg : c->graphs)
+    if (sg.key == key) { hit = &sg; break; }
+  if (hit) {
+    HIPCHK(hipGraphLaunch(hit->exec, s));
+    // the host bookkeeping the body does: wind accumulators, ring position, what is pending where
+    for (int e = 0; e < n; e++)
+      for (int l = 0; l < nl; l++) {
+        const float ax = accumx[(size_t)e * nl + l] + c->deltax[l], ay = accumy[(size_t)e * nl + l] + c->deltay[l];
+        accumx[(size_t)e * nl + l] = ax - (float)(int)ax;
+        accumy[(size_t)e * nl + l] = ay - (float)(int)ay;
+        if (e == 0) { c->frac_x[l] = ax - (float)(int)ax; c->frac_y[l] = ay - (float)(int)ay; }
+      }
+    g->ring_pos = (g->ring_pos + 1) % (g->nhist + 1);
+    c->premoved = true; c->psf_side = true; c->side_joined = true;
+    c->frame_marked = true; c->frame_wait_pending = false; c->screens_dirty_main = false;
+    for (int i = 0; i < AR_N; i++) g_arith[i] += hit->arith[i];
+    memcpy(c->fw_variant, hit->fw_variant, sizeof(c->fw_variant));
+    c->graph_hits++;
+    return 0;
+  }
+  // ---- capture
+  if (g_gemm_split_f16) (void)gemm_sat_counter();          // nothing may allocate during the capture
+  if (c->graphs.size() >= 256) {                            // a caller that cycles through many buffers: start over
+    for (auto &sg : c->graphs) { (void)hipGraphExecDestroy(sg.exec); (void)hipGraphDestroy(sg.graph); }
+    c->graphs.clear();
+  }
+  unsigned long long before[AR_N];
+  for (int i = 0; i < AR_N; i++) before[i] = g_arith[i];
+  HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+  c->capturing = true; c->fork_recorded = false;
+  rc = env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
+  hipError_t je = hipSuccess;
+  if (!rc) {                                                // the side streams join the caller's stream again
+    if (c->psf_side) je = hipStreamWaitEvent(s, c->ev_psf, 0);
+    if (je == hipSuccess && c->premoved) je = hipStreamWaitEvent(s, c->ev_moved, 0);
+  }
+  c->capturing = false;
+  hipGraph_t graph = nullptr;
+  const hipError_t ee = hipStreamEndCapture(s, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (je != hipSuccess || ee != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return fail("env_step: graph capture failed: %s", hipGetErrorString(je != hipSuccess ? je : ee));
+  }
+  c->side_joined = true;
+  aomarl_ctx::StepGraph sg;
+  sg.key = key; sg.graph = graph; sg.exec = nullptr;
+  for (int i = 0; i < AR_N; i++) sg.arith[i] = g_arith[i] - before[i];
+  memcpy(sg.fw_variant, c->fw_variant, sizeof(sg.fw_variant));
+  HIPCHK(hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0));
+  c->graphs.push_back(sg);
+  c->graph_captures++;
+  HIPCHK(hipGraphLaunch(sg.exec, s));
+  return 0;
+}
+
+int aomarl_graph_stats(aomarl_ctx *c, unsigned long long *captures, unsigned long long *replays) {
+  if (!c || !captures || !replays) return fail("graph_stats: null argument");
+  *captures = c->graph_captures; *replays = c->graph_hits;
   return 0;
 }
 
@@ -2311,7 +2452,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     else if (nb == 1) FW_NC(NL, 1, true);                                 \
     else FW_NC(NL, 2, true);                                              \
   } while (0)
-  const bool timed = c->time_fw && c->fw_ev_used + 2 <= c->fw_ev.size();
+  const bool timed = !c->capturing && c->time_fw && c->fw_ev_used + 2 <= c->fw_ev.size();
   // closing event: the "readers of the screens are done" mark the side streams wait for (the closing
   // event of a timed launch doubles as it); only with the prefetch on, which is what creates ev_frame
   hipEvent_t ev_start = nullptr, ev_done = nullptr;
@@ -2321,7 +2462,10 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     ev_done = c->ev_frame;
   }
   if (timed) { ev_start = c->fw_ev[c->fw_ev_used]; ev_done = c->fw_ev[c->fw_ev_used + 1]; c->fw_ev_used += 2; }
+  hipEvent_t ev_mark = nullptr;
+  if (c->capturing) { ev_mark = ev_done; ev_start = nullptr; ev_done = nullptr; }   // a captured dispatch carries no events
   if (c->nlayers == 1) FW_L(1); else FW_L(3);
+  if (ev_mark) { HIPCHK(hipEventRecord(ev_mark, s)); ev_done = ev_mark; }
   c->frame_marked = false;
   c->fw_variant[0] = c->nlayers == 1 ? 1 : 3; c->fw_variant[1] = otf ? nb : 1; c->fw_variant[2] = otf;
   c->fw_variant[3] = noise; c->fw_variant[4] = cube; c->fw_variant[5] = hp;
@@ -2335,6 +2479,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
     // second axis of the PSF window: off the critical path (read by aomarl_comp_strehl at the end of
     // the step), so it goes to the side stream, in front of the next frame's extrusions
     c->ev_frame_cur = ev_done; c->frame_marked = true;
+    c->side_joined = false;
     HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
     hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
     LAUNCHCHK();
@@ -2362,6 +2507,12 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
   int fl = (image_flags | AOMARL_IMG_COG | AOMARL_IMG_NOISE) & ~(AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS);
   const bool defer = c->defer_dm_shape && aomarl_dm_from_voltage_available(c);
   if (aomarl_frame_fused_available(c) && !(fl & AOMARL_IMG_FROM_PHASE_BUFFER)) {
+    if (c->capturing && c->prefetch_atmos) {       // where the extrusion stream forks from the caller's
+      rc = side_stream(c);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(c->ev_fork, (hipStream_t)stream));
+      c->fork_recorded = true;
+    }
     rc = aomarl_frame_fused(c, st, b, n, fl | (defer ? AOMARL_IMG_DM_FROM_VOLTAGE : 0), stream);
     if (rc) return rc;
     if (c->prefetch_atmos && !c->premoved) {     // one frame ahead for ONE range at a time

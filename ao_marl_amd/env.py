@@ -529,6 +529,7 @@ class VecAoEnv(object):
             else:
                 self._ring.zero_()
             self._ring_pos, self._glue = 0, None
+            self._out_pos = 0
         return self.linear_step()
 
     def linear_step(self, return_dict=False):
@@ -664,6 +665,9 @@ class VecAoEnv(object):
             sup.sim._need_bincube()
         self._glue = g
 
+    OUT_RING = 6        # a multiple of the command ring's period (number_of_previous_dm + 1 = 3)
+    _out_ring, _out_pos = None, 0
+
     def _step_native(self, action):
         sup = self.supervisor
         std = sup.config_rl["normalization_std_inside_environment"]
@@ -678,10 +682,22 @@ class VecAoEnv(object):
             self._make_glue()
         g = self._glue
         g.ring_pos = self._ring_pos
-        state = torch.empty(self.nenv, self.state_dim, dtype=torch.float32, device=self.device)
-        r = None
-        if self.layout is not None:
-            r = torch.empty(self.nenv, self.layout.n_agents, dtype=torch.float32, device=self.device)
+        if getattr(sup.sim, "graph_step", False):
+            # graph replay needs the addresses it was captured with: the outputs cycle through a ring of
+            # OUT_RING buffers (a returned state / reward stays valid for OUT_RING - 1 further steps; clone
+            # what must live longer -- DelayedMDP holds a state for delay + 1 steps, the replay copies)
+            if self._out_ring is None:
+                self._out_ring = [(torch.empty(self.nenv, self.state_dim, dtype=torch.float32, device=self.device),
+                                   torch.empty(self.nenv, self.layout.n_agents, dtype=torch.float32, device=self.device)
+                                   if self.layout is not None else None) for _ in range(self.OUT_RING)]
+                self._out_pos = 0
+            state, r = self._out_ring[self._out_pos]
+            self._out_pos = (self._out_pos + 1) % self.OUT_RING
+        else:
+            state = torch.empty(self.nenv, self.state_dim, dtype=torch.float32, device=self.device)
+            r = None
+            if self.layout is not None:
+                r = torch.empty(self.nenv, self.layout.n_agents, dtype=torch.float32, device=self.device)
         ae = sup.autoencoder
         if ae is not None:
             ae._used_fp16 = ae._used_fp16 or not g.denoiser_f32

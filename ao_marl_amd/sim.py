@@ -41,6 +41,7 @@ class HipSim(object):
         # of the shapes triggers _ensure_shape() first)
         self.defer_shape = True
         self.prefetch, self.pending_atmos = False, False     # see prefetch_atmos()
+        self.graph_step = False      # aomarl_env_step replays HIP graphs (set_option("graph_step", 1))
         self._pending_range = (0, 0)
         self._s2m_rows = 0                                   # see set_slopes2modes()
         self._defer_on = False       # the ctx option as currently set
@@ -152,6 +153,8 @@ class HipSim(object):
         la.check(self.lib.aomarl_set_option(self.ctx, name.encode(), int(value)))
         if name == "prefetch_atmos":
             self.prefetch = bool(value)
+        if name == "graph_step":
+            self.graph_step = bool(value)
         if name == "force_unfused_frame" and value:
             self._set_defer(False)
 
@@ -171,6 +174,12 @@ class HipSim(object):
         self._stale = self._defer_on
         if self.prefetch and not self.pending_atmos:
             self.pending_atmos, self._pending_range = True, (0, self.nenv)
+
+    def graph_stats(self):
+        """(graphs captured, graphs replayed) by aomarl_env_step under set_option("graph_step", 1)."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        la.check(self.lib.aomarl_graph_stats(self.ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def _set_defer(self, on):
         on = bool(on)

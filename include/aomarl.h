@@ -465,6 +465,14 @@ typedef struct {
 int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, const float *action_dev,
                     float gain, float *accumx, float *accumy, float *state_out, float *reward_out,
                     void *stream);
+/* aomarl_set_option(ctx, "graph_step", 1): aomarl_env_step replays a HIP graph captured from its own launch
+ * sequence (one per distinct extrusion plan x ring position x buffer addresses; captured the first time a
+ * combination occurs): one hipGraphLaunch instead of ~25 launches + ~8 event operations per step, for the
+ * launch-bound regime (small batches).  Same kernels, same arguments, same results.  Inside a graph the side
+ * streams join the caller's stream at the end of the step, so at large batches the plain path (whose
+ * extrusion chain runs on beside the next step's head) is the faster one: off by default.
+ * aomarl_graph_stats: graphs captured / replayed so far on this context. */
+int aomarl_graph_stats(aomarl_ctx *ctx, unsigned long long *captures, unsigned long long *replays);
 
 /* WFS-image denoiser in the loop (RlSupervisor.autoencoder_denoising, rlSupervisor.py:876-891;
  * DenoisingAutoencoderCNN2DSingleSubapeture.forward, src/autoencoder/autoencoder_models.py:130-197):

@@ -384,3 +384,52 @@ def test_residual_modes_from_slopes_equals_do_control_path():
     eb = b.supervisor.get_err()
     assert (a.supervisor.get_err() - eb).abs().max().item() < 2e-5 * eb.abs().max().item()
     assert torch.equal(a.supervisor.get_command(), ca)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,nenv,rl,n_modal", [
+    ("production_sh_10x10_2m", 8, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5), 1),
+    ("production_sh_40x40_8m_3layers", 4, dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5,
+                                               window_n_zernike=20, include_tip_tilt_windowed=True), 13)])
+def test_graph_step_replays_the_same_step(config, nenv, rl, n_modal):
+    """aomarl_set_option("graph_step", 1): aomarl_env_step captured as HIP graphs (one per extrusion plan x ring
+    position x buffer addresses) and replayed -- bit for bit the plain call's states, rewards, slopes, commands and
+    Strehl over 40 steps, with graphs both captured and replayed along the way."""
+    from ao_marl_amd.env import VecAoEnv
+    out = {}
+    rng = np.random.default_rng(3)
+    actions = None
+    for mode in ("plain", "graph"):
+        env = VecAoEnv(config, nenv, rl, initial_seed=77, seed_stride=16, n_agents_modal=n_modal)
+        sim = env.supervisor.sim
+        sim.set_option("graph_step", 1 if mode == "graph" else 0)
+        if actions is None:
+            actions = torch.from_numpy(rng.uniform(-1, 1, size=(40, nenv, env.action_dim)).astype(np.float32)).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.Stream()):        # the null stream cannot be captured
+            s = env.reset()
+            rec = [s.clone()]
+            abuf = [torch.empty_like(actions[0]) for _ in range(3)]   # stable addresses, as a policy's output ring gives
+            for t in range(40):
+                assert env._native_step_ok(False)
+                abuf[t % 3].copy_(actions[t])
+                s, r, _, _ = env.step(abuf[t % 3])
+                rec += [s.clone(), r.clone()]
+            rec += [env.supervisor.get_slopes().clone(), env.supervisor.get_command().clone(),
+                    env.supervisor.get_strehl().clone()]
+            torch.cuda.synchronize()
+            out[mode] = (rec, sim.graph_stats())
+            # a second episode on the same context: the reset's plain calls and the graphs mix
+            if mode == "graph":
+                s2 = env.reset()
+                for t in range(5):
+                    abuf[t % 3].copy_(actions[t])
+                    s2, _, _, _ = env.step(abuf[t % 3])
+                torch.cuda.synchronize()
+                assert torch.isfinite(s2).all()
+        del env
+    cap, rep = out["graph"][1]
+    # 40 steps: at most (plans x 3 ring positions x 2 output-ring phases) distinct graphs, the rest replays
+    assert out["plain"][1] == (0, 0) and 2 <= cap <= 30 and rep >= 10 and 38 <= cap + rep <= 40, (cap, rep)   # the first step validates the glue on the plain path
+    for a, b in zip(out["plain"][0], out["graph"][0]):
+        assert torch.equal(a, b)
