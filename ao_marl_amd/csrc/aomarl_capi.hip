@@ -52,6 +52,8 @@ struct aomarl_ctx {
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
   int dft_mode = -1;                   // frame kernel DFTs: -1 follow the library's precision mode, 0 fp32 MFMAs, 1 split-fp16 ("force_f32_dft")
   bool reset_untransposed = false;     // "reset_untransposed": the reset's x extrusions on the row-major screen itself
+  int small_move = 1;                  // "small_move": 1 = one k_move_small launch per frame's move where the screens allow it
+  bool small_ok = false;               // every layer has dim <= MOVE_SMALL_DIM, ns + dim <= MOVE_SMALL_K (transposed [A|B] uploaded)
   bool no_extrude_sg = false;          // "extrude_unfused": scatter and gather of consecutive rounds as separate launches
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
   int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
@@ -251,6 +253,8 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
   long long off = 0;
   const float *seenA[AOMARL_MAX_LAYERS]; const float *seenB[AOMARL_MAX_LAYERS];
   const float *devAB[AOMARL_MAX_LAYERS]; int ldab[AOMARL_MAX_LAYERS];
+  const float *devABt[AOMARL_MAX_LAYERS]; int ldt[AOMARL_MAX_LAYERS];
+  c->small_ok = true;
   s.wfs_all_int = 1; s.tar_all_int = 1;
   for (int l = 0; l < d->nlayers; l++) {
     const aomarl_layer_desc &L = d->layers[l];
@@ -290,10 +294,22 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
       float *p;
       UP(float, ab.data(), ab.size(), p);
       devAB[cls] = p; ldab[cls] = ld;
+      devABt[cls] = nullptr; ldt[cls] = 0;
+      if (L.dim <= MOVE_SMALL_DIM && K <= MOVE_SMALL_K) {          // small screens: the transpose for k_move_small
+        const int lt = (L.dim + 63) & ~63;
+        std::vector<float> abt((size_t)K * lt, 0.f);
+        for (int r = 0; r < L.dim; r++)
+          for (int j = 0; j < K; j++) abt[(size_t)j * lt + r] = ab[(size_t)r * ld + j];
+        float *pt;
+        UP(float, abt.data(), abt.size(), pt);
+        devABt[cls] = pt; ldt[cls] = lt;
+      }
       c->ab_scale[cls] = gemm_scale(ab.data(), ab.size());
     }
     c->abclass[l] = cls;
     D.AB = devAB[cls]; D.ldab = ldab[cls];
+    D.ABt = devABt[cls]; D.ldt = ldt[cls];
+    if (!D.ABt) c->small_ok = false;
     D.amp = L.amplitude;
     D.wxo = L.wfs_xoff; D.wyo = L.wfs_yoff; D.txo = L.tar_xoff; D.tyo = L.tar_yoff;
     D.wox = (int)L.wfs_xoff; D.woy = (int)L.wfs_yoff; D.tox = (int)L.tar_xoff; D.toy = (int)L.tar_yoff;
@@ -894,6 +910,19 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
   }
   if (maxr == 0) return 0;
   if ((hipStream_t)stream != c->atm_stream || !c->atm_stream) { int rc = atmos_wait_pending(c, stream); if (rc) return rc; }
+  if (c->small_ok && c->small_move) {            // small screens: the whole move of these environments in one launch
+    hipStream_t s = (hipStream_t)stream;
+    MovePlan mp;
+    for (int l = 0; l < AOMARL_MAX_LAYERS; l++) { mp.kx[l] = l < c->nlayers ? p.kx[l] : 0; mp.ky[l] = l < c->nlayers ? p.ky[l] : 0; }
+    if (c->frame_wait_pending && s == c->atm_stream) {       // it reads AND writes the rings: behind their readers
+      HIPCHK(hipStreamWaitEvent(s, c->ev_frame_cur, 0));
+      c->frame_wait_pending = false;
+    }
+    if (s != c->atm_stream) c->screens_dirty_main = true;
+    hipLaunchKernelGGL(k_move_small, dim3(n, c->nlayers), dim3(MOVE_SMALL_T), 0, s, c->sys, dev_state(st), b, mp);
+    LAUNCHCHK();
+    return 0;
+  }
   std::vector<RoundOps> rounds((size_t)maxr);
   for (int r = 0; r < maxr; r++) {
     RoundOps &o = rounds[r];
@@ -1176,6 +1205,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
+  if (!strcmp(name, "small_move")) { c->small_move = value != 0; return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
   if (!strcmp(name, "time_frame_kernel")) {

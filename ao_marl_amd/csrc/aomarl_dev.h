@@ -16,6 +16,8 @@ struct DevLayer {
   const uint32_t *istT;          // istx with x and y exchanged: the x stencil of the TRANSPOSED screen (reset)
   const float *AB;               // [dim][ldab]: row r = [A[r][0..ns) | B[r][0..dim)]
   int ldab;
+  const float *ABt;              // [ns + dim][ldt], ldt = dim rounded up to 64 (zero padded): the transpose, small screens only
+  int ldt;
   float amp;
   float wxo, wyo, txo, tyo;      // float offsets
   int wox, woy, tox, toy;        // integer parts

@@ -1120,6 +1120,103 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   if (threadIdx.x == 0) ZREF[col] = zref;
 }
 
+// Small screens (dim <= 256, ns + dim <= MOVE_SMALL_K): ALL the extrusions of one frame's move in ONE launch.
+// One block per (environment, layer): per extrusion it gathers Z = [stencil - zref | amp N(0,1)] into LDS,
+// forms the new line zref + [A|B] Z from the transposed matrix (thread = (row, K slice), coalesced over
+// rows, the K slices summed in a fixed order through LDS), writes it into the ring and goes on with the
+// origin and counter it carries in registers: |kx| x-extrusions, then |ky| y-extrusions, as run_plan
+// orders them.  The matrix (a few hundred KB) is re-read from L2 by every block, which is what limits
+// this to small screens: there the step is bound by the host's launches (configs[1]: 6 - 12 launches of
+// the generic rounds become 1), not by the arithmetic.  fp32 vector FMAs in both precision modes.
+constexpr int MOVE_SMALL_K = 4096, MOVE_SMALL_DIM = 256, MOVE_SMALL_T = 512;
+struct MovePlan { int kx[AOMARL_MAX_LAYERS], ky[AOMARL_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(MOVE_SMALL_T) void k_move_small(DevSys sys, DevState st, int env_begin, MovePlan plan) {
+  __shared__ float Zs[MOVE_SMALL_K];
+  __shared__ float Ps[MOVE_SMALL_T];
+  const int e = env_begin + blockIdx.x, li = blockIdx.y, tid = threadIdx.x;
+  const int kx = plan.kx[li], ky = plan.ky[li];
+  const int nx = abs(kx), nit = nx + abs(ky);
+  if (nit == 0) return;
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim, ns = L.ns, K = n + ns, stride = n + RING_PAD, ldt = L.ldt;
+  const int parts = MOVE_SMALL_T / ldt, part = tid / ldt, row = tid - part * ldt;
+  float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  int *o = st.origin + (e * sys.nlayers + li) * 2;
+  int ox = o[0], oy = o[1];
+  uint32_t cnt = st.ext_count[e * sys.nlayers + li];
+  const uint32_t seed = st.seeds[e] + (uint32_t)li;
+  const float amp = L.amp;
+  const float *__restrict__ ABt = L.ABt;
+  for (int it = 0; it < nit; it++) {
+    const int dir = it < nx ? (kx > 0 ? 1 : -1) : (ky > 0 ? 2 : -2);
+    const bool top_right = (dir == 1 || dir == -2);
+    // the ring is rewritten by this block between iterations: a plain vector load, never the scalar cache
+    const float zref = __hip_atomic_load(base + ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, ox, oy, n),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t *ist = (dir == 1 || dir == -1) ? L.istx : L.isty;
+    for (int j = tid; j < ns; j += MOVE_SMALL_T) {
+      const uint32_t xy = ist[j];
+      Zs[j] = __hip_atomic_load(base + ring_idx(xy & 0xFFFF, xy >> 16, ox, oy, n), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_WORKGROUP) - zref;
+    }
+    for (int g = tid; g < (n + 3) / 4; g += MOVE_SMALL_T) {
+      float z4[4];
+      philox_normal4(seed, 0u, cnt, 0u, (uint32_t)g, z4);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (4 * g + u < n) Zs[ns + 4 * g + u] = amp * z4[u];
+    }
+    __syncthreads();
+    if (part < parts) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float *p = ABt + row;
+      int j = part;
+      for (; j + 3 * parts < K; j += 4 * parts) {
+        a0 = fmaf(p[(long long)j * ldt], Zs[j], a0);
+        a1 = fmaf(p[(long long)(j + parts) * ldt], Zs[j + parts], a1);
+        a2 = fmaf(p[(long long)(j + 2 * parts) * ldt], Zs[j + 2 * parts], a2);
+        a3 = fmaf(p[(long long)(j + 3 * parts) * ldt], Zs[j + 3 * parts], a3);
+      }
+      for (; j < K; j += parts) a0 = fmaf(p[(long long)j * ldt], Zs[j], a0);
+      Ps[tid] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (tid < n) {
+      float v = 0.f;
+      for (int q = 0; q < parts; q++) v += Ps[q * ldt + tid];
+      v += zref;
+      const int r = tid;
+      int px, py;
+      if (dir == 1) {
+        px = ox;
+        py = r + oy; py -= (py >= n) ? n : 0;
+      } else if (dir == -1) {
+        px = ox - 1; px += (px < 0) ? n : 0;
+        py = n - 1 - r + oy; py -= (py >= n) ? n : 0;
+      } else if (dir == 2) {
+        py = oy;
+        px = r + ox; px -= (px >= n) ? n : 0;
+      } else {
+        py = oy - 1; py += (py < 0) ? n : 0;
+        px = n - 1 - r + ox; px -= (px >= n) ? n : 0;
+      }
+      base[py * stride + px] = v;
+      if (px < RING_PAD) base[py * stride + n + px] = v;     // mirror columns
+    }
+    if (dir == 1) ox = (ox + 1 >= n) ? 0 : ox + 1;
+    else if (dir == -1) ox = (ox - 1 < 0) ? n - 1 : ox - 1;
+    else if (dir == 2) oy = (oy + 1 >= n) ? 0 : oy + 1;
+    else oy = (oy - 1 < 0) ? n - 1 : oy - 1;
+    cnt += 1u;
+    __syncthreads();                             // the new line is in the ring (block-visible); Zs / Ps are free again
+  }
+  if (tid == 0) {
+    o[0] = ox; o[1] = oy;
+    st.ext_count[e * sys.nlayers + li] = cnt;
+  }
+}
+
 // in-place transposition of the n x n ring of (environment, layer li): 32 x 32 tiles, block = the tile
 // pair (i, j) / (j, i), i <= j; the ring origin is exchanged with it.  The mirror columns are rebuilt by
 // k_refresh_mirror afterwards.
