@@ -98,6 +98,25 @@ struct aomarl_ctx {
   // launched on that stream since (the composites' prefetch reuses it)
   hipEvent_t ev_frame_cur = nullptr;
   bool frame_marked = false;
+  // frame pipeline (aomarl_set_frame_pipeline): frames on a stream of their own, one step ahead of the chains
+  struct FramePipe {
+    bool have_twin = false, active = false;
+    const float *owner_screens = nullptr;          // the state the twin belongs to
+    aomarl_state twin;                             // odd frames: slopes / voltage / dm_shape / work
+    int par = 0;                                   // parity (0: st's buffers, 1: the twin's) of the frame in flight
+    hipStream_t fstream = nullptr;
+    hipEvent_t ev_cmd = nullptr, ev_done[2] = {nullptr, nullptr}, ev_psf[2] = {nullptr, nullptr};
+    hipEvent_t ev_done_cur[2] = {nullptr, nullptr};  // the event each parity's last frame launch carries (ev_done[], or a timing event)
+    bool psf_out[2] = {false, false};              // a PSF finish of that parity may still run
+    int32_t *snap[2] = {nullptr, nullptr};         // ring origins as of each parity's frame
+    size_t snap_ints = 0;
+    unsigned long long steps = 0, overlapped = 0, behind = 0;
+  } pipe;
+  bool pipe_internal = false;            // check_range: the pipelined step itself is calling
+  // first write of a prefetched move: behind the OLDER frame in flight (ev_frame_prev) when the lines the move
+  // rewrites are outside the frame kernel's windows (group_overlap, decided per plan), else behind the newest
+  hipEvent_t ev_frame_prev = nullptr;
+  bool need_prev = false, group_overlap = false;
   bool psf_side = false;                // a k_target_finish_mfma launched on the side stream may still run
   const float *pre_screens = nullptr;
   int pre_b = 0, pre_n = 0;
@@ -121,6 +140,9 @@ struct aomarl_ctx {
   int32_t *geoMap = nullptr;       // stack-array actuator -> j * gh + i of the lattice product
   int geo_ldw = 0, geo_gw = 0, geo_gh = 0, geo_npzt = 0, geo_ldr = 0;
 };
+
+static int pipe_drop(aomarl_ctx *c, void *stream);
+static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream, int slot);
 
 const char *aomarl_last_error(void) { return g_err; }
 int aomarl_abi_version(void) { return AOMARL_ABI_VERSION; }
@@ -568,6 +590,13 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (c) c->graphs.clear();
   if (!c) return 0;
   for (void *p : c->owned) (void)hipFree(p);
+  for (int k = 0; k < 2; k++) {
+    if (c->pipe.snap[k]) (void)hipFree(c->pipe.snap[k]);
+    if (c->pipe.ev_done[k]) (void)hipEventDestroy(c->pipe.ev_done[k]);
+    if (c->pipe.ev_psf[k]) (void)hipEventDestroy(c->pipe.ev_psf[k]);
+  }
+  if (c->pipe.ev_cmd) (void)hipEventDestroy(c->pipe.ev_cmd);
+  if (c->pipe.fstream) { (void)hipStreamSynchronize(c->pipe.fstream); (void)hipStreamDestroy(c->pipe.fstream); }
   // the side streams belong to the process (side_stream): drained here, never destroyed
   if (c->atm_stream) (void)hipStreamSynchronize(c->atm_stream);
   if (c->psf_stream) (void)hipStreamSynchronize(c->psf_stream);
@@ -733,6 +762,10 @@ size_t aomarl_dmshape_stride(const aomarl_ctx *c) { return c ? (size_t)c->sys.sh
 
 static int check_range(const aomarl_ctx *c, const aomarl_state *st, int b, int n) {
   if (!c || !st) return fail("null ctx/state");
+  if (c->pipe.active && !c->pipe_internal && st->screens == c->pipe.owner_screens)
+    return fail("a pipelined frame is in flight on this state (aomarl_set_frame_pipeline): only aomarl_env_step and a "
+                "full-range aomarl_reset are accepted until the reset -- slopes / voltage of odd frames are in the twin, "
+                "the screens a frame ahead");
   if (b < 0 || n < 0 || b + n > st->nenv) return fail("env range [%d, %d) outside [0, %d)", b, b + n, st->nenv);
   if (st->ld_actu < c->sys.nactu) return fail("ld_actu (%d) < nactu (%d)", st->ld_actu, c->sys.nactu);
   if (!st->screens || !st->origin || !st->seeds || !st->ext_count || !st->com || !st->com1 ||
@@ -803,6 +836,18 @@ static int atmos_wait_pending(aomarl_ctx *c, void *stream) {
   return 0;
 }
 
+// the first kernel of a prefetched move that WRITES ring lines waits for the readers of the screens
+static int first_write_wait(aomarl_ctx *c, hipStream_t s) {
+  if (s != c->atm_stream) return 0;
+  if (c->group_overlap && c->ev_frame_prev) {
+    if (c->need_prev) { HIPCHK(hipStreamWaitEvent(s, c->ev_frame_prev, 0)); c->need_prev = false; }
+  } else if (c->frame_wait_pending) {
+    HIPCHK(hipStreamWaitEvent(s, c->ev_frame_cur, 0));
+    c->frame_wait_pending = false; c->need_prev = false;
+  }
+  return 0;
+}
+
 static bool same_round(const RoundOps &a, const RoundOps &b) {
   if (a.nops != b.nops) return false;
   for (int i = 0; i < a.nops; i++)
@@ -852,10 +897,7 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
                      0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp,
                      /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
       LAUNCHCHK();
-      if (c->frame_wait_pending && s == c->atm_stream) {
-        HIPCHK(hipStreamWaitEvent(s, c->ev_frame_cur, 0));
-        c->frame_wait_pending = false;
-      }
+      { int wrc = first_write_wait(c, s); if (wrc) return wrc; }
       if (s != c->atm_stream) c->screens_dirty_main = true;
       if (fuse_next) {
         hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(512), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
@@ -910,14 +952,25 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
   }
   if (maxr == 0) return 0;
   if ((hipStream_t)stream != c->atm_stream || !c->atm_stream) { int rc = atmos_wait_pending(c, stream); if (rc) return rc; }
+  // frame pipeline: may this move run beside the older frame in flight?  The extrusions rewrite the |kx| oldest
+  // columns / |ky| oldest rows of each ring (logical 0.. for a positive shift, dim-1.. for a negative one):
+  // outside every window the one-pass frame kernel reads  <=>  within the margins around the pupil
+  c->group_overlap = false;
+  if (c->ev_frame_prev) {
+    bool fits = true;
+    for (int l = 0; l < c->nlayers; l++) {
+      const DevLayer &L = c->sys.layers[l];
+      const int lox = L.tox, hix = L.dim - L.tox - c->sys.pupdiam, loy = L.toy, hiy = L.dim - L.toy - c->sys.pupdiam;
+      if ((p.kx[l] > 0 ? p.kx[l] > lox : -p.kx[l] > hix) || (p.ky[l] > 0 ? p.ky[l] > loy : -p.ky[l] > hiy)) fits = false;
+    }
+    c->group_overlap = fits;
+    if (fits) c->pipe.overlapped++; else c->pipe.behind++;
+  }
   if (c->small_ok && c->small_move) {            // small screens: the whole move of these environments in one launch
     hipStream_t s = (hipStream_t)stream;
     MovePlan mp;
     for (int l = 0; l < AOMARL_MAX_LAYERS; l++) { mp.kx[l] = l < c->nlayers ? p.kx[l] : 0; mp.ky[l] = l < c->nlayers ? p.ky[l] : 0; }
-    if (c->frame_wait_pending && s == c->atm_stream) {       // it reads AND writes the rings: behind their readers
-      HIPCHK(hipStreamWaitEvent(s, c->ev_frame_cur, 0));
-      c->frame_wait_pending = false;
-    }
+    { int wrc = first_write_wait(c, s); if (wrc) return wrc; }      // it reads AND writes the rings: behind their readers
     if (s != c->atm_stream) c->screens_dirty_main = true;
     hipLaunchKernelGGL(k_move_small, dim3(n, c->nlayers), dim3(MOVE_SMALL_T), 0, s, c->sys, dev_state(st), b, mp);
     LAUNCHCHK();
@@ -1040,6 +1093,11 @@ int aomarl_reset_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *str
 
 int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *seeds, float *accumx,
                  float *accumy, void *stream) {
+  if (c && st && c->pipe.active && st->screens == c->pipe.owner_screens) {
+    if (b != 0 || n != st->nenv) return fail("reset of environments [%d, %d) while a pipelined frame of the whole batch is in flight", b, b + n);
+    int prc = pipe_drop(c, stream);
+    if (prc) return prc;
+  }
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
   if (n == 0) return 0;
@@ -2002,16 +2060,12 @@ int aomarl_actor_forward(const aomarl_actor_desc *d, const float *state, const f
                               d->bias, d->sc_agent, d->sc_local, eps, seed, counter, action, mean, stream);
 }
 
-static int env_step_body(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
-                         float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
+static int env_step_validate(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float *state_out,
+                             float *reward_out) {
   if (!c || !st || !g || !state_out) return fail("env_step: null argument");
   if (g->nhist < 0 || g->nhist > 5) return fail("env_step: 0..5 command histories");
   const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1;
   if (g->ring_pos < 0 || g->ring_pos >= R) return fail("env_step: ring position out of range");
-  const size_t slot = (size_t)n * nm;
-  float *newest = g->modes_ring + (size_t)g->ring_pos * slot;
-  const int nxt = (g->ring_pos + 1) % R;
-  float *mnew = g->modes_ring + (size_t)nxt * slot;
   int rc = check_range(c, st, 0, n);
   if (rc) return rc;
   if (!c->v2m || !c->m2v) return fail("env_step: no modal basis (aomarl_set_modal)");
@@ -2035,50 +2089,118 @@ static int env_step_body(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, co
       if (h[i] < 0 || h[i] >= nm) return fail("env_step: glue->sel[%zu] = %d is outside the %d modes", i, h[i], nm);
     c->sel_checked = g->sel; c->sel_checked_n = g->dm_dim; c->sel_checked_nm = nm;
   }
-  hipStream_t s = (hipStream_t)stream;
-  Work w = work_layout(c, st->nenv);
-  DevState ds = dev_state(st);
-  const int na = c->sys.nactu;
-  // Fused form of the chain (same arithmetic, same order of every sum -- the results are bit for bit
-  // those of the entry points called one by one): every split-K reduction happens in the kernel that
-  // consumes the product, independent small kernels share a launch.  10 launches per step on the
-  // main stream instead of 14.
+  return 0;
+}
+
+// may the chain run in its fused form?  (ktt: index of the tip-tilt mirror)
+static bool env_step_fusable(aomarl_ctx *c, const aomarl_env_glue *g, int *ktt_out) {
   int ktt = -1, ntt = 0, nother = 0;
   for (int k = 0; k < c->ndm; k++) {
     if (c->sys.dms[k].type == AOMARL_DM_TT) { ktt = k; ntt++; } else nother++;
   }
   const bool defer = c->defer_dm_shape && aomarl_dm_from_voltage_available(c);
-  const bool fused = !(g->flags & AOMARL_ENV_STEP_UNFUSED) && ntt == 1 && (defer || nother == 0);
+  if (ktt_out) *ktt_out = ktt;
+  return !(g->flags & AOMARL_ENV_STEP_UNFUSED) && ntt == 1 && (defer || nother == 0);
+}
+
+// ---- AoEnv.rl_step, fused form: Btt correction from the coordinates at hand (+ the per-agent rewards of the
+// residual measured before this action reaches the DM), delay line, tip-tilt shape, Strehl commit.
+// `stv`: the state whose voltage / dm_shape / pending PSF window this call writes and commits (st itself, or
+// the frame pipeline's view of the parity the NEXT frame uses).  ahead: the delay line is evaluated one frame
+// ahead (the voltages of the frame that follows the one in flight): weights shifted by one command.
+static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *stv, aomarl_env_glue *g, const float *action,
+                               float gain, float *reward_out, int ktt, bool ahead, hipEvent_t psf_ev, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1, na = c->sys.nactu;
+  const size_t slot = (size_t)n * nm;
+  float *newest = g->modes_ring + (size_t)g->ring_pos * slot;
+  float *mnew = g->modes_ring + (size_t)((g->ring_pos + 1) % R) * slot;
+  Work w = work_layout(c, st->nenv);
+  DevState dsv = dev_state(stv);
+  float *modes = st->work + w.MODES;
+  const int cx = (nm + 255) / 256;
+  hipLaunchKernelGGL(k_compose_rewards, dim3(cx + (reward_out ? g->n_agents : 0), n), dim3(256), 0, s, nm, newest,
+                     g->res_modes, gain, action, c->nact, c->amode_inv, c->freedom, modes, w.ldm, mnew, cx,
+                     g->n_agents, g->lohi, g->reward_factor, reward_out);
+  LAUNCHCHK();
+  int nsp = 0;
+  float alpha = 1.f;
+  launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, st->com, st->ld_actu, s,
+                 st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, true, 16.f, c->m2v_scale, &alpha, 288);
+  LAUNCHCHK();
+  const float d = c->delay;
+  float wa, wb, wc;
+  if (d <= 1.f) { wa = 1.f - d; wb = d; wc = 0.f; } else { wa = 0.f; wb = 2.f - d; wc = d - 1.f; }
+  if (ahead) { wa = wb; wb = wc; wc = 0.f; }       // v(t+1) = wb c(t) + wc c(t-1): only with wa == 0 (delay >= 1)
+  if (nsp > 0)
+    hipLaunchKernelGGL(k_delay_sum, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1,
+                       st->work + w.GEMM, nsp, alpha, n);
+  else
+    hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1);
+  LAUNCHCHK();
+  if (psf_ev) HIPCHK(hipStreamWaitEvent(s, psf_ev, 0));
+  else if (stv == st) { int rc = psf_wait_pending(c, stream); if (rc) return rc; }
+  hipLaunchKernelGGL(k_post_delay, dim3(2 * n), dim3(256), 0, s, c->sys, dsv, 0, n, stv->work + w.PEND, 1, ktt,
+                     stv->voltage, st->ld_actu);
+  LAUNCHCHK();
+  return 0;
+}
+
+// ---- the rest of AoEnv.linear_step behind do_control: v2m . err, the state blocks
+static int env_step_tail(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, bool fused, float *state_out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1, na = c->sys.nactu;
+  const size_t slot = (size_t)n * nm;
+  const int nxt = (g->ring_pos + 1) % R;
+  float *mnew = g->modes_ring + (size_t)nxt * slot;
+  Work w = work_layout(c, st->nenv);
+  int rc = 0;
+  AssemblePart part = {nullptr, 0, 0, 1.f, nullptr};
   if (fused) {
-    // ---- AoEnv.rl_step: Btt correction from the coordinates at hand (+ the per-agent rewards of the
-    // residual measured before this action reaches the DM), delay line, tip-tilt shape, Strehl
-    float *modes = st->work + w.MODES;
-    const int cx = (nm + 255) / 256;
-    hipLaunchKernelGGL(k_compose_rewards, dim3(cx + (reward_out ? g->n_agents : 0), n), dim3(256), 0, s, nm, newest,
-                       g->res_modes, gain, action, c->nact, c->amode_inv, c->freedom, modes, w.ldm, mnew, cx,
-                       g->n_agents, g->lohi, g->reward_factor, reward_out);
-    LAUNCHCHK();
     int nsp = 0;
     float alpha = 1.f;
-    launch_gemm_nt(n, na, nm, 1.0f, modes, w.ldm, c->m2v, c->ld_m2v, 0.0f, st->com, st->ld_actu, s,
-                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, true, 16.f, c->m2v_scale, &alpha, 288);
+    launch_gemm_nt(n, nm, na, 1.0f, st->err, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, g->res_modes, nm, s,
+                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, /* volts */ true, 1.f, c->v2m_scale, &alpha, 288);
     LAUNCHCHK();
-    const float d = c->delay;
-    float wa, wb, wc;
-    if (d <= 1.f) { wa = 1.f - d; wb = d; wc = 0.f; } else { wa = 0.f; wb = 2.f - d; wc = d - 1.f; }
-    if (nsp > 0)
-      hipLaunchKernelGGL(k_delay_sum, dim3((na + 255) / 256, n), dim3(256), 0, s, ds, na, st->ld_actu, wa, wb, wc, 0, 1,
-                         st->work + w.GEMM, nsp, alpha, n);
-    else
-      hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, s, ds, na, st->ld_actu, wa, wb, wc, 0, 1);
-    LAUNCHCHK();
-    rc = psf_wait_pending(c, stream);
+    if (nsp > 0) { part.part = st->work + w.GEMM; part.nsplit = nsp; part.pn = nm; part.alpha = alpha; part.sum_out = g->res_modes; }
+  } else {
+    rc = aomarl_volts2modes(c, st, n, st->err, st->ld_actu, g->res_modes, stream);
     if (rc) return rc;
-    const int W = 2 * c->sys.hw;
-    hipLaunchKernelGGL(k_post_delay, dim3(2 * n), dim3(256), 0, s, c->sys, ds, 0, n, st->work + w.PEND, 1, ktt,
-                       st->voltage, st->ld_actu);
-    (void)W;
-    LAUNCHCHK();
+  }
+  const float *src[8], *mean[8], *sd[8];
+  int32_t ld[8], dim[8];
+  int nb = 0;
+  for (int h = g->nhist; h >= 1; h--) {                       // oldest first
+    src[nb] = g->modes_ring + (size_t)((nxt - h + R * 8) % R) * slot;
+    mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+  }
+  src[nb] = mnew; mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+  src[nb] = g->res_modes; mean[nb] = g->mean_res; sd[nb] = g->std_res; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+  const bool norm = g->mean_dm && g->std_dm && g->mean_res && g->std_res;
+  rc = assemble_state_impl(n, nb, src, ld, dim, norm ? mean : nullptr, norm ? sd : nullptr, g->sel, state_out, stream,
+                           &part);
+  if (rc) return rc;
+  g->ring_pos = nxt;
+  return 0;
+}
+
+static int env_step_body(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
+                         float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
+  int rc = env_step_validate(c, st, g, action, state_out, reward_out);
+  if (rc) return rc;
+  const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1;
+  const size_t slot = (size_t)n * nm;
+  float *newest = g->modes_ring + (size_t)g->ring_pos * slot;
+  float *mnew = g->modes_ring + (size_t)((g->ring_pos + 1) % R) * slot;
+  // Fused form of the chain (same arithmetic, same order of every sum -- the results are bit for bit
+  // those of the entry points called one by one): every split-K reduction happens in the kernel that
+  // consumes the product, independent small kernels share a launch.  10 launches per step on the
+  // main stream instead of 14.
+  int ktt = -1;
+  const bool fused = env_step_fusable(c, g, &ktt);
+  if (fused) {
+    rc = env_step_head_fused(c, st, st, g, action, gain, reward_out, ktt, false, nullptr, stream);
+    if (rc) return rc;
   } else {
     // ---- AoEnv.rl_step: Btt correction from the coordinates at hand, delay line, Strehl
     rc = aomarl_rl_control_modes(c, st, 0, n, newest, g->res_modes, gain, action, mnew, stream);
@@ -2120,34 +2242,191 @@ static int env_step_body(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, co
     rc = aomarl_next_part_one(c, st, 0, n, accumx, accumy, 0, stream);
   }
   if (rc) return rc;
-  AssemblePart part = {nullptr, 0, 0, 1.f, nullptr};
-  if (fused) {
-    int nsp = 0;
-    float alpha = 1.f;
-    launch_gemm_nt(n, nm, na, 1.0f, st->err, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, g->res_modes, nm, s,
-                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, /* volts */ true, 1.f, c->v2m_scale, &alpha, 288);
-    LAUNCHCHK();
-    if (nsp > 0) { part.part = st->work + w.GEMM; part.nsplit = nsp; part.pn = nm; part.alpha = alpha; part.sum_out = g->res_modes; }
-  } else {
-    rc = aomarl_volts2modes(c, st, n, st->err, st->ld_actu, g->res_modes, stream);
-    if (rc) return rc;
+  return env_step_tail(c, st, g, fused, state_out, stream);
+}
+
+// ---------------------------------------------------------------- frame pipeline (aomarl_set_frame_pipeline)
+// Step t of the plain order:  head(a_t) -> v_t | frame_t | do_control_t, tail -> state_{t+1}.  With delay == 1
+// v_{t+1} = c_t is known after head(a_t), so frame_{t+1} is launched by the call of step t, on the frame stream,
+// BEFORE that call reduces frame_t: the frame kernels run back to back, the control / agent chain of frame t
+// (do_control_t .. actor .. head(a_{t+1})) runs beside frame_{t+1}, the move for frame t+2 beside it too.
+//   buffers: parity 0 = st's slopes / voltage / dm_shape / work (PSF rows, pending window), parity 1 = the twin's;
+//   ring origins: per-parity snapshots (the live origins move with the prefetched atmosphere).
+static aomarl_state pipe_view(aomarl_ctx *c, const aomarl_state *st, int par) {
+  aomarl_state v = *st;
+  if (par) {
+    v.slopes = c->pipe.twin.slopes; v.voltage = c->pipe.twin.voltage; v.dm_shape = c->pipe.twin.dm_shape;
+    v.work = c->pipe.twin.work;
   }
-  const float *src[8], *mean[8], *sd[8];
-  int32_t ld[8], dim[8];
-  int nb = 0;
-  for (int h = g->nhist; h >= 1; h--) {                       // oldest first
-    src[nb] = g->modes_ring + (size_t)((nxt - h + R * 8) % R) * slot;
-    mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
-  }
-  src[nb] = mnew; mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
-  src[nb] = g->res_modes; mean[nb] = g->mean_res; sd[nb] = g->std_res; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
-  const bool norm = g->mean_dm && g->std_dm && g->mean_res && g->std_res;
-  rc = assemble_state_impl(n, nb, src, ld, dim, norm ? mean : nullptr, norm ? sd : nullptr, g->sel, state_out, stream,
-                           &part);
+  return v;
+}
+
+static bool pipe_eligible(aomarl_ctx *c, const aomarl_state *st, const aomarl_env_glue *g, const float *accumx,
+                          const float *accumy) {
+  const auto &P = c->pipe;
+  return P.have_twin && P.owner_screens == st->screens && !c->graph_step && !c->capturing && c->prefetch_atmos &&
+         c->delay == 1.f && c->sys.noise < 0.f && !g->denoiser && accumx && accumy && !c->subpixel_flow &&
+         aomarl_frame_fused_available(c) && c->defer_dm_shape && aomarl_dm_from_voltage_available(c) &&
+         env_step_fusable(c, g, nullptr);
+}
+
+static int pipe_init(aomarl_ctx *c, const aomarl_state *st) {
+  auto &P = c->pipe;
+  int rc = side_stream(c);
   if (rc) return rc;
-  g->ring_pos = nxt;
+  if (!P.fstream) {
+    HIPCHK(hipStreamCreateWithFlags(&P.fstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&P.ev_cmd, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+      HIPCHK(hipEventCreateWithFlags(&P.ev_done[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&P.ev_psf[k], hipEventDisableTiming));
+    }
+  }
+  const size_t ints = (size_t)st->nenv * c->nlayers * 2;
+  if (P.snap_ints < ints) {
+    for (int k = 0; k < 2; k++) {
+      if (P.snap[k]) (void)hipFree(P.snap[k]);
+      P.snap[k] = nullptr;
+      HIPCHK(hipMalloc((void **)&P.snap[k], sizeof(int32_t) * ints));
+    }
+    P.snap_ints = ints;
+  }
   return 0;
 }
+
+// the frame of parity q on the frame stream: behind everything issued on `stream` so far (that parity's voltages,
+// tip-tilt shape and committed PSF window) and behind the prefetched move, whose origins are in snap[q]
+static int pipe_launch_frame(aomarl_ctx *c, aomarl_state *st, int q, void *stream) {
+  auto &P = c->pipe;
+  HIPCHK(hipEventRecord(P.ev_cmd, (hipStream_t)stream));
+  HIPCHK(hipStreamWaitEvent(P.fstream, P.ev_cmd, 0));
+  if (!c->premoved || c->pre_screens != st->screens || c->pre_b != 0 || c->pre_n != st->nenv)
+    return fail("frame pipeline: no prefetched atmosphere frame of the whole batch is pending");
+  HIPCHK(hipStreamWaitEvent(P.fstream, c->ev_moved, 0));
+  c->premoved = false;
+  aomarl_state v = pipe_view(c, st, q);
+  v.origin = P.snap[q];
+  return frame_fused_impl(c, &v, 0, st->nenv, AOMARL_IMG_COG | AOMARL_IMG_NOISE | AOMARL_IMG_DM_FROM_VOLTAGE,
+                          (void *)P.fstream, q);
+}
+
+// the move for the frame after the newest one in flight, on the atmosphere stream: beside the newest frame when
+// the plan allows (run_plan), behind the older one in any case; then the origins that frame will use
+static int pipe_prefetch(aomarl_ctx *c, aomarl_state *st, float *accumx, float *accumy, int older, int newest) {
+  auto &P = c->pipe;
+  if (c->premoved) return fail("frame pipeline: a prefetched frame is already pending");
+  c->side_joined = false;
+  c->ev_frame_prev = P.ev_done_cur[older]; c->need_prev = true;
+  c->ev_frame_cur = P.ev_done_cur[newest]; c->frame_wait_pending = true;
+  int rc = move_atmos_now(c, st, 0, st->nenv, accumx, accumy, (void *)c->atm_stream);
+  if (!rc && c->need_prev && c->frame_wait_pending)      // nothing written: the snapshot still overwrites what the older frame reads
+    rc = hipStreamWaitEvent(c->atm_stream, c->ev_frame_prev, 0) == hipSuccess ? 0 : fail("frame pipeline: hipStreamWaitEvent failed");
+  c->ev_frame_prev = nullptr; c->need_prev = false; c->frame_wait_pending = false; c->group_overlap = false;
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(P.snap[older], st->origin, sizeof(int32_t) * (size_t)st->nenv * c->nlayers * 2,
+                        hipMemcpyDeviceToDevice, c->atm_stream));
+  c->screens_dirty_main = false;
+  HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
+  c->premoved = true; c->pre_screens = st->screens; c->pre_b = 0; c->pre_n = st->nenv;
+  return 0;
+}
+
+static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
+                              float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
+  auto &P = c->pipe;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = st->nenv;
+  int ktt = -1;
+  env_step_fusable(c, g, &ktt);
+  if (!P.active) {
+    // ---- first step: the plain order, then the next frame ahead
+    int rc = env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
+    if (rc) return rc;
+    if (!c->premoved || !c->psf_side) return 0;      // (the plain step did not leave the steady state behind: stay plain)
+    rc = pipe_init(c, st);
+    if (rc) return rc;
+    P.ev_done_cur[0] = c->ev_frame_cur;              // the plain frame used st's buffers: parity 0
+    HIPCHK(hipEventRecord(P.ev_psf[0], c->psf_stream));
+    P.psf_out[0] = true; P.psf_out[1] = false;
+    c->psf_side = false;
+    // v(t+1) = c(t), the newest entry of the delay line after its shift; tip-tilt shape from it
+    aomarl_state v1 = pipe_view(c, st, 1);
+    HIPCHK(hipMemcpyAsync(v1.voltage, st->com1, sizeof(float) * (size_t)n * st->ld_actu, hipMemcpyDeviceToDevice, s));
+    Work w = work_layout(c, st->nenv);
+    hipLaunchKernelGGL(k_post_delay, dim3(2 * n), dim3(256), 0, s, c->sys, dev_state(&v1), 0, n, v1.work + w.PEND, 0, ktt,
+                       v1.voltage, st->ld_actu);
+    LAUNCHCHK();
+    // the origins of the move the plain step prefetched
+    HIPCHK(hipMemcpyAsync(P.snap[1], st->origin, sizeof(int32_t) * (size_t)n * c->nlayers * 2, hipMemcpyDeviceToDevice,
+                          c->atm_stream));
+    HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
+    c->pipe_internal = true;
+    rc = pipe_launch_frame(c, st, 1, stream);
+    if (!rc) rc = pipe_prefetch(c, st, accumx, accumy, 0, 1);
+    c->pipe_internal = false;
+    if (rc) return rc;
+    P.active = true; P.par = 1;
+    return 0;
+  }
+  // ---- steady state: the frame of parity p is in flight
+  const int p = P.par, q = 1 - p;
+  c->pipe_internal = true;
+  int rc = env_step_validate(c, st, g, action, state_out, reward_out);
+  aomarl_state vq = pipe_view(c, st, q), vp = pipe_view(c, st, p);
+  if (!rc) rc = env_step_head_fused(c, st, &vq, g, action, gain, reward_out, ktt, true, P.psf_out[q] ? P.ev_psf[q] : nullptr, stream);
+  if (!rc) { P.psf_out[q] = false; rc = pipe_launch_frame(c, st, q, stream); }
+  if (!rc) rc = pipe_prefetch(c, st, accumx, accumy, p, q);
+  // ---- reduce frame p
+  if (!rc && hipStreamWaitEvent(s, P.ev_done_cur[p], 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
+  if (!rc) rc = aomarl_do_control(c, &vp, 0, n, stream);
+  if (!rc) rc = env_step_tail(c, st, g, true, state_out, stream);
+  c->pipe_internal = false;
+  if (rc) return rc;
+  P.par = q; P.steps++;
+  return 0;
+}
+
+// everything the pipeline has in flight joins `stream`; the frame in flight is dropped (full-range reset)
+static int pipe_drop(aomarl_ctx *c, void *stream) {
+  auto &P = c->pipe;
+  hipStream_t s = (hipStream_t)stream;
+  if (P.ev_done_cur[P.par]) HIPCHK(hipStreamWaitEvent(s, P.ev_done_cur[P.par], 0));
+  for (int k = 0; k < 2; k++)
+    if (P.psf_out[k]) { HIPCHK(hipStreamWaitEvent(s, P.ev_psf[k], 0)); P.psf_out[k] = false; }
+  P.active = false; P.par = 0;
+  return 0;
+}
+
+int aomarl_set_frame_pipeline(aomarl_ctx *c, const aomarl_state *st, const aomarl_state *twin) {
+  if (!c) return fail("set_frame_pipeline: null context");
+  auto &P = c->pipe;
+  if (P.active) return fail("set_frame_pipeline: a frame is in flight (reset first)");
+  if (!twin) { P.have_twin = false; P.owner_screens = nullptr; return 0; }
+  if (!st) return fail("set_frame_pipeline: null state");
+  int rc = check_range(c, st, 0, st->nenv);
+  if (rc) return rc;
+  if (twin->nenv != st->nenv || twin->ld_actu != st->ld_actu) return fail("set_frame_pipeline: the twin's nenv / ld_actu differ");
+  if (twin->screens != st->screens || twin->origin != st->origin || twin->seeds != st->seeds || twin->ext_count != st->ext_count ||
+      twin->com != st->com || twin->com1 != st->com1 || twin->com2 != st->com2 || twin->err != st->err ||
+      twin->strehl != st->strehl || twin->le_img != st->le_img || twin->frame != st->frame)
+    return fail("set_frame_pipeline: the twin must share every buffer of the state except slopes, voltage, dm_shape, work");
+  if (!twin->slopes || !twin->voltage || !twin->dm_shape || !twin->work || twin->slopes == st->slopes ||
+      twin->voltage == st->voltage || twin->dm_shape == st->dm_shape || twin->work == st->work)
+    return fail("set_frame_pipeline: the twin needs slopes, voltage, dm_shape and work buffers of its own");
+  P.twin = *twin; P.have_twin = true; P.owner_screens = st->screens;
+  return 0;
+}
+
+int aomarl_frame_pipeline_state(aomarl_ctx *c, int *in_flight, int *consumed_in_twin, unsigned long long *steps,
+                                unsigned long long *overlapped) {
+  if (!c) return fail("frame_pipeline_state: null context");
+  if (in_flight) *in_flight = c->pipe.active ? 1 : 0;
+  if (consumed_in_twin) *consumed_in_twin = c->pipe.active ? (1 - c->pipe.par) : 0;
+  if (steps) *steps = c->pipe.steps;
+  if (overlapped) *overlapped = c->pipe.overlapped;
+  return 0;
+}
+
 
 
 // ---------------------------------------------------------------- aomarl_env_step as a HIP graph ("graph_step")
@@ -2174,6 +2453,11 @@ static bool step_plan_uniform(const aomarl_ctx *c, int n, const float *accumx, c
 int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
                     float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
   if (!c || !st || !g || !state_out) return fail("env_step: null argument");
+  if (pipe_eligible(c, st, g, accumx, accumy))
+    return env_step_pipelined(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
+  if (c->pipe.active && c->pipe.owner_screens == st->screens)
+    return fail("env_step: a pipelined frame is in flight but this call is not eligible for the frame pipeline "
+                "(options, glue or arguments changed within an episode): reset first");
   if (!c->graph_step || c->capturing) return env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
   const int n = st->nenv, nl = c->nlayers;
   // the steady state only: a prefetched move of exactly this batch is pending, the glue has been validated by a
@@ -2437,13 +2721,24 @@ int aomarl_frame_fused_available(aomarl_ctx *c) {
 
 // science-path PSF (pending, like aomarl_target_psf) + WFS image / slopes (like aomarl_comp_image
 // without the NO_ATMOS / NO_DMS / FROM_PHASE_BUFFER variants) from one pass over the phase
+// `slot` (frame pipeline): the launch goes to `stream` = the frame stream with parity slot's buffers in `st` (a
+// view), carries ev_done[slot] (or a timing event) and its PSF finish records ev_psf[slot]; the caller has ordered
+// `stream` behind the atmosphere and the previous users of that parity's buffers.
+static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream, int slot);
+
 int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream) {
+  return frame_fused_impl(c, st, b, n, flags, stream, -1);
+}
+
+static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream, int slot) {
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
-  rc = atmos_wait_pending(c, stream);
-  if (rc) return rc;
-  rc = psf_wait_pending(c, stream);
-  if (rc) return rc;
+  if (slot < 0) {
+    rc = atmos_wait_pending(c, stream);
+    if (rc) return rc;
+    rc = psf_wait_pending(c, stream);
+    if (rc) return rc;
+  }
   if (!c->sys.fused_ok) return fail("frame_fused: geometry not eligible (see aomarl_frame_fused_available)");
   if (flags & (AOMARL_IMG_FROM_PHASE_BUFFER | AOMARL_IMG_NO_ATMOS | AOMARL_IMG_NO_DMS))
     return fail("frame_fused: FROM_PHASE_BUFFER / NO_ATMOS / NO_DMS are not supported here");
@@ -2489,7 +2784,7 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
   if (c->prefetch_atmos) {
     rc = side_stream(c);
     if (rc) return rc;
-    ev_done = c->ev_frame;
+    ev_done = slot < 0 ? c->ev_frame : c->pipe.ev_done[slot];
   }
   if (timed) { ev_start = c->fw_ev[c->fw_ev_used]; ev_done = c->fw_ev[c->fw_ev_used + 1]; c->fw_ev_used += 2; }
   hipEvent_t ev_mark = nullptr;
@@ -2505,6 +2800,15 @@ int aomarl_frame_fused(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags,
 #undef FW_H
 #undef FW
   LAUNCHCHK();
+  if (slot >= 0) {
+    c->pipe.ev_done_cur[slot] = ev_done;
+    HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
+    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
+    LAUNCHCHK();
+    HIPCHK(hipEventRecord(c->pipe.ev_psf[slot], c->psf_stream));
+    c->pipe.psf_out[slot] = true;
+    return 0;
+  }
   if (c->prefetch_atmos) {
     // second axis of the PSF window: off the critical path (read by aomarl_comp_strehl at the end of
     // the step), so it goes to the side stream, in front of the next frame's extrusions

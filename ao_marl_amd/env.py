@@ -379,7 +379,7 @@ class VecAoEnv(object):
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
                  strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None,
-                 geo=False, prefetch_atmos=True):
+                 geo=False, prefetch_atmos=True, frame_pipeline=False):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -459,6 +459,10 @@ class VecAoEnv(object):
         # covers (see _native_step_ok); the same launches in the same order as the call-by-call path
         self.native_step = True
         self.fused_tail = True       # ... with the reductions folded into their consumers (see include/aomarl.h)
+        # frames one step ahead of the chains (aomarl_set_frame_pipeline; loop delay of one frame, noise-free
+        # sensor -- the library takes the plain order whenever a step is not eligible).  Opt-in: between two
+        # resets such an environment takes step() calls only (no call-by-call pieces, no linear_control steps).
+        self.frame_pipeline = bool(frame_pipeline)
         # Btt coordinates of the last number_of_previous_dm + 1 commands, newest in slot _ring_pos
         self._ring, self._ring_pos, self._ring_next_valid = None, 0, False
         self._res_modes, self._glue, self._glue_keep = None, None, None
@@ -667,6 +671,7 @@ class VecAoEnv(object):
 
     OUT_RING = 6        # a multiple of the command ring's period (number_of_previous_dm + 1 = 3)
     _out_ring, _out_pos = None, 0
+    _pipe_checked = False
 
     def _step_native(self, action):
         sup = self.supervisor
@@ -701,6 +706,11 @@ class VecAoEnv(object):
         ae = sup.autoencoder
         if ae is not None:
             ae._used_fp16 = ae._used_fp16 or not g.denoiser_f32
+        if self.frame_pipeline and not self._pipe_checked:
+            self._pipe_checked = True
+            if (hasattr(sup.sim, "enable_frame_pipeline") and ae is None and sup.s.delay == 1.0 and sup.s.noise < 0 and
+                    sup.prefetch_atmos and not getattr(sup.sim, "graph_step", False)):
+                sup.sim.enable_frame_pipeline()
         sup.sim.env_step(g, action, sup.gain, state, r)
         self._ring_pos = g.ring_pos
         self._last_res_modes = self._res_modes

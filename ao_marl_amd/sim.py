@@ -125,11 +125,50 @@ class HipSim(object):
 
     @property
     def voltage(self):
-        return self.t["voltage"][:, :self.s.nactu]
+        return self._frame_buf("voltage")[:, :self.s.nactu]
 
     @property
     def slopes(self):
-        return self.t["slopes"]
+        return self._frame_buf("slopes")
+
+    # ------------------------------------------------------------------ frame pipeline
+    def enable_frame_pipeline(self, on=True):
+        """aomarl_set_frame_pipeline: hand the library a twin of the state (own slopes / voltage / dm_shape /
+        work, everything else shared) so that aomarl_env_step keeps one frame in flight -- frame t+1 beside
+        the control / agent chain of frame t (loop delay of one frame only; the library takes the plain
+        path whenever a step is not eligible).  While a frame is in flight only env_step and reset are
+        accepted; `slopes` / `voltage` return the buffers of the last REDUCED frame."""
+        if not on:
+            la.check(self.lib.aomarl_set_frame_pipeline(self.ctx, C.byref(self.st), None))
+            self._twin, self._twin_st = None, None
+            return
+        if getattr(self, "_twin", None) is not None:
+            return
+        f32 = dict(dtype=torch.float32, device=self.device)
+        tw = {"voltage": torch.zeros(self.nenv, self.ld_actu, **f32),
+              "slopes": torch.zeros(self.nenv, self.s.nslope, **f32),
+              # only the tip-tilt slot of every environment is ever touched (stack-array DM from the voltages)
+              "dm_shape": torch.empty(self.nenv, self.shape_stride, **f32),
+              "work": torch.zeros(self.t["work"].numel(), **f32)}
+        st2 = la.State()
+        for name, _ in la.State._fields_:
+            setattr(st2, name, getattr(self.st, name))
+        for k, v in tw.items():
+            setattr(st2, k, v.data_ptr())
+        la.check(self.lib.aomarl_set_frame_pipeline(self.ctx, C.byref(self.st), C.byref(st2)))
+        self._twin, self._twin_st = tw, st2
+
+    def frame_pipeline_state(self):
+        """(frame in flight, last reduced frame lives in the twin, pipelined steps, moves that ran beside a frame)"""
+        a, b = C.c_int(0), C.c_int(0)
+        n, o = C.c_ulonglong(0), C.c_ulonglong(0)
+        la.check(self.lib.aomarl_frame_pipeline_state(self.ctx, C.byref(a), C.byref(b), C.byref(n), C.byref(o)))
+        return bool(a.value), bool(b.value), int(n.value), int(o.value)
+
+    def _frame_buf(self, name):
+        if getattr(self, "_twin", None) is not None and self.frame_pipeline_state()[1]:
+            return self._twin[name]
+        return self.t[name]
 
     @property
     def strehl(self):

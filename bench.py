@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--residual-shortcut", action="store_true",
                     help="residual modes from one product with v2m.cmat instead of do_control + "
                          "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
+    ap.add_argument("--no-frame-pipeline", action="store_true",
+                    help="plain call order: every frame behind the control / agent chain of the previous one")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="move the atmosphere in front of the image kernels (no side stream)")
     ap.add_argument("--no-defer", action="store_true",
@@ -266,7 +268,7 @@ def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
 class Workload(object):
     """A VecAoEnv + random-init batched SAC actors for one BASELINE configuration."""
 
-    def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True):
+    def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True, pipeline=True):
         import torch
         from ao_marl_amd.agents import BatchedGaussianPolicy
         from ao_marl_amd.env import VecAoEnv, load_norm
@@ -295,7 +297,7 @@ class Workload(object):
         self.first_seed = shard_seeds(1234, envs, rank, stride=16)
         self.env = VecAoEnv(config, envs, rl, initial_seed=self.first_seed, seed_stride=16,
                             n_agents_modal=n_modal, device=device, autoencoder=autoencoder,
-                            prefetch_atmos=prefetch, **norm_kw)
+                            prefetch_atmos=prefetch, frame_pipeline=pipeline and prefetch, **norm_kw)
         self.layout = self.env.layout
         # random-init actors (last layer NOT zeroed, so actions are non-trivial): the cost of a step
         # does not depend on the weights; the loop is not expected to converge (Strehl is reported
@@ -488,7 +490,7 @@ def main():
         denoiser = "shipped"
     libaomarl.set_precision(args.precision)
     w = Workload(args.config, args.envs, rank, world, device, denoiser=denoiser,
-                 prefetch=not args.no_prefetch)
+                 prefetch=not args.no_prefetch, pipeline=not args.no_frame_pipeline)
     env, sim, layout = w.env, w.sim, w.layout
     env.residual_shortcut = bool(args.residual_shortcut)
     if args.unfused:
@@ -517,7 +519,11 @@ def main():
         dist.all_gather_object(got, shards[0])
         shards = got
 
-    # diagnostic pass (outside `value`): every stage with its own event pair
+    pipe_state = sim.frame_pipeline_state()
+    # diagnostic pass (outside `value`): every stage with its own event pair (call by call: behind a reset
+    # when the timed steps left a pipelined frame in flight)
+    if pipe_state[0]:
+        w.reset()
     stage_diag = stage_split(w, min(20, args.steps))
 
     out = None
@@ -543,6 +549,10 @@ def main():
             "roofline": roofline_block(model, fk_ms, kernel_name, args.pmc, args.envs, args.config),
             "launched": {k: v for k, v in launched.items() if v},
             "stage_ms": stage_diag, "atmos_prefetch": bool(env.supervisor.prefetch_atmos),
+            "frame_pipeline": {"on": bool(pipe_state[0]), "pipelined_steps": pipe_state[2], "moves_beside_frame": pipe_state[3],
+                               "what": "frame t+1 launched before frame t is reduced (loop delay = 1 frame): same kernels, "
+                                       "same values, frame kernels back to back with the control / agent and extrusion "
+                                       "chains beside them (aomarl_set_frame_pipeline)"},
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "mean_strehl_le": sr,
             "gathered": {"n": int(ret_all.numel()), "mean_last_step_reward": float(ret_all.mean()),

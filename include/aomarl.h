@@ -474,6 +474,31 @@ int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, co
  * aomarl_graph_stats: graphs captured / replayed so far on this context. */
 int aomarl_graph_stats(aomarl_ctx *ctx, unsigned long long *captures, unsigned long long *replays);
 
+/* Frames one step ahead of the control chain ("frame pipeline").  With a loop delay of exactly one frame
+ * (p_controller.delay == 1, the production files) the voltages frame t+1 is formed with are the commands
+ * of step t (rlSupervisor.py next_part_two: the delay line of shesha's generic controller), known BEFORE
+ * frame t's slopes have been reduced: the frame kernel of step t+1 does not depend on the control / agent
+ * chain of step t.  aomarl_set_frame_pipeline hands the library a TWIN of `st` -- same aomarl_state, own
+ * slopes / voltage / dm_shape / work buffers, every other pointer equal to st's -- and aomarl_env_step then
+ * keeps one frame in flight: the call of step t launches frame t+1 on a stream of its own (even frames in
+ * st's buffers, odd ones in the twin's; ring origins from per-parity snapshots), moves the atmosphere for
+ * frame t+2 beside it when the lines that move rewrites lie outside the windows the frame kernel reads
+ * (checked per move; otherwise behind it), and only then reduces frame t's slopes.  Same kernels, same
+ * arguments, same values as the plain call order, bit for bit; the frame kernels run back to back with the
+ * two latency chains beside them instead of between them.
+ * Used only when the step is eligible (delay == 1, noise-free sensor, one-pass frame kernel with the DM
+ * evaluated from the voltages, prefetch_atmos on, no denoiser, no graph_step, the whole batch); otherwise
+ * aomarl_env_step takes the plain path.  While a frame is in flight the only calls accepted on this state
+ * are aomarl_env_step and a full-range aomarl_reset (which drops it: the episode is over) -- everything
+ * else fails loudly, because slopes / voltage of odd frames live in the twin and the screens are a frame
+ * ahead.  twin == NULL switches the pipeline off (refused while a frame is in flight).
+ * aomarl_frame_pipeline_state: in_flight = a frame is in flight; consumed_in_twin = the slopes / voltage of
+ * the LAST REDUCED frame are in the twin's buffers; steps = pipelined steps so far; overlapped = moves that
+ * ran beside the frame kernel. */
+int aomarl_set_frame_pipeline(aomarl_ctx *ctx, const aomarl_state *st, const aomarl_state *twin);
+int aomarl_frame_pipeline_state(aomarl_ctx *ctx, int *in_flight, int *consumed_in_twin,
+                                unsigned long long *steps, unsigned long long *overlapped);
+
 /* WFS-image denoiser in the loop (RlSupervisor.autoencoder_denoising, rlSupervisor.py:876-891;
  * DenoisingAutoencoderCNN2DSingleSubapeture.forward, src/autoencoder/autoencoder_models.py:130-197):
  * every 16 x 16 spot image of a bincube goes through the conv autoencoder, in place, in one fused

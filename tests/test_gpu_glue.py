@@ -557,3 +557,57 @@ def test_small_screen_move_in_one_launch_equals_the_generic_rounds(layers):
     # and through the step: frames formed from either atmosphere agree
     one.next_part_one(); gen.next_part_one()
     assert (one.slopes - gen.slopes).abs().max().item() < 1e-3 * gen.slopes.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,nenv,rl,n_modal", [
+    ("production_sh_10x10_2m", 8, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5), 1),
+    ("production_sh_40x40_8m_3layers", 4, dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5,
+                                               window_n_zernike=20, include_tip_tilt_windowed=True), 13)])
+def test_frame_pipeline_gives_the_plain_steps(config, nenv, rl, n_modal):
+    """aomarl_set_frame_pipeline (VecAoEnv.frame_pipeline, the default where the loop delay is one frame): frame
+    t+1 launched by the call of step t, before frame t is reduced, the atmosphere moved beside the frame in
+    flight -- bit for bit the plain call order's states, rewards, slopes, voltages, commands and Strehl over two
+    episodes; while a frame is in flight anything but env_step / reset is refused."""
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.libaomarl import AomarlError
+    rng = np.random.default_rng(5)
+    out, actions = {}, None
+    for mode in ("plain", "pipe"):
+        env = VecAoEnv(config, nenv, rl, initial_seed=31, seed_stride=16, n_agents_modal=n_modal)
+        env.frame_pipeline = mode == "pipe"
+        sim = env.supervisor.sim
+        if actions is None:
+            actions = torch.from_numpy(rng.uniform(-1, 1, size=(24, nenv, env.action_dim)).astype(np.float32)).cuda()
+        rec = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for ep in range(2):
+                s = env.reset()
+                rec.append(s.clone())
+                for t in range(24 if ep == 0 else 7):
+                    assert env._native_step_ok(False)
+                    s, r, _, _ = env.step(actions[t])
+                    rec += [s.clone(), r.clone()]
+                    if t in (0, 1, 2, 11, 23):
+                        rec += [env.supervisor.get_slopes().clone(), sim.voltage.clone(), env.supervisor.get_command().clone(),
+                                env.supervisor.get_strehl().clone()]
+                if mode == "pipe":
+                    flying, _, steps, beside = sim.frame_pipeline_state()
+                    assert flying and steps >= 6 and beside >= 6, (steps, beside)
+                    with pytest.raises(AomarlError):
+                        sim.move_atmos()                    # screens are a frame ahead: refused, loudly
+                    with pytest.raises(AomarlError):
+                        sim.comp_strehl()
+            torch.cuda.synchronize()
+        out[mode] = rec
+        if mode == "pipe":
+            env.reset()
+            assert not sim.frame_pipeline_state()[0]        # the reset dropped the frame in flight
+            sim.move_atmos()
+            torch.cuda.synchronize()
+        else:
+            assert sim.frame_pipeline_state() == (False, False, 0, 0)
+        del env
+    assert len(out["plain"]) == len(out["pipe"])
+    for k, (a, b) in enumerate(zip(out["plain"], out["pipe"])):
+        assert torch.equal(a, b), k
