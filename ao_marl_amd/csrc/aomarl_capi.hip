@@ -105,7 +105,7 @@ struct aomarl_ctx {
     aomarl_state twin;                             // odd frames: slopes / voltage / dm_shape / work
     int par = 0;                                   // parity (0: st's buffers, 1: the twin's) of the frame in flight
     hipStream_t fstream = nullptr;
-    hipEvent_t ev_cmd = nullptr, ev_done[2] = {nullptr, nullptr}, ev_psf[2] = {nullptr, nullptr};
+    hipEvent_t ev_cmd = nullptr, ev_commit = nullptr, ev_done[2] = {nullptr, nullptr}, ev_psf[2] = {nullptr, nullptr};
     hipEvent_t ev_done_cur[2] = {nullptr, nullptr};  // the event each parity's last frame launch carries (ev_done[], or a timing event)
     bool psf_out[2] = {false, false};              // a PSF finish of that parity may still run
     int32_t *snap[2] = {nullptr, nullptr};         // ring origins as of each parity's frame
@@ -596,6 +596,7 @@ int aomarl_destroy(aomarl_ctx *c) {
     if (c->pipe.ev_psf[k]) (void)hipEventDestroy(c->pipe.ev_psf[k]);
   }
   if (c->pipe.ev_cmd) (void)hipEventDestroy(c->pipe.ev_cmd);
+  if (c->pipe.ev_commit) (void)hipEventDestroy(c->pipe.ev_commit);
   if (c->pipe.fstream) { (void)hipStreamSynchronize(c->pipe.fstream); (void)hipStreamDestroy(c->pipe.fstream); }
   // the side streams belong to the process (side_stream): drained here, never destroyed
   if (c->atm_stream) (void)hipStreamSynchronize(c->atm_stream);
@@ -2131,18 +2132,27 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
   const float d = c->delay;
   float wa, wb, wc;
   if (d <= 1.f) { wa = 1.f - d; wb = d; wc = 0.f; } else { wa = 0.f; wb = 2.f - d; wc = d - 1.f; }
-  if (ahead) { wa = wb; wb = wc; wc = 0.f; }       // v(t+1) = wb c(t) + wc c(t-1): only with wa == 0 (delay >= 1)
-  if (nsp > 0)
-    hipLaunchKernelGGL(k_delay_sum, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1,
-                       st->work + w.GEMM, nsp, alpha, n);
-  else
-    hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1);
-  LAUNCHCHK();
+  if (ahead) {
+    // delay == 1 (the pipeline's condition): v(t+1) = c(t); the tip-tilt slot in the same launch, and the frame
+    // stream released right behind it -- the Strehl commit below is not on the frame kernel's path
+    hipLaunchKernelGGL(k_delay_ahead, dim3((na + 255) / 256, 2 * n), dim3(256), 0, s, c->sys, dsv, na, st->ld_actu, n,
+                       nsp > 0 ? st->work + w.GEMM : nullptr, nsp, alpha, ktt);
+    LAUNCHCHK();
+    HIPCHK(hipEventRecord(c->pipe.ev_cmd, s));
+  } else {
+    if (nsp > 0)
+      hipLaunchKernelGGL(k_delay_sum, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1,
+                         st->work + w.GEMM, nsp, alpha, n);
+    else
+      hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1);
+    LAUNCHCHK();
+  }
   if (psf_ev) HIPCHK(hipStreamWaitEvent(s, psf_ev, 0));
   else if (stv == st) { int rc = psf_wait_pending(c, stream); if (rc) return rc; }
-  hipLaunchKernelGGL(k_post_delay, dim3(2 * n), dim3(256), 0, s, c->sys, dsv, 0, n, stv->work + w.PEND, 1, ktt,
+  hipLaunchKernelGGL(k_post_delay, dim3(ahead ? n : 2 * n), dim3(256), 0, s, c->sys, dsv, 0, n, stv->work + w.PEND, 1, ktt,
                      stv->voltage, st->ld_actu);
   LAUNCHCHK();
+  if (ahead) HIPCHK(hipEventRecord(c->pipe.ev_commit, s));   // the PSF finish of the frame about to be launched overwrites that window
   return 0;
 }
 
@@ -2275,8 +2285,11 @@ static int pipe_init(aomarl_ctx *c, const aomarl_state *st) {
   int rc = side_stream(c);
   if (rc) return rc;
   if (!P.fstream) {
+    // normal priority, every CU: a low-priority frame stream (0.76 against 0.60 ms per step), CUs reserved for the
+    // chains through a CU mask (0.59 - 1.03) and high-priority chain streams (-1 %) were measured and dropped
     HIPCHK(hipStreamCreateWithFlags(&P.fstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&P.ev_cmd, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&P.ev_commit, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
       HIPCHK(hipEventCreateWithFlags(&P.ev_done[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&P.ev_psf[k], hipEventDisableTiming));
@@ -2298,8 +2311,8 @@ static int pipe_init(aomarl_ctx *c, const aomarl_state *st) {
 // tip-tilt shape and committed PSF window) and behind the prefetched move, whose origins are in snap[q]
 static int pipe_launch_frame(aomarl_ctx *c, aomarl_state *st, int q, void *stream) {
   auto &P = c->pipe;
-  HIPCHK(hipEventRecord(P.ev_cmd, (hipStream_t)stream));
-  HIPCHK(hipStreamWaitEvent(P.fstream, P.ev_cmd, 0));
+  (void)stream;
+  HIPCHK(hipStreamWaitEvent(P.fstream, P.ev_cmd, 0));       // recorded behind the kernel that wrote that parity's voltages / tip-tilt slot
   if (!c->premoved || c->pre_screens != st->screens || c->pre_b != 0 || c->pre_n != st->nenv)
     return fail("frame pipeline: no prefetched atmosphere frame of the whole batch is pending");
   HIPCHK(hipStreamWaitEvent(P.fstream, c->ev_moved, 0));
@@ -2356,6 +2369,8 @@ static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *
     hipLaunchKernelGGL(k_post_delay, dim3(2 * n), dim3(256), 0, s, c->sys, dev_state(&v1), 0, n, v1.work + w.PEND, 0, ktt,
                        v1.voltage, st->ld_actu);
     LAUNCHCHK();
+    HIPCHK(hipEventRecord(P.ev_cmd, s));
+    HIPCHK(hipEventRecord(P.ev_commit, s));
     // the origins of the move the plain step prefetched
     HIPCHK(hipMemcpyAsync(P.snap[1], st->origin, sizeof(int32_t) * (size_t)n * c->nlayers * 2, hipMemcpyDeviceToDevice,
                           c->atm_stream));
@@ -2803,6 +2818,7 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
   if (slot >= 0) {
     c->pipe.ev_done_cur[slot] = ev_done;
     HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
+    HIPCHK(hipStreamWaitEvent(c->psf_stream, c->pipe.ev_commit, 0));   // that parity's pending window has been committed
     hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
     LAUNCHCHK();
     HIPCHK(hipEventRecord(c->pipe.ev_psf[slot], c->psf_stream));

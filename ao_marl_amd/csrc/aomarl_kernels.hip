@@ -2817,6 +2817,50 @@ __global__ void k_delay_sum(DevState st, int nactu, int ld, float a, float b, fl
   }
 }
 
+// Frame pipeline, loop delay of exactly one frame: the voltages of the NEXT frame are the new commands
+// (k_delay's expression with weights (0, 1, 0), evaluated one shift earlier), the delay line shifts, and the
+// tip-tilt slot of that frame's dm_shape is filled by the same launch (rows >= n: dm_shape_tt_body with the
+// voltages it needs recomputed by the rows' own expression), so that the frame kernel waits for ONE kernel
+// behind the m2v product.  P: split-K partial tiles of that product (nsplit > 0) or null (st.com holds it).
+__global__ void k_delay_ahead(DevSys sys, DevState st, int nactu, int ld, int n, const float *__restrict__ P,
+                              int nsplit, float alpha, int ktt) {
+  auto newest = [&](int row, int a) -> float {
+    if (nsplit > 0) {
+      float s = 0.f;
+      for (int z = 0; z < nsplit; z++) s += P[((long long)z * n + row) * nactu + a];
+      return alpha * s;
+    }
+    return st.com[(long long)row * ld + a];
+  };
+  if ((int)blockIdx.y < n) {
+    const int e = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nactu) return;
+    const long long o = (long long)e * ld + i;
+    const float c0 = newest(e, i);
+    if (nsplit > 0) st.com[o] = c0;
+    const float c1 = st.com1[o];
+    st.voltage[o] = c0;
+    st.com2[o] = c1;
+    st.com1[o] = c0;
+  } else if (blockIdx.x == 0 && ktt >= 0) {
+    const int row = blockIdx.y - n, p = threadIdx.x;
+    const DevDm &D = sys.dms[ktt];
+    float *shape = st.dm_shape + (long long)row * sys.shape_stride + D.shape_off;
+    if (p < 2) shape[p] = newest(row, D.com_off + p);
+    if (p == 2 && sys.fused_ok) {
+      const DevDm &Z = sys.dms[0];
+      const int half = sys.pupdiam / 2, zp = (half + Z.toy) * Z.dim + half + Z.tox;
+      const int ss2 = Z.ss * Z.ss, s0 = Z.influstart[zp], cn = Z.ninflu[zp];
+      float acc = 0.f;
+      for (int t = 0; t < cn; t++) {
+        const int pos = Z.influpos[s0 + t];
+        acc += Z.influ[pos] * newest(row, Z.com_off + pos / ss2);
+      }
+      shape[2] = acc;
+    }
+  }
+}
+
 __global__ void k_copy_rows(float *__restrict__ dst, int ldd, const float *__restrict__ src,
                             int lds, int ncols) {
   const int r = blockIdx.y;

@@ -50,24 +50,25 @@ class SnapOracleVecSim(OracleVecSim):
         self.snap = [([scr.copy() for scr in o.screens], list(o.ext_count)) for o in self.sims]
 
 
-@pytest.mark.parametrize("precision", ["f32", "split_f16"])
-def test_env_step_40x40_windowed_agents_match_the_oracle_env(monkeypatch, precision):
+@pytest.mark.parametrize("precision,pipeline", [("f32", False), ("f32", True), ("split_f16", True)])
+def test_env_step_40x40_windowed_agents_match_the_oracle_env(monkeypatch, precision, pipeline):
+    """pipeline: the frame pipeline bench.py runs with (frame t+1 in flight while frame t is reduced)."""
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     keep = la.get_precision()
     la.set_precision(precision)
     try:
-        _run(monkeypatch, precision)
+        _run(monkeypatch, precision, pipeline)
     finally:
         la.set_precision(keep)
 
 
-def _run(monkeypatch, precision):
+def _run(monkeypatch, precision, pipeline):
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     PushedSim = _pushed_sim_class()
     env = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cuda:0",
-                   sim_factory=PushedSim)
+                   sim_factory=PushedSim, frame_pipeline=pipeline)
     lay = env.layout
     assert lay.n_agents == 14 and lay.state_shapes()[0] == 552 and lay.state_shapes()[-1] == 168
     assert env._native_glue and env._default_state_layout
@@ -133,6 +134,8 @@ def _run(monkeypatch, precision):
         worst["com"] = max(worst["com"], dc)
         assert dc < 5e-4, ("com", it, dc)
     assert used_native == NSTEP                      # every step went through aomarl_env_step
+    flying, _, piped, beside = env.supervisor.sim.frame_pipeline_state()
+    assert (flying, piped, beside) == ((True, NSTEP - 1, NSTEP) if pipeline else (False, 0, 0))
     launched = {k: v for k, v in la.arith_launches().items() if v}
     if precision == "f32":
         assert not any("split" in k for k in launched), launched
