@@ -112,6 +112,7 @@ struct aomarl_ctx {
     size_t snap_ints = 0;
     unsigned long long steps = 0, overlapped = 0, behind = 0;
   } pipe;
+  bool pipe_enabled = true;              // "frame_pipeline": 0 = plain call order although a twin is set
   bool pipe_internal = false;            // check_range: the pipelined step itself is calling
   // first write of a prefetched move: behind the OLDER frame in flight (ev_frame_prev) when the lines the move
   // rewrites are outside the frame kernel's windows (group_overlap, decided per plan), else behind the newest
@@ -1264,6 +1265,10 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "force_generic_dm")) { c->force_generic_dm = value != 0; return 0; }
   if (!strcmp(name, "force_valu_target")) { c->force_valu_target = value != 0; return 0; }
   if (!strcmp(name, "defer_dm_shape")) { c->defer_dm_shape = value != 0; return 0; }
+  if (!strcmp(name, "frame_pipeline")) {
+    if (c->pipe.active) return fail("frame_pipeline: a frame is in flight (reset first)");
+    c->pipe_enabled = value != 0; return 0;
+  }
   if (!strcmp(name, "small_move")) { c->small_move = value != 0; return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
@@ -2274,7 +2279,7 @@ static aomarl_state pipe_view(aomarl_ctx *c, const aomarl_state *st, int par) {
 static bool pipe_eligible(aomarl_ctx *c, const aomarl_state *st, const aomarl_env_glue *g, const float *accumx,
                           const float *accumy) {
   const auto &P = c->pipe;
-  return P.have_twin && P.owner_screens == st->screens && !c->graph_step && !c->capturing && c->prefetch_atmos &&
+  return P.have_twin && c->pipe_enabled && P.owner_screens == st->screens && !c->graph_step && !c->capturing && c->prefetch_atmos &&
          c->delay == 1.f && c->sys.noise < 0.f && !g->denoiser && accumx && accumy && !c->subpixel_flow &&
          aomarl_frame_fused_available(c) && c->defer_dm_shape && aomarl_dm_from_voltage_available(c) &&
          env_step_fusable(c, g, nullptr);

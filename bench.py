@@ -53,6 +53,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime initialises: see ao_marl_amd/__init__.py
+
 WORKLOAD = "production_sh_40x40_8m_3layers"
 SMALL = "production_sh_10x10_2m"
 NOISY = "production_sh_40x40_8m_3layers_d0_noise"
@@ -520,16 +522,32 @@ def main():
         shards = got
 
     pipe_state = sim.frame_pipeline_state()
-    # diagnostic pass (outside `value`): every stage with its own event pair (call by call: behind a reset
-    # when the timed steps left a pipelined frame in flight)
+    # the same steps in the plain call order (frame kernel alone on the GPU, the chains behind it): what the
+    # pipeline buys, and the frame kernel's duration without the chains' kernels beside it
+    plain = None
     if pipe_state[0]:
         w.reset()
+        sim.set_option("frame_pipeline", 0)
+        e_p, _, fk_p = w.timed(min(args.steps, 40), min(args.warmup, 5), dist, backend)
+        plain = {"ms_per_step_no_reset": e_p / min(args.steps, 40) * 1e3, "frame_kernel_ms": fk_p}
+        w.reset()
+        sim.set_option("frame_pipeline", 1)
+    # diagnostic pass (outside `value`): every stage with its own event pair (call by call: behind a reset
+    # when the timed steps left a pipelined frame in flight)
     stage_diag = stage_split(w, min(20, args.steps))
 
     out = None
     if rank == 0:
         s = env.supervisor.s
         model = frame_kernel_model(s, args.envs)
+        roof = roofline_block(model, fk_ms, kernel_name, args.pmc, args.envs, args.config)
+        if plain is not None and plain["frame_kernel_ms"]:
+            # `achieved` / `frac` above: the launches of the timed region, which share the GPU with the kernels of
+            # the control / agent and extrusion chains (the frame pipeline).  The kernel by itself:
+            alone = roofline_block(model, plain["frame_kernel_ms"], kernel_name, args.pmc, args.envs, args.config)
+            roof["alone"] = {"avg_launch_ms": alone["avg_launch_ms"], "achieved": alone["achieved"], "frac": alone["frac"],
+                             "how": "the same launches in the plain call order (no other kernel beside the frame kernel), "
+                                    "%d steps behind the timed region" % min(args.steps, 40)}
         out = {
             "metric": "env steps/sec (AO frames/sec)", "value": value, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -546,10 +564,11 @@ def main():
             "value_no_reset": envs_total * args.steps / elapsed,
             "ms_per_step_no_reset": elapsed / args.steps * 1e3,
             "reset_ms": reset_s * 1e3,
-            "roofline": roofline_block(model, fk_ms, kernel_name, args.pmc, args.envs, args.config),
+            "roofline": roof,
             "launched": {k: v for k, v in launched.items() if v},
             "stage_ms": stage_diag, "atmos_prefetch": bool(env.supervisor.prefetch_atmos),
             "frame_pipeline": {"on": bool(pipe_state[0]), "pipelined_steps": pipe_state[2], "moves_beside_frame": pipe_state[3],
+                               "plain_order_ms_per_step_no_reset": plain["ms_per_step_no_reset"] if plain else None,
                                "what": "frame t+1 launched before frame t is reduced (loop delay = 1 frame): same kernels, "
                                        "same values, frame kernels back to back with the control / agent and extrusion "
                                        "chains beside them (aomarl_set_frame_pipeline)"},
