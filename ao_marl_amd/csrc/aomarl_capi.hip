@@ -2393,7 +2393,11 @@ static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *
   c->pipe_internal = true;
   int rc = env_step_validate(c, st, g, action, state_out, reward_out);
   aomarl_state vq = pipe_view(c, st, q), vp = pipe_view(c, st, p);
-  if (!rc) rc = env_step_head_fused(c, st, &vq, g, action, gain, reward_out, ktt, true, P.psf_out[q] ? P.ev_psf[q] : nullptr, stream);
+  hipEvent_t pe = P.psf_out[q] ? P.ev_psf[q] : nullptr;     // the PSF finish of the last frame of parity q
+  if (!rc) rc = env_step_head_fused(c, st, &vq, g, action, gain, reward_out, ktt, true, pe, stream);
+  // the frame stream is released behind k_delay_ahead, in front of the Strehl commit that waits for that finish:
+  // the frame kernel overwrites the PSF rows it reads, so the frame stream waits for it itself
+  if (!rc && pe && hipStreamWaitEvent(P.fstream, pe, 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
   if (!rc) { P.psf_out[q] = false; rc = pipe_launch_frame(c, st, q, stream); }
   if (!rc) rc = pipe_prefetch(c, st, accumx, accumy, p, q);
   // ---- reduce frame p
