@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--residual-shortcut", action="store_true",
                     help="residual modes from one product with v2m.cmat instead of do_control + "
                          "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="nothing but warm-up + the timed region on the GPU (profiling): no plain-order pass, no stage split")
     ap.add_argument("--no-frame-pipeline", action="store_true",
                     help="plain call order: every frame behind the control / agent chain of the previous one")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -525,7 +527,7 @@ def main():
     # the same steps in the plain call order (frame kernel alone on the GPU, the chains behind it): what the
     # pipeline buys, and the frame kernel's duration without the chains' kernels beside it
     plain = None
-    if pipe_state[0]:
+    if pipe_state[0] and not args.timed_only:
         w.reset()
         sim.set_option("frame_pipeline", 0)
         e_p, _, fk_p = w.timed(min(args.steps, 40), min(args.warmup, 5), dist, backend)
@@ -534,7 +536,9 @@ def main():
         sim.set_option("frame_pipeline", 1)
     # diagnostic pass (outside `value`): every stage with its own event pair (call by call: behind a reset
     # when the timed steps left a pipelined frame in flight)
-    stage_diag = stage_split(w, min(20, args.steps))
+    if pipe_state[0] and args.timed_only:
+        w.reset()
+    stage_diag = None if args.timed_only else stage_split(w, min(20, args.steps))
 
     out = None
     if rank == 0:
