@@ -365,6 +365,31 @@ class Workload(object):
             elapsed = float(t.item())
         return elapsed, t_enq, fk_ms
 
+    def pick_order(self, steps=16):
+        """Untimed probe BEFORE the timed region: the pipelined against the plain call order on this process's
+        streams.  The HIP runtime multiplexes streams onto hardware queues (ao_marl_amd/__init__.py); if the
+        caller's stream happens to share one with the library's frame stream the pipelined order serialises and
+        is the SLOWER one (1.0 against 0.65 ms per step, seen with a second caller stream) -- then the timed
+        region runs in the plain order.  Returns {order: ms per step} or None when the pipeline is off."""
+        if not self.env.frame_pipeline:
+            return None
+        torch, res = self.torch, {}
+        for name, on in (("pipelined", 1), ("plain", 0)):
+            self.reset()
+            self.sim.set_option("frame_pipeline", on)
+            for _ in range(4):
+                self.one_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.one_step()
+            torch.cuda.synchronize()
+            res[name] = (time.perf_counter() - t0) / steps * 1e3
+        self.reset()
+        self.sim.set_option("frame_pipeline", 1 if res["pipelined"] <= res["plain"] else 0)
+        res["chosen"] = "pipelined" if res["pipelined"] <= res["plain"] else "plain"
+        return res
+
     def time_reset(self, dist=None, backend="nccl"):
         """One env.reset() (RlSupervisor.reset: 2n extrusions per layer + the first frame), MAX over ranks."""
         torch = self.torch
@@ -423,6 +448,7 @@ def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None)
         try:
             w.reset()
             reset_s = w.time_reset()
+            w.pick_order()
             elapsed, _, fk = w.timed(steps, warmup, time_frame=True)
             rec = {"dtype": libaomarl.dtype_string(w.launched),
                    "value": amortised(envs, steps, elapsed, reset_s, episode_len),
@@ -504,6 +530,7 @@ def main():
 
     w.reset()
     reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
+    order_probe = w.pick_order()                    # untimed: which call order this process's streams favour
     elapsed, t_enq, fk_ms = w.timed(args.steps, args.warmup, dist, backend)
     envs_total = args.envs * world
     value = amortised(envs_total, args.steps, elapsed, reset_s, args.episode_len)
@@ -573,6 +600,7 @@ def main():
             "stage_ms": stage_diag, "atmos_prefetch": bool(env.supervisor.prefetch_atmos),
             "frame_pipeline": {"on": bool(pipe_state[0]), "pipelined_steps": pipe_state[2], "moves_beside_frame": pipe_state[3],
                                "plain_order_ms_per_step_no_reset": plain["ms_per_step_no_reset"] if plain else None,
+                               "order_probe_ms_per_step": order_probe,
                                "what": "frame t+1 launched before frame t is reduced (loop delay = 1 frame): same kernels, "
                                        "same values, frame kernels back to back with the control / agent and extrusion "
                                        "chains beside them (aomarl_set_frame_pipeline)"},
