@@ -611,3 +611,39 @@ def test_frame_pipeline_gives_the_plain_steps(config, nenv, rl, n_modal):
     assert len(out["plain"]) == len(out["pipe"])
     for k, (a, b) in enumerate(zip(out["plain"], out["pipe"])):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_frame_pipeline_is_not_used_where_the_voltages_depend_on_the_new_command():
+    """Loop delay below one frame: the voltages of a frame contain the command computed from the previous frame's
+    slopes, nothing can run ahead -- an environment that asks for the pipeline steps in the plain order (same
+    values as one that does not ask), and a partial reset while a frame IS in flight is refused."""
+    from ao_marl_amd import params
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.libaomarl import AomarlError
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    outs = []
+    for pipe in (True, False):
+        ps = params.builtin("production_sh_10x10_2m")
+        for c in ps.p_controllers:
+            c.delay = 0.5
+        env = VecAoEnv(ps.validate(), 4, rl, initial_seed=9, n_agents_modal=1, frame_pipeline=pipe)
+        s = env.reset()
+        g = torch.Generator(device="cuda:0").manual_seed(3)
+        for it in range(6):
+            assert env._native_step_ok(False)
+            s, r, _, _ = env.step(torch.rand(4, env.action_dim, device="cuda:0", generator=g) * 2 - 1)
+        assert env.supervisor.sim.frame_pipeline_state()[:3] == (False, False, 0)
+        outs.append((s.clone(), r.clone(), env.supervisor.get_slopes().clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    env = VecAoEnv("production_sh_10x10_2m", 4, rl, initial_seed=9, n_agents_modal=1, frame_pipeline=True)
+    env.reset()
+    for it in range(3):
+        env.step(torch.zeros(4, env.action_dim, device="cuda:0"))
+    sim = env.supervisor.sim
+    assert sim.frame_pipeline_state()[0]
+    with pytest.raises(AomarlError):
+        sim.reset([1, 2], env_begin=0, env_count=2)
+    env.reset()
+    assert not sim.frame_pipeline_state()[0]
