@@ -54,6 +54,8 @@ struct aomarl_ctx {
   bool reset_untransposed = false;     // "reset_untransposed": the reset's x extrusions on the row-major screen itself
   int small_move = 1;                  // "small_move": 1 = one k_move_small launch per frame's move where the screens allow it
   bool small_ok = false;               // every layer has dim <= MOVE_SMALL_DIM, ns + dim <= MOVE_SMALL_K (transposed [A|B] uploaded)
+  int reset_streams = 2;               // "reset_streams": a batch reset in that many parts side by side, one stream each (1..4)
+  hipEvent_t ev_reset = nullptr, ev_reset2[3] = {nullptr, nullptr, nullptr};
   bool no_extrude_sg = false;          // "extrude_unfused": scatter and gather of consecutive rounds as separate launches
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
   int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
@@ -596,6 +598,8 @@ int aomarl_destroy(aomarl_ctx *c) {
     if (c->pipe.ev_done[k]) (void)hipEventDestroy(c->pipe.ev_done[k]);
     if (c->pipe.ev_psf[k]) (void)hipEventDestroy(c->pipe.ev_psf[k]);
   }
+  if (c->ev_reset) (void)hipEventDestroy(c->ev_reset);
+  for (int k = 0; k < 3; k++) if (c->ev_reset2[k]) (void)hipEventDestroy(c->ev_reset2[k]);
   if (c->pipe.ev_cmd) (void)hipEventDestroy(c->pipe.ev_cmd);
   if (c->pipe.ev_commit) (void)hipEventDestroy(c->pipe.ev_commit);
   if (c->pipe.fstream) { (void)hipStreamSynchronize(c->pipe.fstream); (void)hipStreamDestroy(c->pipe.fstream); }
@@ -861,17 +865,22 @@ static bool same_round(const RoundOps &a, const RoundOps &b) {
 // normals -> Z, Z . [A|B]^T (split-K tiles), new line -> ring.  Two consecutive rounds with the same
 // operations share a launch for the scatter of the first and the gather of the second (k_extrude_sg):
 // 2 launches per round instead of 3 -- every round of a reset (1296 of them), most rounds of a frame.
-static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const RoundOps *rounds, int nrounds,
-                          void *stream) {
-  if (n == 0 || nrounds == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  DevState ds = dev_state(st);
-  Work w = work_layout(c, st->nenv);
-  float *Z = st->work + w.Z, *NEWL = st->work + w.NEWL, *ZREF = st->work + w.ZREF;
-  bool gathered = false;                        // Z / ZREF of the coming round are already in place
-  for (int r = 0; r < nrounds; r++) {
+struct ExtrudeRun {          // one range of environments walking through a sequence of rounds on one stream
+  aomarl_ctx *c; aomarl_state *st; int b, n; hipStream_t s; bool ordered;
+  Work w; DevState ds; float *Z, *NEWL, *ZREF, *WS; size_t ws_floats; bool gathered;
+  // ordered = false: the caller has ordered the stream behind every reader of the screens (reset)
+  ExtrudeRun(aomarl_ctx *c_, aomarl_state *st_, int b_, int n_, void *stream, bool ordered_ = true)
+      : c(c_), st(st_), b(b_), n(n_), s((hipStream_t)stream), ordered(ordered_), gathered(false) {
+    w = work_layout(c, st->nenv);
+    ds = dev_state(st);
+    // the range's own part of every work area (columns are numbered from the range's first environment):
+    // two ranges may run side by side on two streams
+    const size_t col0 = (size_t)b * (c->nlayers > 0 ? c->nlayers : 1), ncols = (size_t)n * (c->nlayers > 0 ? c->nlayers : 1);
+    Z = st->work + w.Z + col0 * w.ldz; NEWL = st->work + w.NEWL + col0 * w.ldn; ZREF = st->work + w.ZREF + col0;
+    WS = st->work + w.GEMM_ATM + 8 * col0 * w.ldn; ws_floats = 8 * ncols * w.ldn;
+  }
+  int step(const RoundOps *rounds, int r, int nrounds) {
     // one sub-round per [A|B] class
-    int nsub = 0;
     for (int cls = 0; cls < c->nclass; cls++) {
       RoundOps ops;
       ops.nops = 0;
@@ -882,7 +891,6 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
           ops.tflag[ops.nops] = rounds[r].tflag[i]; ops.nops++; ref = rounds[r].layer[i];
         }
       if (ops.nops == 0) continue;
-      nsub++;
       const int dimc = c->dim[ref], nsc = c->ns[ref], K = dimc + nsc;
       const int ncol = n * ops.nops;
       // fusing across rounds only when the round is ONE sub-round (one class) and the next round repeats it
@@ -896,23 +904,36 @@ static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const R
       int nsp = 0;
       float pscale = 1.f;
       launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
-                     0.0f, NEWL, w.ldn, s, st->work + w.GEMM_ATM, w.gemm_floats, nullptr, &nsp,
+                     0.0f, NEWL, w.ldn, s, WS, ws_floats, nullptr, &nsp,
                      /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
       LAUNCHCHK();
-      { int wrc = first_write_wait(c, s); if (wrc) return wrc; }
-      if (s != c->atm_stream) c->screens_dirty_main = true;
+      if (ordered) {
+        int wrc = first_write_wait(c, s);
+        if (wrc) return wrc;
+        if (s != c->atm_stream) c->screens_dirty_main = true;
+      }
       if (fuse_next) {
         hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(512), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
-                           st->work + w.GEMM_ATM, nsp, ncol, dimc, pscale, Z, w.ldz);
+                           WS, nsp, ncol, dimc, pscale, Z, w.ldz);
         gathered = true;
       } else {
         hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
-                           ZREF, st->work + w.GEMM_ATM, nsp, ncol, dimc, pscale);
+                           ZREF, WS, nsp, ncol, dimc, pscale);
         gathered = false;
       }
       LAUNCHCHK();
     }
-    (void)nsub;
+    return 0;
+  }
+};
+
+static int extrude_rounds(aomarl_ctx *c, aomarl_state *st, int b, int n, const RoundOps *rounds, int nrounds,
+                          void *stream) {
+  if (n == 0 || nrounds == 0) return 0;
+  ExtrudeRun run(c, st, b, n, stream);
+  for (int r = 0; r < nrounds; r++) {
+    int rc = run.step(rounds, r, nrounds);
+    if (rc) return rc;
   }
   return 0;
 }
@@ -1162,8 +1183,47 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
         o.layer[o.nops] = l; o.dir[o.nops] = tr ? 2 * dx : dx; o.tflag[o.nops] = tr ? 1 : 0; o.nops++;
       }
   }
-  rc = extrude_rounds(c, st, b, n, rounds.data(), maxr, stream);
-  if (rc) return rc;
+  if (c->reset_streams > 1 && c->prefetch_atmos && n >= 16 * c->reset_streams && !c->capturing && side_stream(c) == 0) {
+    // The batch in parts side by side, one stream each (the caller's, the extrusion stream, two more of the
+    // process): a round is gather | GEMM | scatter + gather, 45 us of which 15 are latency (launch, first operand
+    // lines, the dependent loads of the stencil gather) that one part's kernels hide for the others' -- 1296
+    // dependent rounds.  Same kernels on the same columns; the split-K rule sees a part's columns per product.
+    static hipStream_t g_rst[64][2] = {{nullptr}};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const int parts = c->reset_streams > 4 ? 4 : c->reset_streams;
+    hipStream_t str[4] = {s, c->atm_stream, nullptr, nullptr};
+    for (int k = 2; k < parts; k++) {
+      if (dev < 0 || dev >= 64) return fail("reset: device ordinal %d", dev);
+      if (!g_rst[dev][k - 2]) HIPCHK(hipStreamCreateWithFlags(&g_rst[dev][k - 2], hipStreamNonBlocking));
+      str[k] = g_rst[dev][k - 2];
+    }
+    if (!c->ev_reset) {
+      HIPCHK(hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming));
+      for (int k = 0; k < 3; k++) HIPCHK(hipEventCreateWithFlags(&c->ev_reset2[k], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(c->ev_reset, s));
+    std::vector<ExtrudeRun> runs;
+    int e0 = b;
+    for (int k = 0; k < parts; k++) {
+      const int nk = (b + n - e0) / (parts - k);
+      if (k) HIPCHK(hipStreamWaitEvent(str[k], c->ev_reset, 0));
+      runs.emplace_back(c, st, e0, nk, (void *)str[k], false);
+      e0 += nk;
+    }
+    for (int r = 0; r < maxr; r++)
+      for (auto &run : runs) {
+        rc = run.step(rounds.data(), r, maxr);
+        if (rc) return rc;
+      }
+    for (int k = 1; k < parts; k++) {
+      HIPCHK(hipEventRecord(c->ev_reset2[k - 1], str[k]));
+      HIPCHK(hipStreamWaitEvent(s, c->ev_reset2[k - 1], 0));
+    }
+  } else {
+    rc = extrude_rounds(c, st, b, n, rounds.data(), maxr, stream);
+    if (rc) return rc;
+  }
   if (!c->reset_untransposed) {
     for (int l = 0; l < c->nlayers; l++) {
       const int T = (c->dim[l] + 31) / 32;
@@ -1270,6 +1330,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
     c->pipe_enabled = value != 0; return 0;
   }
   if (!strcmp(name, "small_move")) { c->small_move = value != 0; return 0; }
+  if (!strcmp(name, "reset_streams")) { c->reset_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
   if (!strcmp(name, "time_frame_kernel")) {
