@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--residual-shortcut", action="store_true",
                     help="residual modes from one product with v2m.cmat instead of do_control + "
                          "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
+    ap.add_argument("--frame-pipeline-always", action="store_true",
+                    help="no probe of the call order in front of the timed region: pipelined whenever eligible")
     ap.add_argument("--timed-only", action="store_true",
                     help="nothing but warm-up + the timed region on the GPU (profiling): no plain-order pass, no stage split")
     ap.add_argument("--no-frame-pipeline", action="store_true",
@@ -365,29 +367,33 @@ class Workload(object):
             elapsed = float(t.item())
         return elapsed, t_enq, fk_ms
 
-    def pick_order(self, steps=16):
+    def pick_order(self, steps=40, margin=1.05):
         """Untimed probe BEFORE the timed region: the pipelined against the plain call order on this process's
         streams.  The HIP runtime multiplexes streams onto hardware queues (ao_marl_amd/__init__.py); if the
         caller's stream happens to share one with the library's frame stream the pipelined order serialises and
         is the SLOWER one (1.0 against 0.65 ms per step, seen with a second caller stream) -- then the timed
-        region runs in the plain order.  Returns {order: ms per step} or None when the pipeline is off."""
+        region runs in the plain order.  Period = time between the states of step 8 and step `steps` becoming
+        ready on the caller's stream (device events: the frame the pipelined order keeps in flight beyond the last
+        step is not charged to it); the plain order is chosen only when the pipelined one is more than `margin`
+        times slower.  Returns {order: ms per step} or None when the pipeline is off."""
         if not self.env.frame_pipeline:
             return None
         torch, res = self.torch, {}
         for name, on in (("pipelined", 1), ("plain", 0)):
             self.reset()
             self.sim.set_option("frame_pipeline", on)
-            for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for k in range(steps):
                 self.one_step()
+                if k == 7:
+                    e0.record()
+            e1.record()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                self.one_step()
-            torch.cuda.synchronize()
-            res[name] = (time.perf_counter() - t0) / steps * 1e3
+            res[name] = e0.elapsed_time(e1) / (steps - 8)
         self.reset()
-        self.sim.set_option("frame_pipeline", 1 if res["pipelined"] <= res["plain"] else 0)
-        res["chosen"] = "pipelined" if res["pipelined"] <= res["plain"] else "plain"
+        plain = res["pipelined"] > margin * res["plain"]
+        self.sim.set_option("frame_pipeline", 0 if plain else 1)
+        res["chosen"] = "plain" if plain else "pipelined"
         return res
 
     def time_reset(self, dist=None, backend="nccl"):
@@ -530,7 +536,8 @@ def main():
 
     w.reset()
     reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
-    order_probe = w.pick_order()                    # untimed: which call order this process's streams favour
+    # untimed: which call order this process's streams favour (skipped with --frame-pipeline-always)
+    order_probe = None if args.frame_pipeline_always else w.pick_order()
     elapsed, t_enq, fk_ms = w.timed(args.steps, args.warmup, dist, backend)
     envs_total = args.envs * world
     value = amortised(envs_total, args.steps, elapsed, reset_s, args.episode_len)

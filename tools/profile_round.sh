@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for MODE in f32 split_f16 f32_plain_order; do
   D=$R/gpurun_out/prof_${TAG}_$MODE
   rm -rf $D
-  EXTRA=""; PREC=$MODE
+  EXTRA="--frame-pipeline-always"; PREC=$MODE
   if [ $MODE = f32_plain_order ]; then EXTRA="--no-frame-pipeline"; PREC=f32; fi
   timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $D -o t --output-format csv -- python3 $R/bench.py --steps 60 --warmup 10 --no-side-configs --no-cpu-baseline --timed-only $EXTRA --precision $PREC > $R/gpurun_out/${TAG}_bench_line_under_rocprofv3_$MODE.json 2> $R/gpurun_out/${TAG}_prof_$MODE.err
   T=$(find $D -name '*kernel_trace.csv' | head -1)
