@@ -67,7 +67,8 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=40,
+                    help="untimed steps in front of the timed region (the first ~40 steps behind a reset run 5-10 % slower)")
     ap.add_argument("--envs", type=int, default=256, help="environments per GPU")
     ap.add_argument("--config", default=WORKLOAD)
     ap.add_argument("--episode-len", type=int, default=1000,
