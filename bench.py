@@ -655,7 +655,7 @@ def main():
             for key, cfg, ne, dn, st in (("configs[1]", SMALL, 64, None, 200),
                                          ("configs[4]", NOISY, args.envs, "shipped", 30)):
                 try:
-                    out["configs"][key] = side_config(cfg, ne, device, st, 5, args.episode_len, dn)
+                    out["configs"][key] = side_config(cfg, ne, device, st, 40 if cfg == SMALL else 5, args.episode_len, dn)
                 except Exception as e:
                     out["configs"][key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
