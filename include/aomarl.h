@@ -288,6 +288,15 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * one in-place transposition: same screens, bit for bit, 46 instead of 60 ms per 256 environments),
  * "extrude_unfused" (1: scatter and gather of two consecutive extrusion rounds with the same operations
  * as separate launches; default 0: one launch, k_extrude_sg -- same values),
+ * "reset_streams" (default 2: a reset of >= 32 environments runs its 1296 dependent extrusion rounds in two
+ * halves of the batch side by side, the second on the library's extrusion stream, each half's kernels filling the
+ * other's latency -- 59 -> 51 ms per 256 environments; 1: one chain on the caller's stream; same kernels on the same
+ * columns, the split-K rule of a product sees its half's columns; only with "prefetch_atmos" on),
+ * "small_move" (default 1: screens of <= 256 pixels with stencil + dim <= 4096 -- the 10x10 files -- move in ONE
+ * launch per frame, k_move_small, instead of gather / GEMM / scatter rounds; fp32 vector FMAs in both precision
+ * modes; 0: the rounds),
+ * "frame_pipeline" (default 1; 0 = plain call order although aomarl_set_frame_pipeline gave a twin; refused while
+ * a frame is in flight),
  * "defer_dm_shape" (the composites
  * aomarl_next_part_two / aomarl_next_part_one use AOMARL_APPLY_DEFER_STACK_SHAPE /
  * AOMARL_IMG_DM_FROM_VOLTAGE when available: st->voltage is the DM state and the stack-array
