@@ -647,3 +647,40 @@ def test_frame_pipeline_is_not_used_where_the_voltages_depend_on_the_new_command
         sim.reset([1, 2], env_begin=0, env_count=2)
     env.reset()
     assert not sim.frame_pipeline_state()[0]
+
+
+@pytest.mark.gpu
+def test_frame_pipeline_over_a_long_episode_with_ring_wraps():
+    """700 pipelined steps of the production system (every ring wraps at least once, the fastest layer three
+    times; every extrusion plan of the file occurs) against the plain order: states and rewards of every 50th
+    step, slopes, voltages, commands and Strehl at the end, bit for bit; every move of the pipelined run went beside
+    the frame in flight."""
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5, window_n_zernike=20,
+              include_tip_tilt_windowed=True)
+    nenv, nstep = 4, 700
+    rec = {}
+    for mode in ("plain", "pipe"):
+        env = VecAoEnv("production_sh_40x40_8m_3layers", nenv, rl, initial_seed=5, seed_stride=16, n_agents_modal=13,
+                       frame_pipeline=mode == "pipe")
+        sim = env.supervisor.sim
+        g = torch.Generator(device="cuda:0").manual_seed(17)
+        out = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            s = env.reset()
+            for t in range(nstep):
+                a = (torch.rand(nenv, env.action_dim, device="cuda:0", generator=g) * 2 - 1) * 0.05
+                s, r, _, _ = env.step(a)
+                if t % 50 == 49:
+                    out += [s.clone(), r.clone()]
+            out += [env.supervisor.get_slopes().clone(), sim.voltage.clone(), env.supervisor.get_command().clone(),
+                    env.supervisor.get_strehl().clone()]
+            if mode == "pipe":
+                flying, _, steps, beside = sim.frame_pipeline_state()
+                assert flying and steps == nstep - 1 and beside == nstep, (steps, beside)
+            torch.cuda.synchronize()
+        rec[mode] = out
+        assert torch.isfinite(out[-1]).all() and float(out[-1][:, 1].min()) > 0.0
+        del env
+    for k, (a, b) in enumerate(zip(rec["plain"], rec["pipe"])):
+        assert torch.equal(a, b), k
