@@ -36,6 +36,8 @@ def main(argv=None):
                          "README's `--n_reverse_filtered_from_cmat 5 --n_zernike_start_end 0 80` the controlled modes "
                          "75..79 enter the state divided by 1e-8: inputs of 1e6..1e8, the critic's loss starts at 1e12 and "
                          "the 80-mode agent never learns (profiles/r03_learning_acceptance.txt)")
+    ap.add_argument("--frame-pipeline", action="store_true",
+                    help="the RL episodes with a frame in flight (aomarl_set_frame_pipeline): same environment, bit for bit")
     ap.add_argument("--torch-update", action="store_true",
                     help="the torch-autograd statement of the SAC update instead of aomarl_sac_update (slow; A/B)")
     a = ap.parse_args(argv)
@@ -52,7 +54,8 @@ def main(argv=None):
         from ao_marl_amd.normalization import obtain_normalization
         norm, zn, _ = obtain_normalization("production_sh_10x10_2m", modes_filtered=5)
         norm_kw = dict(norm=norm, zn_norm=zn)
-    env = VecAoEnv("production_sh_10x10_2m", a.envs, rl, initial_seed=a.seed, seed_stride=16, n_agents_modal=1, **norm_kw)
+    env = VecAoEnv("production_sh_10x10_2m", a.envs, rl, initial_seed=a.seed, seed_stride=16, n_agents_modal=1,
+                   frame_pipeline=a.frame_pipeline, **norm_kw)
     sac = BatchedSAC(env.layout, dict(updates_per_episode_rpc=a.updates, memory_size=1000000), seed=a.seed,
                      native=not a.torch_update)
     print("config production_sh_10x10_2m  envs %d  agents %d (state dims %s, action dims %s)  %d steps + %d updates per "
