@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 for envs in (64, 256):
-    w = bench.Workload(bench.SMALL, envs, 0, 1, "cuda:0")
+    w = bench.Workload(bench.SMALL, envs, 0, 1, "cuda:0", pipeline=True)
     with torch.cuda.stream(torch.cuda.Stream()):
         for small in (1, 0, 1, 0):
             w.sim.set_option("small_move", small)
