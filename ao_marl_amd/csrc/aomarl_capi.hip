@@ -2549,19 +2549,28 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   // plain call, every environment moves by the same plan
   Plan plan;
   // (the null stream cannot be captured: a caller on it gets the plain path)
-  const bool steady = stream && c->prefetch_atmos && aomarl_frame_fused_available(c) && accumx && accumy && c->premoved &&
-                      c->pre_screens == st->screens && c->pre_b == 0 && c->pre_n == n &&
+  // (with "prefetch_atmos" off the whole step is ONE stream: a linear graph, no fork / join -- the form that replays
+  // cheaply on this runtime, tools/graphbench.hip: 13 small kernels 29 us per replay against 37 us launched one by one)
+  const bool pf = c->prefetch_atmos;
+  const bool steady = stream && aomarl_frame_fused_available(c) && accumx && accumy &&
+                      (pf ? (c->premoved && c->pre_screens == st->screens && c->pre_b == 0 && c->pre_n == n) : !c->premoved) &&
                       (!g->sel || (c->sel_checked == g->sel && c->sel_checked_n == g->dm_dim && c->sel_checked_nm == g->nmodes)) &&
                       g->nhist >= 0 && g->nhist <= 5 && g->ring_pos >= 0 && g->ring_pos <= g->nhist &&
                       step_plan_uniform(c, n, accumx, accumy, plan);
   if (!steady) return env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
   hipStream_t s = (hipStream_t)stream;
-  int rc = side_stream(c);
-  if (rc) return rc;
-  if (!c->side_joined) {        // work issued on the side streams by plain calls: wait for it OUTSIDE the graph
-    HIPCHK(hipStreamWaitEvent(s, c->ev_moved, 0));
-    if (c->psf_side) HIPCHK(hipStreamWaitEvent(s, c->ev_psf, 0));
-    c->side_joined = true;
+  int rc = 0;
+  if (pf) {
+    rc = side_stream(c);
+    if (rc) return rc;
+    if (!c->side_joined) {        // work issued on the side streams by plain calls: wait for it OUTSIDE the graph
+      HIPCHK(hipStreamWaitEvent(s, c->ev_moved, 0));
+      if (c->psf_side) HIPCHK(hipStreamWaitEvent(s, c->ev_psf, 0));
+      c->side_joined = true;
+    }
+  } else if (c->psf_side) {       // a PSF finish left on the side stream by an earlier call with the prefetch on
+    rc = psf_wait_pending(c, stream);
+    if (rc) return rc;
   }
   std::vector<long long> key;
   auto kp = [&](const void *p) { key.push_back((long long)(uintptr_t)p); };
@@ -2574,6 +2583,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   kp(g->sel); kp(g->mean_dm); kp(g->std_dm); kp(g->mean_res); kp(g->std_res); kp(g->lohi); kp(g->modes_ring); kp(g->res_modes);
   kp(g->denoiser); kp(c->cmat); kp(c->v2m); kp(c->m2v); kp(c->freedom); kp(c->amode_inv);
   key.push_back(n); key.push_back(g_precision); key.push_back(g_gemm_split_f16 ? 1 : 0); key.push_back(c->dft_mode);
+  key.push_back(pf ? 1 : 0); key.push_back(c->small_move);
   key.push_back(c->defer_dm_shape ? 1 : 0); key.push_back(g_gemm_target_blocks); key.push_back(c->fused_debug);
   { int gi; memcpy(&gi, &c->gain, sizeof(gi)); key.push_back(gi); }
   aomarl_ctx::StepGraph *hit = nullptr;
@@ -2590,8 +2600,12 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
         if (e == 0) { c->frac_x[l] = ax - (float)(int)ax; c->frac_y[l] = ay - (float)(int)ay; }
       }
     g->ring_pos = (g->ring_pos + 1) % (g->nhist + 1);
-    c->premoved = true; c->psf_side = true; c->side_joined = true;
-    c->frame_marked = true; c->frame_wait_pending = false; c->screens_dirty_main = false;
+    if (pf) {
+      c->premoved = true; c->psf_side = true; c->side_joined = true;
+      c->frame_marked = true; c->frame_wait_pending = false; c->screens_dirty_main = false;
+    } else {
+      c->frame_marked = false; c->screens_dirty_main = true;
+    }
     for (int i = 0; i < AR_N; i++) g_arith[i] += hit->arith[i];
     memcpy(c->fw_variant, hit->fw_variant, sizeof(c->fw_variant));
     c->graph_hits++;
@@ -2609,7 +2623,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   c->capturing = true; c->fork_recorded = false;
   rc = env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
   hipError_t je = hipSuccess;
-  if (!rc) {                                                // the side streams join the caller's stream again
+  if (!rc && pf) {                                          // the side streams join the caller's stream again
     if (c->psf_side) je = hipStreamWaitEvent(s, c->ev_psf, 0);
     if (je == hipSuccess && c->premoved) je = hipStreamWaitEvent(s, c->ev_moved, 0);
   }
@@ -2621,7 +2635,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
     if (graph) (void)hipGraphDestroy(graph);
     return fail("env_step: graph capture failed: %s", hipGetErrorString(je != hipSuccess ? je : ee));
   }
-  c->side_joined = true;
+  if (pf) c->side_joined = true;
   aomarl_ctx::StepGraph sg;
   sg.key = key; sg.graph = graph; sg.exec = nullptr;
   for (int i = 0; i < AR_N; i++) sg.arith[i] = g_arith[i] - before[i];

@@ -387,20 +387,22 @@ def test_residual_modes_from_slopes_equals_do_control_path():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,nenv,rl,n_modal", [
-    ("production_sh_10x10_2m", 8, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5), 1),
+@pytest.mark.parametrize("config,nenv,rl,n_modal,prefetch", [
+    ("production_sh_10x10_2m", 8, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5), 1, True),
+    ("production_sh_10x10_2m", 8, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5), 1, False),
     ("production_sh_40x40_8m_3layers", 4, dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5,
-                                               window_n_zernike=20, include_tip_tilt_windowed=True), 13)])
-def test_graph_step_replays_the_same_step(config, nenv, rl, n_modal):
+                                               window_n_zernike=20, include_tip_tilt_windowed=True), 13, True)])
+def test_graph_step_replays_the_same_step(config, nenv, rl, n_modal, prefetch):
     """aomarl_set_option("graph_step", 1): aomarl_env_step captured as HIP graphs (one per extrusion plan x ring
     position x buffer addresses) and replayed -- bit for bit the plain call's states, rewards, slopes, commands and
-    Strehl over 40 steps, with graphs both captured and replayed along the way."""
+    Strehl over 40 steps, with graphs both captured and replayed along the way.  prefetch False: the whole step on
+    ONE stream, a linear graph (no fork / join), the form meant for the host-bound small systems."""
     from ao_marl_amd.env import VecAoEnv
     out = {}
     rng = np.random.default_rng(3)
     actions = None
     for mode in ("plain", "graph"):
-        env = VecAoEnv(config, nenv, rl, initial_seed=77, seed_stride=16, n_agents_modal=n_modal)
+        env = VecAoEnv(config, nenv, rl, initial_seed=77, seed_stride=16, n_agents_modal=n_modal, prefetch_atmos=prefetch)
         sim = env.supervisor.sim
         sim.set_option("graph_step", 1 if mode == "graph" else 0)
         if actions is None:
