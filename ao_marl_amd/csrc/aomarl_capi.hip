@@ -114,6 +114,8 @@ struct aomarl_ctx {
     size_t snap_ints = 0;
     unsigned long long steps = 0, overlapped = 0, behind = 0;
   } pipe;
+  int32_t *snap_target = nullptr;        // a pipelined move: where the scatter kernels also write the origins they advance
+  bool snap_complete = false;            // ... and whether every layer of every environment group was advanced by it
   bool pipe_enabled = true;              // "frame_pipeline": 0 = plain call order although a twin is set
   bool pipe_internal = false;            // check_range: the pipelined step itself is calling
   // first write of a prefetched move: behind the OLDER frame in flight (ev_frame_prev) when the lines the move
@@ -789,6 +791,7 @@ static DevState dev_state(const aomarl_state *st) {
   d.slopes = st->slopes; d.dm_shape = st->dm_shape; d.bincube = st->bincube;
   d.wfs_phase = st->wfs_phase; d.tar_phase = st->tar_phase; d.strehl = st->strehl;
   d.le_img = st->le_img; d.frame = st->frame; d.work = st->work;
+  d.origin_snap = nullptr;
   return d;
 }
 
@@ -873,6 +876,7 @@ struct ExtrudeRun {          // one range of environments walking through a sequ
       : c(c_), st(st_), b(b_), n(n_), s((hipStream_t)stream), ordered(ordered_), gathered(false) {
     w = work_layout(c, st->nenv);
     ds = dev_state(st);
+    if (ordered) ds.origin_snap = c->snap_target;
     // the range's own part of every work area (columns are numbered from the range's first environment):
     // two ranges may run side by side on two streams
     const size_t col0 = (size_t)b * (c->nlayers > 0 ? c->nlayers : 1), ncols = (size_t)n * (c->nlayers > 0 ? c->nlayers : 1);
@@ -973,6 +977,8 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
     int len = abs(p.kx[l]) + abs(p.ky[l]);
     if (len > maxr) maxr = len;
   }
+  for (int l = 0; l < c->nlayers; l++)
+    if (p.kx[l] == 0 && p.ky[l] == 0) c->snap_complete = false;   // a ring that does not move this frame: nobody writes its snapshot entry
   if (maxr == 0) return 0;
   if ((hipStream_t)stream != c->atm_stream || !c->atm_stream) { int rc = atmos_wait_pending(c, stream); if (rc) return rc; }
   // frame pipeline: may this move run beside the older frame in flight?  The extrusions rewrite the |kx| oldest
@@ -995,7 +1001,9 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
     for (int l = 0; l < AOMARL_MAX_LAYERS; l++) { mp.kx[l] = l < c->nlayers ? p.kx[l] : 0; mp.ky[l] = l < c->nlayers ? p.ky[l] : 0; }
     { int wrc = first_write_wait(c, s); if (wrc) return wrc; }      // it reads AND writes the rings: behind their readers
     if (s != c->atm_stream) c->screens_dirty_main = true;
-    hipLaunchKernelGGL(k_move_small, dim3(n, c->nlayers), dim3(MOVE_SMALL_T), 0, s, c->sys, dev_state(st), b, mp);
+    DevState dsm = dev_state(st);
+    dsm.origin_snap = c->snap_target;
+    hipLaunchKernelGGL(k_move_small, dim3(n, c->nlayers), dim3(MOVE_SMALL_T), 0, s, c->sys, dsm, b, mp);
     LAUNCHCHK();
     return 0;
   }
@@ -2397,13 +2405,19 @@ static int pipe_prefetch(aomarl_ctx *c, aomarl_state *st, float *accumx, float *
   c->side_joined = false;
   c->ev_frame_prev = P.ev_done_cur[older]; c->need_prev = true;
   c->ev_frame_cur = P.ev_done_cur[newest]; c->frame_wait_pending = true;
+  // the kernels that advance the ring origins write them into that frame's snapshot as well (behind the same wait
+  // as their ring writes); a copy of all origins only when some ring did not move at all
+  c->snap_target = P.snap[older]; c->snap_complete = true;
   int rc = move_atmos_now(c, st, 0, st->nenv, accumx, accumy, (void *)c->atm_stream);
-  if (!rc && c->need_prev && c->frame_wait_pending)      // nothing written: the snapshot still overwrites what the older frame reads
+  const bool complete = c->snap_complete;
+  c->snap_target = nullptr;
+  if (!rc && !complete && c->need_prev && c->frame_wait_pending)   // nothing written yet: the copy overwrites what the older frame reads
     rc = hipStreamWaitEvent(c->atm_stream, c->ev_frame_prev, 0) == hipSuccess ? 0 : fail("frame pipeline: hipStreamWaitEvent failed");
   c->ev_frame_prev = nullptr; c->need_prev = false; c->frame_wait_pending = false; c->group_overlap = false;
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(P.snap[older], st->origin, sizeof(int32_t) * (size_t)st->nenv * c->nlayers * 2,
-                        hipMemcpyDeviceToDevice, c->atm_stream));
+  if (!complete)
+    HIPCHK(hipMemcpyAsync(P.snap[older], st->origin, sizeof(int32_t) * (size_t)st->nenv * c->nlayers * 2,
+                          hipMemcpyDeviceToDevice, c->atm_stream));
   c->screens_dirty_main = false;
   HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
   c->premoved = true; c->pre_screens = st->screens; c->pre_b = 0; c->pre_n = st->nenv;

@@ -91,6 +91,7 @@ struct DevState {
   float *strehl, *le_img;
   uint32_t *frame;
   float *work;
+  int32_t *origin_snap;   // frame pipeline: the kernels that advance a ring origin also write it here (or null)
 };
 
 // ---------------------------------------------------------------- Philox4x32-10 + normals

@@ -1062,6 +1062,7 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
   __syncthreads();
   if (threadIdx.x == 0) {
     o[0] = nox; o[1] = noy;
+    if (st.origin_snap) { st.origin_snap[(e * sys.nlayers + li) * 2] = nox; st.origin_snap[(e * sys.nlayers + li) * 2 + 1] = noy; }
     st.ext_count[e * sys.nlayers + li] += 1u;
   }
 }
@@ -1086,6 +1087,7 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   __syncthreads();                               // the new line is in the ring (block-visible); ZREF[col] was read by everyone
   if (threadIdx.x == 0) {
     o[0] = nox; o[1] = noy;
+    if (st.origin_snap) { st.origin_snap[(e * sys.nlayers + li) * 2] = nox; st.origin_snap[(e * sys.nlayers + li) * 2 + 1] = noy; }
     st.ext_count[e * sys.nlayers + li] = cnt + 1u;
   }
   // the gather of extrude_gather_item, restated so that one thread's loads are independent of each
@@ -1213,6 +1215,7 @@ __global__ __launch_bounds__(MOVE_SMALL_T) void k_move_small(DevSys sys, DevStat
   }
   if (tid == 0) {
     o[0] = ox; o[1] = oy;
+    if (st.origin_snap) { st.origin_snap[(e * sys.nlayers + li) * 2] = ox; st.origin_snap[(e * sys.nlayers + li) * 2 + 1] = oy; }
     st.ext_count[e * sys.nlayers + li] = cnt;
   }
 }
