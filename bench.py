@@ -90,6 +90,8 @@ def parse_args():
                     help="nothing but warm-up + the timed region on the GPU (profiling): no plain-order pass, no stage split")
     ap.add_argument("--no-frame-pipeline", action="store_true",
                     help="plain call order: every frame behind the control / agent chain of the previous one")
+    ap.add_argument("--graph-step", action="store_true",
+                    help="aomarl_env_step replayed as HIP graphs (with --no-prefetch: ONE stream, a linear graph)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="move the atmosphere in front of the image kernels (no side stream)")
     ap.add_argument("--no-defer", action="store_true",
@@ -534,6 +536,9 @@ def main():
         sim.set_option("force_unfused_frame", 1)
     if args.no_defer:
         sim.defer_shape = False
+    if args.graph_step:
+        sim.set_option("graph_step", 1)
+        w.policy.out_ring = 6                       # stable output addresses for the replays
 
     w.reset()
     reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
