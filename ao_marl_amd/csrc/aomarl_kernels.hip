@@ -1135,14 +1135,16 @@ struct MovePlan { int kx[AOMARL_MAX_LAYERS], ky[AOMARL_MAX_LAYERS]; };
 
 __global__ __launch_bounds__(MOVE_SMALL_T) void k_move_small(DevSys sys, DevState st, int env_begin, MovePlan plan) {
   __shared__ float Zs[MOVE_SMALL_K];
-  __shared__ float Ps[MOVE_SMALL_T];
+  __shared__ __attribute__((aligned(16))) float Ps[4 * MOVE_SMALL_T];     // parts x ldt partial sums
   const int e = env_begin + blockIdx.x, li = blockIdx.y, tid = threadIdx.x;
   const int kx = plan.kx[li], ky = plan.ky[li];
   const int nx = abs(kx), nit = nx + abs(ky);
   if (nit == 0) return;
   const DevLayer &L = sys.layers[li];
   const int n = L.dim, ns = L.ns, K = n + ns, stride = n + RING_PAD, ldt = L.ldt;
-  const int parts = MOVE_SMALL_T / ldt, part = tid / ldt, row = tid - part * ldt;
+  // thread = (group of 4 rows, K slice): one 16-byte load of the transposed matrix per k, ldt / 4 row groups,
+  // 4 * MOVE_SMALL_T / ldt slices (8 .. 32): many independent loads in flight per thread instead of one per row
+  const int rgs = ldt >> 2, parts = MOVE_SMALL_T / rgs, part = tid / rgs, rg = tid - part * rgs;
   float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   int *o = st.origin + (e * sys.nlayers + li) * 2;
   int ox = o[0], oy = o[1];
@@ -1171,17 +1173,22 @@ __global__ __launch_bounds__(MOVE_SMALL_T) void k_move_small(DevSys sys, DevStat
     }
     __syncthreads();
     if (part < parts) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      const float *p = ABt + row;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+      const float4 *p = reinterpret_cast<const float4 *>(ABt) + rg;
+      auto acc = [](float4 &a, const float4 m, float z) {
+        a.x = fmaf(m.x, z, a.x); a.y = fmaf(m.y, z, a.y); a.z = fmaf(m.z, z, a.z); a.w = fmaf(m.w, z, a.w);
+      };
       int j = part;
       for (; j + 3 * parts < K; j += 4 * parts) {
-        a0 = fmaf(p[(long long)j * ldt], Zs[j], a0);
-        a1 = fmaf(p[(long long)(j + parts) * ldt], Zs[j + parts], a1);
-        a2 = fmaf(p[(long long)(j + 2 * parts) * ldt], Zs[j + 2 * parts], a2);
-        a3 = fmaf(p[(long long)(j + 3 * parts) * ldt], Zs[j + 3 * parts], a3);
+        const float4 m0 = p[(long long)j * rgs], m1 = p[(long long)(j + parts) * rgs];
+        const float4 m2 = p[(long long)(j + 2 * parts) * rgs], m3 = p[(long long)(j + 3 * parts) * rgs];
+        acc(a0, m0, Zs[j]); acc(a1, m1, Zs[j + parts]); acc(a2, m2, Zs[j + 2 * parts]); acc(a3, m3, Zs[j + 3 * parts]);
       }
-      for (; j < K; j += parts) a0 = fmaf(p[(long long)j * ldt], Zs[j], a0);
-      Ps[tid] = (a0 + a1) + (a2 + a3);
+      for (; j < K; j += parts) acc(a0, p[(long long)j * rgs], Zs[j]);
+      float4 t;
+      t.x = (a0.x + a1.x) + (a2.x + a3.x); t.y = (a0.y + a1.y) + (a2.y + a3.y);
+      t.z = (a0.z + a1.z) + (a2.z + a3.z); t.w = (a0.w + a1.w) + (a2.w + a3.w);
+      reinterpret_cast<float4 *>(Ps)[part * rgs + rg] = t;
     }
     __syncthreads();
     if (tid < n) {
