@@ -58,7 +58,7 @@ struct aomarl_ctx {
   hipEvent_t ev_reset = nullptr, ev_reset2[3] = {nullptr, nullptr, nullptr};
   bool no_extrude_sg = false;          // "extrude_unfused": scatter and gather of consecutive rounds as separate launches
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly
-  int fused_debug = 0;                 // development switches of k_frame_fused (tools/kbench.py)
+  int fused_debug = 0;                 // development switches of k_frame_fused (tools/fw_ab.py, tools/fw_pmc.py)
   // "prefetch_atmos": the composite moves the atmosphere of the NEXT frame on a side stream as soon
   // as this frame's image kernels are done, so the extrusion chain runs beside do_control / the
   // agents / next_part_two instead of in front of the next image
@@ -811,7 +811,7 @@ static int side_stream(aomarl_ctx *c) {
     // (high / normal / low priority for it: +-0.5 %, measured)
     // ONE pair of side streams per device for every context of the process: the runtime multiplexes streams
     // onto four hardware queues, and two contexts with a pair each (a training and an evaluation
-    // environment, say) ran at 0.89 ms per step instead of 0.56 (tools/diag/two_sims.py)
+    // environment, say) ran at 0.89 ms per step instead of 0.56 (round-2 script two_sims.py, since removed)
     static hipStream_t g_atm[64] = {nullptr}, g_psf[64] = {nullptr};
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));

@@ -893,7 +893,7 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     // up) x k-tiles per block (whole groups of three for the pipelined kernels, + 2 tiles of fill / drain).
     // min_chunk: the control chain's products ask for at least three groups of three k-tiles per block
     // (288): below that the fill / drain of the load pipeline and the wider reduce cost more than the
-    // extra blocks bring (tools/diag/gemm_split_time.py).
+    // extra blocks bring (round-2 script gemm_split_time.py, since removed).
     const int ncu = 256, tiles = bx * by;
     if (g_gemm_target_blocks > 0) {              // "gemm_target_blocks" > 0: the plain rule (about that many blocks)
       nsplit = (g_gemm_target_blocks + tiles - 1) / tiles;
