@@ -1,6 +1,6 @@
 """A/B timing of the one-pass frame kernel (development aid): AOMARL_LIB=<variant .so> python tools/fw_ab.py [nenv]
 Times aomarl_frame_fused (no noise, COG, stack-array DM from the voltages) through the library's own
-event pairs in both arithmetics, plus the kernel's development switches ("fused_debug": 1 no WFS path, 2 no PSF rows).
+event pairs in both arithmetics, plus the kernel's development switches ("fused_debug": 1 no WFS path, 2 no PSF rows)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
