@@ -52,6 +52,8 @@ struct aomarl_ctx {
   bool force_generic_spot = false, force_generic_target = false, force_unfused_frame = false;
   int dft_mode = -1;                   // frame kernel DFTs: -1 follow the library's precision mode, 0 fp32 MFMAs, 1 split-fp16 ("force_f32_dft")
   bool reset_untransposed = false;     // "reset_untransposed": the reset's x extrusions on the row-major screen itself
+  int small_chain = 1;                 // "small_chain": small systems run the control / agent chain of aomarl_env_step as two kernels
+  bool skip_do_control = false;        // (aomarl_env_step's small chain: aomarl_next_part_one leaves do_control to its tail kernel)
   int small_move = 1;                  // "small_move": 1 = one k_move_small launch per frame's move where the screens allow it
   bool small_ok = false;               // every layer has dim <= MOVE_SMALL_DIM, ns + dim <= MOVE_SMALL_K (transposed [A|B] uploaded)
   int reset_streams = 2;               // "reset_streams": a batch reset in that many parts side by side, one stream each (1..4)
@@ -1338,6 +1340,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
     c->pipe_enabled = value != 0; return 0;
   }
   if (!strcmp(name, "small_move")) { c->small_move = value != 0; return 0; }
+  if (!strcmp(name, "small_chain")) { c->small_chain = value != 0; return 0; }
   if (!strcmp(name, "reset_streams")) { c->reset_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
@@ -2167,6 +2170,121 @@ static int env_step_validate(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g
   return 0;
 }
 
+// ---------------------------------------------------------------- small systems: the chain in two kernels
+// With <= 512 actuators / modes and <= 1024 slopes (the 10x10 files: 90 / 85 / 152) the three products of the
+// control chain are a few thousand multiply-adds per environment: as GEMMs they are three launches + their
+// neighbours (compose, delay line, Strehl commit; integrate, state assembly), 8 launches of ~5 us on a step that is
+// bound by launches (configs[1]).  One workgroup per environment does each half of the chain by itself:
+//   k_small_head: Btt compose (+ per-agent rewards), m2v product, delay line, tip-tilt slot, Strehl commit
+//   k_small_tail: -cmat . s, integrator, v2m . err, the state blocks
+// Same formulas as the kernels they stand for; the sums of the products run in one thread each, in index order
+// (the split-K GEMM sums tiles): fp32 round-off apart, the same numbers ("small_chain" = 0: the general chain).
+constexpr int SMALL_NM = 512, SMALL_NA = 512, SMALL_NSL = 1024;
+struct SmallHead {
+  int nm, na, nact, n_agents, ld_m2v, ld_actu, ktt, do_strehl;
+  float gain, factor, wa, wb, wc;
+  const float *m0, *m1, *action, *freedom, *m2v, *PEND;
+  const int32_t *amode_inv, *lohi;
+  float *modes_out, *rew;
+};
+__global__ __launch_bounds__(256) void k_small_head(DevSys sys, DevState st, SmallHead p) {
+  __shared__ float sm[SMALL_NM], sv[SMALL_NA];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int m = tid; m < p.nm; m += 256) {
+    float v = p.m0[(long long)e * p.nm + m] + p.gain * p.m1[(long long)e * p.nm + m];
+    if (p.action) {
+      const int j = p.amode_inv[m];
+      if (j >= 0) v += p.action[(long long)e * p.nact + j] * p.freedom[m];
+    }
+    sm[m] = v;
+    if (p.modes_out) p.modes_out[(long long)e * p.nm + m] = v;
+  }
+  if (p.rew)
+    for (int a = wv; a < p.n_agents; a += 4) {
+      const int lo = p.lohi[2 * a], hi = p.lohi[2 * a + 1];
+      float q = 0.f;
+      for (int m = lo + lane; m < hi; m += 64) { const float v = p.m1[(long long)e * p.nm + m]; q += v * v; }
+      q = wave_sum(q);
+      if (lane == 0) p.rew[(long long)e * p.n_agents + a] = -p.factor * q / (float)(hi - lo);
+    }
+  __syncthreads();
+  for (int a = tid; a < p.na; a += 256) {
+    const float *row = p.m2v + (long long)a * p.ld_m2v;
+    float c0 = 0.f;
+    for (int m = 0; m < p.nm; m++) c0 = fmaf(sm[m], row[m], c0);
+    const long long o = (long long)e * p.ld_actu + a;
+    const float c1 = st.com1[o], c2 = st.com2[o];
+    const float v = p.wa * c0 + p.wb * c1 + p.wc * c2;
+    st.com[o] = c0; st.voltage[o] = v; st.com2[o] = c1; st.com1[o] = c0;
+    sv[a] = v;
+  }
+  __syncthreads();
+  if (p.ktt >= 0 && tid < 3) {                   // dm_shape_tt_body on the voltages just formed
+    const DevDm &D = sys.dms[p.ktt];
+    float *shape = st.dm_shape + (long long)e * sys.shape_stride + D.shape_off;
+    if (tid < 2) shape[tid] = sv[D.com_off + tid];
+    if (tid == 2 && sys.fused_ok) {
+      const DevDm &Z = sys.dms[0];
+      const int half = sys.pupdiam / 2, zp = (half + Z.toy) * Z.dim + half + Z.tox;
+      const int ss2 = Z.ss * Z.ss, s0 = Z.influstart[zp], cn = Z.ninflu[zp];
+      float acc = 0.f;
+      for (int t = 0; t < cn; t++) {
+        const int pos = Z.influpos[s0 + t];
+        acc += Z.influ[pos] * sv[Z.com_off + pos / ss2];
+      }
+      shape[2] = acc;
+    }
+  }
+  if (p.do_strehl) strehl_commit_body(sys, st, 0, e, p.PEND);
+}
+
+struct SmallTail {
+  int nsl, na, nm, ld_cmat, ld_v2m, ld_actu;
+  float gain;
+  const float *cmat, *v2m;
+  float *res_modes;
+};
+__global__ __launch_bounds__(256) void k_small_tail(DevState st, SmallTail p, StateBlocks sb, float *__restrict__ out) {
+  __shared__ float ss[SMALL_NSL], se[SMALL_NA], sr[SMALL_NM];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < p.nsl; k += 256) ss[k] = st.slopes[(long long)e * p.nsl + k];
+  __syncthreads();
+  for (int a = tid; a < p.na; a += 256) {
+    const float *row = p.cmat + (long long)a * p.ld_cmat;
+    float acc = 0.f;
+    for (int k = 0; k < p.nsl; k++) acc = fmaf(ss[k], row[k], acc);
+    const float v = -acc;
+    const long long o = (long long)e * p.ld_actu + a;
+    st.err[o] = v;
+    st.com[o] += p.gain * v;
+    se[a] = v;
+  }
+  __syncthreads();
+  for (int m = tid; m < p.nm; m += 256) {
+    const float *row = p.v2m + (long long)m * p.ld_v2m;
+    float acc = 0.f;
+    for (int a = 0; a < p.na; a++) acc = fmaf(se[a], row[a], acc);
+    p.res_modes[(long long)e * p.nm + m] = acc;
+    sr[m] = acc;
+  }
+  __syncthreads();
+  for (int j = tid; j < sb.total; j += 256) {
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) if (k < sb.nblocks && j >= sb.off[k]) b = k;
+    const int i = j - sb.off[b];
+    const int col = sb.sel ? sb.sel[i] : i;
+    float v = (b == sb.nblocks - 1) ? sr[col] : sb.src[b][(long long)e * sb.ld[b] + col];
+    if (sb.mean[b]) v = (v - sb.mean[b][i]) / sb.std[b][i];
+    out[(long long)e * sb.total + j] = v;
+  }
+}
+
+static bool small_chain_ok(const aomarl_ctx *c, const aomarl_env_glue *g) {
+  return c->small_chain && c->sys.nactu <= SMALL_NA && c->sys.nslope <= SMALL_NSL && g->nmodes <= SMALL_NM &&
+         (long long)c->sys.nactu * c->sys.nslope <= 65536 && c->cmat && !c->env_gain;
+}
+
 // may the chain run in its fused form?  (ktt: index of the tip-tilt mirror)
 static bool env_step_fusable(aomarl_ctx *c, const aomarl_env_glue *g, int *ktt_out) {
   int ktt = -1, ntt = 0, nother = 0;
@@ -2192,6 +2310,22 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
   float *mnew = g->modes_ring + (size_t)((g->ring_pos + 1) % R) * slot;
   Work w = work_layout(c, st->nenv);
   DevState dsv = dev_state(stv);
+  if (small_chain_ok(c, g)) {
+    const float d = c->delay;
+    SmallHead p;
+    if (d <= 1.f) { p.wa = 1.f - d; p.wb = d; p.wc = 0.f; } else { p.wa = 0.f; p.wb = 2.f - d; p.wc = d - 1.f; }
+    if (ahead) { p.wa = p.wb; p.wb = p.wc; p.wc = 0.f; }
+    p.nm = nm; p.na = na; p.nact = c->nact; p.n_agents = reward_out ? g->n_agents : 0; p.ld_m2v = c->ld_m2v;
+    p.ld_actu = st->ld_actu; p.ktt = ktt; p.do_strehl = 1; p.gain = gain; p.factor = g->reward_factor;
+    p.m0 = newest; p.m1 = g->res_modes; p.action = action; p.freedom = c->freedom; p.m2v = c->m2v;
+    p.PEND = stv->work + w.PEND; p.amode_inv = c->amode_inv; p.lohi = g->lohi; p.modes_out = mnew; p.rew = reward_out;
+    if (psf_ev) HIPCHK(hipStreamWaitEvent(s, psf_ev, 0));
+    else if (stv == st) { int rc = psf_wait_pending(c, stream); if (rc) return rc; }
+    hipLaunchKernelGGL(k_small_head, dim3(n), dim3(256), 0, s, c->sys, dsv, p);
+    LAUNCHCHK();
+    if (ahead) { HIPCHK(hipEventRecord(c->pipe.ev_cmd, s)); HIPCHK(hipEventRecord(c->pipe.ev_commit, s)); }
+    return 0;
+  }
   float *modes = st->work + w.MODES;
   const int cx = (nm + 255) / 256;
   hipLaunchKernelGGL(k_compose_rewards, dim3(cx + (reward_out ? g->n_agents : 0), n), dim3(256), 0, s, nm, newest,
@@ -2231,7 +2365,8 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
 }
 
 // ---- the rest of AoEnv.linear_step behind do_control: v2m . err, the state blocks
-static int env_step_tail(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, bool fused, float *state_out, void *stream) {
+static int env_step_tail(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, bool fused, float *state_out, void *stream,
+                         const aomarl_state *slopes_view = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1, na = c->sys.nactu;
   const size_t slot = (size_t)n * nm;
@@ -2239,6 +2374,37 @@ static int env_step_tail(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, bo
   float *mnew = g->modes_ring + (size_t)nxt * slot;
   Work w = work_layout(c, st->nenv);
   int rc = 0;
+  if (slopes_view) {
+    // small systems: do_control, v2m . err and the state blocks in ONE kernel (the caller has NOT run do_control)
+    const float *src[8], *mean[8], *sd[8];
+    int32_t ld[8], dim[8];
+    int nb = 0;
+    for (int h = g->nhist; h >= 1; h--) {
+      src[nb] = g->modes_ring + (size_t)((nxt - h + R * 8) % R) * slot;
+      mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+    }
+    src[nb] = mnew; mean[nb] = g->mean_dm; sd[nb] = g->std_dm; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+    src[nb] = g->res_modes; mean[nb] = g->mean_res; sd[nb] = g->std_res; ld[nb] = nm; dim[nb] = g->dm_dim; nb++;
+    const bool norm = g->mean_dm && g->std_dm && g->mean_res && g->std_res;
+    StateBlocks sb;
+    int off = 0;
+    for (int k = 0; k < 8; k++) {
+      const bool on = k < nb;
+      sb.src[k] = on ? src[k] : nullptr; sb.ld[k] = on ? ld[k] : 0; sb.dim[k] = on ? dim[k] : 0;
+      sb.mean[k] = (on && norm) ? mean[k] : nullptr; sb.std[k] = (on && norm) ? sd[k] : nullptr;
+      sb.off[k] = off;
+      if (on) off += dim[k];
+    }
+    sb.nblocks = nb; sb.total = off; sb.sel = g->sel;
+    sb.part = nullptr; sb.nsplit = 0; sb.pn = 0; sb.alpha = 1.f; sb.sum_out = nullptr;
+    SmallTail p;
+    p.nsl = c->sys.nslope; p.na = na; p.nm = nm; p.ld_cmat = c->ld_cmat; p.ld_v2m = c->ld_v2m; p.ld_actu = st->ld_actu;
+    p.gain = c->gain; p.cmat = c->cmat; p.v2m = c->v2m; p.res_modes = g->res_modes;
+    hipLaunchKernelGGL(k_small_tail, dim3(n), dim3(256), 0, s, dev_state(slopes_view), p, sb, state_out);
+    LAUNCHCHK();
+    g->ring_pos = nxt;
+    return 0;
+  }
   AssemblePart part = {nullptr, 0, 0, 1.f, nullptr};
   if (fused) {
     int nsp = 0;
@@ -2323,7 +2489,12 @@ static int env_step_body(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, co
     if (rc) return rc;
     rc = aomarl_do_control(c, st, 0, n, stream);
   } else {
+    const bool small = fused && small_chain_ok(c, g);
+    c->skip_do_control = small;                  // the small chain's tail kernel does it
     rc = aomarl_next_part_one(c, st, 0, n, accumx, accumy, 0, stream);
+    c->skip_do_control = false;
+    if (rc) return rc;
+    if (small) return env_step_tail(c, st, g, fused, state_out, stream, st);
   }
   if (rc) return rc;
   return env_step_tail(c, st, g, fused, state_out, stream);
@@ -2477,8 +2648,11 @@ static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *
   if (!rc) rc = pipe_prefetch(c, st, accumx, accumy, p, q);
   // ---- reduce frame p
   if (!rc && hipStreamWaitEvent(s, P.ev_done_cur[p], 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
-  if (!rc) rc = aomarl_do_control(c, &vp, 0, n, stream);
-  if (!rc) rc = env_step_tail(c, st, g, true, state_out, stream);
+  if (!rc && small_chain_ok(c, g)) rc = env_step_tail(c, st, g, true, state_out, stream, &vp);
+  else {
+    if (!rc) rc = aomarl_do_control(c, &vp, 0, n, stream);
+    if (!rc) rc = env_step_tail(c, st, g, true, state_out, stream);
+  }
   c->pipe_internal = false;
   if (rc) return rc;
   P.par = q; P.steps++;
@@ -2597,7 +2771,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   kp(g->sel); kp(g->mean_dm); kp(g->std_dm); kp(g->mean_res); kp(g->std_res); kp(g->lohi); kp(g->modes_ring); kp(g->res_modes);
   kp(g->denoiser); kp(c->cmat); kp(c->v2m); kp(c->m2v); kp(c->freedom); kp(c->amode_inv);
   key.push_back(n); key.push_back(g_precision); key.push_back(g_gemm_split_f16 ? 1 : 0); key.push_back(c->dft_mode);
-  key.push_back(pf ? 1 : 0); key.push_back(c->small_move);
+  key.push_back(pf ? 1 : 0); key.push_back(c->small_move); key.push_back(c->small_chain);
   key.push_back(c->defer_dm_shape ? 1 : 0); key.push_back(g_gemm_target_blocks); key.push_back(c->fused_debug);
   { int gi; memcpy(&gi, &c->gain, sizeof(gi)); key.push_back(gi); }
   aomarl_ctx::StepGraph *hit = nullptr;
@@ -2968,6 +3142,7 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
       rc = prefetch_atmos_impl(c, st, b, n, accumx, accumy, stream, c->frame_marked);
       if (rc) return rc;
     }
+    if (c->skip_do_control) return 0;
     return aomarl_do_control(c, st, b, n, stream);
   }
   rc = aomarl_target_psf(c, st, b, n, stream);
@@ -2983,6 +3158,7 @@ int aomarl_next_part_one(aomarl_ctx *c, aomarl_state *st, int b, int n, float *a
     rc = aomarl_prefetch_atmos(c, st, b, n, accumx, accumy, stream);
     if (rc) return rc;
   }
+  if (c->skip_do_control) return 0;
   return aomarl_do_control(c, st, b, n, stream);
 }
 

@@ -141,6 +141,7 @@ def test_one_call_step_is_the_call_by_call_step(denoise, fused_tail):
     a, b = mk(), mk()
     b.native_step = False
     a.fused_tail = fused_tail       # True: split-K sums folded into their consumers, kernels sharing launches
+    a.supervisor.sim.set_option("small_chain", 0)     # the general chain: the one the call-by-call path is, bit for bit
     sa, sb = a.reset(), b.reset()
     assert torch.equal(sa, sb)
     g = torch.Generator(device="cuda:0").manual_seed(11)
@@ -686,3 +687,32 @@ def test_frame_pipeline_over_a_long_episode_with_ring_wraps():
         del env
     for k, (a, b) in enumerate(zip(rec["plain"], rec["pipe"])):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_small_chain_equals_the_general_chain_to_rounding():
+    """Small systems: the control / agent chain of aomarl_env_step as two workgroup-per-environment kernels
+    (k_small_head / k_small_tail, default) against the general chain of GEMMs and elementwise kernels ("small_chain" =
+    0): same formulas, other summation order -- states, rewards, commands, voltages and Strehl of a 40-step
+    closed loop agree to fp32 round-off, in the plain order and with the frame pipeline."""
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    for pipe in (False, True):
+        envs = [VecAoEnv("production_sh_10x10_2m", 6, rl, initial_seed=41, n_agents_modal=1, frame_pipeline=pipe) for _ in range(2)]
+        envs[1].supervisor.sim.set_option("small_chain", 0)
+        s0, s1 = envs[0].reset(), envs[1].reset()
+        assert torch.equal(s0, s1)
+        g = torch.Generator(device="cuda:0").manual_seed(23)
+        for it in range(40):
+            act = torch.rand(6, envs[0].action_dim, device="cuda:0", generator=g) * 2 - 1
+            (s0, r0, _, _), (s1, r1, _, _) = envs[0].step(act), envs[1].step(act)
+            scale = max(1.0, s1.abs().max().item())
+            assert (s0 - s1).abs().max().item() < 2e-4 * scale, (pipe, it)
+            assert (r0 - r1).abs().max().item() < 2e-4 * max(1e-6, r1.abs().max().item()), (pipe, it)
+        c0, c1 = envs[0].supervisor.get_command(), envs[1].supervisor.get_command()
+        assert (c0 - c1).abs().max().item() < 2e-4 * c1.abs().max().item()
+        v0, v1 = envs[0].supervisor.sim.voltage, envs[1].supervisor.sim.voltage
+        assert (v0 - v1).abs().max().item() < 2e-4 * v1.abs().max().item()
+        assert (envs[0].supervisor.get_strehl() - envs[1].supervisor.get_strehl()).abs().max().item() < 1e-4
+        assert (envs[0].supervisor.get_err() - envs[1].supervisor.get_err()).abs().max().item() < 2e-4 * envs[1].supervisor.get_err().abs().max().item()
+        del envs
