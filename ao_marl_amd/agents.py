@@ -316,7 +316,7 @@ class BatchedGaussianPolicy(object):
         la.check(la.load().aomarl_actor_forward(
                 C.byref(d), state.data_ptr(), eps.data_ptr() if eps is not None else None,
                 self.seed & 0xFFFFFFFF, self._draws & 0xFFFFFFFF, a.data_ptr(), m.data_ptr(),
-                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+                la.raw_stream(self.device)))
         return (m if eval_mode else a), m
 
     def forward(self, state):

@@ -112,6 +112,7 @@ struct aomarl_ctx {
     hipEvent_t ev_cmd = nullptr, ev_commit = nullptr, ev_done[2] = {nullptr, nullptr}, ev_psf[2] = {nullptr, nullptr};
     hipEvent_t ev_done_cur[2] = {nullptr, nullptr};  // the event each parity's last frame launch carries (ev_done[], or a timing event)
     bool psf_out[2] = {false, false};              // a PSF finish of that parity may still run
+    bool cmd_covers_commit = false;                // ev_cmd was recorded behind the Strehl commit and the PSF-finish wait as well
     int32_t *snap[2] = {nullptr, nullptr};         // ring origins as of each parity's frame
     size_t snap_ints = 0;
     unsigned long long steps = 0, overlapped = 0, behind = 0;
@@ -2323,7 +2324,9 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
     else if (stv == st) { int rc = psf_wait_pending(c, stream); if (rc) return rc; }
     hipLaunchKernelGGL(k_small_head, dim3(n), dim3(256), 0, s, c->sys, dsv, p);
     LAUNCHCHK();
-    if (ahead) { HIPCHK(hipEventRecord(c->pipe.ev_cmd, s)); HIPCHK(hipEventRecord(c->pipe.ev_commit, s)); }
+    // ONE kernel wrote the voltages and committed the pending window, behind the wait for that parity's PSF finish:
+    // the release of the frame stream covers all three (no separate commit event, no wait of its own on the frame stream)
+    if (ahead) { HIPCHK(hipEventRecord(c->pipe.ev_cmd, s)); c->pipe.cmd_covers_commit = true; }
     return 0;
   }
   float *modes = st->work + w.MODES;
@@ -2360,7 +2363,7 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
   hipLaunchKernelGGL(k_post_delay, dim3(ahead ? n : 2 * n), dim3(256), 0, s, c->sys, dsv, 0, n, stv->work + w.PEND, 1, ktt,
                      stv->voltage, st->ld_actu);
   LAUNCHCHK();
-  if (ahead) HIPCHK(hipEventRecord(c->pipe.ev_commit, s));   // the PSF finish of the frame about to be launched overwrites that window
+  if (ahead) { HIPCHK(hipEventRecord(c->pipe.ev_commit, s)); c->pipe.cmd_covers_commit = false; }   // the PSF finish of the frame about to be launched overwrites that window
   return 0;
 }
 
@@ -2622,6 +2625,7 @@ static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *
     LAUNCHCHK();
     HIPCHK(hipEventRecord(P.ev_cmd, s));
     HIPCHK(hipEventRecord(P.ev_commit, s));
+    P.cmd_covers_commit = false;
     // the origins of the move the plain step prefetched
     HIPCHK(hipMemcpyAsync(P.snap[1], st->origin, sizeof(int32_t) * (size_t)n * c->nlayers * 2, hipMemcpyDeviceToDevice,
                           c->atm_stream));
@@ -2643,7 +2647,7 @@ static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *
   if (!rc) rc = env_step_head_fused(c, st, &vq, g, action, gain, reward_out, ktt, true, pe, stream);
   // the frame stream is released behind k_delay_ahead, in front of the Strehl commit that waits for that finish:
   // the frame kernel overwrites the PSF rows it reads, so the frame stream waits for it itself
-  if (!rc && pe && hipStreamWaitEvent(P.fstream, pe, 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
+  if (!rc && pe && !P.cmd_covers_commit && hipStreamWaitEvent(P.fstream, pe, 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
   if (!rc) { P.psf_out[q] = false; rc = pipe_launch_frame(c, st, q, stream); }
   if (!rc) rc = pipe_prefetch(c, st, accumx, accumy, p, q);
   // ---- reduce frame p
@@ -3090,7 +3094,8 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
   if (slot >= 0) {
     c->pipe.ev_done_cur[slot] = ev_done;
     HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
-    HIPCHK(hipStreamWaitEvent(c->psf_stream, c->pipe.ev_commit, 0));   // that parity's pending window has been committed
+    if (!c->pipe.cmd_covers_commit)
+      HIPCHK(hipStreamWaitEvent(c->psf_stream, c->pipe.ev_commit, 0));   // that parity's pending window has been committed
     hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
     LAUNCHCHK();
     HIPCHK(hipEventRecord(c->pipe.ev_psf[slot], c->psf_stream));

@@ -302,6 +302,16 @@ def dtype_string(launches):
     return s + "; f32 vector arithmetic elsewhere"
 
 
+def raw_stream(device):
+    """The caller's current HIP stream on `device` as a ctypes pointer.  torch.cuda.current_stream() builds a Stream
+    object (5 us per call, twice per environment step on a host-bound step); the raw handle is one C call."""
+    import torch
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
 def check(rc):
     if rc != 0:
         raise AomarlError(load().aomarl_last_error().decode("utf-8", "replace"))

@@ -94,11 +94,12 @@ class HipSim(object):
         for k, v in t.items():
             setattr(st, k, v.data_ptr() if v is not None else None)
         self.st = st
+        self._st_ref = C.byref(st)
         self.accumx = np.zeros((n, max(s.nscreens, 1)), dtype=np.float32)
         self.accumy = np.zeros((n, max(s.nscreens, 1)), dtype=np.float32)
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return la.raw_stream(self.device)
 
     def __del__(self):
         try:
@@ -204,10 +205,14 @@ class HipSim(object):
         """One TrainerRPC.env_step for every environment in ONE library call (aomarl_env_step):
         rl_control from Btt coordinates, apply_control, Strehl, per-agent rewards, next_part_one,
         v2m . err, state assembly.  `glue` is a libaomarl.EnvGlue the caller owns."""
-        self._set_defer(self.defer_shape and self.dm_from_voltage_available())
-        la.check(self.lib.aomarl_env_step(self.ctx, C.byref(self.st), C.byref(glue), action.data_ptr(),
-                                          float(gain), la.fptr(self.accumx), la.fptr(self.accumy),
-                                          state_out.data_ptr(),
+        want = self.defer_shape and (self._defer_on or self.dm_from_voltage_available())
+        if want != self._defer_on:
+            self._set_defer(want)
+        ptrs = self.__dict__.get("_accum_ptrs")
+        if ptrs is None or ptrs[0] is not self.accumx or ptrs[1] is not self.accumy:    # (numpy -> ctypes costs ~1 us each)
+            ptrs = self._accum_ptrs = (self.accumx, self.accumy, la.fptr(self.accumx), la.fptr(self.accumy))
+        la.check(self.lib.aomarl_env_step(self.ctx, self._st_ref, glue._ref if hasattr(glue, "_ref") else C.byref(glue),
+                                          action.data_ptr(), gain, ptrs[2], ptrs[3], state_out.data_ptr(),
                                           reward_out.data_ptr() if reward_out is not None else None,
                                           self._stream()))
         self._stale = self._defer_on
@@ -692,7 +697,7 @@ class HipGeoTwin(object):
         self.st = st
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return la.raw_stream(self.device)
 
     @property
     def com(self):
