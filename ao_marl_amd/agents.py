@@ -337,8 +337,16 @@ class BatchedGaussianPolicy(object):
         # [A, nenv, act_max] -> [nenv, action_dim]
         return per_agent[self.sc_agent, :, self.sc_local].T.contiguous()
 
-    @torch.no_grad()
     def select_action(self, state, eval_mode=False, eps=None):
+        """See _select_action: the one-call native path goes straight to the library (no autograd context to
+        enter -- nothing there is a torch operation -- and a host-bound step notices the 3 us)."""
+        if self.use_native and self.native_forward and state.dtype == torch.float32 and \
+                state.dim() == 2 and state.shape[1] == self.layout.state_dim:
+            return self._select_action_one_call(state if state.is_contiguous() else state.contiguous(), eval_mode, eps)
+        return self._select_action(state, eval_mode, eps)
+
+    @torch.no_grad()
+    def _select_action(self, state, eval_mode=False, eps=None):
         """(action, mean), both [nenv, action_dim] in [-1, 1]*scale+bias.  A normal sample is
         always drawn, like the reference does even in eval mode (model_rpc.py:137-144).
         On the GPU the whole tail (clamp, exp, sample, tanh, scale, scatter into the global action

@@ -677,10 +677,12 @@ class VecAoEnv(object):
         sup = self.supervisor
         std = sup.config_rl["normalization_std_inside_environment"]
         mean = sup.config_rl["normalization_mean_inside_environment"]
-        action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        if not (isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.device == self.device):
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
         if std != 1.0 or mean != 0.0:
             action = action * std + mean
-        action = action.contiguous()
+        if not action.is_contiguous():
+            action = action.contiguous()
         if action.shape != (self.nenv, self.action_dim):
             raise ValueError("action must be [nenv, %d]" % self.action_dim)
         if self._glue is None:
