@@ -2181,6 +2181,27 @@ static int env_step_validate(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g
 // Same formulas as the kernels they stand for; the sums of the products run in one thread each, in index order
 // (the split-K GEMM sums tiles): fp32 round-off apart, the same numbers ("small_chain" = 0: the general chain).
 constexpr int SMALL_NM = 512, SMALL_NA = 512, SMALL_NSL = 1024;
+// y[o] = sum_k x[k] W[o][k] for o < no, x in LDS, by a 256-thread block: FOUR threads per output (they read 16
+// consecutive bytes of the row per step, two accumulators each, then two xor-shuffles), 64 outputs per pass.
+// done(o, y) runs in the first thread of each quad.
+template <class F>
+__device__ __forceinline__ void small_gemv(const float *__restrict__ W, int ldw, int no, int K, const float *xs, F done) {
+  const int tid = threadIdx.x, q = tid & 3;
+  for (int o0 = 0; o0 < no; o0 += 64) {
+    const int o = o0 + (tid >> 2);
+    float a0 = 0.f, a1 = 0.f;
+    if (o < no) {
+      const float *row = W + (long long)o * ldw;
+      int k = q;
+      for (; k + 4 < K; k += 8) { a0 = fmaf(xs[k], row[k], a0); a1 = fmaf(xs[k + 4], row[k + 4], a1); }
+      if (k < K) a0 = fmaf(xs[k], row[k], a0);
+    }
+    float y = a0 + a1;
+    y += __shfl_xor(y, 1);
+    y += __shfl_xor(y, 2);
+    if (o < no && q == 0) done(o, y);
+  }
+}
 struct SmallHead {
   int nm, na, nact, n_agents, ld_m2v, ld_actu, ktt, do_strehl;
   float gain, factor, wa, wb, wc;
@@ -2209,16 +2230,13 @@ __global__ __launch_bounds__(256) void k_small_head(DevSys sys, DevState st, Sma
       if (lane == 0) p.rew[(long long)e * p.n_agents + a] = -p.factor * q / (float)(hi - lo);
     }
   __syncthreads();
-  for (int a = tid; a < p.na; a += 256) {
-    const float *row = p.m2v + (long long)a * p.ld_m2v;
-    float c0 = 0.f;
-    for (int m = 0; m < p.nm; m++) c0 = fmaf(sm[m], row[m], c0);
+  small_gemv(p.m2v, p.ld_m2v, p.na, p.nm, sm, [&](int a, float c0) {
     const long long o = (long long)e * p.ld_actu + a;
     const float c1 = st.com1[o], c2 = st.com2[o];
     const float v = p.wa * c0 + p.wb * c1 + p.wc * c2;
     st.com[o] = c0; st.voltage[o] = v; st.com2[o] = c1; st.com1[o] = c0;
     sv[a] = v;
-  }
+  });
   __syncthreads();
   if (p.ktt >= 0 && tid < 3) {                   // dm_shape_tt_body on the voltages just formed
     const DevDm &D = sys.dms[p.ktt];
@@ -2250,24 +2268,18 @@ __global__ __launch_bounds__(256) void k_small_tail(DevState st, SmallTail p, St
   const int e = blockIdx.x, tid = threadIdx.x;
   for (int k = tid; k < p.nsl; k += 256) ss[k] = st.slopes[(long long)e * p.nsl + k];
   __syncthreads();
-  for (int a = tid; a < p.na; a += 256) {
-    const float *row = p.cmat + (long long)a * p.ld_cmat;
-    float acc = 0.f;
-    for (int k = 0; k < p.nsl; k++) acc = fmaf(ss[k], row[k], acc);
+  small_gemv(p.cmat, p.ld_cmat, p.na, p.nsl, ss, [&](int a, float acc) {
     const float v = -acc;
     const long long o = (long long)e * p.ld_actu + a;
     st.err[o] = v;
     st.com[o] += p.gain * v;
     se[a] = v;
-  }
+  });
   __syncthreads();
-  for (int m = tid; m < p.nm; m += 256) {
-    const float *row = p.v2m + (long long)m * p.ld_v2m;
-    float acc = 0.f;
-    for (int a = 0; a < p.na; a++) acc = fmaf(se[a], row[a], acc);
+  small_gemv(p.v2m, p.ld_v2m, p.nm, p.na, se, [&](int m, float acc) {
     p.res_modes[(long long)e * p.nm + m] = acc;
     sr[m] = acc;
-  }
+  });
   __syncthreads();
   for (int j = tid; j < sb.total; j += 256) {
     int b = 0;

@@ -295,6 +295,9 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * "small_move" (default 1: screens of <= 256 pixels with stencil + dim <= 4096 -- the 10x10 files -- move in ONE
  * launch per frame, k_move_small, instead of gather / GEMM / scatter rounds; fp32 vector FMAs in both precision
  * modes; 0: the rounds),
+ * "small_chain" (default 1: systems with <= 512 actuators / modes, <= 1024 slopes and nactu x nslope <= 65536 run the
+ * control / agent chain of aomarl_env_step as two workgroup-per-environment kernels, k_small_head / k_small_tail,
+ * instead of three GEMMs and five elementwise kernels; fp32 round-off apart, the same numbers; 0: the general chain),
  * "frame_pipeline" (default 1; 0 = plain call order although aomarl_set_frame_pipeline gave a twin; refused while
  * a frame is in flight),
  * "defer_dm_shape" (the composites
