@@ -1329,6 +1329,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
     return 0;
   }
   if (!strcmp(name, "gemm_xcd_map")) { g_gemm_xcd = value != 0; return 0; }   // process-wide
+  if (!strcmp(name, "gemm_balanced")) { g_gemm_p = value != 0; return 0; }    // process-wide
   if (!strcmp(name, "gemm_target_blocks")) { g_gemm_target_blocks = value > 0 ? value : 0; return 0; }   // process-wide
   if (!strcmp(name, "gemm_split_f16")) { g_gemm_split_f16 = value != 0; return 0; }          // process-wide
   if (!strcmp(name, "precision")) return aomarl_set_precision(value);                        // process-wide

@@ -1,6 +1,7 @@
 // aomarl_kernels.hip -- CDNA4 (gfx950) kernels of the AO environment hot path.
 // wave = 64 lanes; fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) for the DFT and GEMM work.
 #include "aomarl_dev.h"
+#include "aomarl_gemm_p.h"
 
 #define WAVE 64
 
@@ -844,7 +845,8 @@ static unsigned long long g_arith[AR_N] = {0, 0, 0, 0, 0, 0, 0};
 static const char *const g_arith_name[AR_N] = {
     "frame_kernel_dft:f32_mfma", "frame_kernel_dft:split_f16_mfma", "gemm:f32_mfma", "gemm:split_f16_mfma",
     "denoiser:f32_mfma", "denoiser:split_f16_mfma", "actor:f32_mfma"};
-static int g_gemm_xcd = 1;            // "gemm_xcd_map": k_gemm_nt_h's blocks grouped by k-chunk per XCD
+static int g_gemm_xcd = 1;            // "gemm_xcd_map": k_gemm_nt_h's / k_gemm_p's blocks grouped by k-chunk per XCD
+static int g_gemm_p = 1;              // "gemm_balanced": the fp32 products on k_gemm_p (aomarl_gemm_p.h); 0: k_gemm_nt2
 static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
 // Retired after their A/B runs (profiles/r01g_*): the un-pipelined aligned kernel (30 us vs 22 us per
 // call) and an in-kernel split-K reduction through ticket counters (4x slower: every block pays an
@@ -909,6 +911,39 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
         const long long cost = per_cu * (chunk / 32 + 3);
         if (best < 0 || cost < best) { best = cost; nsplit = ns; }
       }
+    }
+  }
+  const bool split_f16 = al && fast && g_gemm_split_f16;
+  if (al && !split_f16 && g_gemm_p) {
+    // round 4: the balanced kernel; tile and k split from its own cost model (memoised per shape)
+    struct Memo { int M, N, K; size_t ws; GemmPCfg c; };
+    static thread_local Memo memo[16];
+    static thread_local int memo_n = 0;
+    const size_t wsf = ws ? ws_floats : 0;
+    const GemmPCfg *cfg = nullptr;
+    for (int i = 0; i < memo_n; i++)
+      if (memo[i].M == M && memo[i].N == N && memo[i].K == K && memo[i].ws == wsf) { cfg = &memo[i].c; break; }
+    if (!cfg) {
+      Memo &m = memo[memo_n < 16 ? memo_n++ : (memo_n = 1, 0)];
+      m.M = M; m.N = N; m.K = K; m.ws = wsf;
+      m.c = gemm_p_pick(M, N, K, wsf, ws ? 16 : 1);
+      cfg = &m.c;
+    }
+    if (cfg->wm > 0 && gemm_p_launch(*cfg, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ws, g_gemm_xcd, s)) {
+      g_arith[AR_GEMM_F32]++;
+      nsplit = cfg->nz;
+      if (nsplit > 1) {
+        const long long tot = (long long)M * N;
+        if (nsplit_out) { *nsplit_out = nsplit; return false; }
+        if (epi) {
+          hipLaunchKernelGGL(k_gemm_reduce_epi, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, M, N,
+                             nsplit, alpha, ws, beta, C, ldc, *epi);
+          return true;
+        }
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, M, N,
+                           nsplit, alpha, ws, beta, C, ldc);
+      }
+      return false;
     }
   }
   int kchunk = ((K + nsplit - 1) / nsplit + 31) & ~31;
