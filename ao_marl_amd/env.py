@@ -379,7 +379,7 @@ class VecAoEnv(object):
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
                  strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None,
-                 geo=False, prefetch_atmos=True, frame_pipeline=False):
+                 geo=False, prefetch_atmos=True, frame_pipeline="auto"):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -460,9 +460,15 @@ class VecAoEnv(object):
         self.native_step = True
         self.fused_tail = True       # ... with the reductions folded into their consumers (see include/aomarl.h)
         # frames one step ahead of the chains (aomarl_set_frame_pipeline; loop delay of one frame, noise-free
-        # sensor -- the library takes the plain order whenever a step is not eligible).  Opt-in: between two
-        # resets such an environment takes step() calls only (no call-by-call pieces, no linear_control steps).
-        self.frame_pipeline = bool(frame_pipeline)
+        # sensor -- the library takes the plain order whenever a step is not eligible).  Between two resets a
+        # pipelined environment takes step() calls only (no call-by-call pieces, no linear_control steps: they
+        # raise, naming this argument).  "auto" (default): pipelined when eligible AND not slower on this
+        # process's streams (one probe of both orders behind the first reset, see _probe_order); True: whenever
+        # eligible, no probe; False: plain call order.
+        if frame_pipeline not in (True, False, "auto"):
+            raise ValueError("frame_pipeline: True, False or 'auto'")
+        self.frame_pipeline = frame_pipeline
+        self.order_probe = None      # {"pipelined": ms/step, "plain": ms/step, "chosen": ...} once probed
         # Btt coordinates of the last number_of_previous_dm + 1 commands, newest in slot _ring_pos
         self._ring, self._ring_pos, self._ring_next_valid = None, 0, False
         self._res_modes, self._glue, self._glue_keep = None, None, None
@@ -534,7 +540,72 @@ class VecAoEnv(object):
                 self._ring.zero_()
             self._ring_pos, self._glue = 0, None
             self._out_pos = 0
-        return self.linear_step()
+        state = self.linear_step()
+        if self.frame_pipeline == "auto" and not self._probing:
+            if self._pipe_eligible():
+                state = self._probe_order(state)
+            else:
+                self.frame_pipeline = False
+        return state
+
+    # call orders probed per (device, caller stream): the HIP runtime multiplexes streams onto hardware queues
+    # (ao_marl_amd/__init__.py); a caller stream that shares one with the library's frame stream serialises the
+    # pipelined order (1.0 against 0.6 ms per step seen).  One probe per process and stream pair.
+    _ORDER_CACHE = {}
+    _probing = False
+
+    def _pipe_eligible(self):
+        sup = self.supervisor
+        return bool(self._native_glue and self._default_state_layout and self._ring is not None and
+                    hasattr(sup.sim, "enable_frame_pipeline") and sup.autoencoder is None and
+                    sup.s.delay == 1.0 and sup.s.noise < 0 and sup.prefetch_atmos and sup.geo is None and
+                    not getattr(sup.sim, "graph_step", False))
+
+    def _probe_order(self, state, steps=28, skip=6, margin=1.03):
+        """Behind the first reset of an eligible environment: `steps` steps with zero actions in the pipelined and
+        in the plain call order, the period between the states of step `skip` and step `steps` becoming ready on the
+        caller's stream (device events).  The pipelined order is kept unless it is more than `margin` times SLOWER
+        than the plain one (aliased hardware queues) -- then a warning says so and the environment runs in the
+        plain order.  The environment is reset again afterwards (same seeds: same episode)."""
+        import warnings
+        key = (str(self.device), int(torch.cuda.current_stream(self.device).cuda_stream), self.nenv,
+               self.supervisor.s.name if hasattr(self.supervisor.s, "name") else "")
+        cached = VecAoEnv._ORDER_CACHE.get(key)
+        if cached is not None:
+            self.order_probe = dict(cached, cached=True)
+            self.frame_pipeline = cached["chosen"] == "pipelined"
+            return state
+        sim = self.supervisor.sim
+        zero = torch.zeros(self.nenv, self.action_dim, device=self.device)
+        res = {}
+        self._probing = True
+        try:
+            for name, on in (("plain", False), ("pipelined", True)):      # (the twin of the second pass stays)
+                self.frame_pipeline, self._pipe_checked = on, False
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for k in range(steps):
+                    self.step(zero)
+                    if k == skip - 1:
+                        e0.record()
+                e1.record()
+                e1.synchronize()
+                res[name] = e0.elapsed_time(e1) / (steps - skip)
+                state = self.reset()
+        finally:
+            self._probing = False
+        slower = res["pipelined"] > margin * res["plain"]
+        res["chosen"] = "plain" if slower else "pipelined"
+        if slower:
+            warnings.warn("VecAoEnv: the pipelined call order is slower than the plain one on this process's streams "
+                          "(%.3f against %.3f ms per step: the caller's stream probably shares a hardware queue with the "
+                          "library's frame stream; GPU_MAX_HW_QUEUES=8 before the first HIP call avoids it); running in "
+                          "the plain order" % (res["pipelined"], res["plain"]))
+        self.frame_pipeline = not slower
+        if slower:
+            sim.enable_frame_pipeline(False)               # (behind a reset: nothing in flight)
+        VecAoEnv._ORDER_CACHE[key] = dict(res)
+        self.order_probe = res
+        return state
 
     def linear_step(self, return_dict=False):
         """ao_env.py:871-909"""
@@ -708,10 +779,9 @@ class VecAoEnv(object):
         ae = sup.autoencoder
         if ae is not None:
             ae._used_fp16 = ae._used_fp16 or not g.denoiser_f32
-        if self.frame_pipeline and not self._pipe_checked:
+        if self.frame_pipeline is True and not self._pipe_checked:
             self._pipe_checked = True
-            if (hasattr(sup.sim, "enable_frame_pipeline") and ae is None and sup.s.delay == 1.0 and sup.s.noise < 0 and
-                    sup.prefetch_atmos and not getattr(sup.sim, "graph_step", False)):
+            if self._pipe_eligible():
                 sup.sim.enable_frame_pipeline()
         sup.sim.env_step(g, action, sup.gain, state, r)
         self._ring_pos = g.ring_pos

@@ -67,8 +67,11 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=40,
-                    help="untimed steps in front of the timed region (the first ~40 steps behind a reset run 5-10 % slower)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps right in front of the timed region")
+    ap.add_argument("--settle", type=int, default=40,
+                    help="episode position of the warm-up: untimed steps behind the reset in front of it.  The first ~40 "
+                         "frames behind a reset run 3-10 %% slower (the loop is still closing); they are timed on their "
+                         "own and their excess over the steady rate is amortised with the reset (`post_reset_transient_ms`)")
     ap.add_argument("--envs", type=int, default=256, help="environments per GPU")
     ap.add_argument("--config", default=WORKLOAD)
     ap.add_argument("--episode-len", type=int, default=1000,
@@ -85,7 +88,10 @@ def parse_args():
                     help="residual modes from one product with v2m.cmat instead of do_control + "
                          "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
     ap.add_argument("--frame-pipeline-always", action="store_true",
-                    help="no probe of the call order in front of the timed region: pipelined whenever eligible")
+                    help="VecAoEnv(frame_pipeline=True): pipelined whenever eligible, without the package's probe of "
+                         "both call orders behind the first reset (the default, frame_pipeline='auto')")
+    ap.add_argument("--no-whole-episode", action="store_true",
+                    help="skip the measured whole episode (reset + episode_len steps) behind the timed region")
     ap.add_argument("--timed-only", action="store_true",
                     help="nothing but warm-up + the timed region on the GPU (profiling): no plain-order pass, no stage split")
     ap.add_argument("--no-frame-pipeline", action="store_true",
@@ -277,7 +283,7 @@ def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
 class Workload(object):
     """A VecAoEnv + random-init batched SAC actors for one BASELINE configuration."""
 
-    def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True, pipeline=True):
+    def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True, pipeline="auto"):
         import torch
         from ao_marl_amd.agents import BatchedGaussianPolicy
         from ao_marl_amd.env import VecAoEnv, load_norm
@@ -306,7 +312,7 @@ class Workload(object):
         self.first_seed = shard_seeds(1234, envs, rank, stride=16)
         self.env = VecAoEnv(config, envs, rl, initial_seed=self.first_seed, seed_stride=16,
                             n_agents_modal=n_modal, device=device, autoencoder=autoencoder,
-                            prefetch_atmos=prefetch, frame_pipeline=pipeline and prefetch, **norm_kw)
+                            prefetch_atmos=prefetch, frame_pipeline=pipeline if prefetch else False, **norm_kw)
         self.layout = self.env.layout
         # random-init actors (last layer NOT zeroed, so actions are non-trivial): the cost of a step
         # does not depend on the weights; the loop is not expected to converge (Strehl is reported
@@ -327,15 +333,24 @@ class Workload(object):
     def reset(self):
         self.state = self.env.reset()
 
-    def timed(self, steps, warmup, dist=None, backend="nccl", time_frame=True):
-        """W untimed + exactly K timed steps between barriers + synchronisations.  Returns (elapsed s
-        -- MAX over ranks --, host enqueue s, frame-kernel ms per launch from the library's events)."""
+    def timed(self, steps, warmup, dist=None, backend="nccl", time_frame=True, settle=0):
+        """`settle` untimed steps (timed on their own: self.settle_s), W untimed warm-up steps, then exactly K timed
+        steps between barriers + synchronisations.  Returns (elapsed s -- MAX over ranks --, host enqueue s,
+        frame-kernel ms per launch from the library's events)."""
         torch = self.torch
         # no cyclic-garbage collection inside the timed region: a collection that frees an earlier
         # configuration's device buffers (hipFree synchronises the device) would be charged to this one
         gc.collect()
         gc.disable()
         try:
+            self.settle_s, self.settle_steps = 0.0, settle
+            if settle:
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for _ in range(settle):
+                    self.one_step()
+                torch.cuda.synchronize()
+                self.settle_s = time.perf_counter() - ts
             for _ in range(warmup):
                 self.one_step()
             torch.cuda.synchronize()
@@ -370,34 +385,35 @@ class Workload(object):
             elapsed = float(t.item())
         return elapsed, t_enq, fk_ms
 
-    def pick_order(self, steps=40, margin=1.05):
-        """Untimed probe BEFORE the timed region: the pipelined against the plain call order on this process's
-        streams.  The HIP runtime multiplexes streams onto hardware queues (ao_marl_amd/__init__.py); if the
-        caller's stream happens to share one with the library's frame stream the pipelined order serialises and
-        is the SLOWER one (1.0 against 0.65 ms per step, seen with a second caller stream) -- then the timed
-        region runs in the plain order.  Period = time between the states of step 8 and step `steps` becoming
-        ready on the caller's stream (device events: the frame the pipelined order keeps in flight beyond the last
-        step is not charged to it); the plain order is chosen only when the pipelined one is more than `margin`
-        times slower.  Returns {order: ms per step} or None when the pipeline is off."""
-        if not self.env.frame_pipeline:
-            return None
-        torch, res = self.torch, {}
-        for name, on in (("pipelined", 1), ("plain", 0)):
-            self.reset()
-            self.sim.set_option("frame_pipeline", on)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for k in range(steps):
-                self.one_step()
-                if k == 7:
-                    e0.record()
-            e1.record()
+    def transient_excess(self, steps, elapsed):
+        """What the `settle` steps behind the reset took beyond the steady rate of the timed region (s, >= 0): the
+        post-reset transient, amortised over the episode like the reset itself."""
+        if not self.settle_steps:
+            return 0.0
+        return max(0.0, self.settle_s - self.settle_steps * elapsed / steps)
+
+    def time_episode(self, episode_len, dist=None, backend="nccl"):
+        """One WHOLE episode, measured: reset + episode_len steps between synchronisations (MAX over ranks)."""
+        torch = self.torch
+        gc.collect()
+        gc.disable()
+        try:
             torch.cuda.synchronize()
-            res[name] = e0.elapsed_time(e1) / (steps - 8)
-        self.reset()
-        plain = res["pipelined"] > margin * res["plain"]
-        self.sim.set_option("frame_pipeline", 0 if plain else 1)
-        res["chosen"] = "plain" if plain else "pipelined"
-        return res
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            self.reset()
+            for _ in range(episode_len):
+                self.one_step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     def time_reset(self, dist=None, backend="nccl"):
         """One env.reset() (RlSupervisor.reset: 2n extrusions per layer + the first frame), MAX over ranks."""
@@ -445,7 +461,7 @@ def roofline_block(model, fk_ms, kernel_name, args_pmc, envs, config):
     return r
 
 
-def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None):
+def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None, settle=40):
     """A BASELINE configuration other than the headline one, same loop, same accounting (1 GPU): the
     all-fp32 pass is the figure, the split-fp16 pass rides along as `fast_mode`."""
     from ao_marl_amd import libaomarl
@@ -457,10 +473,9 @@ def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None)
         try:
             w.reset()
             reset_s = w.time_reset()
-            w.pick_order()
-            elapsed, _, fk = w.timed(steps, warmup, time_frame=True)
+            elapsed, _, fk = w.timed(steps, warmup, time_frame=True, settle=settle)
             rec = {"dtype": libaomarl.dtype_string(w.launched),
-                   "value": amortised(envs, steps, elapsed, reset_s, episode_len),
+                   "value": amortised(envs, steps, elapsed, reset_s + w.transient_excess(steps, elapsed), episode_len),
                    "value_no_reset": envs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
                    "reset_ms": reset_s * 1e3, "frame_kernel_ms": fk,
                    "frame_kernel": w.sim.frame_kernel_name(),
@@ -529,7 +544,8 @@ def main():
         denoiser = "shipped"
     libaomarl.set_precision(args.precision)
     w = Workload(args.config, args.envs, rank, world, device, denoiser=denoiser,
-                 prefetch=not args.no_prefetch, pipeline=not args.no_frame_pipeline)
+                 prefetch=not args.no_prefetch,
+                 pipeline=False if args.no_frame_pipeline else (True if args.frame_pipeline_always else "auto"))
     env, sim, layout = w.env, w.sim, w.layout
     env.residual_shortcut = bool(args.residual_shortcut)
     if args.unfused:
@@ -540,13 +556,13 @@ def main():
         sim.set_option("graph_step", 1)
         w.policy.out_ring = 6                       # stable output addresses for the replays
 
-    w.reset()
+    w.reset()                                       # (the first reset: VecAoEnv probes both call orders behind it)
+    order_probe = env.order_probe
     reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
-    # untimed: which call order this process's streams favour (skipped with --frame-pipeline-always)
-    order_probe = None if args.frame_pipeline_always else w.pick_order()
-    elapsed, t_enq, fk_ms = w.timed(args.steps, args.warmup, dist, backend)
+    elapsed, t_enq, fk_ms = w.timed(args.steps, args.warmup, dist, backend, settle=args.settle)
     envs_total = args.envs * world
-    value = amortised(envs_total, args.steps, elapsed, reset_s, args.episode_len)
+    transient_s = w.transient_excess(args.steps, elapsed)
+    value = amortised(envs_total, args.steps, elapsed, reset_s + transient_s, args.episode_len)
     kernel_name = sim.frame_kernel_name()
     launched = dict(w.launched)
     sr = float(sim.strehl[:, 1].mean())
@@ -564,13 +580,20 @@ def main():
         shards = got
 
     pipe_state = sim.frame_pipeline_state()
+    # one whole episode, measured (reset + episode_len steps): what `value` amortises, without the amortisation
+    whole = None
+    if not args.timed_only and not args.no_whole_episode:
+        ep_s = w.time_episode(args.episode_len, dist, backend)
+        whole = {"steps": args.episode_len, "seconds": ep_s, "value": envs_total * args.episode_len / ep_s,
+                 "ms_per_step": ep_s / args.episode_len * 1e3,
+                 "what": "reset + episode_len steps of the same loop between two synchronisations, behind the timed region"}
     # the same steps in the plain call order (frame kernel alone on the GPU, the chains behind it): what the
     # pipeline buys, and the frame kernel's duration without the chains' kernels beside it
     plain = None
     if pipe_state[0] and not args.timed_only:
         w.reset()
         sim.set_option("frame_pipeline", 0)
-        e_p, _, fk_p = w.timed(min(args.steps, 40), min(args.warmup, 5), dist, backend)
+        e_p, _, fk_p = w.timed(min(args.steps, 40), min(args.warmup, 5), dist, backend, settle=args.settle)
         plain = {"ms_per_step_no_reset": e_p / min(args.steps, 40) * 1e3, "frame_kernel_ms": fk_p}
         w.reset()
         sim.set_option("frame_pipeline", 1)
@@ -608,6 +631,12 @@ def main():
             "value_no_reset": envs_total * args.steps / elapsed,
             "ms_per_step_no_reset": elapsed / args.steps * 1e3,
             "reset_ms": reset_s * 1e3,
+            "post_reset_transient_ms": transient_s * 1e3,
+            "episode_position": {"settle": args.settle, "warmup": args.warmup,
+                                 "what": "the timed steps are frames [settle + warmup, settle + warmup + steps) of an episode; "
+                                         "`value` = steps / (timed seconds + steps / episode_len x (reset + transient excess "
+                                         "of the first `settle` frames)); `whole_episode` is the same thing measured"},
+            "whole_episode": whole,
             "roofline": roof,
             "launched": {k: v for k, v in launched.items() if v},
             "stage_ms": stage_diag, "atmos_prefetch": bool(env.supervisor.prefetch_atmos),
@@ -634,9 +663,9 @@ def main():
                 libaomarl.set_precision("split_f16")
                 w.reset()
                 rs16 = w.time_reset()
-                e16, _, fk16 = w.timed(args.steps, args.warmup)
+                e16, _, fk16 = w.timed(args.steps, args.warmup, settle=args.settle)
                 out["fast_mode"] = {"dtype": libaomarl.dtype_string(w.launched),
-                                    "value": amortised(args.envs, args.steps, e16, rs16, args.episode_len),
+                                    "value": amortised(args.envs, args.steps, e16, rs16 + w.transient_excess(args.steps, e16), args.episode_len),
                                     "value_no_reset": args.envs * args.steps / e16,
                                     "ms_per_step_no_reset": e16 / args.steps * 1e3, "reset_ms": rs16 * 1e3,
                                     "launched": {k: v for k, v in w.launched.items() if v},

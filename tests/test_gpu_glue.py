@@ -136,7 +136,7 @@ def test_one_call_step_is_the_call_by_call_step(denoise, fused_tail):
     if denoise:     # no statistics shipped for the d0 file: those of its d1 sibling (same system) do
         from ao_marl_amd.env import load_norm
         kw["norm"], kw["zn_norm"] = load_norm("production_sh_40x40_8m_3layers_d1_noise")
-    mk = lambda: VecAoEnv(name, 3, rl, n_agents_modal=nag,                       # noqa: E731
+    mk = lambda: VecAoEnv(name, 3, rl, n_agents_modal=nag, frame_pipeline=False,     # noqa: E731  (pieces are mixed in)
                           autoencoder=SubapDenoiser.load(device="cuda:0") if denoise else None, **kw)
     a, b = mk(), mk()
     b.native_step = False
