@@ -568,6 +568,19 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
         s.psf_tw_f = devf;
       }
       UP(uint16_t, tmask.data(), tmask.size(), s.tile_mask);
+      {
+        // tip-tilt planes as the frame kernel reads them (k_frame_wave: tvo): pupil pixel (y, 4 g + j)
+        const DevDm &T = s.dms[1];
+        std::vector<float> tp((size_t)pd * pd * 2);
+        for (int y = 0; y < pd; y++)
+          for (int g = 0; g < pd / 4; g++)
+            for (int j = 0; j < 4; j++) {
+              const size_t o = (size_t)(y + T.toy) * T.dim + T.tox + 4 * g + j;
+              float *dst = &tp[((size_t)y * (pd / 4) + g) * 8];
+              dst[j] = c->h_tt[2 * o]; dst[4 + j] = c->h_tt[2 * o + 1];
+            }
+        UP(float, tp.data(), tp.size(), s.tt_pk);
+      }
       s.fused_ok = 1; s.ntiles = nt;
       // stack-array DM evaluated from the command lattice inside the frame kernel
       const DevDm &Z = s.dms[0];

@@ -1843,6 +1843,130 @@ __device__ __forceinline__ void spot_cog_f32(const DevSys &sys, const DevState &
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packed fp32 vector arithmetic, hand-emitted.  On this chip fp32 matrix instructions run at the PACKED-fp32
+// vector rate and share the issue slots with the vector unit, so a v_pk_fma_f32 does twice
+// the work of a v_fma_f32 for the same 4 issue cycles -- but the compiler's pre-emit peephole splits packed fp32
+// operations that follow matrix instructions back into scalar ones (it assumes a separate matrix pipe), and the
+// vector work of the frame kernel sits exactly there.  Inline asm keeps them packed.  The price: the compiler's
+// hazard recogniser does not look inside inline asm, so the software-visible wait states of gfx950 are kept BY
+// HAND -- a result of v_mfma_f32_16x16x4_f32 (8 passes) must not be read by a vector instruction for 10 wait
+// states, a transcendental's result not by a non-transcendental for 1: every group of packed instructions whose
+// inputs come from matrix or transcendental instructions opens with PK_GUARD_*: a scheduling barrier (everything
+// written before it in the source is issued before it) and an s_nop that covers the longest such distance.
+// All statements are `asm volatile`: they stay in source order among themselves.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PK_GUARD_MFMA() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 10"); } while (0)
+#define PK_GUARD_TRANS() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1"); } while (0)
+// (a group's results feed matrix instructions: two wait states of margin, although gfx950 documents none)
+#define PK_END_TO_MFMA() do { asm volatile("s_nop 1"); __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ __forceinline__ f32x2 pk_lo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 pk_hi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// a * b - c
+__device__ __forceinline__ f32x2 pk_fma_nc(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// c - a * b
+__device__ __forceinline__ f32x2 pk_fma_na(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x4 pk_join(f32x2 lo, f32x2 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
+
+// spot_cog_f32 with its vector arithmetic packed (same formulas, the sums in pairs): 8 + 24 packed instructions for
+// the stage-1 combinations and the P / D sums instead of 16 + 48 scalar ones.
+__device__ __forceinline__ void spot_cog_f32_pk(const DevSys &sys, const DevState &st, int e, int i, int lane,
+                                                const float (&Cc)[4], const float (&Ss)[4], const float (&br)[4],
+                                                const float (&bi)[4], int do_cog, const f32x4 z4) {
+  const int q = lane >> 4, c = lane & 15;
+  // ---- stage 1 (y = c on M, x = 4q + s on K, k = c on N)
+  f32x4 PCr = z4, PCi = z4, PSr = z4, PSi = z4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    PCr = mfma16(br[s], Cc[s], PCr);
+    PCi = mfma16(bi[s], Cc[s], PCi);
+    PSr = mfma16(br[s], Ss[s], PSr);
+    PSi = mfma16(bi[s], Ss[s], PSi);
+  }
+  // [0]: kx = +(k+1/2): (PCr + PSi, PCi - PSr)   [1]: kx = -(k+1/2): (PCr - PSi, PCi + PSr)
+  PK_GUARD_MFMA();
+  const f32x2 tr0l = pk_add(pk_lo(PCr), pk_lo(PSi)), ti0l = pk_sub(pk_lo(PCi), pk_lo(PSr));
+  const f32x2 tr0h = pk_add(pk_hi(PCr), pk_hi(PSi)), ti0h = pk_sub(pk_hi(PCi), pk_hi(PSr));
+  const f32x2 tr1l = pk_sub(pk_lo(PCr), pk_lo(PSi)), ti1l = pk_add(pk_lo(PCi), pk_lo(PSr));
+  const f32x2 tr1h = pk_sub(pk_hi(PCr), pk_hi(PSi)), ti1h = pk_add(pk_hi(PCi), pk_hi(PSr));
+  PK_END_TO_MFMA();
+  const f32x4 TrA[2] = {pk_join(tr0l, tr0h), pk_join(tr1l, tr1h)};
+  const f32x4 TiA[2] = {pk_join(ti0l, ti0h), pk_join(ti1l, ti1h)};
+  f32x2 Pa[2], Pb[2];                            // P of half m in two partial pairs
+  f32x2 Da = {0.f, 0.f}, Db = {0.f, 0.f};        // D over registers (0, 1) and (2, 3), both halves
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const f32x4 Tr = TrA[m], Ti = TiA[m];
+    f32x4 QCr = z4, QCi = z4, QSr = z4, QSi = z4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      QCr = mfma16(Cc[s], Tr[s], QCr);
+      QCi = mfma16(Cc[s], Ti[s], QCi);
+      QSr = mfma16(Ss[s], Tr[s], QSr);
+      QSi = mfma16(Ss[s], Ti[s], QSi);
+    }
+    PK_GUARD_MFMA();
+    const f32x2 crl = pk_lo(QCr), crh = pk_hi(QCr), cil = pk_lo(QCi), cih = pk_hi(QCi);
+    const f32x2 srl = pk_lo(QSr), srh = pk_hi(QSr), sil = pk_lo(QSi), sih = pk_hi(QSi);
+    f32x2 pa = pk_mul(crl, crl), pb = pk_mul(crh, crh);
+    Da = pk_fma(crl, sil, Da); Db = pk_fma(crh, sih, Db);
+    pa = pk_fma(sil, sil, pa); pb = pk_fma(sih, sih, pb);
+    Da = pk_fma_na(cil, srl, Da); Db = pk_fma_na(cih, srh, Db);
+    pa = pk_fma(cil, cil, pa); pb = pk_fma(cih, cih, pb);
+    pa = pk_fma(srl, srl, pa); pb = pk_fma(srh, srh, pb);
+    Pa[m] = pa; Pb[m] = pb;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const f32x2 P0 = pk_add(Pa[0], Pb[0]), P1 = pk_add(Pa[1], Pb[1]);
+  const float Xp = (float)(8 + (c >> 1)), Xm = (float)(7 - (c >> 1));
+  const float p0 = P0.x + P0.y, p1 = P1.x + P1.y, da = Da.x + Da.y, db = Db.x + Db.y;
+  float s0 = p0 + p1;
+  float sx = fmaf(Xm, p1, Xp * p0);
+  float sy = fmaf((float)(3 + 4 * q), db, fmaf((float)(1 + 4 * q), da, 7.5f * s0));
+  s0 = wave_sum_last(s0);
+  sx = wave_sum_last(sx);
+  sy = wave_sum_last(sy);
+  if (do_cog && lane == 63) {
+    float *sl = st.slopes + (long long)e * sys.nslope;
+    if (s0 > 0.f) {
+      const float inv = __builtin_amdgcn_rcpf(s0);       // 1 ulp; slopes are compared at 1e-4"
+      sl[i] = (sx * inv - sys.cog_offset) * sys.cog_scale;
+      sl[sys.nvalid + i] = (sy * inv - sys.cog_offset) * sys.cog_scale;
+    } else {
+      sl[i] = 0.f;
+      sl[sys.nvalid + i] = 0.f;
+    }
+  }
+}
+
 // flux normalisation (+noise), COG on the binned quadrant values v[sy][sx][h]
 template <bool NOISE, bool WRITE_CUBE>
 __device__ __forceinline__ void spot_finish_v(const DevSys &sys, const DevState &st, int e, int i,
@@ -2511,17 +2635,19 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   const float c0 = ttslot[0], c1 = ttslot[1];
   const int half = pd / 2;
   const unsigned pvo = 4u * ((unsigned)(y + D0.toy) * (unsigned)D0.dim + (unsigned)D0.tox + 4u * (unsigned)q);
-  const unsigned tvo = 8u * ((unsigned)(y + D1.toy) * (unsigned)D1.dim + (unsigned)D1.tox + 4u * (unsigned)q);
+  // tip-tilt planes re-arranged per 4 pixels of a pupil row: [x0 x1 x2 x3 | y0 y1 y2 y3] (sys.tt_pk), so that a
+  // lane's two 16-byte halves are the x-plane and the y-plane values of its 4 pixels (pairs for packed FMAs)
+  const unsigned tvo = 32u * ((unsigned)y * (unsigned)(pd >> 2) + (unsigned)q);
   const unsigned mvo = 2u * (unsigned)y * (unsigned)ntl;
   const char *pztb = reinterpret_cast<const char *>(pzt);
-  const char *ttb = reinterpret_cast<const char *>(D1.influ);
+  const char *ttb = reinterpret_cast<const char *>(sys.tt_pk);
   const char *mkb = reinterpret_cast<const char *>(sys.tile_mask);
   // (selected with scalar selects, not in two branches: the descriptor must stay provably wave-uniform, or
   // every load through it is wrapped in a waterfall loop)
   const bool sh_tt = wv < 2;
   const void *shbase = sh_tt ? static_cast<const void *>(ttb) : (HP ? sys.psf_tw_h : sys.psf_tw_f);
   const __amdgpu_buffer_rsrc_t shrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void *>(shbase), 0, sh_tt ? 8 * D1.dim * D1.dim : ntl * 1024, 0x00020000);
+      const_cast<void *>(shbase), 0, sh_tt ? 8 * pd * pd : ntl * 1024, 0x00020000);
   const unsigned shvo = sh_tt ? tvo + 16u * (unsigned)wv : 16u * (unsigned)lane;
   shstep = sh_tt ? 7u : 10u;          // log2 of the bytes per tile (a shift stays on the scalar unit; the
                                       // compiler turns a multiplication into a VECTOR mul24 + waterfall loop)
@@ -2575,6 +2701,16 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   float R0r = 0.f, R0i = 0.f;                                     // kx = 0: row sums of this lane's 4 columns
   float sd = 0.f, sd2 = 0.f, sm = 0.f;
   int nlit = 0;
+  // packed-fp32 form of the tile's vector arithmetic (fp32 arithmetic with the stack-array DM evaluated in here:
+  // the instantiations the loop launches).  The pivot of the variance sums goes into the C operand of the
+  // lattice product, so the phase of the tile comes out as phase - pivot: a piston, invisible to |.|^2 of either
+  // path, and the variance sums take the phase as it stands.
+  constexpr bool PK = OTF && !HP;
+  const f32x4 NP4 = {-pivot, -pivot, -pivot, -pivot};
+  const f32x2 c0c0 = {c0, c0}, c1c1 = {c1, c1};
+  const f32x2 wil2 = {sys.wfs_inv_lambda, sys.wfs_inv_lambda}, til2 = {sys.tar_inv_lambda, sys.tar_inv_lambda};
+  f32x2 sdp = {0.f, 0.f}, sd2p = {0.f, 0.f}, R0rp = {0.f, 0.f}, R0ip = {0.f, 0.f};
+  int nfull = 0;
 
   const const_float_p cflux = (const_float_p)(unsigned long long)sys.flux;
   // Loads of one lit tile.  UNCONDITIONAL: the loops below walk the compact list of this stripe's
@@ -2610,7 +2746,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   auto tile = [&](int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt) {
     const int t = (info >> 24) & 0x7F;
     // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
-    f32x4 S = Z4;
+    f32x4 S = PK ? NP4 : Z4;
     if (OTF) {
       f32x4 U = Z4;
 #pragma unroll
@@ -2636,10 +2772,52 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     // a branch that issues loads makes the compiler wait for ALL loads in flight, vmcnt(0), on both sides)
     // ---- phase of the 4 pixels, both complex amplitudes (registers)
     float wr[4], wi[4], ar[4], ai[4];
-    if (info & FW_FULL) {
+    if constexpr (PK) {
+      // phase - pivot of the 4 pixels as two pairs: S + c0 X + c1 Y + layers (10 packed instructions)
+      const f32x2 X01 = {cur.T[0], cur.T[1]}, X23 = {cur.T[2], cur.T[3]};
+      const f32x2 Y01 = {cur.T[4], cur.T[5]}, Y23 = {cur.T[6], cur.T[7]};
+      PK_GUARD_MFMA();
+      f32x2 p01 = pk_fma(X01, c0c0, pk_lo(S)), p23 = pk_fma(X23, c0c0, pk_hi(S));
+      p01 = pk_fma(Y01, c1c1, p01); p23 = pk_fma(Y23, c1c1, p23);
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const f32x2 l01 = {cur.L[l][0], cur.L[l][1]}, l23 = {cur.L[l][2], cur.L[l][3]};
+        p01 = pk_add(p01, l01); p23 = pk_add(p23, l23);
+      }
+      if (info & FW_FULL) {
+        const f32x2 t01 = pk_mul(p01, wil2), t23 = pk_mul(p23, wil2);
+        const f32x2 b01 = pk_mul(p01, til2), b23 = pk_mul(p23, til2);
+        sdp = pk_add(sdp, p01); sd2p = pk_fma(p01, p01, sd2p);
+        const f32x2 r01 = {rintf(t01.x), rintf(t01.y)}, r23 = {rintf(t23.x), rintf(t23.y)};
+        sdp = pk_add(sdp, p23); sd2p = pk_fma(p23, p23, sd2p);
+        const f32x2 a01 = pk_fma_nc(p01, wil2, r01), a23 = pk_fma_nc(p23, wil2, r23);
+        wr[0] = __builtin_amdgcn_cosf(a01.x); wi[0] = __builtin_amdgcn_sinf(a01.x);
+        wr[1] = __builtin_amdgcn_cosf(a01.y); wi[1] = __builtin_amdgcn_sinf(a01.y);
+        wr[2] = __builtin_amdgcn_cosf(a23.x); wi[2] = __builtin_amdgcn_sinf(a23.x);
+        wr[3] = __builtin_amdgcn_cosf(a23.y); wi[3] = __builtin_amdgcn_sinf(a23.y);
+        ar[0] = __builtin_amdgcn_cosf(b01.x); ai[0] = __builtin_amdgcn_sinf(b01.x);
+        ar[1] = __builtin_amdgcn_cosf(b01.y); ai[1] = __builtin_amdgcn_sinf(b01.y);
+        ar[2] = __builtin_amdgcn_cosf(b23.x); ai[2] = __builtin_amdgcn_sinf(b23.x);
+        ar[3] = __builtin_amdgcn_cosf(b23.y); ai[3] = __builtin_amdgcn_sinf(b23.y);
+        nfull++;
+      } else {
+        const float ph4[4] = {p01.x, p01.y, p23.x, p23.y};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float ph = ph4[j];
+          const bool m = (cur.mrow >> (4 * q + j)) & 1u;
+          float a_ = ph * wfs_il; a_ -= rintf(a_);
+          const float b_ = sci_rev(ph, tar_il);
+          wr[j] = m ? __builtin_amdgcn_cosf(a_) : 0.f; wi[j] = m ? __builtin_amdgcn_sinf(a_) : 0.f;
+          ar[j] = m ? __builtin_amdgcn_cosf(b_) : 0.f; ai[j] = m ? __builtin_amdgcn_sinf(b_) : 0.f;
+          const float d = m ? ph : 0.f;
+          sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
+        }
+      }
+    } else if (info & FW_FULL) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float ph = (OTF ? S[j] : cur.P[OTF ? 0 : j]) + (c0 * cur.T[2 * j] + c1 * cur.T[2 * j + 1]);
+        float ph = (OTF ? S[j] : cur.P[OTF ? 0 : j]) + (c0 * cur.T[j] + c1 * cur.T[4 + j]);
 #pragma unroll
         for (int l = 0; l < NL; l++) ph += cur.L[l][j];
         float a_ = ph * wfs_il; a_ -= rintf(a_);
@@ -2653,7 +2831,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     } else {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float ph = (OTF ? S[j] : cur.P[OTF ? 0 : j]) + (c0 * cur.T[2 * j] + c1 * cur.T[2 * j + 1]);
+        float ph = (OTF ? S[j] : cur.P[OTF ? 0 : j]) + (c0 * cur.T[j] + c1 * cur.T[4 + j]);
 #pragma unroll
         for (int l = 0; l < NL; l++) ph += cur.L[l][j];
         const bool m = (cur.mrow >> (4 * q + j)) & 1u;
@@ -2668,8 +2846,16 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     fetch(infon, nxt);                                       // these loads fly during the MFMAs
     // ---- science path (see the kernel's header)
     if (!(dbg & 2)) {
-      R0r += (ar[0] + ar[1]) + (ar[2] + ar[3]);
-      R0i += (ai[0] + ai[1]) + (ai[2] + ai[3]);
+      if constexpr (PK) {
+        const f32x2 ar01 = {ar[0], ar[1]}, ar23 = {ar[2], ar[3]}, ai01 = {ai[0], ai[1]}, ai23 = {ai[2], ai[3]};
+        PK_GUARD_TRANS();
+        const f32x2 sr_ = pk_add(ar01, ar23), si_ = pk_add(ai01, ai23);
+        R0rp = pk_add(R0rp, sr_); R0ip = pk_add(R0ip, si_);
+        PK_END_TO_MFMA();
+      } else {
+        R0r += (ar[0] + ar[1]) + (ar[2] + ar[3]);
+        R0i += (ai[0] + ai[1]) + (ai[2] + ai[3]);
+      }
       if (HP) {
         const hx8 csH = __builtin_bit_cast(hx8, csP);
         hx8 arH, arL, aiH, aiL;
@@ -2691,7 +2877,8 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         spot_dft_h_v(twh, wr, wi, Z4, v);
         spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, v, do_cog, flux_i);
       } else if (!NOISE && !WRITE_CUBE) {
-        spot_cog_f32(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
+        if constexpr (PK) spot_cog_f32_pk(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
+        else spot_cog_f32(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
       } else {
         spot_core<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, flux_i, Z4);
       }
@@ -2730,6 +2917,10 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   // (c < 8: cos of k = c + 1; c >= 8: sin of k = c - 7); the other half of a +-k pair sits in lane c ^ 8 of
   // the same 16-lane row (row_ror:8).  Lanes c < 8 write kx = -(c + 1), lanes 8 .. 14 kx = +(c - 7), lane 15
   // (k = 8 has no +8 in the window [-8, 8)) writes kx = 0 from the row sums.
+  if constexpr (PK) {
+    R0r += R0rp.x + R0rp.y; R0i += R0ip.x + R0ip.y;
+    sd += sdp.x + sdp.y; sd2 += sd2p.x + sd2p.y; sm += 4.f * (float)nfull;
+  }
   R0r += __shfl_xor(R0r, 16); R0r += __shfl_xor(R0r, 32);          // -> every lane: full sum of row y = c
   R0i += __shfl_xor(R0i, 16); R0i += __shfl_xor(R0i, 32);
 #pragma unroll

@@ -472,6 +472,8 @@ def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None,
         libaomarl.set_precision(mode)
         try:
             w.reset()
+            for _ in range(3):
+                w.one_step()                    # (one-time costs of the first episode, see main)
             reset_s = w.time_reset()
             elapsed, _, fk = w.timed(steps, warmup, time_frame=True, settle=settle)
             rec = {"dtype": libaomarl.dtype_string(w.launched),
@@ -558,6 +560,9 @@ def main():
 
     w.reset()                                       # (the first reset: VecAoEnv probes both call orders behind it)
     order_probe = env.order_probe
+    for _ in range(3):                              # one-time costs of a process's first episode (allocations: 11 ms in
+        w.one_step()                                # the first step) are not a per-episode transient
+    w.reset()
     reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
     elapsed, t_enq, fk_ms = w.timed(args.steps, args.warmup, dist, backend, settle=args.settle)
     envs_total = args.envs * world
@@ -590,13 +595,21 @@ def main():
     # the same steps in the plain call order (frame kernel alone on the GPU, the chains behind it): what the
     # pipeline buys, and the frame kernel's duration without the chains' kernels beside it
     plain = None
-    if pipe_state[0] and not args.timed_only:
+    do_plain = bool(pipe_state[0])
+    if dist is not None:                    # a collective decision: the pass has barriers inside (ranks probe their own
+        t = torch.tensor([int(do_plain)], dtype=torch.int32,      # call order and may differ)
+                         device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        do_plain = bool(int(t.item()))
+    if do_plain and not args.timed_only:
         w.reset()
         sim.set_option("frame_pipeline", 0)
         e_p, _, fk_p = w.timed(min(args.steps, 40), min(args.warmup, 5), dist, backend, settle=args.settle)
         plain = {"ms_per_step_no_reset": e_p / min(args.steps, 40) * 1e3, "frame_kernel_ms": fk_p}
         w.reset()
         sim.set_option("frame_pipeline", 1)
+        if not (plain["frame_kernel_ms"] and pipe_state[0]):
+            plain = None                    # (this rank ran in the plain order anyway)
     # diagnostic pass (outside `value`): every stage with its own event pair (call by call: behind a reset
     # when the timed steps left a pipelined frame in flight)
     if pipe_state[0] and args.timed_only:

@@ -109,7 +109,7 @@ def test_env_with_the_geometric_twin():
     from ao_marl_amd.sac import BatchedSAC, run_episode
     rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
     env = VecAoEnv(NAME, 4, rl, n_agents_modal=1, geo=True)
-    ref = VecAoEnv(NAME, 4, rl, n_agents_modal=1)
+    ref = VecAoEnv(NAME, 4, rl, n_agents_modal=1, frame_pipeline=False)
     sac = BatchedSAC(env.layout, dict(memory_size=16))
     out = run_episode(env, sac, max_steps=40, train=False, linear_control=True)
     base = run_episode(ref, sac, max_steps=40, train=False, linear_control=True)

@@ -75,8 +75,8 @@ def test_state_assembly_and_rewards_match_tensor_ops():
 def test_env_step_with_fused_glue_equals_tensor_op_path():
     from ao_marl_amd.env import VecAoEnv
     rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
-    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
-    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1, frame_pipeline=False)
+    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1, frame_pipeline=False)
     assert a._native_glue and a._default_state_layout
     b._native_glue = False
     sa, sb = a.reset(), b.reset()
@@ -96,8 +96,8 @@ def test_modal_shortcut_equals_full_projection_path():
     projects the command explicitly, to fp32 round-off, over a closed-loop rollout."""
     from ao_marl_amd.env import VecAoEnv
     rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
-    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
-    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1, frame_pipeline=False)
+    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1, frame_pipeline=False)
     b.modal_shortcut = False
     a.native_step = False                        # call by call: supervisor.last_modes is observable
     sa, sb = a.reset(), b.reset()
@@ -350,8 +350,8 @@ def test_residual_modes_from_slopes_equals_do_control_path():
     rewards over a rollout with integrator-only steps in between, then err, command and voltages."""
     from ao_marl_amd.env import VecAoEnv
     rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
-    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
-    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1)
+    a = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1, frame_pipeline=False)
+    b = VecAoEnv("production_sh_10x10_2m", 3, rl, n_agents_modal=1, frame_pipeline=False)
     assert not a.residual_shortcut and not b.residual_shortcut          # opt-in
     a.residual_shortcut = True
     sa, sb = a.reset(), b.reset()
@@ -403,7 +403,7 @@ def test_graph_step_replays_the_same_step(config, nenv, rl, n_modal, prefetch):
     rng = np.random.default_rng(3)
     actions = None
     for mode in ("plain", "graph"):
-        env = VecAoEnv(config, nenv, rl, initial_seed=77, seed_stride=16, n_agents_modal=n_modal, prefetch_atmos=prefetch)
+        env = VecAoEnv(config, nenv, rl, initial_seed=77, seed_stride=16, n_agents_modal=n_modal, prefetch_atmos=prefetch, frame_pipeline=False)
         sim = env.supervisor.sim
         sim.set_option("graph_step", 1 if mode == "graph" else 0)
         if actions is None:
@@ -490,7 +490,7 @@ def test_env_step_refuses_inconsistent_arguments():
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     env = VecAoEnv("production_sh_10x10_2m", 2, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5),
-                   n_agents_modal=1)
+                   n_agents_modal=1, frame_pipeline=False)
     s = env.reset()
     a = torch.zeros(2, env.action_dim, device="cuda")
     s, r, _, _ = env.step(a)                               # builds the glue, validates the selection
@@ -577,7 +577,7 @@ def test_frame_pipeline_gives_the_plain_steps(config, nenv, rl, n_modal):
     rng = np.random.default_rng(5)
     out, actions = {}, None
     for mode in ("plain", "pipe"):
-        env = VecAoEnv(config, nenv, rl, initial_seed=31, seed_stride=16, n_agents_modal=n_modal)
+        env = VecAoEnv(config, nenv, rl, initial_seed=31, seed_stride=16, n_agents_modal=n_modal, frame_pipeline=False)
         env.frame_pipeline = mode == "pipe"
         sim = env.supervisor.sim
         if actions is None:
@@ -716,3 +716,55 @@ def test_small_chain_equals_the_general_chain_to_rounding():
         assert (envs[0].supervisor.get_strehl() - envs[1].supervisor.get_strehl()).abs().max().item() < 1e-4
         assert (envs[0].supervisor.get_err() - envs[1].supervisor.get_err()).abs().max().item() < 2e-4 * envs[1].supervisor.get_err().abs().max().item()
         del envs
+
+
+def test_default_call_order_is_probed_and_falls_back_loudly():
+    """VecAoEnv() default, frame_pipeline='auto': behind the first reset of an eligible environment both call orders
+    are timed on the caller's stream and the pipelined one is kept unless it is the slower one; the fallback (forced
+    here through the probe's margin) warns, drops the twin and runs the plain order.  Either way the episode is the
+    plain order's, bit for bit; an environment that is not eligible (noisy sensor) never probes."""
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    VecAoEnv._ORDER_CACHE.clear()
+    ref = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1, frame_pipeline=False)
+    auto = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1)
+    assert auto.frame_pipeline == "auto" and auto.order_probe is None
+    s0, s1 = ref.reset(), auto.reset()
+    assert ref.order_probe is None
+    p = auto.order_probe
+    assert p is not None and p["chosen"] in ("pipelined", "plain") and p["pipelined"] > 0 and p["plain"] > 0
+    assert auto.frame_pipeline is (p["chosen"] == "pipelined")
+    assert torch.equal(s0, s1)
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    acts = [torch.rand(8, ref.action_dim, device="cuda:0", generator=g) * 2 - 1 for _ in range(12)]
+    for a in acts:
+        (sa, ra, _, _), (sb, rb, _, _) = ref.step(a), auto.step(a)
+        assert torch.equal(sa, sb) and torch.equal(ra, rb)
+    if auto.frame_pipeline:
+        assert auto.supervisor.sim.frame_pipeline_state()[2] >= 10         # pipelined steps were taken
+    # a second environment on the same stream reuses the decision
+    again = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1)
+    again.reset()
+    assert again.order_probe.get("cached") and again.frame_pipeline is auto.frame_pipeline
+    # the fallback, forced: nothing is 'not more than 0 x slower'
+    VecAoEnv._ORDER_CACHE.clear()
+    fb = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1)
+    fb.frame_pipeline = False
+    s2 = fb.reset()
+    fb.frame_pipeline = "auto"
+    with pytest.warns(UserWarning, match="plain order"):
+        s2 = fb._probe_order(s2, margin=0.0)
+    assert fb.frame_pipeline is False and fb.order_probe["chosen"] == "plain"
+    assert getattr(fb.supervisor.sim, "_twin", None) is None
+    assert torch.equal(s2, s0)
+    ref.reset()
+    for a in acts[:6]:
+        (sa, ra, _, _), (sb, rb, _, _) = ref.step(a), fb.step(a)
+        assert torch.equal(sa, sb) and torch.equal(ra, rb)
+    assert fb.supervisor.sim.frame_pipeline_state()[0] is False
+    VecAoEnv._ORDER_CACHE.clear()
+    # not eligible: no probe, plain order
+    noisy = VecAoEnv("production_sh_40x40_8m_3layers_d1_noise", 2,
+                     dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5), n_agents_modal=13)
+    noisy.reset()
+    assert noisy.frame_pipeline is False and noisy.order_probe is None

@@ -80,7 +80,7 @@ def test_reward_formulas_against_numpy():
 def test_env_reward_types_on_the_device():
     from ao_marl_amd.env import VecAoEnv
     env = VecAoEnv("production_sh_10x10_2m", 4, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5),
-                   n_agents_modal=1)
+                   n_agents_modal=1, frame_pipeline=False)
     env.reset()
     g = torch.Generator(device="cuda:0").manual_seed(3)
     for _ in range(3):
