@@ -1616,6 +1616,7 @@ __global__ __launch_bounds__(256) void k_compose_rewards(int nm, const float *__
                                                          float *__restrict__ modes_out, int cx, int n_agents,
                                                          const int32_t *__restrict__ lohi, float factor,
                                                          float *__restrict__ rew) {
+  CHAIN_SETPRIO();
   const int r = blockIdx.y;
   if ((int)blockIdx.x >= cx) {
     if (threadIdx.x >= 64) return;
@@ -1894,6 +1895,7 @@ __device__ __forceinline__ void af_layer(const float *__restrict__ Xs, int kstep
 }
 
 __global__ __launch_bounds__(512) void k_actor_fused(ActorArgs p) {
+  CHAIN_SETPRIO();
   extern __shared__ __attribute__((aligned(16))) float af_lds[];
   const int tiles = (p.nenv + 15) / 16;
   const int q = blockIdx.x & 7, idx = blockIdx.x >> 3;          // q: the XCD this workgroup lands on
@@ -1960,6 +1962,7 @@ struct StateBlocks {
 };
 
 __global__ void k_assemble_state(int nenv, StateBlocks sb, float *__restrict__ out) {
+  CHAIN_SETPRIO();
   const int e = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
   auto psum = [&](int col) {
     float s = 0.f;

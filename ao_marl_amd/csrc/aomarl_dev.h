@@ -6,6 +6,17 @@
 
 #include "../../include/aomarl.h"
 
+// Wave priority of the control / agent chain's kernels against the frame kernel they share the SIMDs with: the issue
+// arbiter serves the oldest ready wave first, and the frame kernel's long-lived waves are always ready -- a chain
+// kernel's waves starve beside them (a 19 us product takes 160).  CHAIN_PRIO > 0 raises the chain's waves.
+#ifndef CHAIN_PRIO
+#define CHAIN_PRIO 0
+#endif
+#define CHAIN_SETPRIO() do { if (CHAIN_PRIO) __builtin_amdgcn_s_setprio(CHAIN_PRIO); } while (0)
+#ifndef ATM_PRIO
+#define ATM_PRIO 0
+#endif
+#define ATM_SETPRIO() do { if (ATM_PRIO) __builtin_amdgcn_s_setprio(ATM_PRIO); } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

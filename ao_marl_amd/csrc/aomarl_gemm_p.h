@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_p(int M, int N, int K, float al
                                                    float *__restrict__ C, int ldc, int kchunk, int nz,
                                                    float *__restrict__ P, int tiles_n, int tiles, int xcd) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
+#ifdef GP_PRIO
+  if (GP_PRIO) __builtin_amdgcn_s_setprio(GP_PRIO);
+#endif
   extern __shared__ __attribute__((aligned(16))) float gp_lds[];
   float *As = gp_lds;                              // [2][BM][GP_LD]
   float *Bs = gp_lds + 2 * BM * GP_LD;             // [2][BN][GP_LD]

@@ -805,6 +805,7 @@ struct GemmEpi {
 
 __global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const float *__restrict__ P,
                                   float beta, float *__restrict__ C, int ldc, GemmEpi ep) {
+  CHAIN_SETPRIO();
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)M * N) return;
   const int row = (int)(i / N), col = (int)(i - (long long)row * N);
@@ -1025,6 +1026,7 @@ __device__ __forceinline__ void extrude_gather_item(const DevSys &sys, const Dev
 __global__ __launch_bounds__(256) void k_extrude_gather(DevSys sys, DevState st, int env_begin,
                                                         RoundOps ops, float *__restrict__ Z,
                                                         int ldz, float *__restrict__ ZREF) {
+  ATM_SETPRIO();
   const int col = blockIdx.x;
   const int e = env_begin + col / ops.nops, li = ops.layer[col % ops.nops];
   const int ox = st.origin[(e * sys.nlayers + li) * 2], oy = st.origin[(e * sys.nlayers + li) * 2 + 1];
@@ -1088,6 +1090,7 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
                                                          const float *__restrict__ ZREF,
                                                          const float *__restrict__ P, int nsplit,
                                                          int ncol, int pn, float pscale) {
+  ATM_SETPRIO();
   const int col = blockIdx.x;
   const int e = env_begin + col / ops.nops, li = ops.layer[col % ops.nops];
   int *o = st.origin + (e * sys.nlayers + li) * 2;
@@ -1112,6 +1115,7 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
                                                     float *__restrict__ ZREF, const float *__restrict__ P,
                                                     int nsplit, int ncol, int pn, float pscale,
                                                     float *__restrict__ Z, int ldz) {
+  ATM_SETPRIO();
   const int col = blockIdx.x;
   const int e = env_begin + col / ops.nops, li = ops.layer[col % ops.nops];
   int *o = st.origin + (e * sys.nlayers + li) * 2;
@@ -2568,7 +2572,10 @@ struct FrameRaw {
 template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 // 3 waves per SIMD (<= 168 VGPRs).  Forcing the fp32 slopes-only instantiation (140 VGPRs) into four (<= 128, 8
 // registers spilled) measured 0.466 against 0.459 ms: the kernel is bound by issue slots, not by latency
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+#ifndef FW_WAVES
+#define FW_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FW_WAVES, FW_WAVES)))
 void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     int env_count, int do_cog,
                                                     float *__restrict__ TR,
@@ -3060,6 +3067,7 @@ __global__ void k_delay_sum(DevState st, int nactu, int ld, float a, float b, fl
 // behind the m2v product.  P: split-K partial tiles of that product (nsplit > 0) or null (st.com holds it).
 __global__ void k_delay_ahead(DevSys sys, DevState st, int nactu, int ld, int n, const float *__restrict__ P,
                               int nsplit, float alpha, int ktt) {
+  CHAIN_SETPRIO();
   auto newest = [&](int row, int a) -> float {
     if (nsplit > 0) {
       float s = 0.f;
@@ -3682,6 +3690,7 @@ __global__ __launch_bounds__(256) void k_strehl_commit(DevSys sys, DevState st, 
 __global__ __launch_bounds__(256) void k_post_delay(DevSys sys, DevState st, int env_begin, int n,
                                                     const float *__restrict__ PEND, int do_strehl, int ktt,
                                                     const float *__restrict__ volts, int ldv) {
+  CHAIN_SETPRIO();
   if ((int)blockIdx.x < n) {
     if (do_strehl) strehl_commit_body(sys, st, env_begin, blockIdx.x, PEND);
   } else {

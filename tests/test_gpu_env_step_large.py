@@ -26,15 +26,26 @@ def _pushed_sim_class():
 
     class PushedSim(HipSim):
         """HipSim whose full reset ends on the ORACLE's screens: the two sides generate theirs with
-        differently ordered fp32 sums over a 1296-step recursion; the step is what is compared here (the
-        reset itself: tests/test_gpu_large.py)."""
+        differently ordered fp32 sums over a 1296-step recursion; the step is what is compared here.  The GPU's own
+        reset is compared with the oracle's screens (all layers, every pixel) right before they are pushed."""
         source = None
+        reset_diff = 0.0
 
         def reset(self, seeds, env_begin=0, env_count=None):
             HipSim.reset(self, seeds, env_begin, env_count)
             src = type(self).source
             if src is not None and env_begin == 0 and env_count in (None, self.nenv):
                 for l in range(self.s.nscreens):
+                    # the GPU's OWN full reset first (2 x 648 dependent extrusion rounds per layer, reset kernels on
+                    # the transposed screen, two streams) against the oracle's, all environments: <= 1e-3 um
+                    want = np.stack([scr[l] for scr, _ in src.snap])
+                    got = self.screen(l).cpu().numpy()
+                    assert got.shape == want.shape
+                    d = float(np.abs(got - want).max())
+                    type(self).reset_diff = max(type(self).reset_diff, d)
+                    assert d < 1e-3 and float(want.std()) > 0.05, ("reset screens, layer %d" % l, d)
+                    cnt = self.t["ext_count"][:, l].cpu().numpy()
+                    assert (cnt == np.array([c[l] for _, c in src.snap])).all()
                     self.set_screen(l, np.stack([scr[l] for scr, _ in src.snap]))
                     self.t["ext_count"][:, l] = torch.tensor([cnt[l] for _, cnt in src.snap], dtype=torch.int32)
                 self.target_psf()           # the pending PSF of the pushed screens
@@ -50,27 +61,37 @@ class SnapOracleVecSim(OracleVecSim):
         self.snap = [([scr.copy() for scr in o.screens], list(o.ext_count)) for o in self.sims]
 
 
-@pytest.mark.parametrize("precision,pipeline", [("f32", False), ("f32", True), ("split_f16", True)])
-def test_env_step_40x40_windowed_agents_match_the_oracle_env(monkeypatch, precision, pipeline):
-    """pipeline: the frame pipeline bench.py runs with (frame t+1 in flight while frame t is reduced)."""
+# the reference's published layout (README.md:116-119, src/error_budget/helper_experiments.py:19-36): 42 agents of 30
+# modes + the tip-tilt agent, here with the `_w20` experiments' window
+RL43 = dict(n_zernike_start_end=[0, 1260], n_reverse_filtered_from_cmat=5, window_n_zernike=20,
+            include_tip_tilt_windowed=True)
+
+
+@pytest.mark.parametrize("precision,pipeline,layout", [("f32", False, 14), ("f32", True, 14), ("split_f16", True, 14),
+                                                       ("f32", True, 43)])
+def test_env_step_40x40_windowed_agents_match_the_oracle_env(monkeypatch, precision, pipeline, layout):
+    """pipeline: the frame pipeline bench.py runs with (frame t+1 in flight while frame t is reduced).
+    layout: the bench's 14 agents, or the reference's published 43."""
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     keep = la.get_precision()
     la.set_precision(precision)
     try:
-        _run(monkeypatch, precision, pipeline)
+        _run(monkeypatch, precision, pipeline, layout)
     finally:
         la.set_precision(keep)
 
 
-def _run(monkeypatch, precision, pipeline):
+def _run(monkeypatch, precision, pipeline, layout=14):
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     PushedSim = _pushed_sim_class()
-    env = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cuda:0",
+    RL = globals()["RL"] if layout == 14 else RL43
+    nmod = layout - 1
+    env = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=nmod, device="cuda:0",
                    sim_factory=PushedSim, frame_pipeline=pipeline)
     lay = env.layout
-    assert lay.n_agents == 14 and lay.state_shapes()[0] == 552 and lay.state_shapes()[-1] == 168
+    assert lay.n_agents == layout and lay.state_shapes()[0] == (552 if layout == 14 else 280) and lay.state_shapes()[-1] == 168
     assert env._native_glue and env._default_state_layout
     cal = env.supervisor.cal
 
@@ -85,7 +106,7 @@ def _run(monkeypatch, precision, pipeline):
         s.cmat = np.ascontiguousarray(cal.cmat)
         return copy.copy(cal)
     monkeypatch.setattr(modal, "calibrate", calibrate)
-    oenv = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cpu",
+    oenv = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=nmod, device="cpu",
                     sim_factory=SnapOracleVecSim)
     monkeypatch.undo()
     assert oenv.supervisor.s.nactu == env.supervisor.s.nactu == 1286
@@ -120,7 +141,7 @@ def _run(monkeypatch, precision, pipeline):
         so_t, ro, _, _ = oenv.step(torch.from_numpy(a))
         so, ro = so_t.numpy(), ro.numpy()
         rg = rg.cpu().numpy()
-        assert rg.shape == ro.shape == (NENV, 14) and done is False
+        assert rg.shape == ro.shape == (NENV, layout) and done is False
         dr = np.abs(rg - ro).max() / np.maximum(np.abs(ro).max(), 1e-12)
         worst["reward"] = max(worst["reward"], dr)
         assert dr < 2e-3, ("reward", it, dr)
@@ -146,4 +167,54 @@ def _run(monkeypatch, precision, pipeline):
     st = env.supervisor.get_strehl().cpu().numpy()
     sto = oenv.supervisor.get_strehl().numpy()
     assert np.abs(st[:, :2] - sto[:, :2]).max() < 2e-4
-    print("worst deviations over %d steps (%s): %s" % (NSTEP, precision, worst))
+    print("worst deviations over %d steps (%s): %s; full reset against the oracle's screens: %.2e um" %
+          (NSTEP, precision, worst, PushedSim.reset_diff))
+
+
+def test_bench_batch_through_env_step_with_the_frame_pipeline():
+    """What bench.py times, at ITS batch, with asserts: 256 environments x 14 windowed agents through
+    aomarl_actor_forward + aomarl_env_step with a frame in flight, 32 steps.  Size-independent properties: equal
+    seeds with equal actions stay equal bit for bit, different seeds decorrelate, everything is finite, the loop
+    closes, and the first environments agree with the same seeds stepped as a batch of 8 (another GEMM tiling:
+    fp32 round-off of differently ordered sums, not bits)."""
+    from ao_marl_amd.agents import BatchedGaussianPolicy
+    from ao_marl_amd.env import VecAoEnv
+    n, small_n, steps = 256, 8, 32
+
+    def make(nenv):
+        env = VecAoEnv(NAME, nenv, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cuda:0",
+                       frame_pipeline=True)
+        seeds = env.supervisor.env_seeds().copy()
+        seeds[1] = seeds[0]                                  # twin environments
+        env.supervisor.env_seeds = lambda: seeds
+        return env
+    big, small = make(n), make(small_n)
+    pol = BatchedGaussianPolicy(big.layout, last_layer_zero=False, seed=7, device="cuda:0")
+    sb, ss = big.reset(), small.reset()
+    assert torch.equal(sb[0], sb[1]) and torch.equal(sb[:small_n], ss)
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    worst = 0.0
+    for it in range(steps):
+        eps = torch.randn(n, big.layout.action_dim, device="cuda:0", generator=g)
+        eps[1] = eps[0]
+        a, _ = pol.select_action(sb, eps=eps)                # k_actor_fused on the batch's states
+        assert torch.equal(a[0], a[1])
+        assert big._native_step_ok(False)
+        sb, rb, _, _ = big.step(a)
+        ss, rs, _, _ = small.step(a[:small_n].contiguous())
+        assert torch.isfinite(sb).all() and torch.isfinite(rb).all() and rb.shape == (n, 14)
+        assert torch.equal(sb[0], sb[1]) and torch.equal(rb[0], rb[1])          # same seed, same actions: same bits
+        sd_dm = big.norm["dm"][1]
+        livec = torch.cat([sd_dm > 1e-3 * sd_dm.median()] * 3 + [big.norm["dm_residual"][1] > 1e-3 * big.norm["dm_residual"][1].median()])
+        d = (sb[:small_n] - ss)[:, livec].abs().max().item() / max(1.0, ss[:, livec].abs().max().item())
+        worst = max(worst, d)
+        assert d < 5e-3, (it, d)                             # batch of 256 against batch of 8, closed loop, 32 steps
+    flying, _, piped, beside = big.supervisor.sim.frame_pipeline_state()
+    assert flying and piped >= steps - 1 and beside >= steps - 2, (piped, beside)
+    sl = big.supervisor.get_slopes()
+    assert torch.isfinite(sl).all() and torch.equal(sl[0], sl[1])
+    c = np.corrcoef(sl[2].cpu().numpy(), sl[3].cpu().numpy())[0, 1]
+    assert abs(c) < 0.3, c                                   # different seeds decorrelate
+    st = big.supervisor.get_strehl().cpu().numpy()
+    assert np.isfinite(st).all() and st[:, 0].min() > 0.0
+    print("256 x 14 agents, %d pipelined steps: batch against batch-of-8 worst %.2e (standardised states)" % (steps, worst))

@@ -168,11 +168,23 @@ def test_one_call_step_is_the_call_by_call_step(denoise, fused_tail):
     assert torch.equal(a.supervisor.get_err(), b.supervisor.get_err())
 
 
-def test_one_call_actor_is_the_layer_by_layer_actor():
+PUBLISHED = dict(n_zernike=[0, 1260], n_modal=42)     # README.md:116-119: 42 x 30 modes + tip-tilt = 43 agents
+
+
+@pytest.mark.parametrize("which", ["bench14", "published43", "published43_w20"])
+def test_one_call_actor_is_the_layer_by_layer_actor(which):
     """aomarl_actor_forward: with AOMARL_ACTOR_LAYER_BY_LAYER the very kernels of the call-by-call
     path (bit for bit); by default ONE kernel (k_actor_fused) whose fp32 sums run in another order:
-    same draws, actions within fp32 round-off of the layered ones, and of a float64 evaluation."""
-    lay = _layout()
+    same draws, actions within fp32 round-off of the layered ones, and of a float64 evaluation.  Layouts: the
+    bench's 14 windowed agents and the reference's published 43 agents (plain: 120-wide states, 30 actions;
+    window 20: 280-wide states)."""
+    if which == "bench14":
+        lay = _layout()
+    else:
+        w20 = which.endswith("w20")
+        lay = AgentLayout(1283, PUBLISHED["n_zernike"], PUBLISHED["n_modal"], include_tip_tilt=True,
+                          window_n_zernike=20 if w20 else -1, include_tip_tilt_windowed=w20, n_filtered=5)
+        assert lay.n_agents == 43 and lay.state_shapes()[0] == (280 if w20 else 120)
     mk = lambda: BatchedGaussianPolicy(lay, last_layer_zero=False, seed=5, device="cuda:0")   # noqa: E731
     a, b, f = mk(), mk(), mk()
     a.layer_by_layer = True

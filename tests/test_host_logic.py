@@ -27,7 +27,11 @@ def test_compute_btt_and_cmat_match_reference(golden_dir):
 
 CASES = {"small": dict(nmodes=87, se=[0, 80], n_modal=1, window=-1, tt_w=False),
          "large": dict(nmodes=1283, se=[0, 1274], n_modal=13, window=20, tt_w=True),
-         "large_notw": dict(nmodes=1283, se=[0, 1274], n_modal=13, window=20, tt_w=False)}
+         "large_notw": dict(nmodes=1283, se=[0, 1274], n_modal=13, window=20, tt_w=False),
+         # the reference's published layout: 43 agents = 42 x 30 modes + tip-tilt (README.md:116-119,
+         # src/error_budget/helper_experiments.py:19-36), plain and with the `_w20` experiments' window
+         "published": dict(nmodes=1283, se=[0, 1260], n_modal=42, window=-1, tt_w=False),
+         "published_w20": dict(nmodes=1283, se=[0, 1260], n_modal=42, window=20, tt_w=True)}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -44,6 +48,8 @@ def test_agent_layout_matches_reference(golden_dir, name):
     for w, (a, b) in lay.agents.items():
         assert [a, b] == list(z["%s_agent%d_modes" % (name, w)])
         assert np.array_equal(lay.modes_chosen[w], z["%s_agent%d_chosen" % (name, w)]), (name, w)
+    if name.startswith("published"):
+        assert lay.n_agents == 43 and lay.state_shapes()[0] == (280 if name.endswith("w20") else 120)
     if name == "large":
         assert lay.state_shapes()[0] == 552 and lay.state_shapes()[-1] == 168
         # reference quirk: the TT agent's window indices are absolute 0..39 in every block

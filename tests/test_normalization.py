@@ -94,6 +94,17 @@ def test_statistics_match_the_references_recorded_compass_runs(name):
     assert abs(r_res - 1) < 0.10
     assert abs(r_zn - 1) < 0.20
     assert np.abs(norm["wfs"]["mean"]).max() < 0.2 * norm["wfs"]["std"].max()
+    # Not only the medians: a mode-number-dependent error (say the high orders 15 % off) would leave a median
+    # alone.  5th / 95th percentile of the per-entry ratios within +-15 %, and the median of every third of the
+    # spectrum (Btt modes are ordered by spatial frequency; slopes: x then y) within +-10 %.
+    for key, sel in (("wfs", slice(None)), ("dm", live), ("dm_residual", live)):
+        ratio = norm[key]["std"][sel] / ref[key]["std"][sel]
+        p5, p95 = np.percentile(ratio, [5, 95])
+        thirds = [float(np.median(t)) for t in np.array_split(ratio, 3)]
+        print("    %-11s ratio: 5th %.3f  95th %.3f  medians of the thirds %s" %
+              (key, p5, p95, " ".join("%.3f" % t for t in thirds)))
+        assert 0.85 < p5 and p95 < 1.15, (key, p5, p95)
+        assert all(abs(t - 1) < 0.10 for t in thirds), (key, thirds)
 
 
 @pytest.mark.gpu

@@ -56,6 +56,11 @@ def g6():
         "small": dict(nmodes=87, se=[0, 80], world=3, window=-1, tt_w=False, nfilt=5),
         "large": dict(nmodes=1283, se=[0, 1274], world=15, window=20, tt_w=True, nfilt=5),
         "large_notw": dict(nmodes=1283, se=[0, 1274], world=15, window=20, tt_w=False, nfilt=5),
+        # the reference's own published layout: 43 agents = 42 x 30 modes + tip-tilt (README.md:116-119,
+        # `--world-size 44 --n_zernike_start_end 0 1260`; src/error_budget/helper_experiments.py:19-36), plain and
+        # with the window of 20 of the `_w20` experiments
+        "published": dict(nmodes=1283, se=[0, 1260], world=44, window=-1, tt_w=False, nfilt=5),
+        "published_w20": dict(nmodes=1283, se=[0, 1260], world=44, window=20, tt_w=True, nfilt=5),
     }
     for name, c in cases.items():
         cfg = types.SimpleNamespace(env_rl={
