@@ -379,7 +379,7 @@ class VecAoEnv(object):
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
                  strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None,
-                 geo=False, prefetch_atmos=True, frame_pipeline="auto"):
+                 geo=False, prefetch_atmos=True, frame_pipeline="auto", dead_columns="mask"):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -411,12 +411,36 @@ class VecAoEnv(object):
         self.wfs_dim = sup.s.nslope
         # standardisation vectors (ao_env.py:470-480), sub-selected like load_norm_parameters does
         self.norm = None
+        # Degenerate statistics: a state column whose recorded standard deviation is ~0 (the modes filtered out of the
+        # command matrix: 1e-10; and, in the reference's own 10x10 file, 10 modes at 4e-9 .. 9e-9) turns round-off
+        # into 1e+3 .. 1e+9 when the state is standardised -- the reference feeds its agents exactly that, and a SAC
+        # trained on it here diverges (alpha -> inf, NaN; profiles/r03_learning_acceptance.txt).  dead_columns:
+        # "mask" (default) standardises such columns to 0 and warns, naming the file; "raise"; "keep" = the
+        # reference's division as it stands.
+        if dead_columns not in ("mask", "raise", "keep"):
+            raise ValueError("dead_columns: 'mask', 'raise' or 'keep'")
+        self.dead_columns = {}
         if normalization_bool:
             self.norm = {}
             for k in ("wfs", "dm", "dm_residual"):
                 m, sd = norm[k]["mean"], norm[k]["std"]
                 if k != "wfs" and self._sel is not None:
                     m, sd = m[ar], sd[ar]
+                sd = np.asarray(sd, dtype=np.float64)
+                pos = sd[sd > 0]
+                dead = sd < 1e-6 * (np.median(pos) if pos.size else 1.0)
+                if dead.any() and dead_columns != "keep":
+                    idx = np.flatnonzero(dead)
+                    msg = ("norm_%s.npz: %d column(s) of %r have a recorded standard deviation below 1e-6 x the median "
+                           "(%.1e .. %.1e; columns %s%s)" % (name, idx.size, k, sd[dead].min(), sd[dead].max(),
+                                                            idx[:12].tolist(), " ..." if idx.size > 12 else ""))
+                    if dead_columns == "raise":
+                        raise ValueError(msg + ": standardising them amplifies round-off by 1 / std "
+                                         "(dead_columns='mask' zeroes them, 'keep' divides like the reference)")
+                    import warnings
+                    warnings.warn(msg + ": standardised to 0 in the states (dead_columns='keep': the reference's division)")
+                    sd = np.where(dead, np.inf, sd)
+                    self.dead_columns[k] = idx
                 self.norm[k] = (torch.as_tensor(m, dtype=torch.float32, device=self.device),
                                 torch.as_tensor(sd, dtype=torch.float32, device=self.device))
         # state layout

@@ -29,7 +29,8 @@ def _run(golden_dir, sim_factory, device, tol_scale=1.0, stock=False, geo=False)
     norm, zn = load_norm("production_sh_10x10_2m")      # the data the reference run used
     env = VecAoEnv(ps, 2, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5),
                    initial_seed=int(z["seed"]), seed_stride=0, n_agents_modal=1, device=device,
-                   norm=norm, zn_norm=zn, sim_factory=sim_factory, geo=geo, frame_pipeline=False)
+                   norm=norm, zn_norm=zn, sim_factory=sim_factory, geo=geo, frame_pipeline=False,
+                   dead_columns="keep")     # the reference divides by whatever it recorded
     sup = env.supervisor
     # --- init-time products vs the reference's (its Btt / cmat were computed by ITS code on ITS
     #     imat through the facade)

@@ -139,3 +139,33 @@ def test_wind_variant_parameter_sets_are_the_references():
         assert norm["wfs"]["std"].shape == (2400,) and zn.shape == (1283,)
     # a variant changes nothing of the base set it was derived from
     assert list(base.p_atmos.winddir) == [0, 45, 90] and base.p_controllers[0].gain == 0.7
+
+
+def test_degenerate_normalisation_columns_are_caught():
+    """The reference's own recorded 10x10 statistics hold 10 controlled Btt modes with a standard deviation of
+    4e-9 .. 9e-9 (plus the filtered ones): standardising amplifies round-off by 1e+8 and a SAC trained on such
+    states diverges.  VecAoEnv masks them (state 0) with a warning that names the file, raises on request, or
+    keeps the reference's division."""
+    import warnings
+    from ao_marl_amd.env import VecAoEnv, load_norm
+    from tests.oracle_vecsim import OracleVecSim
+    name = "production_sh_10x10_2m"
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    norm, _ = load_norm(name)
+    sd = norm["dm"]["std"][:80]
+    assert (sd < 1e-6 * np.median(sd)).sum() >= 5            # the file IS degenerate
+    kw = dict(n_agents_modal=1, device="cpu", sim_factory=OracleVecSim)
+    with pytest.warns(UserWarning, match="norm_production_sh_10x10_2m.npz"):
+        env = VecAoEnv(name, 1, rl, **kw)
+    assert len(env.dead_columns["dm"]) >= 5 and torch.isinf(env.norm["dm"][1]).sum() == len(env.dead_columns["dm"])
+    s = env.reset()
+    assert torch.isfinite(s).all() and float(s.abs().max()) < 1e3
+    dm_dim = env.dm_dim
+    for blk in range(3):
+        assert float(s[:, blk * dm_dim + torch.as_tensor(env.dead_columns["dm"])].abs().max()) == 0.0
+    with pytest.raises(ValueError, match="norm_production_sh_10x10_2m.npz"):
+        VecAoEnv(name, 1, rl, dead_columns="raise", **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        keep = VecAoEnv(name, 1, rl, dead_columns="keep", **kw)
+    assert keep.dead_columns == {} and torch.isfinite(keep.norm["dm"][1]).all()
