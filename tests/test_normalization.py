@@ -98,7 +98,10 @@ def test_statistics_match_the_references_recorded_compass_runs(name):
     # alone.  5th / 95th percentile of the per-entry ratios within +-15 %, and the median of every third of the
     # spectrum (Btt modes are ordered by spatial frequency; slopes: x then y) within +-10 %.
     for key, sel in (("wfs", slice(None)), ("dm", live), ("dm_residual", live)):
-        ratio = norm[key]["std"][sel] / ref[key]["std"][sel]
+        rs = ref[key]["std"][sel]
+        ok = rs > 1e-6 * np.median(rs)          # (the 10x10 file holds 10 dead modes, 4e-9 .. 9e-9: no statistic to match)
+        assert (~ok).sum() <= 10
+        ratio = (norm[key]["std"][sel] / rs)[ok]
         p5, p95 = np.percentile(ratio, [5, 95])
         thirds = [float(np.median(t)) for t in np.array_split(ratio, 3)]
         print("    %-11s ratio: 5th %.3f  95th %.3f  medians of the thirds %s" %
