@@ -86,6 +86,11 @@ struct aomarl_ctx {
   struct StepGraph { std::vector<long long> key; hipGraphExec_t exec; hipGraph_t graph; unsigned long long arith[AR_N]; int fw_variant[6]; };
   std::vector<StepGraph> graphs;
   unsigned long long graph_hits = 0, graph_captures = 0;
+  // bumped by every call that changes a host value captured graphs have baked into their kernel arguments (matrix
+  // scales and leading dimensions, nact, gains, per-context options): part of the graph key, together with the
+  // process-wide g_cfg_epoch -- a re-uploaded matrix usually lands at the SAME address, so the pointers alone
+  // would replay a stale graph
+  unsigned long long cfg_epoch = 0;
   const int32_t *sel_checked = nullptr;     // aomarl_env_step: the column selection last validated
   int sel_checked_n = 0, sel_checked_nm = 0;
   int fw_variant[6] = {0, 0, 0, 0, 0, 0};   // template arguments of the last k_frame_wave launch
@@ -94,6 +99,7 @@ struct aomarl_ctx {
   bool time_fw = false;
   std::vector<hipEvent_t> fw_ev;            // 2 per timed launch, created on demand
   size_t fw_ev_used = 0;
+  std::vector<hipEvent_t> fw_ev_retired;    // timing events a frame in flight still carries as its "done" mark (fw_ev_rewind)
   hipStream_t atm_stream = nullptr, psf_stream = nullptr;
   hipEvent_t ev_frame = nullptr, ev_moved = nullptr, ev_psf = nullptr;
   // the event the screens' readers were last marked with on the caller's stream (ev_frame, or the closing
@@ -150,12 +156,36 @@ struct aomarl_ctx {
 };
 
 static int pipe_drop(aomarl_ctx *c, void *stream);
+// Start the timing events over.  The closing event of a timed frame launch doubles as that frame's "readers are
+// done" mark (pipe.ev_done_cur / ev_frame_cur / ev_frame_prev): one that a frame in flight still carries must not be
+// re-recorded by a later launch, so it is retired (it stays valid for whoever waits on it) and replaced.
+static int fw_ev_rewind(aomarl_ctx *c) {
+  const hipEvent_t held[4] = {c->pipe.ev_done_cur[0], c->pipe.ev_done_cur[1], c->ev_frame_cur, c->ev_frame_prev};
+  for (size_t i = 0; i < c->fw_ev.size(); i++)
+    for (int k = 0; k < 4; k++)
+      if (held[k] && c->fw_ev[i] == held[k]) {
+        hipEvent_t ne;
+        HIPCHK(hipEventCreate(&ne));
+        c->fw_ev_retired.push_back(c->fw_ev[i]);
+        c->fw_ev[i] = ne;
+        break;
+      }
+  if (c->fw_ev_retired.size() > 64 && !c->pipe.active) {      // nothing in flight refers to them any more
+    bool live = false;
+    for (hipEvent_t e : c->fw_ev_retired) for (int k = 0; k < 4; k++) live = live || e == held[k];
+    if (!live) { for (hipEvent_t e : c->fw_ev_retired) (void)hipEventDestroy(e); c->fw_ev_retired.clear(); }
+  }
+  c->fw_ev_used = 0;
+  return 0;
+}
 static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int flags, void *stream, int slot);
 
+static unsigned long long g_cfg_epoch = 0;      // process-wide options / precision changes (see aomarl_ctx::cfg_epoch)
 const char *aomarl_last_error(void) { return g_err; }
 int aomarl_abi_version(void) { return AOMARL_ABI_VERSION; }
 
 int aomarl_set_precision(int mode) {
+  g_cfg_epoch++;
   if (mode != AOMARL_PRECISION_F32 && mode != AOMARL_PRECISION_SPLIT_F16) return fail("set_precision: unknown mode %d", mode);
   g_precision = mode;
   g_gemm_split_f16 = mode == AOMARL_PRECISION_SPLIT_F16;
@@ -630,6 +660,7 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (c->env_gain) (void)hipFree(c->env_gain);
   if (c->seed_stage) (void)hipFree(c->seed_stage);
   for (hipEvent_t e : c->fw_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->fw_ev_retired) (void)hipEventDestroy(e);
   delete c;
   return 0;
 }
@@ -645,6 +676,7 @@ static int replace_dev(aomarl_ctx *c, float **slot, const std::vector<float> &h)
 }
 
 int aomarl_set_cmat(aomarl_ctx *c, const float *cmat) {
+  if (c) c->cfg_epoch++;
   if (!c || !cmat) return fail("aomarl_set_cmat: null argument");
   const int na = c->sys.nactu, nsl = c->sys.nslope;
   const int ld = (nsl + 3) & ~3;
@@ -656,6 +688,7 @@ int aomarl_set_cmat(aomarl_ctx *c, const float *cmat) {
 }
 
 int aomarl_set_slopes2modes(aomarl_ctx *c, int nmodes, const float *s2m) {
+  if (c) c->cfg_epoch++;
   if (!c) return fail("aomarl_set_slopes2modes: null ctx");
   if (!s2m) { c->s2m_nmodes = 0; return 0; }                 // dropped (cmat or basis changed)
   if (nmodes < 1) return fail("aomarl_set_slopes2modes: nmodes must be positive");
@@ -670,12 +703,14 @@ int aomarl_set_slopes2modes(aomarl_ctx *c, int nmodes, const float *s2m) {
 }
 
 int aomarl_set_gain(aomarl_ctx *c, float gain) {
+  if (c) c->cfg_epoch++;
   if (!c) return fail("null ctx");
   c->gain = gain;
   return 0;
 }
 
 int aomarl_set_env_gains(aomarl_ctx *c, const float *gains, int nenv) {
+  if (c) c->cfg_epoch++;
   if (!c) return fail("null ctx");
   if (!gains) {                      // back to the scalar gain
     if (c->env_gain) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->env_gain); }
@@ -694,6 +729,7 @@ int aomarl_set_env_gains(aomarl_ctx *c, const float *gains, int nenv) {
 
 int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m2v,
                      const float *freedom, int nact, const int32_t *amodes) {
+  if (c) c->cfg_epoch++;
   if (!c || !v2m || !m2v) return fail("aomarl_set_modal: null argument");
   const int na = c->sys.nactu;
   if (nmodes <= 0 || nmodes > na) return fail("nmodes out of range");
@@ -1336,6 +1372,8 @@ int aomarl_get_dm_shape(aomarl_ctx *c, aomarl_state *st, int b, int n, int k, fl
 
 int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!name) return fail("set_option: null argument");
+  g_cfg_epoch++;
+  if (c) c->cfg_epoch++;
   if (!strcmp(name, "gemm_kgroups")) {          // process-wide, no context needed
     if (value != 0 && value != 1 && value != 2 && value != 4) return fail("gemm_kgroups: 0, 1, 2 or 4");
     g_gemm_kgroups = value;
@@ -1362,7 +1400,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   if (!strcmp(name, "time_frame_kernel")) {
     // value = number of launches to keep event pairs for (0: off)
     c->time_fw = value > 0;
-    c->fw_ev_used = 0;
+    { const int rrc = fw_ev_rewind(c); if (rrc) return rrc; }
     while (c->fw_ev.size() < 2 * (size_t)std::max(value, 0)) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
@@ -2807,6 +2845,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   key.push_back(pf ? 1 : 0); key.push_back(c->small_move); key.push_back(c->small_chain);
   key.push_back(c->defer_dm_shape ? 1 : 0); key.push_back(g_gemm_target_blocks); key.push_back(c->fused_debug);
   { int gi; memcpy(&gi, &c->gain, sizeof(gi)); key.push_back(gi); }
+  key.push_back((long long)c->cfg_epoch); key.push_back((long long)g_cfg_epoch);
   aomarl_ctx::StepGraph *hit = nullptr;
   for (auto &sg : c->graphs)
     if (sg.key == key) { hit = &sg; break; }
@@ -2840,6 +2879,23 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   }
   unsigned long long before[AR_N];
   for (int i = 0; i < AR_N; i++) before[i] = g_arith[i];
+  // the body advances host bookkeeping while it is being RECORDED (no kernel runs): kept, so that a capture that
+  // fails leaves the host where the device still is
+  struct Snap {
+    std::vector<float> ax, ay; int ring_pos; bool premoved, psf_side, side_joined, frame_marked, frame_wait_pending, screens_dirty_main;
+    float fx[AOMARL_MAX_LAYERS], fy[AOMARL_MAX_LAYERS];
+  } snap;
+  snap.ax.assign(accumx, accumx + (size_t)n * nl); snap.ay.assign(accumy, accumy + (size_t)n * nl);
+  snap.ring_pos = g->ring_pos; snap.premoved = c->premoved; snap.psf_side = c->psf_side; snap.side_joined = c->side_joined;
+  snap.frame_marked = c->frame_marked; snap.frame_wait_pending = c->frame_wait_pending; snap.screens_dirty_main = c->screens_dirty_main;
+  memcpy(snap.fx, c->frac_x, sizeof(snap.fx)); memcpy(snap.fy, c->frac_y, sizeof(snap.fy));
+  auto restore = [&]() {
+    memcpy(accumx, snap.ax.data(), sizeof(float) * snap.ax.size()); memcpy(accumy, snap.ay.data(), sizeof(float) * snap.ay.size());
+    g->ring_pos = snap.ring_pos; c->premoved = snap.premoved; c->psf_side = snap.psf_side; c->side_joined = snap.side_joined;
+    c->frame_marked = snap.frame_marked; c->frame_wait_pending = snap.frame_wait_pending; c->screens_dirty_main = snap.screens_dirty_main;
+    memcpy(c->frac_x, snap.fx, sizeof(snap.fx)); memcpy(c->frac_y, snap.fy, sizeof(snap.fy));
+    for (int i = 0; i < AR_N; i++) g_arith[i] = before[i];
+  };
   HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
   c->capturing = true; c->fork_recorded = false;
   rc = env_step_body(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
@@ -2851,9 +2907,10 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   c->capturing = false;
   hipGraph_t graph = nullptr;
   const hipError_t ee = hipStreamEndCapture(s, &graph);
-  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); restore(); return rc; }
   if (je != hipSuccess || ee != hipSuccess || !graph) {
     if (graph) (void)hipGraphDestroy(graph);
+    restore();
     return fail("env_step: graph capture failed: %s", hipGetErrorString(je != hipSuccess ? je : ee));
   }
   if (pf) c->side_joined = true;
@@ -2861,10 +2918,24 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   sg.key = key; sg.graph = graph; sg.exec = nullptr;
   for (int i = 0; i < AR_N; i++) sg.arith[i] = g_arith[i] - before[i];
   memcpy(sg.fw_variant, c->fw_variant, sizeof(sg.fw_variant));
-  HIPCHK(hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0));
+  {
+    const hipError_t ie = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
+    if (ie != hipSuccess) {
+      (void)hipGraphDestroy(graph);
+      restore();
+      return fail("env_step: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    }
+  }
+  {
+    const hipError_t le = hipGraphLaunch(sg.exec, s);
+    if (le != hipSuccess) {
+      (void)hipGraphExecDestroy(sg.exec); (void)hipGraphDestroy(graph);
+      restore();
+      return fail("env_step: hipGraphLaunch failed: %s", hipGetErrorString(le));
+    }
+  }
   c->graphs.push_back(sg);
   c->graph_captures++;
-  HIPCHK(hipGraphLaunch(sg.exec, s));
   return 0;
 }
 
@@ -3030,7 +3101,7 @@ int aomarl_frame_kernel_time(aomarl_ctx *c, double *total_ms, int *launches) {
     HIPCHK(hipEventElapsedTime(&ms, c->fw_ev[i], c->fw_ev[i + 1]));
     tot += ms; n++;
   }
-  c->fw_ev_used = 0;
+  { const int rrc = fw_ev_rewind(c); if (rrc) return rrc; }
   *total_ms = tot; *launches = n;
   return 0;
 }

@@ -212,7 +212,9 @@ class VecRlSupervisor(object):
         if n:
             raise FloatingPointError(
                     "split-fp16 GEMM: operands left the fp16 range in %d kernel threads since the last check "
-                    "(a diverging loop or policy?); results of that episode are wrong.  Run in the default "
+                    "(a diverging loop or policy?); results of that episode are wrong.  The counter is ONE per "
+                    "device for the whole process and is cleared by whoever reads it: with several live "
+                    "environments the clipping may have happened in another one.  Run in the default "
                     "precision (libaomarl.set_precision('f32'))" % n)
 
     def rl_control(self, action):

@@ -155,7 +155,9 @@ int aomarl_get_precision(void);
  * there, the product is wrong).  Synchronises `stream`, clears the counter.  The internal call sites keep
  * margins of 10^2 .. 10^4 over what a closed loop produces (stencil differences up to 255 um, Btt
  * coordinates up to 4094, slopes up to 65504 arcsec); a diverging policy can leave them.  ao_marl_amd.env
- * checks it at every episode boundary, like aomarl_denoiser_overflow. */
+ * checks it at every episode boundary, like aomarl_denoiser_overflow.  ONE counter per device for the whole
+ * process, cleared by whoever reads it first: with several contexts alive (training + evaluation) a clipping
+ * event is reported to the first reader, whichever context it happened in. */
 int aomarl_gemm_saturated(unsigned *count, void *stream);
 int aomarl_arith_families(void);
 const char *aomarl_arith_family_name(int family);

@@ -1,28 +1,49 @@
-# SQ counters of the split-f16 GEMM alone (development aid): tools/gemm_pmc.sh <tag> [M N K]
+# SQ counters of the balanced fp32 GEMM (k_gemm_p, csrc/aomarl_gemm_p.h) alone on the loop's shapes (development
+# aid; separate --pmc passes, kernel trace only):   bash tools/gemm_pmc.sh <tag>      -> gpurun_out/<tag>_pmc_gemm_p.txt
+# The program after `--` is the native micro-benchmark itself (tools/bin/gemmbench pick).
 set -e
-R=$PWD; TAG=$1; shift
+R=$PWD; TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 i=0
-for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE"; do
+for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/gpmc_$TAG/p$i -o p$i --output-format csv -- python3 $R/tools/diag/gemm_pmc.py "$@" > $R/gpurun_out/gpmc_${TAG}_p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/gpmc_$TAG/p$i -o p$i --output-format csv -- $R/tools/bin/gemmbench pick > $R/gpurun_out/gpmc_${TAG}_p$i.log 2>&1 || echo "pass $i failed"
 done
 cd $R
-python - <<PY
-import csv,glob,collections
-tot=collections.defaultdict(list); dur=[]
-for f in glob.glob("gpurun_out/gpmc_$TAG/**/*counter_collection.csv",recursive=True):
-    per=collections.defaultdict(lambda: collections.defaultdict(float))
+python3 - > gpurun_out/${TAG}_pmc_gemm_p.txt <<PY
+import csv, glob, collections
+# launches of one kernel instantiation with one grid size = one shape of the benchmark
+tot = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/gpmc_$TAG/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    key = {}
     for r in csv.DictReader(open(f)):
-        if "k_gemm_nt_h" in r["Kernel_Name"]:
-            per[int(r["Dispatch_Id"])][r["Counter_Name"]]+=float(r["Counter_Value"])
-    for d in sorted(per)[-4:]:
-        for k,v in per[d].items(): tot[k].append(v)
-for f in glob.glob("gpurun_out/gpmc_$TAG/**/*kernel_trace.csv",recursive=True):
-    rows=[r for r in csv.DictReader(open(f)) if "k_gemm_nt_h" in r["Kernel_Name"]]
-    dur += [(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in rows[-4:]]
-m={k:sum(v)/len(v) for k,v in tot.items()}
-print("$TAG  kernel us (under pmc):", ["%.1f"%d for d in dur])
-for k in sorted(m): print("  %-28s %.5g" % (k, m[k]))
+        if "k_gemm_p" in r["Kernel_Name"]:
+            d = int(r["Dispatch_Id"])
+            per[d][r["Counter_Name"]] += float(r["Counter_Value"])
+            key[d] = (r["Kernel_Name"].split("(")[0], r.get("Grid_Size", ""))
+    for d in per:
+        for k, v in per[d].items():
+            tot[key[d]][k].append(v)
+for f in glob.glob("gpurun_out/gpmc_$TAG/p1/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_gemm_p" in r["Kernel_Name"]:
+            dur[(r["Kernel_Name"].split("(")[0], r.get("Grid_Size", ""))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("# k_gemm_p alone (tools/bin/gemmbench pick), counters per launch, averaged over the launches of a shape")
+for key in sorted(tot):
+    m = {k: sum(v) / len(v) for k, v in tot[key].items()}
+    d = dur.get(key, [0.0])
+    print("%s grid %s: %d launches, %.1f us under the counters" % (key[0], key[1], len(d), sum(d) / max(len(d), 1)))
+    simd_cycles = m.get("GRBM_GUI_ACTIVE", 0) * 1024
+    if m.get("SQ_INSTS_MFMA") and simd_cycles:
+        print("    matrix instructions %.0f -> %.1f %% of the SIMD cycles at 32 cycles each; VALU (incl. matrix) %.0f; LDS %.0f; "
+              "an instruction issued in %.1f %% of a wave's cycles; waves waiting %.1f %%" %
+              (m["SQ_INSTS_MFMA"], 100.0 * m["SQ_INSTS_MFMA"] * 32 / simd_cycles, m.get("SQ_INSTS_VALU", 0), m.get("SQ_INSTS_LDS", 0),
+               100.0 * m.get("SQ_ACTIVE_INST_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1) * 4,
+               100.0 * m.get("SQ_WAIT_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1)))
+    for k in sorted(m):
+        print("    %-28s %.5g" % (k, m[k]))
 PY
 rm -rf gpurun_out/gpmc_$TAG
+cat gpurun_out/${TAG}_pmc_gemm_p.txt | head -60
