@@ -146,6 +146,8 @@ struct aomarl_ctx {
   int env_gain_n = 0;
   uint32_t *seed_stage = nullptr;  // device staging for reset seeds
   int seed_stage_n = 0;
+  // aomarl_reset_prefetch_*: the NEXT episode's screens grown in a shadow state while this episode runs
+  struct ResetPrefetch *rp = nullptr;
   // geometric controller (aomarl_set_geo): host copies of the lattice tables it is built from,
   // projection operands on the device
   std::vector<int32_t> h_grid;     // [gh][gw] actuator index or -1 (stack-array DM 0)
@@ -156,6 +158,7 @@ struct aomarl_ctx {
 };
 
 static int pipe_drop(aomarl_ctx *c, void *stream);
+static void rp_free(aomarl_ctx *c);
 // Start the timing events over.  The closing event of a timed frame launch doubles as that frame's "readers are
 // done" mark (pipe.ev_done_cur / ev_frame_cur / ev_frame_prev): one that a frame in flight still carries must not be
 // re-recorded by a later launch, so it is retired (it stays valid for whoever waits on it) and replaced.
@@ -659,6 +662,7 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (c->ev_psf) (void)hipEventDestroy(c->ev_psf);
   if (c->env_gain) (void)hipFree(c->env_gain);
   if (c->seed_stage) (void)hipFree(c->seed_stage);
+  rp_free(c);
   for (hipEvent_t e : c->fw_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->fw_ev_retired) (void)hipEventDestroy(e);
   delete c;
@@ -1174,8 +1178,74 @@ int aomarl_reset_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *str
   return 0;
 }
 
-int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *seeds, float *accumx,
-                 float *accumy, void *stream) {
+// The rounds of a reset (refresh_screen: 2*dim extrusions along x, sign of deltax, atmosCompass.py:141-145).
+// The 2 n extrusions of a reset all run along x: every new line is a COLUMN of the row-major ring
+// (648 scattered 4-byte writes per environment and layer, and the stencil's full first column 648
+// scattered reads: one 64-byte sector each).  Done on the TRANSPOSED screen they are row
+// operations -- the x stencil with its coordinates exchanged, the zero screen is its own
+// transpose -- and one in-place transposition at the end gives the same screen, bit for bit.
+static void reset_rounds_plan(const aomarl_ctx *c, std::vector<RoundOps> &rounds) {
+  int maxr = 0;
+  for (int l = 0; l < c->nlayers; l++) if (2 * c->dim[l] > maxr) maxr = 2 * c->dim[l];
+  rounds.assign((size_t)maxr, RoundOps());
+  const bool tr = !c->reset_untransposed;
+  for (int r = 0; r < maxr; r++) {
+    RoundOps &o = rounds[r];
+    o.nops = 0;
+    for (int l = 0; l < c->nlayers; l++)
+      if (r < 2 * c->dim[l]) {
+        const int dx = c->deltax[l] > 0.f ? 1 : -1;
+        o.layer[o.nops] = l; o.dir[o.nops] = tr ? 2 * dx : dx; o.tflag[o.nops] = tr ? 1 : 0; o.nops++;
+      }
+  }
+}
+// In how many parts a reset of n environments walks its rounds (each part's products have its own columns: the
+// partition fixes the split-K order of every sum, so the prefetched reset uses the plain one's)
+static int reset_parts(const aomarl_ctx *c, int n) {
+  if (c->reset_streams > 1 && c->prefetch_atmos && n >= 16 * c->reset_streams && !c->capturing)
+    return c->reset_streams > 4 ? 4 : c->reset_streams;
+  return 1;
+}
+// the screens' last step: back from the transposed form, mirror columns
+static int reset_screens_finish(aomarl_ctx *c, aomarl_state *st, int b, int n, hipStream_t s) {
+  if (c->reset_untransposed) return 0;
+  DevState ds = dev_state(st);
+  for (int l = 0; l < c->nlayers; l++) {
+    const int T = (c->dim[l] + 31) / 32;
+    hipLaunchKernelGGL(k_transpose_ring, dim3(T * (T + 1) / 2, n), dim3(256), 0, s, c->sys, ds, b, l, T);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_refresh_mirror, dim3((c->dim[l] * RING_PAD + 255) / 256, n), dim3(256), 0, s, c->sys, ds, b, l);
+    LAUNCHCHK();
+  }
+  return 0;
+}
+// everything of a reset but the screens: seeds, ring origins, counters, integrator vectors, DM shapes, slopes, Strehl
+static int reset_small(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *seeds, float *accumx, float *accumy,
+                       uint32_t *&stage, int &stage_n, hipStream_t s, bool whole_state) {
+  DevState ds = dev_state(st);
+  if (stage_n < n) {
+    if (stage) (void)hipFree(stage);
+    HIPCHK(hipMalloc((void **)&stage, sizeof(uint32_t) * (size_t)st->nenv));
+    stage_n = st->nenv;
+  }
+  HIPCHK(hipMemcpyAsync(stage, seeds, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_reset_env, dim3(n), dim3(256), 0, s, c->sys, ds, b, n, stage, st->ld_actu);
+  LAUNCHCHK();
+  if (!whole_state) return 0;
+  hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, st->dm_shape + (size_t)b * c->sys.shape_stride,
+                     (long long)n * c->sys.shape_stride, 0.f);
+  LAUNCHCHK();
+  hipLaunchKernelGGL(k_fill_f32, dim3(64), dim3(256), 0, s, st->slopes + (size_t)b * c->sys.nslope,
+                     (long long)n * c->sys.nslope, 0.f);
+  LAUNCHCHK();
+  int rc = aomarl_reset_strehl(c, st, b, n, (void *)s);
+  if (rc) return rc;
+  for (int e = b; e < b + n; e++)
+    for (int l = 0; l < c->nlayers; l++) { accumx[(size_t)e * c->nlayers + l] = 0.f; accumy[(size_t)e * c->nlayers + l] = 0.f; }
+  return 0;
+}
+// what a reset checks and drops first: a pipelined frame in flight, a prefetched atmosphere frame
+static int reset_prologue(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
   if (c && st && c->pipe.active && st->screens == c->pipe.owner_screens) {
     if (b != 0 || n != st->nenv) return fail("reset of environments [%d, %d) while a pipelined frame of the whole batch is in flight", b, b + n);
     int prc = pipe_drop(c, stream);
@@ -1184,7 +1254,6 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
   int rc = check_range(c, st, b, n);
   if (rc) return rc;
   if (n == 0) return 0;
-  if (!seeds || !accumx || !accumy) return fail("reset: null argument");
   rc = atmos_wait_pending(c, stream);
   if (rc) return rc;
   if (c->premoved && c->pre_screens == st->screens) {
@@ -1200,50 +1269,27 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
                   "reset the whole prefetched range, or call aomarl_move_atmos on it first",
                   b, b + n, c->pre_b, c->pre_b + c->pre_n);
   }
+  return 0;
+}
+
+int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *seeds, float *accumx,
+                 float *accumy, void *stream) {
+  int rc = reset_prologue(c, st, b, n, stream);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!seeds || !accumx || !accumy) return fail("reset: null argument");
   hipStream_t s = (hipStream_t)stream;
-  DevState ds = dev_state(st);
-  if (c->seed_stage_n < n) {
-    if (c->seed_stage) (void)hipFree(c->seed_stage);
-    HIPCHK(hipMalloc((void **)&c->seed_stage, sizeof(uint32_t) * (size_t)st->nenv));
-    c->seed_stage_n = st->nenv;
-  }
-  HIPCHK(hipMemcpyAsync(c->seed_stage, seeds, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
   c->screens_dirty_main = true;
-  hipLaunchKernelGGL(k_reset_env, dim3(n), dim3(256), 0, s, c->sys, ds, b, n, c->seed_stage, st->ld_actu);
-  LAUNCHCHK();
+  rc = reset_small(c, st, b, n, seeds, accumx, accumy, c->seed_stage, c->seed_stage_n, s, true);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, st->screens + (size_t)b * c->sys.screen_stride,
                      (long long)n * c->sys.screen_stride, 0.f);
   LAUNCHCHK();
-  hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, st->dm_shape + (size_t)b * c->sys.shape_stride,
-                     (long long)n * c->sys.shape_stride, 0.f);
-  LAUNCHCHK();
-  hipLaunchKernelGGL(k_fill_f32, dim3(64), dim3(256), 0, s, st->slopes + (size_t)b * c->sys.nslope,
-                     (long long)n * c->sys.nslope, 0.f);
-  LAUNCHCHK();
-  rc = aomarl_reset_strehl(c, st, b, n, stream);
-  if (rc) return rc;
-  for (int e = b; e < b + n; e++)
-    for (int l = 0; l < c->nlayers; l++) { accumx[(size_t)e * c->nlayers + l] = 0.f; accumy[(size_t)e * c->nlayers + l] = 0.f; }
-  // refresh_screen: 2*dim extrusions along x, sign of deltax (atmosCompass.py:141-145)
-  int maxr = 0;
-  for (int l = 0; l < c->nlayers; l++) if (2 * c->dim[l] > maxr) maxr = 2 * c->dim[l];
-  std::vector<RoundOps> rounds((size_t)maxr);
-  for (int r = 0; r < maxr; r++) {
-    RoundOps &o = rounds[r];
-    o.nops = 0;
-    // The 2 n extrusions of a reset all run along x: every new line is a COLUMN of the row-major ring
-    // (648 scattered 4-byte writes per environment and layer, and the stencil's full first column 648
-    // scattered reads: one 64-byte sector each).  Done on the TRANSPOSED screen they are row
-    // operations -- the x stencil with its coordinates exchanged, the zero screen is its own
-    // transpose -- and one in-place transposition at the end gives the same screen, bit for bit.
-    const bool tr = !c->reset_untransposed;
-    for (int l = 0; l < c->nlayers; l++)
-      if (r < 2 * c->dim[l]) {
-        const int dx = c->deltax[l] > 0.f ? 1 : -1;
-        o.layer[o.nops] = l; o.dir[o.nops] = tr ? 2 * dx : dx; o.tflag[o.nops] = tr ? 1 : 0; o.nops++;
-      }
-  }
-  if (c->reset_streams > 1 && c->prefetch_atmos && n >= 16 * c->reset_streams && !c->capturing && side_stream(c) == 0) {
+  std::vector<RoundOps> rounds;
+  reset_rounds_plan(c, rounds);
+  const int maxr = (int)rounds.size();
+  const int parts = reset_parts(c, n);
+  if (parts > 1 && side_stream(c) == 0) {
     // The batch in parts side by side, one stream each (the caller's, the extrusion stream, two more of the
     // process): a round is gather | GEMM | scatter + gather, 45 us of which 15 are latency (launch, first operand
     // lines, the dependent loads of the stencil gather) that one part's kernels hide for the others' -- 1296
@@ -1251,7 +1297,6 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
     static hipStream_t g_rst[64][2] = {{nullptr}};
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
-    const int parts = c->reset_streams > 4 ? 4 : c->reset_streams;
     hipStream_t str[4] = {s, c->atm_stream, nullptr, nullptr};
     for (int k = 2; k < parts; k++) {
       if (dev < 0 || dev >= 64) return fail("reset: device ordinal %d", dev);
@@ -1284,17 +1329,145 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
     rc = extrude_rounds(c, st, b, n, rounds.data(), maxr, stream);
     if (rc) return rc;
   }
-  if (!c->reset_untransposed) {
-    for (int l = 0; l < c->nlayers; l++) {
-      const int T = (c->dim[l] + 31) / 32;
-      hipLaunchKernelGGL(k_transpose_ring, dim3(T * (T + 1) / 2, n), dim3(256), 0, s, c->sys, ds, b, l, T);
-      LAUNCHCHK();
-      hipLaunchKernelGGL(k_refresh_mirror, dim3((c->dim[l] * RING_PAD + 255) / 256, n), dim3(256), 0, s, c->sys, ds, b, l);
-      LAUNCHCHK();
-    }
-  }
+  rc = reset_screens_finish(c, st, b, n, s);
+  if (rc) return rc;
   // pending PSF of the fresh atmosphere with flat DMs: comp_strehl before the first
   // next_part_one is well defined
+  if (!c->sys.tar_all_int && !st->tar_phase) return 0;
+  return aomarl_target_psf(c, st, b, n, stream);
+}
+
+// ---------------------------------------------------------------- prefetched reset
+// The seeds of the next episode are known while this one runs (train_rpc.py:486-487: seed += 1 per episode), and a
+// reset is 2 x 648 DEPENDENT extrusion rounds per layer -- 45 ms for 256 environments, mostly latency.  So the next
+// episode's screens are grown in a SHADOW state (own screens, ring origins, counters, seeds, workspace) on a stream
+// of the caller's, a few rounds per step of the running episode, beside its kernels; aomarl_reset_adopt then
+// copies them in (1.3 GB device to device: < 1 ms) and does the rest of the reset.  Same kernels, same partition
+// of the batch, same columns, same split-K order as aomarl_reset: the same screens, bit for bit.
+struct ResetPrefetch {
+  aomarl_state shadow;                 // a copy of the caller's struct (its buffers stay the caller's)
+  int b = 0, n = 0, next_round = 0;
+  std::vector<RoundOps> rounds;
+  std::vector<ExtrudeRun> runs;
+  std::vector<uint32_t> seeds;
+  uint32_t *stage = nullptr; int stage_n = 0;
+  hipEvent_t ev = nullptr, ev_copied = nullptr;
+  bool finished = false, copied = false;
+};
+// stream == NULL: the library's own low-priority side stream (the one the PSF finish runs on: no further hardware queue)
+static int rp_stream(aomarl_ctx *c, void *stream, hipStream_t *out) {
+  if (stream) { *out = (hipStream_t)stream; return 0; }
+  int rc = side_stream(c);
+  if (rc) return rc;
+  *out = c->psf_stream;
+  return 0;
+}
+
+static void rp_free(aomarl_ctx *c) {
+  if (!c->rp) return;
+  if (c->rp->stage) (void)hipFree(c->rp->stage);
+  if (c->rp->ev) (void)hipEventDestroy(c->rp->ev);
+  if (c->rp->ev_copied) (void)hipEventDestroy(c->rp->ev_copied);
+  delete c->rp;
+  c->rp = nullptr;
+}
+
+int aomarl_reset_prefetch_begin(aomarl_ctx *c, const aomarl_state *shadow, int b, int n, const uint32_t *seeds, void *stream) {
+  if (!c || !shadow || !seeds) return fail("reset_prefetch_begin: null argument");
+  if (c->pipe.active && shadow->screens == c->pipe.owner_screens) return fail("reset_prefetch_begin: the shadow must not be the live state");
+  int rc = check_range(c, shadow, b, n);
+  if (rc) return rc;
+  if (n == 0) return fail("reset_prefetch_begin: empty range");
+  ResetPrefetch *rp = c->rp;
+  if (!rp) {
+    rp = c->rp = new ResetPrefetch();
+    HIPCHK(hipEventCreateWithFlags(&rp->ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&rp->ev_copied, hipEventDisableTiming));
+  }
+  rp->shadow = *shadow; rp->b = b; rp->n = n; rp->next_round = 0; rp->finished = false;
+  rp->seeds.assign(seeds, seeds + n);
+  hipStream_t s = nullptr;
+  rc = rp_stream(c, stream, &s);
+  if (rc) return rc;
+  stream = (void *)s;
+  if (rp->copied) HIPCHK(hipStreamWaitEvent(s, rp->ev_copied, 0));      // the last adoption has read the shadow
+  // (reset_small with whole_state = false: seeds, origins, counters and the SHADOW's small vectors only)
+  rc = reset_small(c, &rp->shadow, b, n, seeds, nullptr, nullptr, rp->stage, rp->stage_n, s, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, rp->shadow.screens + (size_t)b * c->sys.screen_stride,
+                     (long long)n * c->sys.screen_stride, 0.f);
+  LAUNCHCHK();
+  reset_rounds_plan(c, rp->rounds);
+  rp->runs.clear();
+  const int parts = reset_parts(c, n);
+  int e0 = b;
+  for (int k = 0; k < parts; k++) {         // the plain reset's partition, all parts on the one stream
+    const int nk = (b + n - e0) / (parts - k);
+    rp->runs.emplace_back(c, &rp->shadow, e0, nk, stream, false);
+    e0 += nk;
+  }
+  HIPCHK(hipEventRecord(rp->ev, s));
+  return 0;
+}
+
+int aomarl_reset_prefetch_advance(aomarl_ctx *c, int nrounds, void *stream, int *remaining) {
+  if (!c || !c->rp) return fail("reset_prefetch_advance: no prefetch has begun");
+  ResetPrefetch *rp = c->rp;
+  hipStream_t s = nullptr;
+  { int src = rp_stream(c, stream, &s); if (src) return src; }
+  const int maxr = (int)rp->rounds.size();
+  if (!rp->finished) {
+    for (auto &run : rp->runs) run.s = s;
+    const int end = nrounds < 0 ? maxr : std::min(maxr, rp->next_round + nrounds);
+    for (; rp->next_round < end; rp->next_round++)
+      for (auto &run : rp->runs) {
+        int rc = run.step(rp->rounds.data(), rp->next_round, maxr);
+        if (rc) return rc;
+      }
+    if (rp->next_round >= maxr) {
+      int rc = reset_screens_finish(c, &rp->shadow, rp->b, rp->n, s);
+      if (rc) return rc;
+      rp->finished = true;
+    }
+    HIPCHK(hipEventRecord(rp->ev, s));
+  }
+  if (remaining) *remaining = maxr - rp->next_round;
+  return 0;
+}
+
+int aomarl_reset_prefetch_cancel(aomarl_ctx *c) {
+  if (!c) return fail("reset_prefetch_cancel: null ctx");
+  if (c->rp) { c->rp->runs.clear(); c->rp->finished = false; c->rp->n = 0; }
+  return 0;
+}
+
+int aomarl_reset_adopt(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *seeds, float *accumx, float *accumy,
+                       void *prefetch_stream, void *stream) {
+  if (!c || !c->rp || c->rp->n == 0) return fail("reset_adopt: no prefetched reset");
+  ResetPrefetch *rp = c->rp;
+  if (!seeds || !accumx || !accumy) return fail("reset_adopt: null argument");
+  if (rp->b != b || rp->n != n) return fail("reset_adopt: prefetched environments [%d, %d), asked for [%d, %d)", rp->b, rp->b + rp->n, b, b + n);
+  for (int i = 0; i < n; i++)
+    if (rp->seeds[i] != seeds[i]) return fail("reset_adopt: the prefetched reset was begun with other seeds");
+  if (st->screens == rp->shadow.screens) return fail("reset_adopt: the shadow is the state itself");
+  int rc = reset_prologue(c, st, b, n, stream);
+  if (rc) return rc;
+  if (!rp->finished) {                      // what is left of the rounds, now
+    rc = aomarl_reset_prefetch_advance(c, -1, prefetch_stream, nullptr);
+    if (rc) return rc;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  c->screens_dirty_main = true;
+  rc = reset_small(c, st, b, n, seeds, accumx, accumy, c->seed_stage, c->seed_stage_n, s, true);
+  if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(s, rp->ev, 0));
+  const size_t so = (size_t)b * c->sys.screen_stride, nl = (size_t)c->nlayers;
+  HIPCHK(hipMemcpyAsync(st->screens + so, rp->shadow.screens + so, sizeof(float) * (size_t)n * c->sys.screen_stride, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(st->origin + (size_t)b * nl * 2, rp->shadow.origin + (size_t)b * nl * 2, sizeof(int32_t) * (size_t)n * nl * 2, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(st->ext_count + (size_t)b * nl, rp->shadow.ext_count + (size_t)b * nl, sizeof(uint32_t) * (size_t)n * nl, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipEventRecord(rp->ev_copied, s));
+  rp->copied = true;
+  rp->n = 0; rp->finished = false; rp->runs.clear();          // consumed
   if (!c->sys.tar_all_int && !st->tar_phase) return 0;
   return aomarl_target_psf(c, st, b, n, stream);
 }

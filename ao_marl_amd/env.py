@@ -189,12 +189,49 @@ class VecRlSupervisor(object):
         return self.current_seed
 
     # ---------------------------------------------------------------- loop
+    # The NEXT reset's screens grown beside the running episode (aomarl_reset_prefetch_*, sim.prefetch_reset_*).
+    # reset_prefetch: None (off); "same" (the next reset repeats this one's seeds: benchmarks, evaluation on fixed
+    # seeds); an int w (the next reset follows next_seed_block(w): train_agent).  The rounds are dealt out evenly over
+    # the first `reset_prefetch_span` steps of the episode (default: 95 % of max_steps_per_episode, so that every step
+    # carries the same share); `step_done()` (called by VecAoEnv.step) issues them; a reset that comes earlier runs
+    # what is left.
+    reset_prefetch = None
+    reset_prefetch_span = None
+
+    def _begin_reset_prefetch(self):
+        sim = self.sim
+        if self.reset_prefetch is None or not hasattr(sim, "prefetch_reset_begin"):
+            return
+        if self.reset_prefetch == "same":
+            nxt = self.env_seeds()
+        else:
+            nxt = self.env_seeds() + self.seed_block() * int(self.reset_prefetch)
+        sim.prefetch_reset_begin(nxt)
+        total = 2 * max(self.s.screen_dim) if hasattr(self.s, "screen_dim") else 0
+        span = self.reset_prefetch_span
+        if span is None:                        # evenly over (95 % of) the episode: every step carries the same share
+            span = 0.95 * float(self.config_rl.get("max_steps_per_episode", 1000))
+        self._rp_rate, self._rp_acc = total / max(1.0, float(span)), 0.0
+
+    def step_done(self):
+        """Once per environment step: the prefetched reset's share of rounds (no-op when none is pending)."""
+        if self.reset_prefetch is not None and getattr(self, "_rp_left", 0):
+            self._rp_acc += self._rp_rate
+            k = int(self._rp_acc)
+            if k:
+                self._rp_acc -= k
+                self._rp_left = self.sim.prefetch_reset_advance(k)
+
     def reset(self):
         """rlSupervisor.py:236-246 for every environment (seed e: current_seed + stride*e)."""
         if self.autoencoder is not None and hasattr(self.autoencoder, "check_range"):
             self.autoencoder.check_range()      # a saturated fp16 launch of the last episode is an error
         self.check_range()
         self.sim.reset(self.env_seeds())
+        self._rp_left = 0
+        if self.reset_prefetch is not None:
+            self._begin_reset_prefetch()
+            self._rp_left = -1
         if self.geo is not None:
             self.geo.reset()
         self._control_pending, self._err_stale = False, False
@@ -381,7 +418,8 @@ class VecAoEnv(object):
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
                  strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None,
-                 geo=False, prefetch_atmos=True, frame_pipeline="auto", dead_columns="mask"):
+                 geo=False, prefetch_atmos=True, frame_pipeline="auto", dead_columns="mask",
+                 reset_prefetch=None):
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -398,6 +436,9 @@ class VecAoEnv(object):
                                           autoencoder=autoencoder, geo=geo,
                                           prefetch_atmos=prefetch_atmos)
         sup = self.supervisor
+        # the next reset's screens grown beside the running episode: None, "same" or the number of seed blocks the
+        # trainer moves on by per episode (VecRlSupervisor.reset_prefetch; train_agent sets it)
+        sup.reset_prefetch = reset_prefetch
         self.nenv, self.device = nenv, sup.device
         self.nmodes = sup.nmodes
         if normalization_bool:
@@ -810,6 +851,8 @@ class VecAoEnv(object):
             if self._pipe_eligible():
                 sup.sim.enable_frame_pipeline()
         sup.sim.env_step(g, action, sup.gain, state, r)
+        if sup.reset_prefetch is not None:
+            sup.step_done()
         self._ring_pos = g.ring_pos
         self._last_res_modes = self._res_modes
         sup.last_modes = None
@@ -901,6 +944,8 @@ class VecAoEnv(object):
         _, done, info = self.rl_step(action, linear_control)
         r = self.divide_rewards_for_agents() if self.layout is not None else None
         s_next = self.linear_step()
+        if self.supervisor.reset_prefetch is not None:
+            self.supervisor.step_done()
         return s_next, r, done, info
 
 

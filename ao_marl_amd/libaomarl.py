@@ -92,6 +92,10 @@ SYMBOLS = [
     ("aomarl_screen_stride", C.c_size_t, [_vp]),
     ("aomarl_dmshape_stride", C.c_size_t, [_vp]),
     ("aomarl_reset", _i, _range + [_up, _fp, _fp, _vp]),
+    ("aomarl_reset_prefetch_begin", _i, _range + [_up, _vp]),
+    ("aomarl_reset_prefetch_advance", _i, [_vp, _i, _vp, C.POINTER(_i)]),
+    ("aomarl_reset_prefetch_cancel", _i, [_vp]),
+    ("aomarl_reset_adopt", _i, _range + [_up, _fp, _fp, _vp, _vp]),
     ("aomarl_move_atmos", _i, _range + [_fp, _fp, _vp]),
     ("aomarl_prefetch_atmos", _i, _range + [_fp, _fp, _vp]),
     ("aomarl_extrude", _i, _range + [_i, _ip, _ip, _vp]),

@@ -769,6 +769,10 @@ def train_agent(env, sac, n_episodes, max_steps=None, test_every=50, n_updates=N
     # several ranks = several collectors feeding ONE learner (BatchedSAC.sync_learners): equal weights
     # at the start, averaged learner state after every episode's updates
     sac.sync_learners(init=True)
+    # (VecAoEnv(reset_prefetch=world) grows the next training episode's screens beside this one,
+    # aomarl_reset_prefetch_*: its seeds are this episode's + one block per rank; an evaluation in between resets on
+    # other seeds, the prefetch is dropped and that reset runs in the open.  Opt-in: on this GPU the loop is bound by
+    # instruction issue, the hidden rounds cost the steps what the reset saved -- DESIGN.md)
     for ep in range(int(n_episodes)):
         seed = env.supervisor.current_seed
         out = run_episode(env, sac, max_steps=max_steps, train=True, n_updates=n_updates,

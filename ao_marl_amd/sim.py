@@ -303,13 +303,82 @@ class HipSim(object):
         self._alloc()
 
     # ------------------------------------------------------------------ per-frame API
+    # ------------------------------------------------------------------ prefetched reset
+    def prefetch_reset_begin(self, seeds):
+        """aomarl_reset_prefetch_begin for the whole batch: the screens of the NEXT reset (with these seeds) start
+        growing in a shadow state on a stream of their own; prefetch_reset_advance(k) runs k more of the
+        2 x dim rounds -- call it once per step of the running episode --, and reset(seeds) with the same seeds
+        adopts them (runs what is left first).  Any other reset drops the prefetch."""
+        n = self.nenv
+        seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, (n,)), dtype=np.uint32)
+        if getattr(self, "_rp", None) is None:
+            f32, i32 = dict(dtype=torch.float32, device=self.device), dict(dtype=torch.int32, device=self.device)
+            t = {"screens": torch.zeros(n, self.screen_stride, **f32), "origin": torch.zeros_like(self.t["origin"]),
+                 "seeds": torch.zeros(n, **i32), "ext_count": torch.zeros_like(self.t["ext_count"]),
+                 "frame": torch.zeros(n, **i32), "work": torch.zeros(self.t["work"].numel(), **f32)}
+            for k in ("com", "com1", "com2", "err", "voltage"):
+                t[k] = torch.zeros(n, self.ld_actu, **f32)
+            st2 = la.State()
+            for name, _ in la.State._fields_:
+                setattr(st2, name, getattr(self.st, name))       # (slopes, dm_shape, Strehl ...: never touched through it)
+            for k, v in t.items():
+                setattr(st2, k, v.data_ptr())
+            # rp_own_stream: the rounds on a stream of their own instead of the library's low-priority side stream
+            # (one more hardware queue: measured, it can alias with the frame stream and serialise the pipelined order)
+            own = torch.cuda.Stream(device=self.device) if getattr(self, "rp_own_stream", False) else None
+            self._rp = dict(t=t, st=st2, stream=own, seeds=None, left=0)
+            # the shadow's buffers were zero-filled on the caller's stream just now; the rounds start on another one
+            torch.cuda.current_stream(self.device).synchronize()
+        rp = self._rp
+        if rp["stream"] is not None:
+            rp["stream"].wait_stream(torch.cuda.current_stream(self.device))
+        la.check(self.lib.aomarl_reset_prefetch_begin(self.ctx, C.byref(rp["st"]), 0, n, la.uptr(seeds), self._rp_stream()))
+        rp["seeds"], rp["left"] = seeds.copy(), -1
+
+    def _rp_stream(self):
+        st = self._rp["stream"]
+        return C.c_void_p(st.cuda_stream) if st is not None else None
+
+    def prefetch_reset_advance(self, nrounds):
+        """nrounds more rounds of the begun prefetch (returns the rounds left; 0 when none was begun)."""
+        rp = getattr(self, "_rp", None)
+        if rp is None or rp["seeds"] is None or rp["left"] == 0:
+            return 0
+        left = C.c_int(0)
+        la.check(self.lib.aomarl_reset_prefetch_advance(self.ctx, int(nrounds), self._rp_stream(), C.byref(left)))
+        rp["left"] = int(left.value)
+        return rp["left"]
+
+    def prefetch_reset_pending(self, seeds=None):
+        """True when a prefetch has been begun (for these seeds, if given) and not yet adopted."""
+        rp = getattr(self, "_rp", None)
+        if rp is None or rp["seeds"] is None:
+            return False
+        if seeds is None:
+            return True
+        seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, (self.nenv,)), dtype=np.uint32)
+        return bool(np.array_equal(seeds, rp["seeds"]))
+
     def reset(self, seeds, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.int64) &
                                                      0xFFFFFFFF, (n,)), dtype=np.uint32)
-        la.check(self.lib.aomarl_reset(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
-                                       la.fptr(self.accumx), la.fptr(self.accumy),
-                                       self._stream()))
+        rp = getattr(self, "_rp", None)
+        if rp is not None and rp["seeds"] is not None:
+            if (b, n) == (0, self.nenv) and np.array_equal(seeds, rp["seeds"]):
+                la.check(self.lib.aomarl_reset_adopt(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
+                                                     la.fptr(self.accumx), la.fptr(self.accumy),
+                                                     self._rp_stream(), self._stream()))
+                self.prefetched_resets = getattr(self, "prefetched_resets", 0) + 1
+            else:                               # other seeds / a part of the batch: the prefetch is of no use
+                la.check(self.lib.aomarl_reset_prefetch_cancel(self.ctx))
+                la.check(self.lib.aomarl_reset(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
+                                               la.fptr(self.accumx), la.fptr(self.accumy), self._stream()))
+            rp["seeds"], rp["left"] = None, 0
+        else:
+            la.check(self.lib.aomarl_reset(self.ctx, C.byref(self.st), b, n, la.uptr(seeds),
+                                           la.fptr(self.accumx), la.fptr(self.accumy),
+                                           self._stream()))
         # the library drops a prefetched frame only when the reset covers its range (a reset of a
         # range disjoint from it leaves it pending, one that cuts into it is refused above)
         if self.pending_atmos:

@@ -92,6 +92,10 @@ def parse_args():
                          "both call orders behind the first reset (the default, frame_pipeline='auto')")
     ap.add_argument("--no-whole-episode", action="store_true",
                     help="skip the measured whole episode (reset + episode_len steps) behind the timed region")
+    ap.add_argument("--reset-prefetch", action="store_true",
+                    help="VecAoEnv(reset_prefetch='same') for the MAIN pass: the next episode's screens grow beside the "
+                         "running episode (aomarl_reset_prefetch_*).  Default: resets in the open, and the prefetched "
+                         "form measured as a side figure (`reset_prefetch`: a whole episode with it)")
     ap.add_argument("--timed-only", action="store_true",
                     help="nothing but warm-up + the timed region on the GPU (profiling): no plain-order pass, no stage split")
     ap.add_argument("--no-frame-pipeline", action="store_true",
@@ -283,7 +287,8 @@ def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
 class Workload(object):
     """A VecAoEnv + random-init batched SAC actors for one BASELINE configuration."""
 
-    def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True, pipeline="auto"):
+    def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True, pipeline="auto",
+                 reset_prefetch=None):
         import torch
         from ao_marl_amd.agents import BatchedGaussianPolicy
         from ao_marl_amd.env import VecAoEnv, load_norm
@@ -312,7 +317,8 @@ class Workload(object):
         self.first_seed = shard_seeds(1234, envs, rank, stride=16)
         self.env = VecAoEnv(config, envs, rl, initial_seed=self.first_seed, seed_stride=16,
                             n_agents_modal=n_modal, device=device, autoencoder=autoencoder,
-                            prefetch_atmos=prefetch, frame_pipeline=pipeline if prefetch else False, **norm_kw)
+                            prefetch_atmos=prefetch, frame_pipeline=pipeline if prefetch else False,
+                            reset_prefetch=reset_prefetch, **norm_kw)
         self.layout = self.env.layout
         # random-init actors (last layer NOT zeroed, so actions are non-trivial): the cost of a step
         # does not depend on the weights; the loop is not expected to converge (Strehl is reported
@@ -392,8 +398,9 @@ class Workload(object):
             return 0.0
         return max(0.0, self.settle_s - self.settle_steps * elapsed / steps)
 
-    def time_episode(self, episode_len, dist=None, backend="nccl"):
-        """One WHOLE episode, measured: reset + episode_len steps between synchronisations (MAX over ranks)."""
+    def time_episode(self, episode_len, dist=None, backend="nccl", split_reset=False):
+        """One WHOLE episode, measured: reset + episode_len steps between synchronisations (MAX over ranks).
+        split_reset: one more synchronisation behind the reset; returns (episode s, reset s)."""
         torch = self.torch
         gc.collect()
         gc.disable()
@@ -403,6 +410,10 @@ class Workload(object):
                 dist.barrier()
             t0 = time.perf_counter()
             self.reset()
+            t_reset = None
+            if split_reset:
+                torch.cuda.synchronize()
+                t_reset = time.perf_counter() - t0
             for _ in range(episode_len):
                 self.one_step()
             torch.cuda.synchronize()
@@ -410,10 +421,10 @@ class Workload(object):
         finally:
             gc.enable()
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=self.device if backend == "nccl" else "cpu")
+            t = torch.tensor([dt, t_reset or 0.0], dtype=torch.float64, device=self.device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+            dt, t_reset = float(t[0].item()), (float(t[1].item()) if split_reset else None)
+        return (dt, t_reset) if split_reset else dt
 
     def time_reset(self, dist=None, backend="nccl"):
         """One env.reset() (RlSupervisor.reset: 2n extrusions per layer + the first frame), MAX over ranks."""
@@ -547,7 +558,8 @@ def main():
     libaomarl.set_precision(args.precision)
     w = Workload(args.config, args.envs, rank, world, device, denoiser=denoiser,
                  prefetch=not args.no_prefetch,
-                 pipeline=False if args.no_frame_pipeline else (True if args.frame_pipeline_always else "auto"))
+                 pipeline=False if args.no_frame_pipeline else (True if args.frame_pipeline_always else "auto"),
+                 reset_prefetch="same" if (args.reset_prefetch and not args.no_prefetch) else None)
     env, sim, layout = w.env, w.sim, w.layout
     env.residual_shortcut = bool(args.residual_shortcut)
     if args.unfused:
@@ -563,11 +575,17 @@ def main():
     for _ in range(3):                              # one-time costs of a process's first episode (allocations: 11 ms in
         w.one_step()                                # the first step) are not a per-episode transient
     w.reset()
-    reset_s = w.time_reset(dist, backend)           # one full reset of this rank's batch, timed
+    rp_on = env.supervisor.reset_prefetch is not None
+    # One full reset of this rank's batch in the open, timed (with the reset prefetch on: the rounds the prefetch begun
+    # a moment ago has not run yet -- all of them -- are run by this call: the same figure)
+    reset_open_s = w.time_reset(dist, backend)
     elapsed, t_enq, fk_ms = w.timed(args.steps, args.warmup, dist, backend, settle=args.settle)
     envs_total = args.envs * world
     transient_s = w.transient_excess(args.steps, elapsed)
-    value = amortised(envs_total, args.steps, elapsed, reset_s + transient_s, args.episode_len)
+    # What a reset costs an episode: in the open, all of it; prefetched, the timed steps already carry their share
+    # of the next reset's rounds (dealt out evenly over the episode) and the reset call itself adopts the screens --
+    # measured behind a whole episode below (reset_s is replaced by that figure).
+    reset_s = reset_open_s
     kernel_name = sim.frame_kernel_name()
     launched = dict(w.launched)
     sr = float(sim.strehl[:, 1].mean())
@@ -588,10 +606,31 @@ def main():
     # one whole episode, measured (reset + episode_len steps): what `value` amortises, without the amortisation
     whole = None
     if not args.timed_only and not args.no_whole_episode:
-        ep_s = w.time_episode(args.episode_len, dist, backend)
+        if rp_on:
+            w.time_episode(args.episode_len, dist, backend)      # (an episode whose prefetch runs to its end)
+        ep_s, rs = w.time_episode(args.episode_len, dist, backend, split_reset=True)
         whole = {"steps": args.episode_len, "seconds": ep_s, "value": envs_total * args.episode_len / ep_s,
-                 "ms_per_step": ep_s / args.episode_len * 1e3,
-                 "what": "reset + episode_len steps of the same loop between two synchronisations, behind the timed region"}
+                 "ms_per_step": ep_s / args.episode_len * 1e3, "reset_ms": rs * 1e3,
+                 "what": "reset + episode_len steps of the same loop between two synchronisations (one more behind the "
+                         "reset), behind the timed region%s" % (" and behind one untimed whole episode: the reset ADOPTS the "
+                                                                "screens grown beside that episode" if rp_on else "")}
+        if rp_on:
+            reset_s = rs
+    elif rp_on:
+        reset_s = 0.0 if args.timed_only else reset_open_s
+    value = amortised(envs_total, args.steps, elapsed, reset_s + transient_s, args.episode_len)
+    # side figure: the same whole episode with the NEXT reset's rounds hidden beside it (single-GPU runs)
+    rp_side = None
+    if whole is not None and not rp_on and dist is None and not args.no_prefetch:
+        try:
+            env.supervisor.reset_prefetch = "same"
+            w.time_episode(args.episode_len)             # (begins the prefetch, runs it to its end)
+            ep2, rs2 = w.time_episode(args.episode_len, split_reset=True)
+            rp_side = {"whole_episode_value": envs_total * args.episode_len / ep2, "ms_per_step": ep2 / args.episode_len * 1e3,
+                       "reset_ms": rs2 * 1e3, "prefetched_resets": int(getattr(sim, "prefetched_resets", 0))}
+        finally:
+            env.supervisor.reset_prefetch = None
+            w.reset()
     # the same steps in the plain call order (frame kernel alone on the GPU, the chains behind it): what the
     # pipeline buys, and the frame kernel's duration without the chains' kernels beside it
     plain = None
@@ -644,6 +683,11 @@ def main():
             "value_no_reset": envs_total * args.steps / elapsed,
             "ms_per_step_no_reset": elapsed / args.steps * 1e3,
             "reset_ms": reset_s * 1e3,
+            "reset_in_the_open_ms": reset_open_s * 1e3,
+            "reset_prefetch": {"on": rp_on, "prefetched_resets": int(getattr(sim, "prefetched_resets", 0)), "side_figure": rp_side,
+                               "what": "the next episode's 2 x 648 extrusion rounds per layer run in a shadow state beside this "
+                                       "episode's steps (dealt out evenly: the timed steps carry their share), reset() adopts the "
+                                       "screens: bit-identical to the reset in the open (aomarl_reset_prefetch_*)"},
             "post_reset_transient_ms": transient_s * 1e3,
             "episode_position": {"settle": args.settle, "warmup": args.warmup,
                                  "what": "the timed steps are frames [settle + warmup, settle + warmup + steps) of an episode; "

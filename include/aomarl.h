@@ -190,6 +190,23 @@ size_t aomarl_dmshape_stride(const aomarl_ctx *ctx);  /* floats per env in st->d
  * seeds: host [env_count]; accumx/accumy: host [nenv][nlayers], zeroed for the reset envs. */
 int aomarl_reset(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                  const uint32_t *seeds, float *accumx, float *accumy, void *stream);
+
+/* The next episode's reset, hidden behind the running one.  The trainer knows the next seeds while an episode
+ * runs (train_rpc.py:486-487: `seed += 1`), and refresh_screen is 2 x dim DEPENDENT extrusions per layer
+ * (atmosCompass.py:137-145) -- most of a reset's time.  aomarl_reset_prefetch_begin starts them in a SHADOW state
+ * (own screens / origin / seeds / ext_count / frame / com, com1, com2, err, voltage / work; the other buffers may
+ * alias the live state's: they are not touched), aomarl_reset_prefetch_advance runs `nrounds` more rounds (< 0: all
+ * that are left) -- both on a stream of the caller's choice, beside the live episode --, and aomarl_reset_adopt is
+ * aomarl_reset with the screens COPIED from the shadow (it first runs whatever rounds are left, on
+ * prefetch_stream).  Same kernels on the same columns in the same partition of the batch as aomarl_reset: the
+ * screens are the plain reset's, bit for bit (tests/test_gpu_glue.py).  The seeds must be those of the begin call.
+ * `*remaining` = rounds still to run.  aomarl_reset_prefetch_cancel forgets a begun prefetch. */
+int aomarl_reset_prefetch_begin(aomarl_ctx *ctx, const aomarl_state *shadow, int env_begin, int env_count,
+                                const uint32_t *seeds, void *stream);
+int aomarl_reset_prefetch_advance(aomarl_ctx *ctx, int nrounds, void *stream, int *remaining);
+int aomarl_reset_prefetch_cancel(aomarl_ctx *ctx);
+int aomarl_reset_adopt(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, const uint32_t *seeds,
+                       float *accumx, float *accumy, void *prefetch_stream, void *stream);
 /* Atmos.move_atmos (atmosCompass.py:161). accumx/accumy: host [nenv][nlayers], updated. */
 int aomarl_move_atmos(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                       float *accumx, float *accumy, void *stream);

@@ -8,6 +8,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from ao_marl_amd.agents import AgentLayout, BatchedGaussianPolicy  # noqa: E402
+from tests import helpers  # noqa: E402
 
 
 def _layout():
@@ -782,3 +783,65 @@ def test_default_call_order_is_probed_and_falls_back_loudly():
                      dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5), n_agents_modal=13)
     noisy.reset()
     assert noisy.frame_pipeline is False and noisy.order_probe is None
+
+
+@pytest.mark.parametrize("name,nenv", [("production_sh_10x10_2m", 6), ("production_sh_40x40_8m_3layers", 32)])
+def test_prefetched_reset_is_the_plain_reset_bit_for_bit(name, nenv):
+    """aomarl_reset_prefetch_begin / _advance / aomarl_reset_adopt: the next episode's screens grown in a shadow state
+    beside the running episode (a few rounds per step, on a stream of their own) are the plain reset's -- screens,
+    ring origins, extrusion counters, and the frames that follow -- bit for bit; the running episode is not
+    disturbed; a reset that comes before the rounds are through runs what is left; other seeds drop the prefetch.
+    32 environments of the 40x40 system: the reset walks its rounds in two parts of the batch (reset_streams)."""
+    from ao_marl_amd.sim import HipSim
+    _, s, cal = helpers.calibrated(name)
+    sims = []
+    for _ in range(2):
+        sim = HipSim(s, nenv=nenv)
+        sim.set_modal(cal.volts2modes, cal.modes2volts)
+        sim.set_option("prefetch_atmos", 1)
+        sims.append(sim)
+    a, b = sims
+    s1, s2, s3 = 100 + 16 * np.arange(nenv), 9000 + 16 * np.arange(nenv), 555 + 16 * np.arange(nenv)
+    total = 2 * max(s.screen_dim)
+
+    def frames(k):
+        for _ in range(k):
+            for x in (a, b):
+                x.next_part_two(None)
+                x.next_part_one()
+
+    def same_state(what):
+        for l in range(s.nscreens):
+            assert torch.equal(a.screen(l), b.screen(l)), (what, "screen", l)
+        assert torch.equal(a.t["origin"], b.t["origin"]) and torch.equal(a.t["ext_count"], b.t["ext_count"]), what
+        assert torch.equal(a.t["seeds"], b.t["seeds"]), what
+        assert torch.equal(a.slopes, b.slopes) and torch.equal(a.com, b.com) and torch.equal(a.t["strehl"], b.t["strehl"]), what
+
+    a.reset(s1); b.reset(s1)
+    b.prefetch_reset_begin(s2)
+    assert b.prefetch_reset_pending(s2) and not b.prefetch_reset_pending(s3)
+    left = total
+    while left:                                  # the rounds a few at a time, frames of the live episode in between
+        left = b.prefetch_reset_advance(97)
+        frames(1)
+    same_state("the running episode beside the prefetch")
+    a.reset(s2); b.reset(s2)                     # b adopts
+    assert getattr(b, "prefetched_resets", 0) == 1 and not b.prefetch_reset_pending()
+    same_state("adopted reset")
+    frames(3)
+    same_state("frames behind the adopted reset")
+    # a reset that comes early: what is left of the rounds runs inside it
+    b.prefetch_reset_begin(s3)
+    assert b.prefetch_reset_advance(11) == total - 11
+    frames(2)
+    a.reset(s3); b.reset(s3)
+    assert b.prefetched_resets == 2
+    same_state("early adoption")
+    frames(2)
+    same_state("frames behind the early adoption")
+    # other seeds: the prefetch is dropped, the reset runs in the open
+    b.prefetch_reset_begin(s1)
+    b.prefetch_reset_advance(5)
+    a.reset(s2); b.reset(s2)
+    assert b.prefetched_resets == 2 and not b.prefetch_reset_pending()
+    same_state("dropped prefetch")
