@@ -148,6 +148,8 @@ struct aomarl_ctx {
   int seed_stage_n = 0;
   // aomarl_reset_prefetch_*: the NEXT episode's screens grown in a shadow state while this episode runs
   struct ResetPrefetch *rp = nullptr;
+  // aomarl_target_image: DFT tables and per-environment scratch of the full-frame PSF (on demand)
+  float *timg = nullptr;
   // geometric controller (aomarl_set_geo): host copies of the lattice tables it is built from,
   // projection operands on the device
   std::vector<int32_t> h_grid;     // [gh][gw] actuator index or -1 (stack-array DM 0)
@@ -663,6 +665,7 @@ int aomarl_destroy(aomarl_ctx *c) {
   if (c->env_gain) (void)hipFree(c->env_gain);
   if (c->seed_stage) (void)hipFree(c->seed_stage);
   rp_free(c);
+  if (c->timg) (void)hipFree(c->timg);
   for (hipEvent_t e : c->fw_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->fw_ev_retired) (void)hipEventDestroy(e);
   delete c;
@@ -3253,6 +3256,93 @@ int aomarl_target_psf_buffer(aomarl_ctx *c, aomarl_state *st, int b, int n, void
   if (!st->tar_phase) return fail("target_psf_buffer needs st->tar_phase");
   if (n == 0) return 0;
   return target_psf_impl(c, st, b, n, true, stream);
+}
+
+// ---------------------------------------------------------------- full-frame PSF (on demand)
+// Target.get_tar_image(expo_type = "se") (targetCompass.py:71-92): the whole npsf x npsf short-exposure PSF,
+// |FFT2(pupil . exp(2 pi i phase / lambda))|^2, centred (what fftshift returns).  The hot path only ever forms its
+// central 16 x 16 window; three of the environment's reward branches read the full frame (ao_env.py:621-623,
+// 654-656).  Two DFT passes as products on the library's fp32 GEMM: rows (pupdiam samples -> npsf frequencies), then
+// columns; 28 GFLOP per environment at 40x40 -- an on-demand diagnostic, one environment at a time.
+__global__ void k_timg_tables(float *__restrict__ W1, float *__restrict__ Wc, float *__restrict__ Ws, int pd, int npsf) {
+  // W1 [2 npsf][2 pd]: row (re, k) = [cos | sin], row (im, k) = [-sin | cos] of theta = 2 pi (k - npsf/2) x / npsf
+  // Wc, Ws [npsf][pd]: cos / sin of the same angle (second pass)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)npsf * pd) return;
+  const int k = (int)(i / pd), x = (int)(i - (long long)k * pd);
+  const long long f = (((long long)(k - npsf / 2) * x) % npsf + npsf) % npsf;
+  float sn, cs;
+  sincospif(2.0f * (float)f / (float)npsf, &sn, &cs);
+  Wc[i] = cs; Ws[i] = sn;
+  float *re = W1 + (long long)k * 2 * pd, *im = W1 + (long long)(npsf + k) * 2 * pd;
+  re[x] = cs; re[pd + x] = sn;
+  im[x] = -sn; im[pd + x] = cs;
+}
+__global__ void k_timg_amp(const float *__restrict__ phase, const float *__restrict__ pupil, float inv_lambda,
+                           float *__restrict__ amp, int pd) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pd * pd) return;
+  const int y = p / pd, x = p - y * pd;
+  const float m = pupil[p];
+  float a = phase[p] * inv_lambda;
+  a -= rintf(a);
+  amp[(long long)y * 2 * pd + x] = m != 0.f ? m * __builtin_amdgcn_cosf(a) : 0.f;
+  amp[(long long)y * 2 * pd + pd + x] = m != 0.f ? m * __builtin_amdgcn_sinf(a) : 0.f;
+}
+__global__ void k_timg_abs2(const float *__restrict__ yr, const float *__restrict__ yi, float *__restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = yr[i] * yr[i] + yi[i] * yi[i];
+}
+
+int aomarl_target_image(aomarl_ctx *c, aomarl_state *st, int b, int n, float *out, void *stream) {
+  int rc = check_range(c, st, b, n);
+  if (rc) return rc;
+  if (!out) return fail("target_image: null output");
+  if (n == 0) return 0;
+  if (c->premoved && c->pre_screens == st->screens)
+    return fail("target_image: the screens have already been moved to the next frame (aomarl_prefetch_atmos / "
+                "\"prefetch_atmos\"): the image of THIS frame cannot be formed any more -- run with the prefetch off");
+  rc = atmos_wait_pending(c, stream);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int pd = c->sys.pupdiam, np = c->sys.npsf;
+  const size_t o_w1 = 0, o_wc = o_w1 + (size_t)4 * np * pd, o_ws = o_wc + (size_t)np * pd, o_ph = o_ws + (size_t)np * pd,
+               o_amp = o_ph + (size_t)pd * pd, o_x = o_amp + (size_t)2 * pd * pd, o_yr = o_x + (size_t)2 * np * pd,
+               o_yi = o_yr + (size_t)np * np, total = o_yi + (size_t)np * np;
+  if (!c->timg) {
+    HIPCHK(hipMalloc((void **)&c->timg, sizeof(float) * total));
+    hipLaunchKernelGGL(k_timg_tables, dim3((unsigned)(((long long)np * pd + 255) / 256)), dim3(256), 0, s, c->timg + o_w1,
+                       c->timg + o_wc, c->timg + o_ws, pd, np);
+    LAUNCHCHK();
+  }
+  float *W1 = c->timg + o_w1, *Wc = c->timg + o_wc, *Ws = c->timg + o_ws, *ph = c->timg + o_ph, *amp = c->timg + o_amp;
+  float *X = c->timg + o_x, *Yr = c->timg + o_yr, *Yi = c->timg + o_yi;
+  if (c->defer_dm_shape) {                      // the stack-array shapes exist only as voltages: form them
+    rc = dm_shape_impl(c, st, b, n, nullptr, false, stream);
+    if (rc) return rc;
+  }
+  for (int e = b; e < b + n; e++) {
+    DevState ds = dev_state(st);
+    ds.tar_phase = ph - (long long)e * pd * pd;           // environment e of the kernel lands in the scratch
+    hipLaunchKernelGGL(k_raytrace<true>, dim3((pd * pd + 255) / 256, 1), dim3(256), 0, s, traced_sys(c), ds, e,
+                       AOMARL_TRACE_RESET | AOMARL_TRACE_ATMOS | AOMARL_TRACE_DMS);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_timg_amp, dim3((pd * pd + 255) / 256), dim3(256), 0, s, ph, c->sys.spupil, c->sys.tar_inv_lambda, amp, pd);
+    LAUNCHCHK();
+    // pass 1: X[(re | im, kx)][y] = W1 . amp^T
+    launch_gemm_nt(2 * np, pd, 2 * pd, 1.0f, W1, 2 * pd, amp, 2 * pd, 0.0f, X, pd, s);
+    // pass 2: Y[ky][kx]:  Yr = Wc Xr^T + Ws Xi^T,  Yi = Wc Xi^T - Ws Xr^T
+    const float *Xr = X, *Xi = X + (size_t)np * pd;
+    launch_gemm_nt(np, np, pd, 1.0f, Wc, pd, Xr, pd, 0.0f, Yr, np, s);
+    launch_gemm_nt(np, np, pd, 1.0f, Ws, pd, Xi, pd, 1.0f, Yr, np, s);
+    launch_gemm_nt(np, np, pd, 1.0f, Wc, pd, Xi, pd, 0.0f, Yi, np, s);
+    launch_gemm_nt(np, np, pd, -1.0f, Ws, pd, Xr, pd, 1.0f, Yi, np, s);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_timg_abs2, dim3((unsigned)(((long long)np * np + 255) / 256)), dim3(256), 0, s, Yr, Yi,
+                       out + (size_t)(e - b) * np * np, (long long)np * np);
+    LAUNCHCHK();
+  }
+  return 0;
 }
 
 // ---------------------------------------------------------------- composites

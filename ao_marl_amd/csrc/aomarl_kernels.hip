@@ -3638,30 +3638,75 @@ __global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const fl
   }
 }
 
+// Target.comp_strehl(do_fit = True), the default of every get_strehl call in the reference
+// (shesha/supervisor/components/targetCompass.py:139-159): the PSF peak fitted by two 1-D sincs, along x and along y
+// through the maximum and its two neighbours: y(x) = A sinc(w (x - x0)); gain of one axis = A / y(0) = 1 / sinc(w x0).
+// COMPASS's kernel is not in the reference tree: restated from its name and docstring (UNPINNED); the same
+// algorithm as oracle/aoref.c:aoref_sinc_gain (Newton from the parabola through the three points, fall-backs).
+__device__ __forceinline__ float sincf_(float t) { return fabsf(t) < 1e-2f ? 1.f - t * t * (1.f / 6.f) * (1.f - t * t * 0.05f) : __sinf(t) / t; }
+__device__ __forceinline__ float dsincf_(float t) {
+  return fabsf(t) < 1e-2f ? -t * (1.f / 3.f) * (1.f - t * t * 0.1f) : (__cosf(t) - __sinf(t) / t) / t;
+}
+__device__ float sinc_gain(float ym, float y0, float yp) {
+  if (!(y0 > 0.f)) return 1.f;
+  const float rm = ym / y0, rp = yp / y0;
+  const float a = 0.5f * (rm + rp) - 1.f, b = 0.5f * (rp - rm);
+  if (!(a < -1e-6f)) return 1.f;
+  float x0 = fminf(0.5f, fmaxf(-0.5f, -b / (2.f * a)));
+  const float gpar = 1.f - b * b / (4.f * a);
+  float w = fminf(3.f, fmaxf(1e-3f, sqrtf(-6.f * a / gpar)));
+  for (int it = 0; it < 8; it++) {
+    const float f0 = sincf_(w * x0), d0 = dsincf_(w * x0);
+    const float fm = sincf_(w * (1.f + x0)), dm = dsincf_(w * (1.f + x0));
+    const float fp = sincf_(w * (1.f - x0)), dp = dsincf_(w * (1.f - x0));
+    const float F1 = fm - rm * f0, F2 = fp - rp * f0;
+    const float J11 = (1.f + x0) * dm - rm * x0 * d0, J12 = w * dm - rm * w * d0;
+    const float J21 = (1.f - x0) * dp - rp * x0 * d0, J22 = -w * dp - rp * w * d0;
+    const float det = J11 * J22 - J12 * J21;
+    if (!(fabsf(det) > 1e-12f)) break;
+    w -= (F1 * J22 - F2 * J12) / det;
+    x0 -= (J11 * F2 - J21 * F1) / det;
+    w = fminf(3.f, fmaxf(1e-3f, w));
+    x0 = fminf(0.6f, fmaxf(-0.6f, x0));
+  }
+  const float g = 1.f / sincf_(w * x0);
+  if (g >= 1.f && g < 1.5f) return g;
+  return (gpar >= 1.f && gpar < 1.5f) ? gpar : 1.f;
+}
+// fitted maximum of a W x W window whose maximum sits at `arg` (no fit on the border)
+__device__ float fit_max_2x1d_sinc(const float *img, int W, int arg) {
+  const int ay = arg / W, ax = arg - ay * W;
+  const float m = img[arg];
+  if (ax == 0 || ay == 0 || ax == W - 1 || ay == W - 1) return m;
+  return m * sinc_gain(img[arg - 1], m, img[arg + 1]) * sinc_gain(img[arg - W], m, img[arg + W]);
+}
+
 // publish the pending PSF: LE accumulation, Strehl SE / LE, variance bookkeeping
 __device__ __forceinline__ void strehl_commit_body(const DevSys &sys, const DevState &st, int env_begin, int blk,
                                                    const float *__restrict__ PEND) {
   __shared__ float r0[256], r1[256];
-  __shared__ int ri[256];
+  __shared__ int ri[256], rl[256];
   const int W = 2 * sys.hw;
   const int e = env_begin + blk;
   const float *pend = PEND + (long long)blk * (W * W + 4);
   float *le = st.le_img + (long long)e * W * W;
   float mse = 0.f, mle = 0.f;
-  int arg = 0;
+  int arg = 0, argl = 0;
   for (int o = threadIdx.x; o < W * W; o += blockDim.x) {
     const float p = pend[o];
     const float l = le[o] + p;
     le[o] = l;
     if (p > mse) { mse = p; arg = o; }
-    mle = fmaxf(mle, l);
+    if (l > mle) { mle = l; argl = o; }
   }
-  r0[threadIdx.x] = mse; r1[threadIdx.x] = mle; ri[threadIdx.x] = arg;
+  r0[threadIdx.x] = mse; r1[threadIdx.x] = mle; ri[threadIdx.x] = arg; rl[threadIdx.x] = argl;
   __syncthreads();
+  // (ties go to the lower index, like the scans of the oracle: the sinc fit reads the neighbours of THAT pixel)
   for (int o = 128; o >= 1; o >>= 1) {
     if (threadIdx.x < o) {
-      if (r0[threadIdx.x + o] > r0[threadIdx.x]) { r0[threadIdx.x] = r0[threadIdx.x + o]; ri[threadIdx.x] = ri[threadIdx.x + o]; }
-      r1[threadIdx.x] = fmaxf(r1[threadIdx.x], r1[threadIdx.x + o]);
+      const int t = threadIdx.x, u = t + o;
+      if (r0[u] > r0[t] || (r0[u] == r0[t] && ri[u] < ri[t])) { r0[t] = r0[u]; ri[t] = ri[u]; }
+      if (r1[u] > r1[t] || (r1[u] == r1[t] && rl[u] < rl[t])) { r1[t] = r1[u]; rl[t] = rl[u]; }
     }
     __syncthreads();
   }
@@ -3676,6 +3721,10 @@ __device__ __forceinline__ void strehl_commit_body(const DevSys &sys, const DevS
     s[3] = s[3] + var;
     s[4] = cnt;
     s[5] = (ay == 0 || ax == 0 || ay == W - 1 || ax == W - 1) ? 1.f : 0.f;
+    // comp_strehl(do_fit = True): the same two peaks fitted by 2 x 1-D sincs (le[] was written by this block's
+    // threads above: visible behind the barriers of the reduction)
+    s[6] = fit_max_2x1d_sinc(pend, W, ri[0]) / sys.ref_peak;
+    s[7] = fit_max_2x1d_sinc(le, W, rl[0]) / cnt / sys.ref_peak;
   }
 }
 

@@ -403,12 +403,62 @@ class VecRlSupervisor(object):
     def get_voltages(self):
         return self.sim.voltage
 
-    def get_strehl(self, tar_index=0):
+    def get_tar_image(self, tar_index=0, expo_type="se"):
+        """targetCompass.py:71-92: the full-frame short-exposure PSF of every environment, [nenv, npsf, npsf], centred
+        (formed on demand: aomarl_target_image).  The long-exposure sum is only kept on the Strehl window."""
+        if tar_index != 0:
+            raise NotImplementedError("get_tar_image: target 0 only")
+        if expo_type != "se":
+            raise NotImplementedError("get_tar_image: only the short-exposure image exists full-frame (the long "
+                                      "exposure is accumulated on the Strehl window)")
+        return self.sim.target_image()
+
+    def get_wfs_phase(self):
+        """wfsCompass.get_wfs_phase(0): the phase the sensor sees, atmosphere + mirrors, [nenv, n, n] (ray-traced from
+        the state as it stands)."""
+        self.sim.raytrace_wfs(atm=True, dms=True, reset=True)
+        return self.sim.t["wfs_phase"]
+
+    _projector_phase2modes = None
+
+    @property
+    def projector_phase2modes(self):
+        """get_projector_wfsphase2modes (helper_functions/utils/utils.py:88-160, mode 2): every Btt mode poked on the
+        mirrors (atmosphere off), the WFS phase on the pupil pixels recorded; least-squares projectors of the
+        stack-array modes and of the two tip-tilt modes, stacked: [nmodes, pupil pixels].  Built on first use (it
+        pokes the mirrors of this simulator: call it before an episode, the next reset clears them)."""
+        if self._projector_phase2modes is None:
+            m2v, sim = np.asarray(self.modes2volts, dtype=np.float32), self.sim
+            pup = np.flatnonzero(np.asarray(self.s.mpupil).reshape(-1) != 0)
+            nm = m2v.shape[1]
+            resp = np.zeros((nm, pup.size), dtype=np.float64)
+            for k0 in range(0, nm, sim.nenv):
+                n = min(sim.nenv, nm - k0)
+                cmd = np.zeros((n, m2v.shape[0]), dtype=np.float32)
+                for i in range(n):                  # (a mode drives the stack array OR the tip-tilt mirror: :120-150)
+                    mode = k0 + i
+                    if mode < nm - 2:
+                        cmd[i, :-2] = m2v[:-2, mode]
+                    else:
+                        cmd[i, -2:] = m2v[-2:, mode]
+                sim.comp_dm_shape(torch.from_numpy(cmd).to(sim.device), 0, n)
+                sim.raytrace_wfs(atm=False, dms=True, reset=True, env_begin=0, env_count=n)
+                resp[k0:k0 + n] = sim.t["wfs_phase"][:n].reshape(n, -1)[:, torch.as_tensor(pup, device=sim.device)].double().cpu().numpy()
+            a, t = resp[:nm - 2], resp[nm - 2:]
+            proj = np.concatenate([np.linalg.inv(a @ a.T) @ a, np.linalg.inv(t @ t.T) @ t])
+            self._projector_phase2modes = proj.astype(np.float32)
+        return self._projector_phase2modes
+
+    def get_strehl(self, tar_index=0, do_fit=True):
+        """targetCompass.py:139-159: [SR SE, SR LE, phase variance SE, phase variance LE] per environment; do_fit
+        (default True, like the reference): the PSF peak fitted by two 1-D sincs."""
         if tar_index == 1:
             if self.geo is None:
                 raise RuntimeError("no geometric controller (VecRlSupervisor(..., geo=True))")
-            return self.geo.strehl
-        return self.sim.strehl
+            src = self.geo
+        else:
+            src = self.sim
+        return src.strehl_fit if (do_fit and hasattr(src, "strehl_fit")) else src.strehl
 
 
 class VecAoEnv(object):
@@ -430,6 +480,10 @@ class VecAoEnv(object):
             name = parameters_telescope[:-3] if parameters_telescope.endswith(".py") else \
                 parameters_telescope
             config = name
+        from . import rewards as _R
+        if cfg["reward_type"] in _R.NEEDS_CURRENT_SCREENS:
+            # these rewards read the image / phase of THIS frame: the screens must not run ahead
+            prefetch_atmos, frame_pipeline = False, False
         self.supervisor = VecRlSupervisor(config, cfg, nenv, initial_seed=initial_seed,
                                           seed_stride=seed_stride, device=device,
                                           strehl_halfwin=strehl_halfwin, sim_factory=sim_factory,
@@ -862,8 +916,7 @@ class VecAoEnv(object):
 
     def calculate_reward(self, reward_type=None):
         """ao_env.py:585-860, every branch that reads slopes, err, residual modes or the Strehl tuple
-        (formulas: ao_marl_amd/rewards.py); [nenv].  The four branches that need the full-frame target
-        image or the phase projector raise NotImplementedError with the reason."""
+        (formulas: ao_marl_amd/rewards.py), the full-frame target image (on demand) or the phase projector; [nenv]."""
         from . import rewards as R
         sup = self.supervisor
         rt = self.reward_type if reward_type is None else reward_type
@@ -890,8 +943,17 @@ class VecAoEnv(object):
             return R.modes_reward(rt, self.transform_state_to_zernike(sup.get_err(), return_reward=True))
         if "counterfactual_rpc" in rt:                                           # :855-856: r = None
             return None
-        if rt in R.UNSUPPORTED:
-            raise NotImplementedError("reward type %r: %s" % (rt, R.UNSUPPORTED[rt]))
+        if rt in R.IMAGE:                                                        # :621-623, :654-656
+            return R.image_reward(rt, sup.get_tar_image(0))
+        if rt in R.PROJECTION:                                                   # :736-760
+            ph = sup.get_wfs_phase()                                             # [nenv, n, n], atmosphere + DMs
+            ph = ph - ph.mean(dim=(1, 2), keepdim=True)
+            pup = torch.as_tensor(sup.s.mpupil != 0, device=ph.device).reshape(-1)
+            proj = -(ph.reshape(ph.shape[0], -1)[:, pup] @ self._dev_matrix("projector_phase2modes").T)
+            cur = sup.get_voltages() @ self._dev_matrix("volts2modes").T
+            fr = torch.as_tensor(sup.freedom_vector, dtype=torch.float32, device=ph.device) \
+                if rt == "weighted_projection_comparison" else None
+            return R.projection_reward(rt, proj, cur, self._action_range_t(), fr)
         raise NotImplementedError("This reward type not implemented")
 
     def _dev_matrix(self, name):

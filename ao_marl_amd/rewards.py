@@ -6,10 +6,11 @@ single-agent experiments and its evaluation scripts.  Every branch of the refere
 that reads slopes, the integrator increment, the residual modes or the Strehl tuple is restated here as
 a function of a [nenv, n] tensor; the formulas are NumPy one-liners there (np.var is the population
 variance, np.average the mean, "x / y" halves are s[: n // 2] and s[n // 2 :], ao_env.py:613,665-666).
-Left out, by name, with the reason in the error: the two branches that read the full-frame target image
-(`image_sharpness`, `r_tt_4`: ao_env.py:621-623,654-656 -- only the Strehl window of the PSF is formed on
-the device) and the two that need the phase-to-modes projector
-(`projection_comparison`, `weighted_projection_comparison`, :736-760).
+The branches that read the full-frame target image (`image_sharpness`, `r_tt_4`, `r_tt_4_norm`: ao_env.py:621-623,
+654-656) take it from Target.get_tar_image -- formed on demand (aomarl_target_image), the hot path only keeps the
+Strehl window --, the two that compare the command with the WFS phase projected on the modes
+(`projection_comparison`, `weighted_projection_comparison`, :736-760) use the supervisor's
+projector_phase2modes (utils.py:88-160, built on first use): all 62 names of the chain are served.
 
 A name and name + "_norm" select the same formula (ao_env.py:624-662; the reference compares the
 "_norm" spelling against the configured type rather than the argument -- the same thing whenever the
@@ -78,13 +79,35 @@ def _slopes_table():
 
 
 SLOPES = _slopes_table()
-UNSUPPORTED = {
-    "image_sharpness": "reads the full-frame target image (only the Strehl window of the PSF is formed on the device)",
-    "r_tt_4": "reads the full-frame target image (only the Strehl window of the PSF is formed on the device)",
-    "r_tt_4_norm": "reads the full-frame target image (only the Strehl window of the PSF is formed on the device)",
-    "projection_comparison": "needs the phase-to-modes projector, which this build does not compute",
-    "weighted_projection_comparison": "needs the phase-to-modes projector, which this build does not compute",
-}
+UNSUPPORTED = {}
+IMAGE = ("image_sharpness", "r_tt_4", "r_tt_4_norm")                   # read target.get_tar_image(0)
+PROJECTION = ("projection_comparison", "weighted_projection_comparison")
+# what these five read is the state of THIS frame: screens already moved to the next one (atmosphere prefetch, frame
+# pipeline) would give the next frame's image / phase -- VecAoEnv turns both off for them
+NEEDS_CURRENT_SCREENS = IMAGE + PROJECTION
+
+
+def image_reward(name, img):
+    """Branches that read target.get_tar_image(0): img [nenv, N, N] (any orientation: both formulas are symmetric
+    in the two axes) -> [nenv]."""
+    if name == "image_sharpness":                                                       # :621-623
+        return (img * img).sum(dim=(1, 2)) / img.sum(dim=(1, 2)) ** 2
+    # r_tt_4 (:654-656): -sum((scipy.ndimage.center_of_mass(img) - N / 2)^2), the centre in index units
+    n = img.shape[1]
+    tot = img.sum(dim=(1, 2))
+    idx = torch.arange(n, dtype=img.dtype, device=img.device)
+    c0 = (img.sum(dim=2) * idx).sum(dim=1) / tot
+    c1 = (img.sum(dim=1) * idx).sum(dim=1) / tot
+    return -((c0 - n / 2.0) ** 2 + (c1 - n / 2.0) ** 2)
+
+
+def projection_reward(name, projection_modes, current_modes, action_range, freedom=None):
+    """projection_comparison / weighted_projection_comparison (:736-760): -|| (P . phase)[range] - modes[range] ||
+    (the weighted form multiplies the difference by the freedom vector first)."""
+    d = projection_modes[:, action_range] - current_modes[:, action_range]
+    if name == "weighted_projection_comparison":
+        d = d * freedom[action_range]
+    return -torch.linalg.vector_norm(d, dim=1)
 
 
 def slopes_reward(name, s):

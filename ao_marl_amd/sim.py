@@ -178,6 +178,14 @@ class HipSim(object):
         avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
         return torch.stack([s[:, 0], s[:, 1], s[:, 2], avg], dim=1)
 
+    @property
+    def strehl_fit(self):
+        """The same tuple with comp_strehl(do_fit=True), the reference's default: both Strehl ratios from the PSF
+        peak fitted by two 1-D sincs (targetCompass.py:139-159; k_strehl_commit, strehl slots 6 / 7)."""
+        s = self.t["strehl"]
+        avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
+        return torch.stack([s[:, 6], s[:, 7], s[:, 2], avg], dim=1)
+
     def dm_shape(self, k, env_begin=0, env_count=None):
         """Shape of DM k, [env_count, dim, dim] (materialised on demand: tip-tilt mirrors are
         never stored, their consumers evaluate the two planes on the fly)."""
@@ -553,6 +561,14 @@ class HipSim(object):
         self._ensure_shape()
         la.check(self.lib.aomarl_target_psf(self.ctx, C.byref(self.st), b, n, self._stream()))
 
+    def target_image(self, env_begin=0, env_count=None):
+        """Target.get_tar_image(expo_type="se") (targetCompass.py:71-92) of every environment of the range:
+        [env_count, npsf, npsf], centred, raw |FFT2|^2 (aomarl_target_image: on demand, one environment at a time)."""
+        b, n = self._range(env_begin, env_count)
+        out = torch.empty(n, self.s.npsf, self.s.npsf, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_target_image(self.ctx, C.byref(self.st), b, n, out.data_ptr(), self._stream()))
+        return out
+
     def frame_fused_available(self):
         return bool(self.lib.aomarl_frame_fused_available(self.ctx))
 
@@ -777,6 +793,12 @@ class HipGeoTwin(object):
         s = self.t["strehl"]
         avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
         return torch.stack([s[:, 0], s[:, 1], s[:, 2], avg], dim=1)
+
+    @property
+    def strehl_fit(self):
+        s = self.t["strehl"]
+        avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
+        return torch.stack([s[:, 6], s[:, 7], s[:, 2], avg], dim=1)
 
     def reset(self):
         for k in ("com", "com1", "com2", "err", "voltage", "dm_shape", "strehl", "le_img"):

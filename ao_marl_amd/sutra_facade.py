@@ -23,8 +23,9 @@ orientation (first index = x), the transpose of this repository's [y][x] layout.
 
 Not provided (raise): sensors whose sampling the spot kernel is not specialised for can be
 ray-traced and give geometric slopes but no images (the reference never images its second,
-128-point WFS); LGS, pyramid, KL DMs, ROKET, the cacao / brahma variants; `comp_strehl(do_fit)`'s
-sinc fit is ignored (the peak of the exact PSF window is used).
+128-point WFS); LGS, pyramid, KL DMs, ROKET, the cacao / brahma variants.  `comp_strehl(do_fit)`: the
+two-1-D-sinc fit of the PSF peak on the Strehl window (k_strehl_commit; COMPASS's kernel is not in the reference
+tree: restated).
 """
 import ctypes as C
 import sys
@@ -584,14 +585,16 @@ class TargetSource(Source):
         e.sim.comp_strehl()
         self.strehl_counter += 1
 
-    def comp_strehl(self, do_fit=False):
-        pass                                  # numbers are read from the device on access
+    _fit = True
+
+    def comp_strehl(self, do_fit=True):
+        self._fit = bool(do_fit)              # numbers are read from the device on access: fitted peaks in slots 6 / 7
 
     def _st(self):
         return self._sim().t["strehl"][0].cpu().numpy()
 
-    strehl_se = property(lambda self: float(self._st()[0]))
-    strehl_le = property(lambda self: float(self._st()[1]))
+    strehl_se = property(lambda self: float(self._st()[6 if self._fit else 0]))
+    strehl_le = property(lambda self: float(self._st()[7 if self._fit else 1]))
     phase_var = property(lambda self: float(self._st()[2]))
     phase_var_avg = property(lambda self: float(self._st()[3]))
     phase_var_count = property(lambda self: int(self._st()[4]))

@@ -560,6 +560,14 @@ int aomarl_denoiser_destroy(aomarl_denoiser *dn);
 /* PSF window + phase variance of st->tar_phase as it stands (pending, like aomarl_target_psf) */
 int aomarl_target_psf_buffer(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                              void *stream);
+/* Target.get_tar_image(tar_index, expo_type = "se") (shesha/supervisor/components/targetCompass.py:71-92): the whole
+ * short-exposure PSF of every environment of the range, out [env_count][npsf][npsf] ([ky][kx], zero frequency at
+ * (npsf/2, npsf/2): what fftshift(np.array(d_image_se)) holds, transposed to this library's [y][x] order), raw
+ * |FFT2|^2 like d_image_se.  On demand only -- the hot path forms the central window (aomarl_target_psf); three
+ * reward branches of the reference read the full frame (ao_env.py:621-623, 654-656).  Two DFT passes on the
+ * library's fp32 GEMM, one environment at a time; the phase is ray-traced from the state as it stands (stack-array
+ * shapes are materialised first if they are deferred). */
+int aomarl_target_image(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, float *out, void *stream);
 /* Geometric ("GEO") reference controller: COMPASS's sutra_controller_geo as the reference sets it
  * up (rtc_init.py:418-448 init_proj_sparse over the pupil pixels) and drives it
  * (rlSupervisor.py:989-1013: target.raytrace(atmosphere) -> rtc.do_control(sources=target) ->

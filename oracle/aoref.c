@@ -387,6 +387,61 @@ void aoref_psf(const float *phase, const float *pupil, int n, int nfft, float la
   free(tw);
 }
 
+/* Target.comp_strehl(do_fit = True) -- the default of every get_strehl call in the reference
+ * (shesha/supervisor/components/targetCompass.py:139-159; ao_env.py:592, train_rpc.py:463-610): "fit the PSF with a
+ * sinc before computing SR".  COMPASS's kernel (sutra: fit_max_2x1dSinc) is not in the reference tree: UNPINNED.
+ * Restated as what the name and the docstring say: two 1-D fits, along x and along y through the maximum, of
+ *      y(x) = A sinc(w (x - x0)),     sinc(t) = sin(t) / t,
+ * each through the three samples (max - 1, max, max + 1); the fitted peak is  max * gx * gy,  g = A / y(0) =
+ * 1 / sinc(w x0) >= 1.  (w, x0) by Newton from the parabola through the three points (the sinc's second-order
+ * expansion); a fit that leaves 0 < w < 3, |x0| <= 0.6, 1 <= g < 1.5 falls back to the parabola's peak.  A maximum
+ * on the border of the image has no neighbours: no fit. */
+static double sincd(double t) { return fabs(t) < 1e-4 ? 1.0 - t * t / 6.0 : sin(t) / t; }
+static double dsincd(double t) { return fabs(t) < 1e-4 ? -t / 3.0 : (cos(t) - sin(t) / t) / t; }
+float aoref_sinc_gain(float ym, float y0, float yp) {
+  if (!(y0 > 0.f)) return 1.f;
+  const double rm = ym / y0, rp = yp / y0;
+  const double a = 0.5 * (rm + rp) - 1.0, b = 0.5 * (rp - rm);
+  if (!(a < -1e-6)) return 1.f;
+  double x0 = -b / (2.0 * a);
+  if (x0 > 0.5) x0 = 0.5;
+  if (x0 < -0.5) x0 = -0.5;
+  const double gpar = 1.0 - b * b / (4.0 * a);
+  double w = sqrt(-6.0 * a / gpar);
+  if (!(w > 1e-3)) w = 1e-3;
+  if (w > 3.0) w = 3.0;
+  for (int it = 0; it < 8; it++) {
+    const double f0 = sincd(w * x0), d0 = dsincd(w * x0);
+    const double fm = sincd(w * (1.0 + x0)), dm = dsincd(w * (1.0 + x0));
+    const double fp = sincd(w * (1.0 - x0)), dp = dsincd(w * (1.0 - x0));
+    const double F1 = fm - rm * f0, F2 = fp - rp * f0;
+    const double J11 = (1.0 + x0) * dm - rm * x0 * d0, J12 = w * dm - rm * w * d0;
+    const double J21 = (1.0 - x0) * dp - rp * x0 * d0, J22 = -w * dp - rp * w * d0;
+    const double det = J11 * J22 - J12 * J21;
+    if (!(fabs(det) > 1e-12)) break;
+    w -= (F1 * J22 - F2 * J12) / det;
+    x0 -= (J11 * F2 - J21 * F1) / det;
+    if (!(w > 1e-3)) w = 1e-3;
+    if (w > 3.0) w = 3.0;
+    if (x0 > 0.6) x0 = 0.6;
+    if (x0 < -0.6) x0 = -0.6;
+  }
+  const double g = 1.0 / sincd(w * x0);
+  if (g >= 1.0 && g < 1.5) return (float)g;
+  return (float)((gpar >= 1.0 && gpar < 1.5) ? gpar : 1.0);
+}
+float aoref_fit_max_2x1d_sinc(const float *img, int nx, int ny) {
+  int ax = 0, ay = 0;
+  float m = img[0];
+  for (int y = 0; y < ny; y++)
+    for (int x = 0; x < nx; x++)
+      if (img[(size_t)y * nx + x] > m) { m = img[(size_t)y * nx + x]; ax = x; ay = y; }
+  if (ax == 0 || ay == 0 || ax == nx - 1 || ay == ny - 1) return m;
+  const float gx = aoref_sinc_gain(img[(size_t)ay * nx + ax - 1], m, img[(size_t)ay * nx + ax + 1]);
+  const float gy = aoref_sinc_gain(img[(size_t)(ay - 1) * nx + ax], m, img[(size_t)(ay + 1) * nx + ax]);
+  return m * gx * gy;
+}
+
 float aoref_phase_var(const float *phase, const float *pupil, int n) {
   double s = 0., c = 0.;
   for (size_t p = 0; p < (size_t)n * n; p++)

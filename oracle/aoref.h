@@ -83,6 +83,12 @@ void aoref_psf(const float *phase, const float *pupil, int n, int nfft, float la
                float *psf_full, float *psf_win /*[(2hw)^2], may be NULL*/, float *peak_full,
                float *peak_win);
 float aoref_phase_var(const float *phase, const float *pupil, int n); /* um^2 over pupil>0 */
+/* Target.comp_strehl(do_fit = True) (targetCompass.py:139-159, the default of get_strehl): sub-pixel peak of a PSF
+ * by two 1-D sinc fits through the maximum and its neighbours along x and along y; COMPASS's kernel is absent from
+ * the reference tree -- restated from its name and docstring, UNPINNED (see aoref.c).  aoref_sinc_gain: fitted peak
+ * over the sampled maximum for one axis; aoref_fit_max_2x1d_sinc: the fitted maximum of an image. */
+float aoref_sinc_gain(float ym, float y0, float yp);
+float aoref_fit_max_2x1d_sinc(const float *img, int nx, int ny);
 
 /* ---- threading of the OpenMP loops above (bench.py's cpu_baseline times 1 and N threads):
  * set: threads of the following calls, returns the count in effect; max: what the host offers */

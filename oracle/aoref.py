@@ -57,6 +57,10 @@ def lib():
                                 C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.aoref_phase_var.argtypes = [_f, _f, C.c_int]
         L.aoref_phase_var.restype = C.c_float
+        L.aoref_sinc_gain.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.aoref_sinc_gain.restype = C.c_float
+        L.aoref_fit_max_2x1d_sinc.argtypes = [_f, C.c_int, C.c_int]
+        L.aoref_fit_max_2x1d_sinc.restype = C.c_float
         L.aoref_set_threads.argtypes = [C.c_int]
         L.aoref_set_threads.restype = C.c_int
         L.aoref_max_threads.restype = C.c_int
@@ -142,6 +146,8 @@ class OracleSim(object):
         self.strehl_se = 0.0
         self.strehl_le = 0.0
         self.strehl_se_full = 0.0
+        self.strehl_se_fit = 0.0
+        self.strehl_le_fit = 0.0
         self.phase_var = 0.0
         self.phase_var_sum = 0.0
 
@@ -270,13 +276,20 @@ class OracleSim(object):
         self.strehl_se = pw.value / self.ref_peak
         self.strehl_se_full = pf.value / self.ref_peak
         self.strehl_le = float(self.le_img.max()) / self.strehl_count / self.ref_peak
+        # comp_strehl(do_fit=True), the reference's default: the peaks fitted by two 1-D sincs
+        fit = lambda img: float(self.L.aoref_fit_max_2x1d_sinc(np.ascontiguousarray(img, dtype=np.float32).reshape(-1),  # noqa: E731
+                                                               2 * hw, 2 * hw))
+        self.strehl_se_fit = fit(win) / self.ref_peak
+        self.strehl_le_fit = fit(self.le_img) / self.strehl_count / self.ref_peak
         self.phase_var = float(self.L.aoref_phase_var(self.tar_phase.reshape(-1),
                                                       s.spupil.reshape(-1), s.pupdiam))
         self.phase_var_sum += self.phase_var
         return self.get_strehl()
 
-    def get_strehl(self):
+    def get_strehl(self, do_fit=False):
         avg = self.phase_var_sum / self.strehl_count if self.strehl_count > 0 else 0.0
+        if do_fit:
+            return [self.strehl_se_fit, self.strehl_le_fit, self.phase_var, avg]
         return [self.strehl_se, self.strehl_le, self.phase_var, avg]
 
     # ---------------------------------------------------------------- composite frames

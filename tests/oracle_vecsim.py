@@ -76,6 +76,25 @@ class OracleVecSim(object):
     def strehl(self):
         return torch.tensor([o.get_strehl() for o in self.sims], dtype=torch.float32)
 
+    def target_image(self):
+        """Target.get_tar_image("se") of every environment from the oracle: the full |FFT2|^2 of the science phase
+        as it stands (atmosphere + mirrors), centred."""
+        import ctypes as C
+        out = []
+        for o in self.sims:
+            o.raytrace_target()
+            s = o.s
+            full = np.zeros((s.npsf, s.npsf), dtype=np.float32)
+            pf, pw = C.c_float(0), C.c_float(0)
+            o.L.aoref_psf(o.tar_phase.reshape(-1), s.spupil.reshape(-1), s.pupdiam, s.npsf, s.tar_lambda, s.strehl_halfwin,
+                          full.ctypes.data_as(C.c_void_p), None, C.byref(pf), C.byref(pw))
+            out.append(np.fft.fftshift(full))
+        return torch.from_numpy(np.stack(out))
+
+    @property
+    def strehl_fit(self):
+        return torch.tensor([o.get_strehl(do_fit=True) for o in self.sims], dtype=torch.float32)
+
     # per-frame API
     def reset(self, seeds):
         seeds = np.broadcast_to(np.asarray(seeds), (self.nenv,))

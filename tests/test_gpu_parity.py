@@ -273,6 +273,12 @@ def test_target_psf_and_strehl_match_oracle(setup, valu):
         assert abs(st[e, 1] - want[1]) < 2e-5 * max(want[1], 1e-3) + 1e-7
         assert abs(st[e, 2] - want[2]) < 1e-4 * want[2] + 1e-9
         assert abs(st[e, 3] - want[3]) < 1e-4 * want[3] + 1e-9
+        # comp_strehl(do_fit=True), the reference's default: the peaks fitted by two 1-D sincs (oracle: the same
+        # algorithm in double precision on its own window)
+        fit, sf = o.get_strehl(do_fit=True), sim.strehl_fit.cpu().numpy()
+        assert fit[0] >= want[0] and fit[1] >= want[1] and fit[0] < 1.2 * want[0] + 1e-6
+        assert abs(sf[e, 0] - fit[0]) < 1e-4 * max(fit[0], 1e-3) + 1e-7, (sf[e], fit)
+        assert abs(sf[e, 1] - fit[1]) < 1e-4 * max(fit[1], 1e-3) + 1e-7, (sf[e], fit)
     sim.set_option("force_valu_target", 0)
     sim.set_option("force_generic_target", 0)
 

@@ -197,3 +197,25 @@ def test_closed_loop_statistics_match_recorded_compass(small):
     r_res = np.median(res.std(axis=0) / norm["dm_residual"]["std"])
     assert 0.8 < r_res < 1.25, r_res
     assert o.strehl_le > 0.7
+
+
+def test_sinc_fit_of_the_psf_peak():
+    """comp_strehl(do_fit=True) as restated in oracle/aoref.c (COMPASS's kernel is absent: unpinned): samples of an
+    exact  A sinc(w (x - x0))  at x = -1, 0, 1 give back A; a symmetric triple gives its own maximum; a maximum on the
+    border of the image is left alone; the separable 2-D form multiplies the two gains."""
+    from oracle import aoref
+    L = aoref.lib()
+    sinc = lambda t: np.sinc(t / np.pi)            # noqa: E731  sin(t) / t
+    for A, w, x0 in ((3.0, 0.9, 0.3), (1.0, 1.4, -0.45), (7.5, 0.5, 0.0), (2.0, 2.0, 0.2)):
+        ym, y0, yp = (A * sinc(w * (x - x0)) for x in (-1.0, 0.0, 1.0))
+        g = L.aoref_sinc_gain(np.float32(ym), np.float32(y0), np.float32(yp))
+        assert abs(g * y0 - A) < 2e-5 * A, (A, w, x0, g * y0)
+    assert L.aoref_sinc_gain(0.8, 1.0, 0.8) == pytest.approx(1.0, abs=1e-6)
+    assert L.aoref_sinc_gain(1.0, 1.0, 1.0) == 1.0 and L.aoref_sinc_gain(0.5, 0.0, 0.5) == 1.0
+    # 2-D: a separable sinc x sinc core
+    yy, xx = np.mgrid[0:16, 0:16].astype(np.float64)
+    img = (5.0 * sinc(0.8 * (xx - 8.3)) * sinc(1.1 * (yy - 7.6))).astype(np.float32)
+    assert abs(L.aoref_fit_max_2x1d_sinc(img.reshape(-1), 16, 16) - 5.0) < 1e-4 * 5.0
+    edge = np.zeros((16, 16), dtype=np.float32)
+    edge[0, 5] = 2.0
+    assert L.aoref_fit_max_2x1d_sinc(edge.reshape(-1), 16, 16) == 2.0

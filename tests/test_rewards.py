@@ -73,7 +73,23 @@ def test_reward_formulas_against_numpy():
         np.testing.assert_allclose(got, want, rtol=1e-12, err_msg=name)
     assert not R.is_modes_reward("avg_squared_modes_from_measurements")
     # the reference's chain has 61 named branches + the generic "avg_squared_modes_<factor>" + counterfactual
-    assert len(R.SLOPES) == 39 and len(R.STREHL) == 13 and len(R.UNSUPPORTED) == 5
+    assert len(R.SLOPES) == 39 and len(R.STREHL) == 13 and len(R.IMAGE) == 3 and len(R.PROJECTION) == 2 and not R.UNSUPPORTED
+    # the branches that read the full-frame target image (ao_env.py:621-623, 654-656)
+    from scipy.ndimage import center_of_mass
+    img = torch.rand(3, 32, 32, generator=g, dtype=torch.float64) ** 4
+    np.testing.assert_allclose(R.image_reward("image_sharpness", img).numpy(),
+                               [np.sum(np.square(a)) / np.square(np.sum(a)) for a in img.numpy()], rtol=1e-12)
+    for nm in ("r_tt_4", "r_tt_4_norm"):
+        np.testing.assert_allclose(R.image_reward(nm, img).numpy(),
+                                   [-np.sum(np.square(np.array(center_of_mass(a)) - a.shape[0] / 2.0)) for a in img.numpy()], rtol=1e-10)
+    # ... and the projection comparisons (:736-760)
+    pm, cm, fr = torch.randn(4, 87, generator=g, dtype=torch.float64), torch.randn(4, 87, generator=g, dtype=torch.float64), \
+        torch.rand(87, generator=g, dtype=torch.float64)
+    rng = torch.arange(5, 60)
+    np.testing.assert_allclose(R.projection_reward("projection_comparison", pm, cm, rng).numpy(),
+                               [-np.linalg.norm(a[5:60] - b[5:60]) for a, b in zip(pm.numpy(), cm.numpy())], rtol=1e-12)
+    np.testing.assert_allclose(R.projection_reward("weighted_projection_comparison", pm, cm, rng, fr).numpy(),
+                               [-np.linalg.norm((a[5:60] - b[5:60]) * fr.numpy()[5:60]) for a, b in zip(pm.numpy(), cm.numpy())], rtol=1e-12)
 
 
 @pytest.mark.gpu
@@ -119,8 +135,74 @@ def test_env_reward_types_on_the_device():
         want = np.array([_np_modes(name, msel[i]) for i in range(4)])
         np.testing.assert_allclose(env.calculate_reward(name).cpu().numpy(), want, rtol=1e-4, err_msg=name)
     assert env.calculate_reward("counterfactual_rpc") is None
-    for name in R.UNSUPPORTED:
-        with pytest.raises(NotImplementedError):
-            env.calculate_reward(name)
     with pytest.raises(NotImplementedError):
         env.calculate_reward("no_such_reward")
+    # this environment moves its screens ahead (atmosphere prefetch): the image of THIS frame is gone, loudly
+    from ao_marl_amd.libaomarl import AomarlError
+    with pytest.raises(AomarlError, match="next frame"):
+        env.calculate_reward("image_sharpness")
+
+
+@pytest.mark.gpu
+def test_full_frame_image_and_projection_rewards_on_the_device():
+    """The last five names of the reference's reward chain: Target.get_tar_image (aomarl_target_image: the whole
+    npsf x npsf PSF on demand) against the oracle's full FFT, the three rewards that read it against NumPy / SciPy on
+    the oracle's image, the phase-to-modes projector's defining property, and the two projection rewards against
+    NumPy on the same device data.  An environment configured with one of these rewards keeps its screens on the
+    current frame (no atmosphere prefetch, no frame pipeline)."""
+    from scipy.ndimage import center_of_mass
+    from ao_marl_amd.env import VecAoEnv
+    from tests.oracle_vecsim import OracleVecSim
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, reward_type="image_sharpness")
+    # (no agent layout: the per-agent reward's factor is parsed from the reward type's name, helper_rewards.py:18,
+    # which only the avg_squared_modes_<factor> family carries)
+    env = VecAoEnv("production_sh_10x10_2m", 2, rl, initial_seed=21)
+    oenv = VecAoEnv("production_sh_10x10_2m", 2, rl, initial_seed=21, device="cpu", sim_factory=OracleVecSim)
+    assert env.supervisor.prefetch_atmos is False and env.frame_pipeline is False
+    env.reset(); oenv.reset()
+    g = torch.Generator().manual_seed(3)
+    for _ in range(3):
+        a = torch.rand(2, env.action_dim, generator=g) * 2 - 1
+        env.step(a.cuda()); oenv.step(a)
+    img = env.supervisor.get_tar_image(0).cpu().numpy().astype(np.float64)
+    want = oenv.supervisor.get_tar_image(0).numpy().astype(np.float64)
+    n = env.supervisor.s.npsf
+    assert img.shape == want.shape == (2, n, n)
+    assert np.abs(img - want).max() < 5e-4 * want.max()        # (two closed loops three frames on: 2e-4 of the peak measured)
+    assert np.unravel_index(np.argmax(img[0]), img[0].shape) == np.unravel_index(np.argmax(want[0]), want[0].shape)
+    np.testing.assert_allclose(env.calculate_reward("image_sharpness").cpu().numpy(),
+                               [np.sum(np.square(x)) / np.square(np.sum(x)) for x in want], rtol=2e-3)
+    np.testing.assert_allclose(env.calculate_reward("r_tt_4").cpu().numpy(),
+                               [-np.sum(np.square(np.array(center_of_mass(x)) - n / 2.0)) for x in want], rtol=2e-2, atol=1e-3)
+    with pytest.raises(NotImplementedError):
+        env.supervisor.get_tar_image(0, expo_type="le")
+    # projector: P . response^T = identity on the stack-array modes and on the tip-tilt pair
+    sup = env.supervisor
+    P = sup.projector_phase2modes.astype(np.float64)
+    pup = np.flatnonzero(np.asarray(sup.s.mpupil).reshape(-1) != 0)
+    assert P.shape == (sup.nmodes, pup.size)
+    sim, m2v = sup.sim, np.asarray(sup.modes2volts, dtype=np.float32)
+    for mode in (0, 7, sup.nmodes - 3, sup.nmodes - 1):
+        cmd = np.zeros((1, m2v.shape[0]), dtype=np.float32)
+        if mode < sup.nmodes - 2:
+            cmd[0, :-2] = m2v[:-2, mode]
+        else:
+            cmd[0, -2:] = m2v[-2:, mode]
+        sim.comp_dm_shape(torch.from_numpy(cmd).cuda(), 0, 1)
+        sim.raytrace_wfs(atm=False, dms=True, reset=True, env_begin=0, env_count=1)
+        ph = sim.t["wfs_phase"][0].reshape(-1).cpu().numpy().astype(np.float64)[pup]
+        got = P @ ph
+        blk = slice(0, sup.nmodes - 2) if mode < sup.nmodes - 2 else slice(sup.nmodes - 2, sup.nmodes)
+        e = np.zeros(sup.nmodes); e[mode] = 1.0
+        assert np.abs(got[blk] - e[blk]).max() < 2e-3, (mode, np.abs(got[blk] - e[blk]).max())
+    env.reset()
+    env.step(torch.zeros(2, env.action_dim, device="cuda:0"))
+    ph = sup.get_wfs_phase().clone()
+    ph = (ph - ph.mean(dim=(1, 2), keepdim=True)).reshape(2, -1).cpu().numpy().astype(np.float64)[:, pup]
+    proj = -(ph @ P.T)
+    cur = sup.get_voltages().cpu().numpy().astype(np.float64) @ np.asarray(sup.volts2modes, dtype=np.float64).T
+    rng = np.asarray(sup.obtain_action_range_modal())
+    np.testing.assert_allclose(env.calculate_reward("projection_comparison").cpu().numpy(),
+                               -np.linalg.norm(proj[:, rng] - cur[:, rng], axis=1), rtol=2e-3)
+    np.testing.assert_allclose(env.calculate_reward("weighted_projection_comparison").cpu().numpy(),
+                               -np.linalg.norm((proj[:, rng] - cur[:, rng]) * np.asarray(sup.freedom_vector)[rng], axis=1), rtol=2e-3)

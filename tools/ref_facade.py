@@ -340,10 +340,13 @@ class TargetSource(Source):
             self.strehl_counter += 1
         self._new_image = True
 
-    def comp_strehl(self, do_fit=False):
-        self.strehl_se = self.peak_win / self.ref
+    def comp_strehl(self, do_fit=True):
+        # (do_fit: the PSF peak fitted by two 1-D sincs -- COMPASS's default, aoref_fit_max_2x1d_sinc)
+        W = 2 * self.HW
+        peak = lambda img: float(L.aoref_fit_max_2x1d_sinc(np.ascontiguousarray(img, dtype=f32).reshape(-1), W, W))  # noqa: E731
+        self.strehl_se = (peak(self.win) if do_fit else self.peak_win) / self.ref
         if self.strehl_counter > 0:
-            self.strehl_le = float(self.le.max()) / self.strehl_counter / self.ref
+            self.strehl_le = (peak(self.le) if do_fit else float(self.le.max())) / self.strehl_counter / self.ref
         if getattr(self, "_new_image", False):     # variance bookkeeping once per image
             self.phase_var = float(L.aoref_phase_var(self.phase.reshape(-1),
                                                      self.tel.spupil.reshape(-1), self.size))
