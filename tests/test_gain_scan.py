@@ -31,7 +31,7 @@ def _sequential_reference(sup_factory, gains, modes_list, episodes, steps):
             for _ in range(steps):
                 o.next_part_one()
                 o.next_part_two(None)
-            sr = o.get_strehl()[1]
+            sr = o.get_strehl(do_fit=True)[1]          # (the reference reads get_strehl(0)[1]: do_fit defaults to True)
         return sr                                  # the last episode's long-exposure Strehl
     sr_modes = [run(0.5, mf) for mf in modes_list]
     best_mf = modes_list[int(np.argmax(sr_modes))]
