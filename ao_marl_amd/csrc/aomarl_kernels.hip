@@ -1899,6 +1899,31 @@ __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
   return d;
 }
 __device__ __forceinline__ f32x4 pk_join(f32x2 lo, f32x2 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
+// in-place forms for accumulators that live across branches / loop iterations (an "=v" result is a new register: the
+// compiler then copies it back where control flow joins) and forms whose constant operand stays in a scalar register
+// pair (a loop-invariant pair in vector registers is re-materialised from its scalars every iteration: one
+// v_mov_b64 each; a packed instruction may read one scalar pair)
+__device__ __forceinline__ void pk_acc_add(f32x2 &acc, f32x2 x) { asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+__device__ __forceinline__ void pk_acc_fma(f32x2 &acc, f32x2 a, f32x2 b) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
+// acc -= a * b
+__device__ __forceinline__ void pk_acc_fnma(f32x2 &acc, f32x2 a, f32x2 b) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ f32x2 pk_fma_s(f32x2 a, f32x2 bs, f32x2 c) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(bs), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_nc_s(f32x2 a, f32x2 bs, f32x2 c) {
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "s"(bs), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul_s(f32x2 a, f32x2 bs) {
+  f32x2 d;
+  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(bs));
+  return d;
+}
 
 // spot_cog_f32 with its vector arithmetic packed (same formulas, the sums in pairs): 8 + 24 packed instructions for
 // the stage-1 combinations and the P / D sums instead of 16 + 48 scalar ones.
@@ -1925,7 +1950,7 @@ __device__ __forceinline__ void spot_cog_f32_pk(const DevSys &sys, const DevStat
   const f32x4 TrA[2] = {pk_join(tr0l, tr0h), pk_join(tr1l, tr1h)};
   const f32x4 TiA[2] = {pk_join(ti0l, ti0h), pk_join(ti1l, ti1h)};
   f32x2 Pa[2], Pb[2];                            // P of half m in two partial pairs
-  f32x2 Da = {0.f, 0.f}, Db = {0.f, 0.f};        // D over registers (0, 1) and (2, 3), both halves
+  f32x2 Da, Db;                                  // D over registers (0, 1) and (2, 3), both halves
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     const f32x4 Tr = TrA[m], Ti = TiA[m];
@@ -1941,11 +1966,12 @@ __device__ __forceinline__ void spot_cog_f32_pk(const DevSys &sys, const DevStat
     const f32x2 crl = pk_lo(QCr), crh = pk_hi(QCr), cil = pk_lo(QCi), cih = pk_hi(QCi);
     const f32x2 srl = pk_lo(QSr), srh = pk_hi(QSr), sil = pk_lo(QSi), sih = pk_hi(QSi);
     f32x2 pa = pk_mul(crl, crl), pb = pk_mul(crh, crh);
-    Da = pk_fma(crl, sil, Da); Db = pk_fma(crh, sih, Db);
-    pa = pk_fma(sil, sil, pa); pb = pk_fma(sih, sih, pb);
-    Da = pk_fma_na(cil, srl, Da); Db = pk_fma_na(cih, srh, Db);
-    pa = pk_fma(cil, cil, pa); pb = pk_fma(cih, cih, pb);
-    pa = pk_fma(srl, srl, pa); pb = pk_fma(srh, srh, pb);
+    if (m == 0) { Da = pk_mul(crl, sil); Db = pk_mul(crh, sih); }
+    else { pk_acc_fma(Da, crl, sil); pk_acc_fma(Db, crh, sih); }
+    pk_acc_fma(pa, sil, sil); pk_acc_fma(pb, sih, sih);
+    pk_acc_fnma(Da, cil, srl); pk_acc_fnma(Db, cih, srh);
+    pk_acc_fma(pa, cil, cil); pk_acc_fma(pb, cih, cih);
+    pk_acc_fma(pa, srl, srl); pk_acc_fma(pb, srh, srh);
     Pa[m] = pa; Pb[m] = pb;
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -2784,20 +2810,20 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       const f32x2 X01 = {cur.T[0], cur.T[1]}, X23 = {cur.T[2], cur.T[3]};
       const f32x2 Y01 = {cur.T[4], cur.T[5]}, Y23 = {cur.T[6], cur.T[7]};
       PK_GUARD_MFMA();
-      f32x2 p01 = pk_fma(X01, c0c0, pk_lo(S)), p23 = pk_fma(X23, c0c0, pk_hi(S));
-      p01 = pk_fma(Y01, c1c1, p01); p23 = pk_fma(Y23, c1c1, p23);
+      f32x2 p01 = pk_fma_s(X01, c0c0, pk_lo(S)), p23 = pk_fma_s(X23, c0c0, pk_hi(S));
+      p01 = pk_fma_s(Y01, c1c1, p01); p23 = pk_fma_s(Y23, c1c1, p23);
 #pragma unroll
       for (int l = 0; l < NL; l++) {
         const f32x2 l01 = {cur.L[l][0], cur.L[l][1]}, l23 = {cur.L[l][2], cur.L[l][3]};
         p01 = pk_add(p01, l01); p23 = pk_add(p23, l23);
       }
       if (info & FW_FULL) {
-        const f32x2 t01 = pk_mul(p01, wil2), t23 = pk_mul(p23, wil2);
-        const f32x2 b01 = pk_mul(p01, til2), b23 = pk_mul(p23, til2);
-        sdp = pk_add(sdp, p01); sd2p = pk_fma(p01, p01, sd2p);
+        const f32x2 t01 = pk_mul_s(p01, wil2), t23 = pk_mul_s(p23, wil2);
+        const f32x2 b01 = pk_mul_s(p01, til2), b23 = pk_mul_s(p23, til2);
+        pk_acc_add(sdp, p01); pk_acc_fma(sd2p, p01, p01);
         const f32x2 r01 = {rintf(t01.x), rintf(t01.y)}, r23 = {rintf(t23.x), rintf(t23.y)};
-        sdp = pk_add(sdp, p23); sd2p = pk_fma(p23, p23, sd2p);
-        const f32x2 a01 = pk_fma_nc(p01, wil2, r01), a23 = pk_fma_nc(p23, wil2, r23);
+        pk_acc_add(sdp, p23); pk_acc_fma(sd2p, p23, p23);
+        const f32x2 a01 = pk_fma_nc_s(p01, wil2, r01), a23 = pk_fma_nc_s(p23, wil2, r23);
         wr[0] = __builtin_amdgcn_cosf(a01.x); wi[0] = __builtin_amdgcn_sinf(a01.x);
         wr[1] = __builtin_amdgcn_cosf(a01.y); wi[1] = __builtin_amdgcn_sinf(a01.y);
         wr[2] = __builtin_amdgcn_cosf(a23.x); wi[2] = __builtin_amdgcn_sinf(a23.x);
@@ -2857,7 +2883,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         const f32x2 ar01 = {ar[0], ar[1]}, ar23 = {ar[2], ar[3]}, ai01 = {ai[0], ai[1]}, ai23 = {ai[2], ai[3]};
         PK_GUARD_TRANS();
         const f32x2 sr_ = pk_add(ar01, ar23), si_ = pk_add(ai01, ai23);
-        R0rp = pk_add(R0rp, sr_); R0ip = pk_add(R0ip, si_);
+        pk_acc_add(R0rp, sr_); pk_acc_add(R0ip, si_);
         PK_END_TO_MFMA();
       } else {
         R0r += (ar[0] + ar[1]) + (ar[2] + ar[3]);

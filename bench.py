@@ -60,7 +60,7 @@ SMALL = "production_sh_10x10_2m"
 NOISY = "production_sh_40x40_8m_3layers_d0_noise"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
-PMC_FILE = "r03_pmc_frame_kernel.json"
+PMC_FILE = "r04_pmc_frame_kernel.json"
 
 
 def parse_args():
