@@ -1963,6 +1963,15 @@ int aomarl_comp_strehl(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stre
   return 0;
 }
 
+int aomarl_strehl_fit(aomarl_ctx *c, aomarl_state *st, int b, int n, void *stream) {
+  if (!c || !st) return fail("strehl_fit: null ctx/state");
+  if (b < 0 || n < 0 || b + n > st->nenv || !st->strehl || !st->le_img) return fail("strehl_fit: bad range / state");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_strehl_fit_le, dim3(n), dim3(64), 0, (hipStream_t)stream, c->sys, dev_state(st), b);
+  LAUNCHCHK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- agent-side glue (A12 - A15)
 // The reference does these in NumPy / torch on the host, a handful of tiny operations per agent
 // per step; on the device each of them would be its own ~5 us launch, so the chains are fused.

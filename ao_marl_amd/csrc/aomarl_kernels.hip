@@ -3260,6 +3260,69 @@ __global__ __launch_bounds__(256) void k_target_rows(DevSys sys, DevState st, in
   }
 }
 
+// Target.comp_strehl(do_fit = True), the default of every get_strehl call in the reference
+// (shesha/supervisor/components/targetCompass.py:139-159): the PSF peak fitted by two 1-D sincs, along x and along y
+// through the maximum and its two neighbours: y(x) = A sinc(w (x - x0)); gain of one axis = A / y(0) = 1 / sinc(w x0).
+// COMPASS's kernel is not in the reference tree: restated from its name and docstring (UNPINNED); the same
+// algorithm as oracle/aoref.c:aoref_sinc_gain (Newton from the parabola through the three points, fall-backs).
+__device__ __forceinline__ float sincf_(float t) { return fabsf(t) < 1e-2f ? 1.f - t * t * (1.f / 6.f) * (1.f - t * t * 0.05f) : __sinf(t) / t; }
+__device__ __forceinline__ float dsincf_(float t) {
+  return fabsf(t) < 1e-2f ? -t * (1.f / 3.f) * (1.f - t * t * 0.1f) : (__cosf(t) - __sinf(t) / t) / t;
+}
+__device__ float sinc_gain(float ym, float y0, float yp) {
+  if (!(y0 > 0.f)) return 1.f;
+  const float rm = ym / y0, rp = yp / y0;
+  const float a = 0.5f * (rm + rp) - 1.f, b = 0.5f * (rp - rm);
+  if (!(a < -1e-6f)) return 1.f;
+  float x0 = fminf(0.5f, fmaxf(-0.5f, -b / (2.f * a)));
+  const float gpar = 1.f - b * b / (4.f * a);
+  float w = fminf(3.f, fmaxf(1e-3f, sqrtf(-6.f * a / gpar)));
+  for (int it = 0; it < 8; it++) {
+    const float f0 = sincf_(w * x0), d0 = dsincf_(w * x0);
+    const float fm = sincf_(w * (1.f + x0)), dm = dsincf_(w * (1.f + x0));
+    const float fp = sincf_(w * (1.f - x0)), dp = dsincf_(w * (1.f - x0));
+    const float F1 = fm - rm * f0, F2 = fp - rp * f0;
+    const float J11 = (1.f + x0) * dm - rm * x0 * d0, J12 = w * dm - rm * w * d0;
+    const float J21 = (1.f - x0) * dp - rp * x0 * d0, J22 = -w * dp - rp * w * d0;
+    const float det = J11 * J22 - J12 * J21;
+    if (!(fabsf(det) > 1e-12f)) break;
+    const float dw = (F1 * J22 - F2 * J12) / det, dx = (J11 * F2 - J21 * F1) / det;
+    w = fminf(3.f, fmaxf(1e-3f, w - dw));
+    x0 = fminf(0.6f, fmaxf(-0.6f, x0 - dx));
+    if (fabsf(dw) + fabsf(dx) < 1e-6f) break;          // (quadratic convergence: 2 - 4 iterations)
+  }
+  const float g = 1.f / sincf_(w * x0);
+  if (g >= 1.f && g < 1.5f) return g;
+  return (gpar >= 1.f && gpar < 1.5f) ? gpar : 1.f;
+}
+// one axis (0: x, 1: y) of the fit of a W x W window whose maximum sits at `arg` (1 on the border: no fit)
+__device__ float fit_axis_gain(const float *img, int W, int arg, int axis) {
+  const int ay = arg / W, ax = arg - ay * W;
+  if (ax == 0 || ay == 0 || ax == W - 1 || ay == W - 1) return 1.f;
+  const int d = axis ? W : 1;
+  return sinc_gain(img[arg - d], img[arg], img[arg + d]);
+}
+
+// The short-exposure window's fit, done where the window is formed (the PSF finish kernels run on the library's side
+// stream, off the control chain): gain of both axes -> pend[W * W + 1].  One wave: argmax (lowest index on ties,
+// like the commit's reduction and the oracle's scan), then lanes 0 / 1 solve the two axes.  Call behind a barrier that
+// makes pend[0 .. W*W) visible.
+__device__ __forceinline__ void psf_window_fit(float *pend, int W) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  float m = -1.f;
+  int arg = 0;
+  for (int o = lane; o < W * W; o += 64) { const float v = pend[o]; if (v > m) { m = v; arg = o; } }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float m2 = __shfl_xor(m, d);
+    const int a2 = __shfl_xor(arg, d);
+    if (m2 > m || (m2 == m && a2 < arg)) { m = m2; arg = a2; }
+  }
+  const float g = lane < 2 ? fit_axis_gain(pend, W, arg, lane) : 1.f;
+  const float g1 = __shfl(g, 1);
+  if (lane == 0) pend[W * W + 1] = g * g1;
+}
+
 // stage 2: G[ky][kx] = sum_y R[y][kx] exp(-2 pi i ky y / Npsf); |G|^2 -> pending window;
 // variance from the block partials -> pending[W*W]
 __global__ __launch_bounds__(256) void k_target_finish(DevSys sys, const float *__restrict__ TR,
@@ -3282,6 +3345,8 @@ __global__ __launch_bounds__(256) void k_target_finish(DevSys sys, const float *
     }
     pend[o] = gr * gr + gi * gi;
   }
+  __syncthreads();
+  psf_window_fit(pend, W);
   if (threadIdx.x == 0) {
     double sd = 0., sd2 = 0., sm = 0.;
     for (int k = 0; k < nblk; k++) {
@@ -3654,6 +3719,8 @@ __global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const fl
     for (int w4 = 0; w4 < 4; w4++) { gr += red[(w4 * 2) * 256 + tid]; gi += red[(w4 * 2 + 1) * 256 + tid]; }
     pend[tid] = gr * gr + gi * gi;                     // tid = ky * 16 + kx
   }
+  __syncthreads();
+  psf_window_fit(pend, 16);
   if (tid == 0) {
     double sd = 0., sd2 = 0., sm = 0.;
     for (int k = 0; k < 64; k++) { sd += dred[0][k]; sd2 += dred[1][k]; sm += dred[2][k]; }
@@ -3662,49 +3729,6 @@ __global__ __launch_bounds__(256) void k_target_finish_mfma(DevSys sys, const fl
     pend[256] = (float)var;
     if (frame) frame[b] += 1u;                         // WFS noise frame counter (one-pass path)
   }
-}
-
-// Target.comp_strehl(do_fit = True), the default of every get_strehl call in the reference
-// (shesha/supervisor/components/targetCompass.py:139-159): the PSF peak fitted by two 1-D sincs, along x and along y
-// through the maximum and its two neighbours: y(x) = A sinc(w (x - x0)); gain of one axis = A / y(0) = 1 / sinc(w x0).
-// COMPASS's kernel is not in the reference tree: restated from its name and docstring (UNPINNED); the same
-// algorithm as oracle/aoref.c:aoref_sinc_gain (Newton from the parabola through the three points, fall-backs).
-__device__ __forceinline__ float sincf_(float t) { return fabsf(t) < 1e-2f ? 1.f - t * t * (1.f / 6.f) * (1.f - t * t * 0.05f) : __sinf(t) / t; }
-__device__ __forceinline__ float dsincf_(float t) {
-  return fabsf(t) < 1e-2f ? -t * (1.f / 3.f) * (1.f - t * t * 0.1f) : (__cosf(t) - __sinf(t) / t) / t;
-}
-__device__ float sinc_gain(float ym, float y0, float yp) {
-  if (!(y0 > 0.f)) return 1.f;
-  const float rm = ym / y0, rp = yp / y0;
-  const float a = 0.5f * (rm + rp) - 1.f, b = 0.5f * (rp - rm);
-  if (!(a < -1e-6f)) return 1.f;
-  float x0 = fminf(0.5f, fmaxf(-0.5f, -b / (2.f * a)));
-  const float gpar = 1.f - b * b / (4.f * a);
-  float w = fminf(3.f, fmaxf(1e-3f, sqrtf(-6.f * a / gpar)));
-  for (int it = 0; it < 8; it++) {
-    const float f0 = sincf_(w * x0), d0 = dsincf_(w * x0);
-    const float fm = sincf_(w * (1.f + x0)), dm = dsincf_(w * (1.f + x0));
-    const float fp = sincf_(w * (1.f - x0)), dp = dsincf_(w * (1.f - x0));
-    const float F1 = fm - rm * f0, F2 = fp - rp * f0;
-    const float J11 = (1.f + x0) * dm - rm * x0 * d0, J12 = w * dm - rm * w * d0;
-    const float J21 = (1.f - x0) * dp - rp * x0 * d0, J22 = -w * dp - rp * w * d0;
-    const float det = J11 * J22 - J12 * J21;
-    if (!(fabsf(det) > 1e-12f)) break;
-    w -= (F1 * J22 - F2 * J12) / det;
-    x0 -= (J11 * F2 - J21 * F1) / det;
-    w = fminf(3.f, fmaxf(1e-3f, w));
-    x0 = fminf(0.6f, fmaxf(-0.6f, x0));
-  }
-  const float g = 1.f / sincf_(w * x0);
-  if (g >= 1.f && g < 1.5f) return g;
-  return (gpar >= 1.f && gpar < 1.5f) ? gpar : 1.f;
-}
-// fitted maximum of a W x W window whose maximum sits at `arg` (no fit on the border)
-__device__ float fit_max_2x1d_sinc(const float *img, int W, int arg) {
-  const int ay = arg / W, ax = arg - ay * W;
-  const float m = img[arg];
-  if (ax == 0 || ay == 0 || ax == W - 1 || ay == W - 1) return m;
-  return m * sinc_gain(img[arg - 1], m, img[arg + 1]) * sinc_gain(img[arg - W], m, img[arg + W]);
 }
 
 // publish the pending PSF: LE accumulation, Strehl SE / LE, variance bookkeeping
@@ -3736,6 +3760,9 @@ __device__ __forceinline__ void strehl_commit_body(const DevSys &sys, const DevS
     }
     __syncthreads();
   }
+  // comp_strehl(do_fit = True): the short exposure's fitted gain comes with the window (psf_window_fit, computed
+  // where the window was formed: this kernel sits on the control chain's critical path); the long exposure's is
+  // solved when somebody reads it (k_strehl_fit_le): slot 7 holds the un-fitted value until then.
   if (threadIdx.x == 0) {
     float *s = st.strehl + (long long)e * 8;
     const float cnt = s[4] + 1.f;
@@ -3747,10 +3774,8 @@ __device__ __forceinline__ void strehl_commit_body(const DevSys &sys, const DevS
     s[3] = s[3] + var;
     s[4] = cnt;
     s[5] = (ay == 0 || ax == 0 || ay == W - 1 || ax == W - 1) ? 1.f : 0.f;
-    // comp_strehl(do_fit = True): the same two peaks fitted by 2 x 1-D sincs (le[] was written by this block's
-    // threads above: visible behind the barriers of the reduction)
-    s[6] = fit_max_2x1d_sinc(pend, W, ri[0]) / sys.ref_peak;
-    s[7] = fit_max_2x1d_sinc(le, W, rl[0]) / cnt / sys.ref_peak;
+    s[6] = r0[0] * pend[W * W + 1] / sys.ref_peak;
+    s[7] = r1[0] / cnt / sys.ref_peak;
   }
 }
 
@@ -3770,6 +3795,28 @@ __global__ __launch_bounds__(256) void k_post_delay(DevSys sys, DevState st, int
     if (do_strehl) strehl_commit_body(sys, st, env_begin, blockIdx.x, PEND);
   } else {
     dm_shape_tt_body(sys, st, env_begin, blockIdx.x - n, ktt, volts, ldv, threadIdx.x);
+  }
+}
+
+// comp_strehl(do_fit = True), long exposure: the fitted peak of the accumulated window -> slot 7 (on demand:
+// aomarl_strehl_fit; one wave per environment)
+__global__ __launch_bounds__(64) void k_strehl_fit_le(DevSys sys, DevState st, int env_begin) {
+  __shared__ float g2[4];
+  const int W = 2 * sys.hw, e = env_begin + blockIdx.x, lane = threadIdx.x;
+  float *le = st.le_img + (long long)e * W * W;
+  float m = -1.f;
+  int arg = 0;
+  for (int o = lane; o < W * W; o += 64) { const float v = le[o]; if (v > m) { m = v; arg = o; } }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float m2 = __shfl_xor(m, d);
+    const int a2 = __shfl_xor(arg, d);
+    if (m2 > m || (m2 == m && a2 < arg)) { m = m2; arg = a2; }
+  }
+  if (lane < 2) g2[lane] = fit_axis_gain(le, W, arg, lane);
+  __syncthreads();
+  if (lane == 0) {
+    float *s = st.strehl + (long long)e * 8;
+    s[7] = s[4] > 0.f ? m * g2[0] * g2[1] / s[4] / sys.ref_peak : 0.f;
   }
 }
 

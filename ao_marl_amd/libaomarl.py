@@ -93,6 +93,7 @@ SYMBOLS = [
     ("aomarl_dmshape_stride", C.c_size_t, [_vp]),
     ("aomarl_reset", _i, _range + [_up, _fp, _fp, _vp]),
     ("aomarl_target_image", _i, _range + [_vp, _vp]),
+    ("aomarl_strehl_fit", _i, _range + [_vp]),
     ("aomarl_reset_prefetch_begin", _i, _range + [_up, _vp]),
     ("aomarl_reset_prefetch_advance", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("aomarl_reset_prefetch_cancel", _i, [_vp]),

@@ -182,6 +182,7 @@ class HipSim(object):
     def strehl_fit(self):
         """The same tuple with comp_strehl(do_fit=True), the reference's default: both Strehl ratios from the PSF
         peak fitted by two 1-D sincs (targetCompass.py:139-159; k_strehl_commit, strehl slots 6 / 7)."""
+        la.check(self.lib.aomarl_strehl_fit(self.ctx, C.byref(self.st), 0, self.nenv, self._stream()))
         s = self.t["strehl"]
         avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
         return torch.stack([s[:, 6], s[:, 7], s[:, 2], avg], dim=1)
@@ -796,6 +797,7 @@ class HipGeoTwin(object):
 
     @property
     def strehl_fit(self):
+        la.check(self.lib.aomarl_strehl_fit(self.ctx, C.byref(self.st), 0, self.sim.nenv, self._stream()))
         s = self.t["strehl"]
         avg = torch.where(s[:, 4] > 0, s[:, 3] / s[:, 4].clamp(min=1), torch.zeros_like(s[:, 3]))
         return torch.stack([s[:, 6], s[:, 7], s[:, 2], avg], dim=1)

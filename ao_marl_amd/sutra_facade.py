@@ -591,7 +591,10 @@ class TargetSource(Source):
         self._fit = bool(do_fit)              # numbers are read from the device on access: fitted peaks in slots 6 / 7
 
     def _st(self):
-        return self._sim().t["strehl"][0].cpu().numpy()
+        sim = self._sim()
+        if self._fit:
+            la.check(sim.lib.aomarl_strehl_fit(sim.ctx, C.byref(sim.st), 0, sim.nenv, sim._stream()))
+        return sim.t["strehl"][0].cpu().numpy()
 
     strehl_se = property(lambda self: float(self._st()[6 if self._fit else 0]))
     strehl_le = property(lambda self: float(self._st()[7 if self._fit else 1]))

@@ -588,6 +588,13 @@ int aomarl_geo_control(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env
 /* Target.comp_image + comp_strehl (targetCompass.py:193,205): publish the pending PSF */
 int aomarl_comp_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                        void *stream);
+/* Target.comp_strehl(do_fit = True), the default of the reference's get_strehl (targetCompass.py:139-159): the Strehl
+ * record of an environment is 8 floats -- [0] SR SE, [1] SR LE, [2] phase variance, [3] its sum, [4] frames, [5] peak on
+ * the window edge, [6] SR SE with the PSF peak fitted by two 1-D sincs (filled by every commit: the fit comes with
+ * the window), [7] SR LE fitted -- which THIS call brings up to date from the accumulated window (it is not on the
+ * control chain; between two calls slot 7 holds the un-fitted value of the last commit).  Reads only the state's
+ * own record and long-exposure window: allowed while a pipelined frame is in flight. */
+int aomarl_strehl_fit(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, void *stream);
 int aomarl_reset_strehl(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                         void *stream);
 /* modes[row][nmodes] = v2m . vec[row][0..nactu)  (AoEnv.transform_state_to_zernike,
