@@ -2402,7 +2402,10 @@ static int env_step_validate(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g
   if (g->sel && (c->sel_checked != g->sel || c->sel_checked_n != g->dm_dim || c->sel_checked_nm != nm)) {
     // column selection of the state blocks: validated once per (pointer, size) -- a synchronous copy of
     // dm_dim indices, never again in the steady state
+    // (every stream first: a selection just written by a kernel of a non-blocking stream is not ordered
+    // with a synchronous copy -- seen as garbage indices under bench.py's own stream)
     std::vector<int32_t> h((size_t)g->dm_dim);
+    HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h.data(), g->sel, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < h.size(); i++)
       if (h[i] < 0 || h[i] >= nm) return fail("env_step: glue->sel[%zu] = %d is outside the %d modes", i, h[i], nm);

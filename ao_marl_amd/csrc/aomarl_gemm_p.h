@@ -14,8 +14,8 @@
 //   * a wave owns (16 WM) x (16 WN) outputs = WM x WN independent v_mfma_f32_16x16x4_f32 accumulators (12 - 16
 //     chains: the instruction's 40-cycle dependent latency never shows), fed by WM + WN ds_read_b128 per 4 WM WN
 //     matrix instructions; one block barrier per 8 WM WN of them (96 - 128);
-//   * operands go global -> registers (two k-tiles in flight) -> LDS (two buffers, row pitch 36 floats: the
-//     16 lanes of a ds_read_b128 pass hit 16 different bank groups);
+//   * operands go global -> registers (two k-tiles in flight) -> LDS (two buffers; rows unpadded, their 16-byte
+//     pieces XOR-swizzled by row: the 16 lanes of a 128-bit pass hit 16 different bank groups, writing and reading);
 //   * the matrix instruction is issued with the operands exchanged (a = B fragment, b = A fragment), so a lane
 //     holds four CONSECUTIVE columns of one output row: 16-byte stores;
 //   * workgroups are numbered so that the ones sharing a k-chunk sit on one XCD (its L2 sees that chunk of both
@@ -32,7 +32,18 @@ typedef float gp_f32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) gp_f4u { float v[4]; };
 #endif
 
+#ifndef GP_SWZ
+#define GP_SWZ 1
+#endif
+#if GP_SWZ
+// LDS rows unpadded (32 floats = 8 pieces of 16 bytes), piece p of row r stored at piece p ^ ((r >> 1) & 7): the 16 lanes
+// of a 128-bit access pass -- 2 rows x 8 pieces when staging, 16 rows x 1 piece when reading operands -- then always
+// touch 16 different bank groups (a padded pitch of 36 made the staging writes of rows r, r + 1 collide: 34 % of the
+// LDS cycles were conflicts, profiles/r04_pmc_gemm_p.txt)
+#define GP_LD 32
+#else
 #define GP_LD 36          // LDS row pitch (floats): 32 k + 4; pitch / 4 odd -> conflict-free 128-bit operand reads
+#endif
 #define GP_KT 32          // k-tile
 
 #ifndef GP_DBG
@@ -84,8 +95,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_p(int M, int N, int K, float al
     for (int p = 0; p < WN; p++) rb[st][p] = *reinterpret_cast<const float4 *>(pb[p] + k);
   };
   auto lstore = [&](int buf, int st, int kt) {
-    float *as = As + buf * BM * GP_LD + lr * GP_LD + lc;
-    float *bs = Bs + buf * BN * GP_LD + lr * GP_LD + lc;
+#if GP_SWZ
+    const int lcs = (((tid & 7) ^ ((lr >> 1) & 7)) << 2);
+#else
+    const int lcs = lc;
+#endif
+    float *as = As + buf * BM * GP_LD + lr * GP_LD + lcs;
+    float *bs = Bs + buf * BN * GP_LD + lr * GP_LD + lcs;
     const int k = kb + kt * GP_KT + lc;
     if (kb + (kt + 1) * GP_KT > ke) {              // wave-uniform: the tile crosses the end of the chunk
       const bool v0 = k < ke, v1 = k + 1 < ke, v2 = k + 2 < ke, v3 = k + 3 < ke;
@@ -111,11 +127,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_p(int M, int N, int K, float al
   // operand fragments: lane (q = lane >> 4, i = lane & 15) reads 4 floats of row i at k = 8 q + 4 j; component c of
   // them is the K lane q of matrix instruction (j, c) -- the same k permutation on both operands.  Two fragment
   // sets (j = 0, 1) so that every LDS read is issued a half-tile of matrix instructions before its first use.
-  const int fo = (lane & 15) * GP_LD + 8 * (lane >> 4);
+#if GP_SWZ
+  const int fo0 = (lane & 15) * GP_LD + (((2 * (lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 2);
+  const int fo1 = (lane & 15) * GP_LD + (((2 * (lane >> 4) + 1) ^ (((lane & 15) >> 1) & 7)) << 2);
+#else
+  const int fo0 = (lane & 15) * GP_LD + 8 * (lane >> 4), fo1 = fo0 + 4;
+#endif
   float4 fa[2][WM], fb[2][WN];
   auto fread = [&](int buf, int j) {
-    const float *as = As + buf * BM * GP_LD + wm * (16 * WM) * GP_LD + fo + 4 * j;
-    const float *bs = Bs + buf * BN * GP_LD + wn * (16 * WN) * GP_LD + fo + 4 * j;
+    const float *as = As + buf * BM * GP_LD + wm * (16 * WM) * GP_LD + (j ? fo1 : fo0);
+    const float *bs = Bs + buf * BN * GP_LD + wn * (16 * WN) * GP_LD + (j ? fo1 : fo0);
 #pragma unroll
     for (int g = 0; g < WM; g++) fa[j][g] = GP_DBG >= 4 ? ra[0][g] : *reinterpret_cast<const float4 *>(as + g * 16 * GP_LD);
 #pragma unroll

@@ -717,10 +717,11 @@ class VecAoEnv(object):
         slower = res["pipelined"] > margin * res["plain"]
         res["chosen"] = "plain" if slower else "pipelined"
         if slower:
-            warnings.warn("VecAoEnv: the pipelined call order is slower than the plain one on this process's streams "
-                          "(%.3f against %.3f ms per step: the caller's stream probably shares a hardware queue with the "
-                          "library's frame stream; GPU_MAX_HW_QUEUES=8 before the first HIP call avoids it); running in "
-                          "the plain order" % (res["pipelined"], res["plain"]))
+            warnings.warn("VecAoEnv: the pipelined call order is slower than the plain one here (%.3f against %.3f ms per "
+                          "step) -- small batches gain nothing from a frame in flight; at production size the caller's "
+                          "stream probably shares a hardware queue with the library's frame stream (GPU_MAX_HW_QUEUES=8 "
+                          "before the first HIP call avoids that); running in the plain order"
+                          % (res["pipelined"], res["plain"]))
         self.frame_pipeline = not slower
         if slower:
             sim.enable_frame_pipeline(False)               # (behind a reset: nothing in flight)

@@ -288,13 +288,15 @@ class Workload(object):
     """A VecAoEnv + random-init batched SAC actors for one BASELINE configuration."""
 
     def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True, pipeline="auto",
-                 reset_prefetch=None):
+                 reset_prefetch=None, agents=None):
         import torch
         from ao_marl_amd.agents import BatchedGaussianPolicy
         from ao_marl_amd.env import VecAoEnv, load_norm
         self.config, self.envs, self.device = config, envs, device
         if "10x10" in config:
             rl, n_modal = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5), 1
+        elif agents == 43:              # the reference's published layout (README.md:116-119): 42 x 30 modes + tip-tilt
+            rl, n_modal = dict(n_zernike_start_end=[0, 1260], n_reverse_filtered_from_cmat=5), 42
         else:
             rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5,
                       window_n_zernike=20, include_tip_tilt_windowed=True)
@@ -472,11 +474,11 @@ def roofline_block(model, fk_ms, kernel_name, args_pmc, envs, config):
     return r
 
 
-def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None, settle=40):
+def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None, settle=40, agents=None):
     """A BASELINE configuration other than the headline one, same loop, same accounting (1 GPU): the
     all-fp32 pass is the figure, the split-fp16 pass rides along as `fast_mode`."""
     from ao_marl_amd import libaomarl
-    w = Workload(config, envs, 0, 1, device, denoiser=denoiser)
+    w = Workload(config, envs, 0, 1, device, denoiser=denoiser, agents=agents)
     out = {"workload": config + (" + shipped denoiser" if denoiser else ""), "envs": envs,
            "agents": w.layout.n_agents, "steps": steps}
     for mode in ("f32", "split_f16"):
@@ -743,10 +745,14 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_side_configs and main_is_headline:
             out["configs"] = {}
-            for key, cfg, ne, dn, st in (("configs[1]", SMALL, 64, None, 200),
-                                         ("configs[4]", NOISY, args.envs, "shipped", 30)):
+            # (+ the configuration the reference publishes, README.md:116-119: `_d1_noise` + the shipped autoencoder,
+            # 43 agents = 42 x 30 modes + tip-tilt)
+            for key, cfg, ne, dn, st, ag in (("configs[1]", SMALL, 64, None, 200, None),
+                                             ("configs[4]", NOISY, args.envs, "shipped", 30, None),
+                                             ("published_43_agents", NOISY.replace("_d0_", "_d1_"), args.envs, "shipped", 30, 43)):
                 try:
-                    out["configs"][key] = side_config(cfg, ne, device, st, 40 if cfg == SMALL else 5, args.episode_len, dn)
+                    out["configs"][key] = side_config(cfg, ne, device, st, 40 if cfg == SMALL else 5, args.episode_len, dn,
+                                                      agents=ag)
                 except Exception as e:
                     out["configs"][key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()

@@ -184,3 +184,41 @@ def test_supervisor_branch_is_that_sequence(noisy, precision):
         sim.do_control()
     assert torch.equal(sup.get_slopes(), sim.slopes)
     assert torch.equal(sup.get_command(), sim.com)
+
+
+def test_published_configuration_episode_slice():
+    """The configuration the reference publishes (README.md:116-119: `production_sh_40x40_8m_3layers_d1_noise` + the
+    shipped autoencoder, `--world-size 44 --n_zernike_start_end 0 1260`: 42 agents of 30 modes + tip-tilt), end to
+    end through the two library calls per step: noisy frame kernel -> denoiser -> centroids -> control, 43 actors
+    in k_actor_fused, 43 per-agent rewards.  16 steps: every step native, finite, equal seeds with equal actions
+    equal bit for bit (the noise streams are keyed by seed and frame), different seeds apart, the denoiser inside
+    its declared range, the loop closing."""
+    from ao_marl_amd.agents import BatchedGaussianPolicy
+    from ao_marl_amd.env import VecAoEnv
+    name = "production_sh_40x40_8m_3layers_d1_noise"
+    rl = dict(n_zernike_start_end=[0, 1260], n_reverse_filtered_from_cmat=5)
+    env = VecAoEnv(name, 4, rl, initial_seed=1234, seed_stride=16, n_agents_modal=42, autoencoder=SubapDenoiser.load(device="cuda:0"))
+    lay = env.layout
+    assert lay.n_agents == 43 and lay.state_shapes()[0] == 120 and lay.state_shapes()[-1] == 8 and lay.action_dim == 1262
+    assert env.frame_pipeline in (False, "auto")             # a noisy sensor with a denoiser: never pipelined
+    seeds = env.supervisor.env_seeds().copy()
+    seeds[1] = seeds[0]
+    env.supervisor.env_seeds = lambda: seeds
+    pol = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=3, device="cuda:0")
+    s = env.reset()
+    assert env.frame_pipeline is False and s.shape == (4, env.state_dim) and torch.equal(s[0], s[1])
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    for it in range(16):
+        eps = torch.randn(4, lay.action_dim, device="cuda:0", generator=g) * 0.1
+        eps[1] = eps[0]
+        a, _ = pol.select_action(s, eps=eps)
+        assert env._native_step_ok(False)
+        s, r, _, _ = env.step(a)
+        assert r.shape == (4, 43) and torch.isfinite(s).all() and torch.isfinite(r).all()
+        assert torch.equal(s[0], s[1]) and torch.equal(r[0], r[1])
+        assert not torch.equal(s[0], s[2])
+    env.supervisor.autoencoder.check_range()
+    sl = env.supervisor.get_slopes()
+    assert torch.isfinite(sl).all() and torch.equal(sl[0], sl[1]) and float(sl.std()) > 0
+    st = env.supervisor.get_strehl().cpu().numpy()
+    assert np.isfinite(st).all() and (st[:, 1] > 0).all() and (st[:, 0] <= 1.0 + 1e-3).all()
