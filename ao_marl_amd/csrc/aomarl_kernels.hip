@@ -306,112 +306,6 @@ __device__ __forceinline__ void g2_mainloop(const float *__restrict__ A, int lda
   }
 }
 
-// Three k-tiles of global loads in flight per thread (register stages, loop unrolled by three), the same
-// software pipeline as the split-fp16 kernel below (see the notes there: no branch around a load, no select on
-// a load's result, scheduling barriers): with the 10-20 k-tiles a split-K block walks and two blocks per CU,
-// one tile ahead (g2_mainloop) left the matrix pipe waiting for L2 on every iteration.  The loop runs whole
-// groups of three tiles; a tile past the end of the chunk is masked to zero as it is staged into LDS.
-__device__ __forceinline__ void g3_mainloop(const float *__restrict__ A, int lda,
-                                            const float *__restrict__ B, int ldb, int M, int N,
-                                            int m0, int n0, int kb, int ke, float *As, float *Bs,
-                                            f32x16 &acc) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-  const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const float *pa0 = A + (long long)min(m0 + lr, M - 1) * lda;
-  const float *pa1 = A + (long long)min(m0 + lr + 32, M - 1) * lda;
-  const float *pb0 = B + (long long)min(n0 + lr, N - 1) * ldb;
-  const float *pb1 = B + (long long)min(n0 + lr + 32, N - 1) * ldb;
-  const int klast = (ke - 1) & ~3;               // last 16-byte group that holds a valid element (lda, ldb >= its end)
-  constexpr int ST = 3;
-  float4 ra0[ST], ra1[ST], rb0[ST], rb1[ST];
-  auto gload = [&](int k0, int st) {
-    const int k = min(k0 + lc, klast);
-    ra0[st] = *reinterpret_cast<const float4 *>(pa0 + k); ra1[st] = *reinterpret_cast<const float4 *>(pa1 + k);
-    rb0[st] = *reinterpret_cast<const float4 *>(pb0 + k); rb1[st] = *reinterpret_cast<const float4 *>(pb1 + k);
-  };
-  auto lstore = [&](int buf, int st, int k0) {
-    float *as = As + buf * 64 * G2_LD, *bs = Bs + buf * 64 * G2_LD;
-    float4 a0 = ra0[st], a1 = ra1[st], b0 = rb0[st], b1 = rb1[st];
-    if (k0 + 32 > ke) {                          // wave-uniform: the tile crosses the end of the chunk
-      const int k = k0 + lc;
-      const bool m0_ = k < ke, m1_ = k + 1 < ke, m2_ = k + 2 < ke, m3_ = k + 3 < ke;
-      auto msk = [&](float4 &v) { v.x = m0_ ? v.x : 0.f; v.y = m1_ ? v.y : 0.f; v.z = m2_ ? v.z : 0.f; v.w = m3_ ? v.w : 0.f; };
-      msk(a0); msk(a1); msk(b0); msk(b1);
-    }
-    *reinterpret_cast<float4 *>(as + lr * G2_LD + lc) = a0;
-    *reinterpret_cast<float4 *>(as + (lr + 32) * G2_LD + lc) = a1;
-    *reinterpret_cast<float4 *>(bs + lr * G2_LD + lc) = b0;
-    *reinterpret_cast<float4 *>(bs + (lr + 32) * G2_LD + lc) = b1;
-  };
-  const int ro = (lane & 31) * G2_LD + 16 * (lane >> 5);
-#pragma unroll
-  for (int st = 0; st < ST; st++) gload(kb + 32 * st, st);
-  __builtin_amdgcn_sched_barrier(0);
-  lstore(0, 0, kb);
-  gload(kb + 32 * ST, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kb; k0 < ke; k0 += 32 * ST) {
-#pragma unroll
-    for (int u = 0; u < ST; u++) {
-      const int kc = k0 + 32 * u;                // the tile in LDS buffer `buf` (all zeros past the end)
-      lstore(buf ^ 1, (u + 1) % ST, kc + 32);
-      gload(kc + 32 * (ST + 1), (u + 1) % ST);
-      __builtin_amdgcn_sched_barrier(0);
-      const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
-      const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
-      float4 a4[4], b4[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        a4[j] = *reinterpret_cast<const float4 *>(as + 4 * j);
-        b4[j] = *reinterpret_cast<const float4 *>(bs + 4 * j);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      buf ^= 1;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alpha,
-                                                  const float *__restrict__ A, int lda,
-                                                  const float *__restrict__ B, int ldb, float beta,
-                                                  float *__restrict__ C, int ldc, int kchunk,
-                                                  float *__restrict__ P) {
-  __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  g3_mainloop(A, lda, B, ldb, M, N, m0, n0, kb, ke, As, Bs, acc);
-  const int col = n0 + wn * 32 + (lane & 31);
-  const bool split = gridDim.z > 1;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < M && col < N) {
-      if (split) {
-        P[((long long)blockIdx.z * M + row) * N + col] = acc[r];
-      } else {
-        float *c = C + (long long)row * ldc + col;
-        float v = alpha * acc[r];
-        if (beta != 0.f) v += beta * (*c);
-        *c = v;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // The same GEMM on the f16 matrix pipe with SPLIT operands: every fp32 value v is carried as
 // hi = f16(v), lo = f16(v - hi), both rounded to nearest (23 significant bits, unbiased) and a product
@@ -419,7 +313,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(int M, int N, int K, float alp
 // each per 16 k against sixteen 64-cycle v_mfma_f32_32x32x2_f32 (fp32 matrix instructions run at the
 // packed-fp32 vector rate on this chip) -- 10x less matrix-pipe time; what is left is the splitting
 // (2 vector instructions per element as it is staged into LDS) and the LDS traffic.
-// Operands stay fp32 in memory, same interface as k_gemm_nt2 plus a power-of-two scale per operand
+// Operands stay fp32 in memory, same interface as k_gemm_nt plus a power-of-two scale per operand
 // (sa, sb; applied as the values are staged, undone through alpha): the scaled values must stay
 // below 65504 (they saturate above) and lose low bits of `lo` below 6e-5 (absolute error <= 3e-8
 // of the scaled value).  gemm_scale() picks the scale of a static matrix from its largest entry.
@@ -619,7 +513,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
 // The three products of a linear layer y = x W (W stored [in][out]) are
 //     forward  y  = x . W        TA = 0, TB = 1        backward dx = dy . W^T     TA = 0, TB = 0
 //     weights  dW = x^T . dy     TA = 1, TB = 1
-// Same tile / LDS image / MFMA loop as k_gemm_nt2; a k-strided operand is read with 128-bit loads
+// Same tile / LDS image / MFMA loop as k_gemm_nt_batched2 (g2_mainloop); a k-strided operand is read with 128-bit loads
 // along its contiguous (row) direction and transposed on the way into LDS.
 // ---------------------------------------------------------------------------------------------
 template <bool T>
@@ -847,7 +741,6 @@ static const char *const g_arith_name[AR_N] = {
     "frame_kernel_dft:f32_mfma", "frame_kernel_dft:split_f16_mfma", "gemm:f32_mfma", "gemm:split_f16_mfma",
     "denoiser:f32_mfma", "denoiser:split_f16_mfma", "actor:f32_mfma"};
 static int g_gemm_xcd = 1;            // "gemm_xcd_map": k_gemm_nt_h's / k_gemm_p's blocks grouped by k-chunk per XCD
-static int g_gemm_p = 1;              // "gemm_balanced": the fp32 products on k_gemm_p (aomarl_gemm_p.h); 0: k_gemm_nt2
 static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
 // Retired after their A/B runs (profiles/r01g_*): the un-pipelined aligned kernel (30 us vs 22 us per
 // call) and an in-kernel split-K reduction through ticket counters (4x slower: every block pays an
@@ -915,7 +808,7 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     }
   }
   const bool split_f16 = al && fast && g_gemm_split_f16;
-  if (al && !split_f16 && g_gemm_p) {
+  if (al && !split_f16) {
     // round 4: the balanced kernel; tile and k split from its own cost model (memoised per shape)
     struct Memo { int M, N, K; size_t ws; GemmPCfg c; };
     static thread_local Memo memo[16];
@@ -960,11 +853,7 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
                        ldc, kchunk, ws, sa, sb, g_gemm_xcd, sat);
     g_arith[AR_GEMM_SPLIT]++;
   }
-  else if (al) {
-    hipLaunchKernelGGL(k_gemm_nt2, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C,
-                       ldc, kchunk, ws);
-    g_arith[AR_GEMM_F32]++;
-  } else {
+  else {
     hipLaunchKernelGGL(k_gemm_nt<false>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb,
                        beta, C, ldc, kchunk, ws);
     g_arith[AR_GEMM_F32]++;

@@ -292,9 +292,8 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * (separate target and WFS passes in aomarl_next_part_one), "force_f32_dft" (one-pass frame
  * kernel: 1 = fp32 MFMAs through LDS tiles, 0 = split-fp16 MFMAs from registers, -1 = follow
  * aomarl_set_precision, the default), "precision" (= aomarl_set_precision; process-wide, ctx may be NULL),
- * "gemm_target_blocks" (split-K target of the round-3 fp32 GEMM, k_gemm_nt2),
- * "gemm_balanced" (default 1: the internal fp32 products run on k_gemm_p, csrc/aomarl_gemm_p.h -- tile and k split
- * chosen so that every CU gets the same share; 0: on k_gemm_nt2; process-wide, ctx may be NULL),
+ * "gemm_target_blocks" (split-K target of the fast mode's split-fp16 GEMM; the fp32 products run on k_gemm_p,
+ * csrc/aomarl_gemm_p.h, which picks tile and k split so that every CU gets the same share),
  * "gemm_xcd_map" (default 1: the split-f16 GEMM's blocks are renumbered so that one XCD works on one k-chunk and
  * its L2 holds that slice of both operands; 0: plain grid order; same values; process-wide, ctx may be NULL),
  * "time_frame_kernel" (see aomarl_frame_kernel_time),

@@ -17,9 +17,8 @@ o = [aoref.OracleSim(s, seed=sd) for sd in seeds]
 want = [np.stack([x.screens[l] for x in o]) for l in range(s.nscreens)]
 for mode in ("f32", "split_f16"):
     la.set_precision(mode)
-    for bal in (1, 0):
+    for bal in (1,):            # (profiles/r04_reset_parity.txt also holds round 3's k_gemm_nt2, removed since: gemm_balanced=0)
         sim = HipSim(s, nenv=len(seeds))
-        sim.set_option("gemm_balanced", bal)
         sim.reset(seeds)
         line = "%-9s gemm_balanced=%d:" % (mode, bal)
         for l in range(s.nscreens):
