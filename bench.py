@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps right in front of the timed region")
-    ap.add_argument("--settle", type=int, default=40,
+    ap.add_argument("--settle", type=int, default=100,
                     help="episode position of the warm-up: untimed steps behind the reset in front of it.  The first ~40 "
                          "frames behind a reset run 3-10 %% slower (the loop is still closing); they are timed on their "
                          "own and their excess over the steady rate is amortised with the reset (`post_reset_transient_ms`)")
@@ -474,7 +474,7 @@ def roofline_block(model, fk_ms, kernel_name, args_pmc, envs, config):
     return r
 
 
-def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None, settle=40, agents=None):
+def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None, settle=100, agents=None):
     """A BASELINE configuration other than the headline one, same loop, same accounting (1 GPU): the
     all-fp32 pass is the figure, the split-fp16 pass rides along as `fast_mode`."""
     from ao_marl_amd import libaomarl
