@@ -75,10 +75,10 @@ __device__ __forceinline__ void add4_ring(float acc[4], const float *row, int px
 }
 
 // =============================================================================================
-// fp32 GEMM  C[M][N] = alpha * A[M][K] . B[N][K]^T + beta * C     (both operands K-contiguous)
+// fp32 GEMM  C[M][N] = alpha * A[M][K] . B[N][K]^T + beta * C     (both operands K-contiguous), ANY alignment:
+// the fallback behind k_gemm_p (aomarl_gemm_p.h), which wants 16-byte aligned rows.  Element-wise loads,
 // 256 threads = 4 waves in 2x2, block tile 64x64, one v_mfma_f32_32x32x2_f32 accumulator/wave.
 // =============================================================================================
-template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alpha,
                                                  const float *__restrict__ A, int lda,
                                                  const float *__restrict__ B, int ldb, float beta,
@@ -102,24 +102,14 @@ __global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alph
     float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
     const int gk = k0 + lc;
     if (gm < M) {
-      if (ALIGNED && gk + 3 < ke) {
-        float4 t = *reinterpret_cast<const float4 *>(pa + gk);
-        va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w;
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (gk + j < ke) va[j] = pa[gk + j];
-      }
+      for (int j = 0; j < 4; j++)
+        if (gk + j < ke) va[j] = pa[gk + j];
     }
     if (gn < N) {
-      if (ALIGNED && gk + 3 < ke) {
-        float4 t = *reinterpret_cast<const float4 *>(pb + gk);
-        vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (gk + j < ke) vb[j] = pb[gk + j];
-      }
+      for (int j = 0; j < 4; j++)
+        if (gk + j < ke) vb[j] = pb[gk + j];
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -744,7 +734,7 @@ static int g_gemm_xcd = 1;            // "gemm_xcd_map": k_gemm_nt_h's / k_gemm_
 static int g_gemm_kgroups = 0;       // batched general GEMM: 0 = by heuristic; 1 / 2 / 4 forced
 // Retired after their A/B runs (profiles/r01g_*): the un-pipelined aligned kernel (30 us vs 22 us per
 // call) and an in-kernel split-K reduction through ticket counters (4x slower: every block pays an
-// L2 write-back for its __threadfence).  k_gemm_nt<false> / k_gemm_nt_batched stay as the fallback
+// L2 write-back for its __threadfence).  k_gemm_nt / k_gemm_nt_batched stay as the fallback
 // for operands that are not 16-byte aligned.
 
 // Threads of k_gemm_nt_h launches that staged an operand beyond the fp16 range (clipped to +-65504): one
@@ -854,7 +844,7 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     g_arith[AR_GEMM_SPLIT]++;
   }
   else {
-    hipLaunchKernelGGL(k_gemm_nt<false>, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb,
+    hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb,
                        beta, C, ldc, kchunk, ws);
     g_arith[AR_GEMM_F32]++;
   }
