@@ -22,7 +22,7 @@
 //     operands once).
 // Tails: rows / columns past M / N are clamped on load and not stored; a k-tile that crosses the end of the
 // block's chunk is zeroed as it is staged (wave-uniform branch).  Operands must be 16-byte aligned with leading
-// dimensions that are multiples of 4 (the caller falls back to k_gemm_nt<false> otherwise).
+// dimensions that are multiples of 4 (the caller falls back to k_gemm_nt otherwise).
 #pragma once
 #include <hip/hip_runtime.h>
 
