@@ -845,3 +845,39 @@ def test_prefetched_reset_is_the_plain_reset_bit_for_bit(name, nenv):
     a.reset(s2); b.reset(s2)
     assert b.prefetched_resets == 2 and not b.prefetch_reset_pending()
     same_state("dropped prefetch")
+
+
+@pytest.mark.parametrize("pipe", [False, True])
+def test_environment_with_prefetched_resets_gives_the_same_episodes(pipe):
+    """VecAoEnv(reset_prefetch=...): the next episode's screens grow beside the running one (a share of the rounds per
+    step, the rest inside reset()); states, rewards and Strehl of three episodes -- same seeds ("same") and a
+    trainer's seed schedule (next_seed_block) -- equal the plain environment's bit for bit, with and without a frame
+    in flight; an episode on unexpected seeds drops the prefetch and resets in the open."""
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, max_steps_per_episode=30)
+    mk = lambda rp: VecAoEnv("production_sh_10x10_2m", 5, rl, initial_seed=11, n_agents_modal=1, frame_pipeline=pipe,  # noqa: E731
+                             reset_prefetch=rp)
+    g = torch.Generator(device="cuda:0").manual_seed(8)
+    acts = [torch.rand(5, 82, device="cuda:0", generator=g) * 2 - 1 for _ in range(30)]
+
+    def episodes(env, schedule):
+        rec = []
+        for ep, nsteps in enumerate((30, 12, 30)):
+            s = env.reset()
+            rec.append(s.clone())
+            for t in range(nsteps):
+                s, r, _, _ = env.step(acts[t])
+                rec += [s.clone(), r.clone()]
+            rec.append(env.supervisor.get_strehl().clone())
+            if schedule == "blocks":
+                env.next_seed_block(1)
+            elif schedule == "surprise" and ep == 0:
+                env.set_sim_seed(4242)
+        return rec
+
+    for rp, schedule in (("same", "same"), (1, "blocks"), ("same", "surprise")):
+        a, b = mk(None), mk(rp)
+        ra, rb = episodes(a, schedule), episodes(b, schedule)
+        assert len(ra) == len(rb) and all(torch.equal(x, y) for x, y in zip(ra, rb)), (rp, schedule)
+        want = 1 if schedule == "surprise" else 2          # the surprise episode's reset ran in the open
+        assert getattr(b.supervisor.sim, "prefetched_resets", 0) == want and getattr(a.supervisor.sim, "prefetched_resets", 0) == 0
