@@ -1876,6 +1876,98 @@ __device__ __forceinline__ void spot_cog_f32_pk(const DevSys &sys, const DevStat
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Slopes only, fp32, WITHOUT the spot: the three moments of the binned image as quadratic forms of the
+// pupil field (28 matrix instructions per sub-aperture instead of 48, 8 packed vector instructions instead of 32).
+//
+// The binned image covers the central 32 x 32 frequencies f = +-(j + 1/2), j = 0 .. 15 of the half-pixel-shifted
+// 64-point transform, every one of them exactly once (npix * nrebin = 32), and the pixel coordinate of a frequency
+// depends on one axis only: X(+-(j + 1/2)) = 7.5 +- u_j, u_j = 1/2 + (j >> 1).  A sum  sum_f w_x(fx) w_y(fy) |F(fx, fy)|^2
+// with F = sum_{x, y} E[y][x] exp(-2 pi i (fx x + fy y) / 64) is then
+//     sum_{x, x', y, y'} E[y][x] conj(E[y'][x']) K_wx[x'][x] K_wy[y'][y],    K_w[x'][x] = sum_f w(f) exp(2 pi i f (x' - x) / 64),
+// and for w = 1 the kernel is the real symmetric Toeplitz matrix  M[d] = 2 sum_j cos(2 pi (j + 1/2) d / 64), for the
+// odd weight w = +-u_j it is i S with  S[d] = 2 sum_j u_j sin(2 pi (j + 1/2) d / 64)  real and antisymmetric.  With
+// E = Er + i Ei (rows y, columns x) the imaginary parts cancel and
+//     sum I           = < M, Er M Er^T + Ei M Ei^T >
+//     sum (X - 7.5) I =  2 < M, Ei S Er^T >
+//     sum (Y - 7.5) I =  2 < S, Ei M Er^T >            (< A, B > = sum_{y', y} A[y'][y] B[y'][y])
+// -- the same numbers as transform, |.|^2, 2 x 2 binning and centre of gravity, to fp32 round-off (2e-7 pixels
+// against the 64 x 64 FFT in float64, tools/qf_cog_check.py).  Not usable with noise or when the image is wanted.
+//
+// On the matrix cores: lane (q, c) holds E[y = c][x = 4q + s], which is the A operand of a product E . (..) AND
+// the B operand of a product (..) . E^T:  W = M Er^T, M Ei^T, S Er^T  (A = the constant [x' = c][x = 4q + s], 12
+// instructions) come out as [x' = 4q + r][y = c], the B operand of  Er W, Ei W  (16 instructions), whose results
+// [y' = 4q + r][y = c] meet the same constants again (M symmetric, S antisymmetric) in 8 packed multiply-adds.
+struct SpotQf { f32x2 Ml, Mh, Sl, Sh; };          // M[c][4q + s], S[c - (4q + s)], s = 0 .. 3
+
+__device__ __forceinline__ SpotQf spot_qf_consts(int lane, const float2 *sTw /* [128]: cos, sin(2 pi k / 128) */) {
+  const int q = lane >> 4, c = lane & 15;
+  float m[4], sv[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int d = c - (4 * q + s);
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < 16; j++) {
+      const float2 w = sTw[((2 * j + 1) * d) & 127];
+      a += w.x;
+      b = fmaf(0.5f + (float)(j >> 1), w.y, b);
+    }
+    // exact zeros of the Dirichlet kernel (even d != 0) come out as round-off: clear them
+    m[s] = (d != 0 && (d & 1) == 0) ? 0.f : 2.f * a;
+    sv[s] = 2.f * b;
+  }
+  SpotQf k;
+  k.Ml = f32x2{m[0], m[1]}; k.Mh = f32x2{m[2], m[3]};
+  k.Sl = f32x2{sv[0], sv[1]}; k.Sh = f32x2{sv[2], sv[3]};
+  return k;
+}
+
+__device__ __forceinline__ void spot_cog_qf(const DevSys &sys, const DevState &st, int e, int i, int lane,
+                                            const SpotQf &K, const float (&er)[4], const float (&ei)[4],
+                                            int do_cog, const f32x4 z4) {
+  const float Mc[4] = {K.Ml.x, K.Ml.y, K.Mh.x, K.Mh.y}, Sc[4] = {K.Sl.x, K.Sl.y, K.Sh.x, K.Sh.y};
+  f32x4 Wr = z4, Wi = z4, V = z4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    Wr = mfma16(Mc[s], er[s], Wr);               // (M Er^T)[x'][y]
+    Wi = mfma16(Mc[s], ei[s], Wi);               // (M Ei^T)[x'][y]
+    V = mfma16(Sc[s], er[s], V);                 // (S Er^T)[x'][y]
+  }
+  f32x4 G1a = z4, G1b = z4, G2 = z4, G3 = z4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    G1a = mfma16(er[s], Wr[s], G1a);             // (Er M Er^T)[y'][y]
+    G1b = mfma16(ei[s], Wi[s], G1b);             // (Ei M Ei^T)[y'][y]
+    G2 = mfma16(ei[s], Wr[s], G2);               // (Ei M Er^T)[y'][y]
+    G3 = mfma16(ei[s], V[s], G3);                // (Ei S Er^T)[y'][y]
+  }
+  // constants in the result layout: M[4q + r][c] = M[c][4q + r] = Mc[r];  S[(4q + r) - c] = -Sc[r]
+  PK_GUARD_MFMA();
+  f32x2 p0 = pk_mul(pk_lo(G1a), K.Ml);
+  f32x2 px = pk_mul(pk_lo(G3), K.Ml);
+  f32x2 py = pk_mul(pk_lo(G2), K.Sl);
+  pk_acc_fma(p0, pk_hi(G1a), K.Mh);
+  pk_acc_fma(px, pk_hi(G3), K.Mh);
+  pk_acc_fma(py, pk_hi(G2), K.Sh);
+  pk_acc_fma(p0, pk_lo(G1b), K.Ml);
+  pk_acc_fma(p0, pk_hi(G1b), K.Mh);
+  float s0 = p0.x + p0.y, tx = px.x + px.y, ty = py.x + py.y;
+  s0 = wave_sum_last(s0);
+  tx = wave_sum_last(tx);
+  ty = wave_sum_last(ty);
+  if (do_cog && lane == 63) {
+    float *sl = st.slopes + (long long)e * sys.nslope;
+    if (s0 > 0.f) {
+      const float inv = 2.f * __builtin_amdgcn_rcpf(s0);  // 1 ulp; slopes are compared at 1e-4"
+      sl[i] = (fmaf(tx, inv, 7.5f) - sys.cog_offset) * sys.cog_scale;
+      sl[sys.nvalid + i] = (fmaf(-ty, inv, 7.5f) - sys.cog_offset) * sys.cog_scale;
+    } else {
+      sl[i] = 0.f;
+      sl[sys.nvalid + i] = 0.f;
+    }
+  }
+}
+
 // flux normalisation (+noise), COG on the binned quadrant values v[sy][sx][h]
 template <bool NOISE, bool WRITE_CUBE>
 __device__ __forceinline__ void spot_finish_v(const DevSys &sys, const DevState &st, int e, int i,
@@ -2480,6 +2572,9 @@ template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 #ifndef FW_WAVES
 #define FW_WAVES 3
 #endif
+#ifndef FW_QF
+#define FW_QF 1            // 0: the slopes-only fp32 instantiation goes through the pruned transform (spot_cog_f32_pk)
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FW_WAVES, FW_WAVES)))
 void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     int env_count, int do_cog,
@@ -2515,6 +2610,10 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   }
   SpotTwH twh;
   if (HP) twh = spot_tw_h(Cc, Ss);
+  // slopes only, fp32: the moments as quadratic forms of the field (spot_cog_qf): no transform, no Cc / Ss
+  constexpr bool QF = FW_QF && OTF && !HP && !NOISE && !WRITE_CUBE;
+  SpotQf qfk;
+  if constexpr (QF) qfk = spot_qf_consts(lane, sTw);
   // shared loads: wave 0 / 1: the two 16-byte halves of the lane's tip-tilt pairs, wave 2 (and 3, a
   // duplicate that hits in the L1): the PSF operand of the lane, [t][64] x 16 B
   unsigned shstep;
@@ -2789,7 +2888,8 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         spot_dft_h_v(twh, wr, wi, Z4, v);
         spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, v, do_cog, flux_i);
       } else if (!NOISE && !WRITE_CUBE) {
-        if constexpr (PK) spot_cog_f32_pk(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
+        if constexpr (QF) spot_cog_qf(sys, st, e, info & 0xFFFF, lane, qfk, wr, wi, do_cog, Z4);
+        else if constexpr (PK) spot_cog_f32_pk(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
         else spot_cog_f32(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
       } else {
         spot_core<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, flux_i, Z4);
