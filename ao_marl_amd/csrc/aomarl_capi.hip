@@ -565,6 +565,29 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
         }
         UP(int32_t, linfo.data(), linfo.size(), s.lit_info);
         UP(int32_t, lcount.data(), lcount.size(), s.lit_count);
+        // the same tiles in pairs (2 g, 2 g + 1): the frame kernel fetches the layer rows of a pair as whole
+        // 128-byte pieces
+        const int npm = (nt + 1) / 2 + 2;
+        std::vector<int32_t> pinfo((size_t)nt * npm * 2, 0), pcount(nt, 0);
+        for (int r = 0; r < nt; r++) {
+          int k = 0;
+          int32_t *row = &pinfo[(size_t)r * npm * 2];
+          for (int g = 0; 2 * g < nt; g++) {
+            const int ta = 2 * g, tb = 2 * g + 1 < nt ? 2 * g + 1 : 2 * g;
+            const int32_t va = tinfo[(size_t)r * nt + ta], vb = 2 * g + 1 < nt ? tinfo[(size_t)r * nt + tb] : 0;
+            if (!((va | vb) & 0x10000)) continue;
+            row[2 * k] = ((va & 0x10000) ? va : 0) | (ta << 24);
+            row[2 * k + 1] = ((vb & 0x10000) ? vb : 0) | (tb << 24);
+            k++;
+          }
+          pcount[r] = k;
+          for (int kk = k; kk < npm; kk++) {
+            row[2 * kk] = k ? row[2 * (k - 1)] : 0;
+            row[2 * kk + 1] = k ? row[2 * (k - 1) + 1] : 0;
+          }
+        }
+        UP(int32_t, pinfo.data(), pinfo.size(), s.pair_info);
+        UP(int32_t, pcount.data(), pcount.size(), s.pair_count);
       }
       {
         std::vector<int32_t> order(nt), work(nt, 0);

@@ -69,7 +69,10 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
   if (w.nblk != c->sys.ntiles) return fail("frame_fused: internal stripe count mismatch");
   const int nb = otf ? c->sys.otf_nb : 1;
   const bool hp = c->dft_mode < 0 ? g_precision != 0 : c->dft_mode == 1;
-  const size_t smm = sizeof(float) * (2 * 128 + (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + 8192 + 128;
+  // twiddles + command lattice + the block's shared-data slots (two tiles x two parities with the pair walk) + one
+  // image of a tile pair's layer rows per wave (FW_DMA: the stack-array-from-voltages instantiations)
+  const size_t smm = sizeof(float) * (2 * 128 + (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + 16384 + 128 +
+                     (otf && (hp || FW_DMA_F32) ? 4 * FWD_WAVE(c->nlayers == 1 ? 1 : 3) : 0);
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
 // the events ride on the dispatch itself (its start / completion signal): no marker packets of their own
 // on the queue in front of and behind the kernel

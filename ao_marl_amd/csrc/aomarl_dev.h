@@ -80,6 +80,11 @@ struct DevSys {
   const int32_t *lit_info;       // [ntiles][ntiles + 4]: the stripe's LIT tiles in x order, compact: tile_info | tile << 24;
                                  //   entries past the last one repeat it
   const int32_t *lit_count;      // [ntiles] lit tiles per stripe
+  // the same walk in PAIRS of adjacent tiles (2 g, 2 g + 1) with at least one lit tile: [ntiles][(ntiles + 1) / 2 + 2][2]
+  // entries (tile A, tile B) of the lit_info form (bit 16 clear: that tile of the pair is not lit; the tile index is
+  // valid either way); entries past the last pair repeat it
+  const int32_t *pair_info;
+  const int32_t *pair_count;     // [ntiles] pairs per stripe
   const uint16_t *tile_mask;     // [pupdiam][ntiles]: bit b = spupil[y][16 t + b] != 0
   // stack-array DM phase from the command lattice inside the frame kernel (separable lattice whose
   // pitch divides the tile size): nodes per axis that reach a tile <= 4 otf_nb
@@ -167,9 +172,9 @@ __device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, 
 // n + RING_PAD floats long: columns [n, n + RING_PAD) mirror columns [0, RING_PAD), so up to
 // RING_PAD consecutive logical pixels starting at a physical column < n are consecutive floats:
 // a 16-pixel tile row whose first pixel is in range needs no wrap test per lane (the one-pass
-// frame kernel wraps once per tile, on the scalar unit); the extrusion scatter keeps the mirror
-// up to date.
-#define RING_PAD 16
+// frame kernel wraps once per tile -- once per PAIR of tiles, 32 pixels, when it fetches whole 128-byte row
+// pieces -- on the scalar unit); the extrusion scatter keeps the mirror up to date.
+#define RING_PAD 32
 __device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
   int px = x + ox;
   px -= (px >= n) ? n : 0;

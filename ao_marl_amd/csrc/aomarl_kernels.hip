@@ -2,6 +2,7 @@
 // wave = 64 lanes; fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) for the DFT and GEMM work.
 #include "aomarl_dev.h"
 #include "aomarl_gemm_p.h"
+#include <type_traits>
 
 #define WAVE 64
 
@@ -2575,6 +2576,24 @@ template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 #ifndef FW_QF
 #define FW_QF 1            // 0: the slopes-only fp32 instantiation goes through the pruned transform (spot_cog_f32_pk)
 #endif
+#ifndef FW_DMA
+#define FW_DMA 1           // 0: layer rows fetched per tile into vector registers (16 rows x 64 B per instruction)
+#endif
+#ifndef FW_DMA_F32
+#define FW_DMA_F32 0       // 1: the pair walk for the fp32 instantiations too (measured: no gain there, see below)
+#endif
+// Layer rows of a PAIR of adjacent tiles as whole 128-byte pieces, straight into LDS (FW_DMA, the stack-array-from-
+// voltages instantiations).  A load instruction that covers 16 rows x 64 B (the compute layout: lane (q, c) = row c,
+// pixels 4q .. 4q + 3) makes the memory pipeline handle every 128-byte line twice, half a line at a time; as
+// 8 rows x 128 contiguous bytes the same bytes arrive 25 % faster (tools/dmabench.hip: 3.9 -> 4.9 TB/s on this access
+// pattern alone) and the second fetch of a line two neighbouring tiles share disappears.  The pieces are written by
+// buffer_load_dwordx4 ... lds -- no vector registers in flight -- into the wave's own LDS image: per layer two blocks of
+// 8 rows x 8 chunks of 16 bytes in LANE order (what that instruction can write), the second block 128 bytes further,
+// the chunk a lane fetches XOR-ed with its row (lane = 8 row + (chunk ^ row)): the compute layout's ds_read_b128
+// (row c, chunk 4 h + q of tile h) then finds its 16 lanes in 16 different bank groups.
+#define FWD_BLK 1152                       // bytes from block 0 to block 1 of a layer image
+#define FWD_IMG (2 * 1024 + 128)           // bytes of a layer image
+#define FWD_WAVE(nl) ((nl) * FWD_IMG)      // bytes per wave
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FW_WAVES, FW_WAVES)))
 void k_frame_wave(DevSys sys, DevState st, int env_begin,
                                                     int env_count, int do_cog,
@@ -2586,7 +2605,9 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2 *sTw = reinterpret_cast<float2 *>(smem);            // [128] WFS twiddles
   float *lat_all = reinterpret_cast<float *>(sTw + 128);     // [4 waves][4 NB][latw]
-  float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // [2][4][64]
+  float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // [2][4][64]; DMA: [2][2][4][64]
+  constexpr bool DMA = FW_DMA && OTF && (HP || FW_DMA_F32);
+  char *dimg = reinterpret_cast<char *>(shb + 1024) + (DMA ? wv * FWD_WAVE(NL) : 0);            // this wave's layer images
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
   // blocks are dispatched x-fastest: x = group of 4 environments, y = rank of the stripe by
@@ -2754,7 +2775,10 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   };
 
   // one lit tile: consume `cur`, then issue the loads of the tile `infon` describes into `nxt`
-  auto tile = [&](int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt) {
+  // (dma_slot != nullptr: the pair walk below -- cur.L / mrow / F are filled in by the caller, the block's shared data
+  // of this tile is already in `dma_slot`, nothing is fetched in here)
+  auto tile = [&](int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt, auto dma_tag, float4 *dma_slot) {
+    constexpr bool DM = decltype(dma_tag)::value;
     const int t = (info >> 24) & 0x7F;
     // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
     f32x4 S = PK ? NP4 : Z4;
@@ -2770,10 +2794,12 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     }
     const float flux_i = cur.F;
     // environment-independent data of the tile through the block's LDS slot
-    float4 *slot = shb + (nlit & 1) * 256;
-    nlit++;
-    slot[wv * 64 + lane] = make_float4(cur.SH.v[0], cur.SH.v[1], cur.SH.v[2], cur.SH.v[3]);
-    __syncthreads();
+    float4 *slot = DM ? dma_slot : shb + (nlit & 1) * 256;
+    if constexpr (!DM) {
+      nlit++;
+      slot[wv * 64 + lane] = make_float4(cur.SH.v[0], cur.SH.v[1], cur.SH.v[2], cur.SH.v[3]);
+      __syncthreads();
+    }
     const float4 t0 = slot[lane], t1 = slot[64 + lane];
     cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
     cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
@@ -2854,7 +2880,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
       }
     }
-    fetch(infon, nxt);                                       // these loads fly during the MFMAs
+    if constexpr (!DM) fetch(infon, nxt);                    // these loads fly during the MFMAs
     // ---- science path (see the kernel's header)
     if (!(dbg & 2)) {
       if constexpr (PK) {
@@ -2901,6 +2927,82 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   // the last one repeat it, so the prefetch at the end of the list needs no test: the last tile is
   // loaded again, from L2, and dropped).  TWO tiles of loads are in flight (two register sets, list
   // walked in pairs; an odd first tile goes on its own).  The list is read with scalar loads.
+  if constexpr (DMA) {
+    // ---- the stripe's lit tiles in PAIRS (sys.pair_info): per pair ONE wait for everything fetched a pair ago, the
+    // layer rows out of the wave's LDS image into registers, the block's shared data of both tiles into its slots,
+    // ONE barrier, then the fetches of the next pair (in flight during the two tiles of this one) and the tiles.
+    const std::integral_constant<bool, true> dm;
+    const int np = sys.pair_count[r];
+    const const_int_p pinfo = (const_int_p)(unsigned long long)(sys.pair_info + r * (2 * ((ntl + 1) / 2 + 2)));
+    // loader role of the lane: row rr of an 8-row block, chunk (lane & 7) ^ rr of the 128-byte row piece
+    const int rr = lane >> 3, kk = (lane & 7) ^ rr;
+    unsigned dvo[NL][2];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const DevLayer &L = sys.layers[l];
+      int py = L.toy + st.origin[(e * sys.nlayers + l) * 2 + 1]; py -= (py >= L.dim) ? L.dim : 0;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        unsigned pr = (unsigned)(16 * r + 8 * b + rr) + (unsigned)py; pr = min(pr, pr - ldim[l]);
+        dvo[l][b] = 4u * (pr * (ldim[l] + RING_PAD)) + 16u * (unsigned)kk;
+      }
+    }
+    // reader role: row c = 8 bc + rc, chunk 4 h + q of tile h
+    const int bc = c >> 3, rc = c & 7;
+    const char *rdp[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) rdp[h] = dimg + bc * FWD_BLK + 16 * (rc * 8 + ((4 * h + q) ^ rc));
+    const unsigned dimg_lds = (unsigned)(unsigned long long)dimg;       // LDS byte address of the wave's images
+    FrameRaw<NL, OTF> A, B;
+    f32x4 shA, shB;
+    unsigned mrA, mrB;
+    float fA, fB;
+    auto issue = [&](int ia, int ib) {
+      const int ta = (ia >> 24) & 0x7F, tb = (ib >> 24) & 0x7F;
+      shA = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, (unsigned)ta << shstep, 0));
+      shB = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, (unsigned)tb << shstep, 0));
+      mrA = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)ta + mvo);
+      mrB = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)tb + mvo);
+      fA = cflux[ia & 0xFFFF];
+      fB = cflux[ib & 0xFFFF];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        unsigned sx = 16u * (unsigned)(ta & ~1) + lpxs[l]; sx -= (sx >= ldim[l]) ? ldim[l] : 0u;   // scalar; 32 pixels never wrap
+        const unsigned so = 4u * sx;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const unsigned m0v = dimg_lds + l * FWD_IMG + b * FWD_BLK;
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(dvo[l][b]), "s"(lrs[l]), "s"(m0v), "s"(so) : "memory");
+        }
+      }
+    };
+    int ia = pinfo[0], ib = pinfo[1];
+    if (np > 0) issue(ia, ib);
+    for (int k = 0; k < np; k++) {
+      const int ja = pinfo[2 * k + 2], jb = pinfo[2 * k + 3];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this pair's layer images (and shA / shB / masks) have landed
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const float4 va = *reinterpret_cast<const float4 *>(rdp[0] + l * FWD_IMG);
+        const float4 vb = *reinterpret_cast<const float4 *>(rdp[1] + l * FWD_IMG);
+        A.L[l][0] = va.x; A.L[l][1] = va.y; A.L[l][2] = va.z; A.L[l][3] = va.w;
+        B.L[l][0] = vb.x; B.L[l][1] = vb.y; B.L[l][2] = vb.z; B.L[l][3] = vb.w;
+      }
+      float4 *slots = shb + (k & 1) * 512;
+      slots[wv * 64 + lane] = make_float4(shA[0], shA[1], shA[2], shA[3]);
+      slots[256 + wv * 64 + lane] = make_float4(shB[0], shB[1], shB[2], shB[3]);
+      A.mrow = mrA; A.F = fA; B.mrow = mrB; B.F = fB;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the image has been read: the next pair may overwrite it
+      __syncthreads();
+      if (k + 1 < np) issue(ja, jb);
+      if (ia & FW_LIT) tile(ia, 0, A, A, dm, slots);
+      if (ib & FW_LIT) tile(ib, 0, B, B, dm, slots + 256);
+      ia = ja; ib = jb;
+    }
+  } else {
+  const std::integral_constant<bool, false> nd;
   const int nl = sys.lit_count[r];
   const const_int_p linfo = (const_int_p)(unsigned long long)(sys.lit_info + r * (ntl + 4));
   {
@@ -2909,7 +3011,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     if (nl & 1) {
       const int i0 = linfo[0];
       fetch(i0, raw0);
-      tile(i0, i0, raw0, raw0);
+      tile(i0, i0, raw0, raw0, nd, nullptr);
       k = 1;
     }
     if (k < nl) {
@@ -2918,11 +3020,12 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       fetch(i1, raw1);
       for (; k < nl; k += 2) {
         const int i2 = linfo[k + 2], i3 = linfo[k + 3];
-        tile(i0, i2, raw0, raw0);
-        tile(i1, i3, raw1, raw1);
+        tile(i0, i2, raw0, raw0, nd, nullptr);
+        tile(i1, i3, raw1, raw1, nd, nullptr);
         i0 = i2; i1 = i3;
       }
     }
+  }
   }
   if (!active) return;
   // ---- PSF rows of this stripe.  Register j of lane (q, c): row y = 4q + j, column c of the merged operand

@@ -125,6 +125,72 @@ __global__ __launch_bounds__(256) void k_read_wide(const float *__restrict__ scr
   if (acc == 12345.678f) out[0] = acc;
 }
 
+// PAIR pattern: the lane -> pixel mapping of MAP 1 (what the frame kernel computes on), but the loads of two
+// adjacent tiles (the two 64-byte halves of the same rows) are issued back to back, DEPTH pairs in flight.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_read_pair(const float *__restrict__ scr, long long env_stride,
+                                                   const int *__restrict__ org, float *__restrict__ out, int nenv) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = blockIdx.x, e = 4 * blockIdx.y + wv;
+  if (e >= nenv) return;
+  const int row = lane & 15, col = 4 * (lane >> 4);
+  const float *lay[NL];
+  unsigned lpx[NL], lrow[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    lay[l] = scr + (long long)e * env_stride + (long long)l * DIM * LD;
+    unsigned px = org[(e * NL + l) * 2] + 4, py = org[(e * NL + l) * 2 + 1] + 4 + 16 * r + row;
+    px -= px >= DIM ? DIM : 0; py -= py >= DIM ? DIM : 0;
+    lpx[l] = px + col; lrow[l] = py * LD;
+  }
+  float raw[DEPTH][2][NL][4];
+  auto fetch = [&](int g, int slot) {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        unsigned px = 16u * (2 * g + h) + lpx[l]; px = min(px, px - DIM);
+        const f4u v = *reinterpret_cast<const f4u *>(lay[l] + (lrow[l] + px));
+#pragma unroll
+        for (int j = 0; j < 4; j++) raw[slot][h][l][j] = v.v[j];
+      }
+  };
+  constexpr int NG = NT / 2;
+  float acc = 0.f;
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) fetch(d, d);
+  for (int k = 0; k < NG; k += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+      if (k + d < NG) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int l = 0; l < NL; l++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += raw[d][h][l][j];
+        if (k + d + DEPTH < NG) fetch(k + d + DEPTH, d);
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int DEPTH>
+float run_pair(const float *scr, long long es, const int *org, float *out, int nenv) {
+  dim3 grid(NT, (nenv + 3) / 4), blk(256);
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_read_pair<DEPTH>), grid, blk, 0, 0, scr, es, org, out, nenv);
+  CK(hipEventRecord(a));
+  const int reps = 10;
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_read_pair<DEPTH>), grid, blk, 0, 0, scr, es, org, out, nenv);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
 template <int W, int DEPTH>
 float run_wide(const float *scr, long long es, const int *org, float *out, int nenv) {
   dim3 grid(NT, (nenv + 3) / 4), blk(256);
@@ -183,6 +249,10 @@ int main() {
     float ms = run_wide<W, DEPTH>(scr, es, org, out, nenv);                                    \
     printf("wide %d tiles per group, depth %d groups : %.3f ms  %.2f TB/s\n", W, DEPTH, ms, bytes / ms * 1e-9); \
   } while (0)
+  for (int dp = 1; dp <= 2; dp++) {
+    float ms = dp == 1 ? run_pair<1>(scr, es, org, out, nenv) : run_pair<2>(scr, es, org, out, nenv);
+    printf("pair (map 1, two adjacent tiles back to back), depth %d pairs : %.3f ms  %.2f TB/s\n", dp, ms, bytes / ms * 1e-9);
+  }
   RW(2, 1); RW(2, 2); RW(4, 1); RW(4, 2); RW(8, 1);
   // every environment at the SAME ring origin (what a simulation has: one wind for all) -- do the
   // environments' equal row offsets, one environment stride apart, fall on the same memory channels?
