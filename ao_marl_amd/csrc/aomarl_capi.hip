@@ -555,13 +555,13 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
       UP(int32_t, tinfo.data(), tinfo.size(), s.tile_info);
       {
         if (nt > 127) { aomarl_destroy(c); return fail("pupil too wide for the frame kernel's tile list"); }
-        std::vector<int32_t> linfo((size_t)nt * (nt + 4), 0), lcount(nt, 0);
+        std::vector<int32_t> linfo((size_t)nt * (nt + 8), 0), lcount(nt, 0);
         for (int r = 0; r < nt; r++) {
           int k = 0;
           for (int t = 0; t < nt; t++)
-            if (tinfo[(size_t)r * nt + t] & 0x10000) linfo[(size_t)r * (nt + 4) + k++] = tinfo[(size_t)r * nt + t] | (t << 24);
+            if (tinfo[(size_t)r * nt + t] & 0x10000) linfo[(size_t)r * (nt + 8) + k++] = tinfo[(size_t)r * nt + t] | (t << 24);
           lcount[r] = k;
-          for (int kk = k; kk < nt + 4; kk++) linfo[(size_t)r * (nt + 4) + kk] = k ? linfo[(size_t)r * (nt + 4) + k - 1] : 0;
+          for (int kk = k; kk < nt + 8; kk++) linfo[(size_t)r * (nt + 8) + kk] = k ? linfo[(size_t)r * (nt + 8) + k - 1] : 0;
         }
         UP(int32_t, linfo.data(), linfo.size(), s.lit_info);
         UP(int32_t, lcount.data(), lcount.size(), s.lit_count);

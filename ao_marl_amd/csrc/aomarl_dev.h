@@ -77,7 +77,7 @@ struct DevSys {
   int fused_ok, ntiles;          // ntiles = pupdiam / 16 tiles per axis
   const int32_t *stripe_order;   // [ntiles] stripes by decreasing number of lit tiles
   const int32_t *tile_info;      // [ntiles][ntiles] (stripe, tile): sub-aperture | lit / full / has-sub bits
-  const int32_t *lit_info;       // [ntiles][ntiles + 4]: the stripe's LIT tiles in x order, compact: tile_info | tile << 24;
+  const int32_t *lit_info;       // [ntiles][ntiles + 8]: the stripe's LIT tiles in x order, compact: tile_info | tile << 24;
                                  //   entries past the last one repeat it
   const int32_t *lit_count;      // [ntiles] lit tiles per stripe
   // the same walk in PAIRS of adjacent tiles (2 g, 2 g + 1) with at least one lit tile: [ntiles][(ntiles + 1) / 2 + 2][2]

@@ -1740,7 +1740,11 @@ __device__ __forceinline__ void spot_cog_f32(const DevSys &sys, const DevState &
 // written before it in the source is issued before it) and an s_nop that covers the longest such distance.
 // All statements are `asm volatile`: they stay in source order among themselves.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef FW_DBG_NONOP                              // (timing experiment: hazards unprotected, garbage results)
+#define PK_GUARD_MFMA() do { __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define PK_GUARD_MFMA() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 10"); } while (0)
+#endif
 #define PK_GUARD_TRANS() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1"); } while (0)
 // (a group's results feed matrix instructions: two wait states of margin, although gfx950 documents none)
 #define PK_END_TO_MFMA() do { asm volatile("s_nop 1"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -2579,8 +2583,11 @@ template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 #ifndef FW_DMA
 #define FW_DMA 1           // 0: layer rows fetched per tile into vector registers (16 rows x 64 B per instruction)
 #endif
+#ifndef FW_DEPTH
+#define FW_DEPTH 2         // lit tiles of loads in flight per wave in the per-tile walk (register sets)
+#endif
 #ifndef FW_DMA_F32
-#define FW_DMA_F32 0       // 1: the pair walk for the fp32 instantiations too (measured: no gain there, see below)
+#define FW_DMA_F32 1       // 0: the pair walk for the split-fp16 instantiations only
 #endif
 // Layer rows of a PAIR of adjacent tiles as whole 128-byte pieces, straight into LDS (FW_DMA, the stack-array-from-
 // voltages instantiations).  A load instruction that covers 16 rows x 64 B (the compute layout: lane (q, c) = row c,
@@ -2777,8 +2784,10 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   // one lit tile: consume `cur`, then issue the loads of the tile `infon` describes into `nxt`
   // (dma_slot != nullptr: the pair walk below -- cur.L / mrow / F are filled in by the caller, the block's shared data
   // of this tile is already in `dma_slot`, nothing is fetched in here)
-  auto tile = [&](int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt, auto dma_tag, float4 *dma_slot) {
-    constexpr bool DM = decltype(dma_tag)::value;
+  // mode 0: the tile of the per-tile walk; 2: the same without the fetch of a further tile (the last tiles of a stripe)
+  auto tile = [&](int info, int infon, FrameRaw<NL, OTF> &cur, FrameRaw<NL, OTF> &nxt, auto mode_tag, float4 *dma_slot) {
+    constexpr bool DM = decltype(mode_tag)::value == 1;
+    constexpr bool NOFETCH = decltype(mode_tag)::value != 0;
     const int t = (info >> 24) & 0x7F;
     // ---- stack-array DM phase of the tile on the matrix cores (independent of the loads)
     f32x4 S = PK ? NP4 : Z4;
@@ -2798,7 +2807,9 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     if constexpr (!DM) {
       nlit++;
       slot[wv * 64 + lane] = make_float4(cur.SH.v[0], cur.SH.v[1], cur.SH.v[2], cur.SH.v[3]);
+#ifndef FW_DBG_NOBAR                             // (timing experiment: garbage results)
       __syncthreads();
+#endif
     }
     const float4 t0 = slot[lane], t1 = slot[64 + lane];
     cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
@@ -2880,7 +2891,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         sd += d; sd2 += d * d; sm += m ? 1.f : 0.f;
       }
     }
-    if constexpr (!DM) fetch(infon, nxt);                    // these loads fly during the MFMAs
+    if constexpr (!NOFETCH) fetch(infon, nxt);               // these loads fly during the MFMAs
     // ---- science path (see the kernel's header)
     if (!(dbg & 2)) {
       if constexpr (PK) {
@@ -2931,7 +2942,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     // ---- the stripe's lit tiles in PAIRS (sys.pair_info): per pair ONE wait for everything fetched a pair ago, the
     // layer rows out of the wave's LDS image into registers, the block's shared data of both tiles into its slots,
     // ONE barrier, then the fetches of the next pair (in flight during the two tiles of this one) and the tiles.
-    const std::integral_constant<bool, true> dm;
+    const std::integral_constant<int, 1> dm;
     const int np = sys.pair_count[r];
     const const_int_p pinfo = (const_int_p)(unsigned long long)(sys.pair_info + r * (2 * ((ntl + 1) / 2 + 2)));
     // loader role of the lane: row rr of an 8-row block, chunk (lane & 7) ^ rr of the 128-byte row piece
@@ -2954,13 +2965,19 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
     for (int h = 0; h < 2; h++) rdp[h] = dimg + bc * FWD_BLK + 16 * (rc * 8 + ((4 * h + q) ^ rc));
     const unsigned dimg_lds = (unsigned)(unsigned long long)dimg;       // LDS byte address of the wave's images
     FrameRaw<NL, OTF> A, B;
-    f32x4 shA, shB;
     unsigned mrA, mrB;
     float fA, fB;
-    auto issue = [&](int ia, int ib) {
+    const unsigned shb_lds = (unsigned)(unsigned long long)shb + 1024u * (unsigned)wv;   // this wave's quarter of a slot
+    auto dma16 = [&](unsigned vo, __amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned so) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(vo), "s"(rs), "s"(lds_addr), "s"(so) : "memory");
+    };
+    // (par: parity of the pair the loads are for -- its two shared-data slots are filled in place, one quarter per wave)
+    auto issue = [&](int ia, int ib, int par) {
       const int ta = (ia >> 24) & 0x7F, tb = (ib >> 24) & 0x7F;
-      shA = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, (unsigned)ta << shstep, 0));
-      shB = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shrs, shvo, (unsigned)tb << shstep, 0));
+      dma16(shvo, shrs, shb_lds + (unsigned)par * 8192u, (unsigned)ta << shstep);
+      dma16(shvo, shrs, shb_lds + (unsigned)par * 8192u + 4096u, (unsigned)tb << shstep);
       mrA = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)ta + mvo);
       mrB = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)tb + mvo);
       fA = cflux[ia & 0xFFFF];
@@ -2970,19 +2987,14 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         unsigned sx = 16u * (unsigned)(ta & ~1) + lpxs[l]; sx -= (sx >= ldim[l]) ? ldim[l] : 0u;   // scalar; 32 pixels never wrap
         const unsigned so = 4u * sx;
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-          const unsigned m0v = dimg_lds + l * FWD_IMG + b * FWD_BLK;
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(dvo[l][b]), "s"(lrs[l]), "s"(m0v), "s"(so) : "memory");
-        }
+        for (int b = 0; b < 2; b++) dma16(dvo[l][b], lrs[l], dimg_lds + l * FWD_IMG + b * FWD_BLK, so);
       }
     };
     int ia = pinfo[0], ib = pinfo[1];
-    if (np > 0) issue(ia, ib);
+    if (np > 0) issue(ia, ib, 0);
     for (int k = 0; k < np; k++) {
       const int ja = pinfo[2 * k + 2], jb = pinfo[2 * k + 3];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this pair's layer images (and shA / shB / masks) have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this pair's layer images, shared quarters and masks have landed
 #pragma unroll
       for (int l = 0; l < NL; l++) {
         const float4 va = *reinterpret_cast<const float4 *>(rdp[0] + l * FWD_IMG);
@@ -2991,40 +3003,42 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         B.L[l][0] = vb.x; B.L[l][1] = vb.y; B.L[l][2] = vb.z; B.L[l][3] = vb.w;
       }
       float4 *slots = shb + (k & 1) * 512;
-      slots[wv * 64 + lane] = make_float4(shA[0], shA[1], shA[2], shA[3]);
-      slots[256 + wv * 64 + lane] = make_float4(shB[0], shB[1], shB[2], shB[3]);
       A.mrow = mrA; A.F = fA; B.mrow = mrB; B.F = fB;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the image has been read: the next pair may overwrite it
       __syncthreads();
-      if (k + 1 < np) issue(ja, jb);
+      if (k + 1 < np) issue(ja, jb, (k + 1) & 1);
       if (ia & FW_LIT) tile(ia, 0, A, A, dm, slots);
       if (ib & FW_LIT) tile(ib, 0, B, B, dm, slots + 256);
       ia = ja; ib = jb;
     }
   } else {
-  const std::integral_constant<bool, false> nd;
+  // The stripe's lit tiles, compact (sys.lit_info[r][k], tile index in bits 24..30; the entries past the last one
+  // repeat it, so the prefetches at the end of the list need no test: the last tile is loaded again, from L2, and
+  // dropped).  FW_DEPTH tiles of loads are in flight (as many register sets, the list walked in groups of that
+  // many; the tiles left over come last, on data the last group prefetched).  The list is read with scalar loads.
+  const std::integral_constant<int, 0> nd;
+  const std::integral_constant<int, 2> nf;
   const int nl = sys.lit_count[r];
-  const const_int_p linfo = (const_int_p)(unsigned long long)(sys.lit_info + r * (ntl + 4));
+  const const_int_p linfo = (const_int_p)(unsigned long long)(sys.lit_info + r * (ntl + 8));
   {
-    FrameRaw<NL, OTF> raw0, raw1;
-    int k = 0;
-    if (nl & 1) {
-      const int i0 = linfo[0];
-      fetch(i0, raw0);
-      tile(i0, i0, raw0, raw0, nd, nullptr);
-      k = 1;
+    constexpr int D = FW_DEPTH;
+    FrameRaw<NL, OTF> raw[D];
+    int inf[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { inf[d] = linfo[d]; fetch(inf[d], raw[d]); }
+    const int rem = nl % D, nfull = nl - rem;
+    for (int k = 0; k < nfull; k += D) {
+      int nx[D];
+#pragma unroll
+      for (int d = 0; d < D; d++) nx[d] = linfo[k + D + d];
+#pragma unroll
+      for (int d = 0; d < D; d++) tile(inf[d], nx[d], raw[d], raw[d], nd, nullptr);
+#pragma unroll
+      for (int d = 0; d < D; d++) inf[d] = nx[d];
     }
-    if (k < nl) {
-      int i0 = linfo[k], i1 = linfo[k + 1];
-      fetch(i0, raw0);
-      fetch(i1, raw1);
-      for (; k < nl; k += 2) {
-        const int i2 = linfo[k + 2], i3 = linfo[k + 3];
-        tile(i0, i2, raw0, raw0, nd, nullptr);
-        tile(i1, i3, raw1, raw1, nd, nullptr);
-        i0 = i2; i1 = i3;
-      }
-    }
+#pragma unroll
+    for (int d = 0; d + 1 < D; d++)
+      if (rem > d) tile(inf[d], inf[d], raw[d], raw[d], nf, nullptr);
   }
   }
   if (!active) return;
