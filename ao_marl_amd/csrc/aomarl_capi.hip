@@ -813,7 +813,7 @@ int aomarl_set_modal(aomarl_ctx *c, int nmodes, const float *v2m, const float *m
 
 // ---- workspace layout (floats)
 struct Work {
-  size_t Z, NEWL, ZREF, MODES, TR, TPART, PEND, GEMM, GEMM_ATM, gemm_floats, total;
+  size_t Z, Z2, NEWL, ZREF, ZREF2, MODES, TR, TPART, PEND, GEMM, GEMM_ATM, gemm_floats, total;
   int ldz, ldn, ldm, nblk;
 };
 
@@ -831,6 +831,8 @@ static Work work_layout(const aomarl_ctx *c, int nenv) {
   w.Z = take(ncol * w.ldz);
   w.NEWL = take(ncol * w.ldn);
   w.ZREF = take(ncol);
+  w.Z2 = take(ncol * w.ldz);       // the fused scatter + gather writes the NEXT round's operand while this round's is in use
+  w.ZREF2 = take(ncol);
   w.MODES = take((size_t)nenv * w.ldm);
   w.TR = take((size_t)nenv * s.pupdiam * W * 2);
   w.TPART = take((size_t)nenv * w.nblk * 4);

@@ -62,30 +62,44 @@ static int first_write_wait(aomarl_ctx *c, hipStream_t s) {
   return 0;
 }
 
-static bool same_round(const RoundOps &a, const RoundOps &b) {
+// the round behind `a` as k_extrude_sg wants it; false when `b` holds a layer that `a` does not (never the case for
+// the rounds of a frame or of a reset: a layer's operations fill consecutive rounds from the first one on)
+static bool next_round(const RoundOps &a, const RoundOps &b, RoundNext &nx) {
+  nx.nops = b.nops;
+  for (int i = 0; i < AOMARL_MAX_LAYERS; i++) { nx.idx[i] = -1; nx.dir[i] = 0; nx.tflag[i] = 0; }
+  for (int j = 0; j < b.nops; j++) {
+    int at = -1;
+    for (int i = 0; i < a.nops; i++) if (a.layer[i] == b.layer[j]) at = i;
+    if (at < 0) return false;
+    nx.idx[at] = j; nx.dir[j] = b.dir[j]; nx.tflag[j] = b.tflag[j];
+  }
+#ifdef SG_SAME_ONLY                              // (A/B builds: fuse only two rounds with the same operations, as before)
   if (a.nops != b.nops) return false;
   for (int i = 0; i < a.nops; i++)
     if (a.layer[i] != b.layer[i] || a.dir[i] != b.dir[i] || a.tflag[i] != b.tflag[i]) return false;
-  return true;
+#endif
+  return b.nops > 0;
 }
 
 // A sequence of extrusion rounds (round = at most one operation per layer).  Per round: stencil gather +
-// normals -> Z, Z . [A|B]^T (split-K tiles), new line -> ring.  Two consecutive rounds with the same
-// operations share a launch for the scatter of the first and the gather of the second (k_extrude_sg):
-// 2 launches per round instead of 3 -- every round of a reset (1296 of them), most rounds of a frame.
+// normals -> Z, Z . [A|B]^T (split-K tiles), new line -> ring.  Two consecutive rounds share a launch for the
+// scatter of the first and the gather of the second (k_extrude_sg; the second may hold fewer layers and other
+// directions): 2 launches per round instead of 3 -- every round of a reset (1296 of them) and of a frame.
 struct ExtrudeRun {          // one range of environments walking through a sequence of rounds on one stream
   aomarl_ctx *c; aomarl_state *st; int b, n; hipStream_t s; bool ordered;
-  Work w; DevState ds; float *Z, *NEWL, *ZREF, *WS; size_t ws_floats; bool gathered;
+  Work w; DevState ds; float *Zb[2], *NEWL, *ZREFb[2], *WS; size_t ws_floats; bool gathered; int par;
   // ordered = false: the caller has ordered the stream behind every reader of the screens (reset)
   ExtrudeRun(aomarl_ctx *c_, aomarl_state *st_, int b_, int n_, void *stream, bool ordered_ = true)
-      : c(c_), st(st_), b(b_), n(n_), s((hipStream_t)stream), ordered(ordered_), gathered(false) {
+      : c(c_), st(st_), b(b_), n(n_), s((hipStream_t)stream), ordered(ordered_), gathered(false), par(0) {
     w = work_layout(c, st->nenv);
     ds = dev_state(st);
     if (ordered) ds.origin_snap = c->snap_target;
     // the range's own part of every work area (columns are numbered from the range's first environment):
     // two ranges may run side by side on two streams
     const size_t col0 = (size_t)b * (c->nlayers > 0 ? c->nlayers : 1), ncols = (size_t)n * (c->nlayers > 0 ? c->nlayers : 1);
-    Z = st->work + w.Z + col0 * w.ldz; NEWL = st->work + w.NEWL + col0 * w.ldn; ZREF = st->work + w.ZREF + col0;
+    Zb[0] = st->work + w.Z + col0 * w.ldz; Zb[1] = st->work + w.Z2 + col0 * w.ldz;
+    NEWL = st->work + w.NEWL + col0 * w.ldn;
+    ZREFb[0] = st->work + w.ZREF + col0; ZREFb[1] = st->work + w.ZREF2 + col0;
     WS = st->work + w.GEMM_ATM + 8 * col0 * w.ldn; ws_floats = 8 * ncols * w.ldn;
   }
   int step(const RoundOps *rounds, int r, int nrounds) {
@@ -104,7 +118,11 @@ struct ExtrudeRun {          // one range of environments walking through a sequ
       const int ncol = n * ops.nops;
       // fusing across rounds only when the round is ONE sub-round (one class) and the next round repeats it
       const bool single = ops.nops == rounds[r].nops;
-      const bool fuse_next = single && !c->no_extrude_sg && r + 1 < nrounds && same_round(rounds[r], rounds[r + 1]);
+      RoundNext nx;
+      bool fuse_next = single && !c->no_extrude_sg && r + 1 < nrounds && next_round(rounds[r], rounds[r + 1], nx);
+      if (fuse_next)                             // (the next round must be one sub-round too: same class)
+        for (int i = 0; i < rounds[r + 1].nops; i++) fuse_next = fuse_next && c->abclass[rounds[r + 1].layer[i]] == cls;
+      float *Z = Zb[par], *ZREF = ZREFb[par];
       if (!(gathered && single)) {
         hipLaunchKernelGGL(k_extrude_gather, dim3(ncol, (nsc + (dimc + 3) / 4 + 255) / 256), dim3(256), 0, s, c->sys, ds, b,
                            ops, Z, w.ldz, ZREF);
@@ -123,7 +141,8 @@ struct ExtrudeRun {          // one range of environments walking through a sequ
       }
       if (fuse_next) {
         hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(512), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
-                           WS, nsp, ncol, dimc, pscale, Z, w.ldz);
+                           WS, nsp, ncol, dimc, pscale, Zb[par ^ 1], w.ldz, ZREFb[par ^ 1], nx);
+        par ^= 1;
         gathered = true;
       } else {
         hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,

@@ -872,6 +872,14 @@ struct RoundOps {
   int dir[AOMARL_MAX_LAYERS];
   int tflag[AOMARL_MAX_LAYERS];     // 1: the screen holds the transpose (reset): dir is +-2, stencil istT
 };
+// the round behind a round, as the fused scatter + gather sees it: idx[i] = position of operation i's layer in the next
+// round (-1: that layer is done), dir / tflag of the next round's operations
+struct RoundNext {
+  int nops;
+  int idx[AOMARL_MAX_LAYERS];
+  int dir[AOMARL_MAX_LAYERS];
+  int tflag[AOMARL_MAX_LAYERS];
+};
 
 // Z[col][0..ns) = screen[stencil] - zref ; Z[col][ns..ns+n) = amplitude * N(0,1)
 // work item j of column col, for a ring origin (ox, oy) and an extrusion counter cnt given by the caller
@@ -985,19 +993,23 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
   }
 }
 
-// scatter of round r and gather of round r + 1 in one launch, for two consecutive rounds with the SAME
-// operations (every round of a reset; most rounds of a frame): the dependency is column-local -- a
+// scatter of round r and gather of round r + 1 in one launch: the dependency is column-local -- a
 // column's next stencil reads only that column's screen, including the line just written -- so one
 // block does both, with the advanced origin and counter carried in registers (never re-read: a
 // uniform re-load could come from the scalar cache, which the block's own stores do not update).
+// The next round may hold fewer layers (a frame's rounds thin out as the slower layers finish) and other
+// directions: `nx` says where this column's layer sits in it; its Z / ZREF are a second pair of buffers
+// (ZN / ZREFN: the next round numbers its columns anew, another block may still need this round's ZREF entry).
 __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int env_begin, RoundOps ops,
                                                     const float *__restrict__ NEWL, int ldn,
-                                                    float *__restrict__ ZREF, const float *__restrict__ P,
+                                                    const float *__restrict__ ZREF, const float *__restrict__ P,
                                                     int nsplit, int ncol, int pn, float pscale,
-                                                    float *__restrict__ Z, int ldz) {
+                                                    float *__restrict__ Z, int ldz, float *__restrict__ ZREFN,
+                                                    RoundNext nx) {
   ATM_SETPRIO();
   const int col = blockIdx.x;
-  const int e = env_begin + col / ops.nops, li = ops.layer[col % ops.nops];
+  const int el = col / ops.nops, oi = col % ops.nops;
+  const int e = env_begin + el, li = ops.layer[oi];
   int *o = st.origin + (e * sys.nlayers + li) * 2;
   const int ox = o[0], oy = o[1];
   const uint32_t cnt = st.ext_count[e * sys.nlayers + li];
@@ -1012,12 +1024,15 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   // the gather of extrude_gather_item, restated so that one thread's loads are independent of each
   // other (index loads first, then the screen loads): with one block per column instead of six, a
   // dependent pair of loads per item was the whole kernel
+  const int ni = nx.idx[oi];
+  if (ni < 0) return;                            // this layer has no operation in the next round
+  const int col2 = el * nx.nops + ni;            // its column there
   const DevLayer &L = sys.layers[li];
-  const int n = L.dim, ns = L.ns, dir = ops.dir[col % ops.nops];
+  const int n = L.dim, ns = L.ns, dir = nx.dir[ni];
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const bool top_right = (dir == 1 || dir == -2);
   const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, nox, noy, n)];
-  const uint32_t *ist = ops.tflag[col % ops.nops] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
+  const uint32_t *ist = nx.tflag[ni] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
   constexpr int U = 4;
   for (int j0 = threadIdx.x; j0 < ns; j0 += U * blockDim.x) {
     uint32_t xy[U];
@@ -1028,7 +1043,7 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
     for (int u = 0; u < U; u++) v[u] = base[ring_idx(xy[u] & 0xFFFF, xy[u] >> 16, nox, noy, n)];
 #pragma unroll
     for (int u = 0; u < U; u++)
-      if (j0 + u * (int)blockDim.x < ns) Z[(long long)col * ldz + j0 + u * blockDim.x] = v[u] - zref;
+      if (j0 + u * (int)blockDim.x < ns) Z[(long long)col2 * ldz + j0 + u * blockDim.x] = v[u] - zref;
   }
   const uint32_t seed = st.seeds[e] + (uint32_t)li;
   for (int g = threadIdx.x; g < (n + 3) / 4; g += blockDim.x) {
@@ -1036,9 +1051,9 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
     philox_normal4(seed, 0u, cnt + 1u, 0u, (uint32_t)g, z4);
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (4 * g + u < n) Z[(long long)col * ldz + ns + 4 * g + u] = L.amp * z4[u];
+      if (4 * g + u < n) Z[(long long)col2 * ldz + ns + 4 * g + u] = L.amp * z4[u];
   }
-  if (threadIdx.x == 0) ZREF[col] = zref;
+  if (threadIdx.x == 0) ZREFN[col2] = zref;
 }
 
 // Small screens (dim <= 256, ns + dim <= MOVE_SMALL_K): ALL the extrusions of one frame's move in ONE launch.
