@@ -203,3 +203,47 @@ def test_size_independent_properties_at_bench_batch(large):
             b.next_part_two(None, env_begin=e0, env_count=c)
             b.next_part_one(env_begin=e0, env_count=c)
     assert torch.equal(a.slopes, b.slopes) and torch.equal(a.com, b.com)
+
+
+def test_quadratic_form_slopes_match_the_image_forming_launch(large):
+    """The slopes-only launch takes the centre of gravity as quadratic forms of the pupil field (spot_cog_qf: no
+    transform, no image); a launch that also writes the bincube goes through the pruned transform, the binned image and
+    its moments (spot_core).  Same state, same frame: the two sets of slopes agree far inside the 1e-4 arcsec they are
+    both held to against the oracle, for every sub-aperture, and the stored image's own centre of gravity says the same."""
+    from ao_marl_amd import libaomarl as la
+    from ao_marl_amd.sim import HipSim
+    _, s, cal = large
+    assert la.get_precision() == "f32"
+    nenv = 6
+    sim = HipSim(s, nenv=nenv, keep_bincube=True)
+    sim.defer_shape = True
+    sim.set_modal(cal.volts2modes, cal.modes2volts)
+    rng = np.random.default_rng(5)
+    for l in range(len(s.screen_dim)):       # smooth random screens of a few microns: no need for the 1296-round reset here
+        d = s.screen_dim[l]
+        f = rng.normal(size=(nenv, d // 8 + 2, d // 8 + 2))
+        up = np.kron(f, np.ones((8, 8)))[:, :d, :d]
+        k = np.ones(15) / 15.0
+        for ax in (1, 2):
+            up = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, up)
+        sim.set_screen(l, (1.5 * up).astype(np.float32))
+    sim.t["voltage"][:, :s.nactu] = torch.randn(nenv, s.nactu, device="cuda") * 0.3
+    sim._stale = True
+    sim.frame_fused(noise=False, write_bincube=False, cog=True, dm_from_voltage=True)
+    assert sim.frame_kernel_name().endswith("true, false, false, false>")
+    qf = sim.slopes.cpu().numpy().copy()
+    sim.slopes.zero_()
+    sim.frame_fused(noise=False, write_bincube=True, cog=True, dm_from_voltage=True)
+    assert sim.frame_kernel_name().endswith("true, false, true, false>")
+    dft = sim.slopes.cpu().numpy().copy()
+    assert np.isfinite(qf).all() and np.abs(qf).max() > 0.05          # real slopes (arcsec), not a flat wavefront
+    assert np.abs(qf - dft).max() < 2e-5, np.abs(qf - dft).max()
+    cube = sim.t["bincube"].cpu().numpy().reshape(nenv, s.nvalid, s.npix, s.npix).astype(np.float64)
+    tot = cube.sum(axis=(2, 3))
+    X = np.arange(s.npix)
+    cx = (cube.sum(axis=2) @ X) / tot
+    cy = (cube.sum(axis=3) @ X) / tot
+    # slopes = (cog - offset) * scale, x block then y block (rtc_init.py:208-229, ao_env.py:665-666)
+    sx, sy = qf[:, :s.nvalid], qf[:, s.nvalid:]
+    assert np.abs(sx - (cx - s.cog_offset) * s.cog_scale).max() < 3e-5
+    assert np.abs(sy - (cy - s.cog_offset) * s.cog_scale).max() < 3e-5
