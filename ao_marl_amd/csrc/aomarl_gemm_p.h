@@ -25,6 +25,7 @@
 // dimensions that are multiples of 4 (the caller falls back to k_gemm_nt otherwise).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #ifndef GP_TYPES
 #define GP_TYPES
@@ -49,6 +50,10 @@ struct __attribute__((packed, aligned(4))) gp_f4u { float v[4]; };
 #ifndef GP_DBG
 #define GP_DBG 0
 #endif
+#ifndef GP_GLDS
+#define GP_GLDS 0         // 1: k-tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), three LDS buffers
+#endif
+#define GP_NB (GP_GLDS ? 3 : 2)                   // LDS buffers per operand
 template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void k_gemm_p(int M, int N, int K, float alpha,
                                                    const float *__restrict__ A, int lda,
@@ -60,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_p(int M, int N, int K, float al
   if (GP_PRIO) __builtin_amdgcn_s_setprio(GP_PRIO);
 #endif
   extern __shared__ __attribute__((aligned(16))) float gp_lds[];
-  float *As = gp_lds;                              // [2][BM][GP_LD]
-  float *Bs = gp_lds + 2 * BM * GP_LD;             // [2][BN][GP_LD]
+  float *As = gp_lds;                              // [GP_NB][BM][GP_LD]
+  float *Bs = gp_lds + GP_NB * BM * GP_LD;         // [GP_NB][BN][GP_LD]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
 
@@ -142,11 +147,98 @@ __global__ __launch_bounds__(256, 2) void k_gemm_p(int M, int N, int K, float al
 #pragma unroll
     for (int h = 0; h < WN; h++) fb[j][h] = GP_DBG >= 4 ? rb[0][h] : *reinterpret_cast<const float4 *>(bs + h * 16 * GP_LD);
   };
+#if GP_GLDS
+  // ---- operands straight into LDS.  One wave-instruction writes 64 x 16 bytes in LANE order = 8 rows of a k-tile
+  // (128 bytes each); the XOR swizzle of the 16-byte pieces goes on the SOURCE address (lane = 8 row + slot loads
+  // piece slot ^ ((row >> 1) & 7)).  Wave w stages row groups w, w + 4, ... of both operands: WM + WN instructions
+  // per k-tile.  Three LDS buffers, tiles kt + 1 and kt + 2 in flight; a wave waits for ITS pieces of tile kt + 1
+  // (counted vmcnt) in front of the k-tile's barrier.  A k-tile that crosses the end of the chunk (only ever the
+  // last one) is staged through registers with the mask, as before.
+  {
+    const int rl = lane >> 3, slot = lane & 7;
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, 0x7fffffff, 0x00020000);
+    unsigned voa[WM], vob[WN];
+#pragma unroll
+    for (int p = 0; p < WM; p++) {
+      const int r = 8 * (4 * p + wv) + rl;
+      voa[p] = 4u * ((unsigned)min(m0 + r, M - 1) * (unsigned)lda) + 16u * (unsigned)(slot ^ ((r >> 1) & 7));
+    }
+#pragma unroll
+    for (int p = 0; p < WN; p++) {
+      const int r = 8 * (4 * p + wv) + rl;
+      vob[p] = 4u * ((unsigned)min(n0 + r, N - 1) * (unsigned)ldb) + 16u * (unsigned)(slot ^ ((r >> 1) & 7));
+    }
+    const unsigned as_lds = (unsigned)(unsigned long long)As, bs_lds = (unsigned)(unsigned long long)Bs;
+    auto dma16 = [&](unsigned vo, __amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned so) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(vo), "s"(rs), "s"(lds_addr), "s"(so) : "memory");
+    };
+    // stage k-tile kt into buffer `buf`: by DMA when it is whole, through registers (synchronously) when it is not
+    auto stage = [&](int kt, int buf) {
+      if (kb + (kt + 1) * GP_KT <= ke) {           // wave-uniform
+        const unsigned so = 4u * (unsigned)(kb + kt * GP_KT);
+#pragma unroll
+        for (int p = 0; p < WM; p++) dma16(voa[p], rsa, as_lds + 4u * (unsigned)(buf * BM * GP_LD + 8 * (4 * p + wv) * GP_LD), so);
+#pragma unroll
+        for (int p = 0; p < WN; p++) dma16(vob[p], rsb, bs_lds + 4u * (unsigned)(buf * BN * GP_LD + 8 * (4 * p + wv) * GP_LD), so);
+      } else {
+        gload(kt, 0);
+        lstore(buf, 0, kt);
+      }
+    };
+    constexpr int PW = WM + WN;                    // DMA instructions of one wave per k-tile
+    auto wait_tiles_in_flight = [&](bool one) {    // all of this wave's stagings but (at most) the newest tile's have landed
+      if (one) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
 #define GP_MMA(j, c)                                                                                              \
   _Pragma("unroll") for (int g = 0; g < WM; g++)                                                                  \
   _Pragma("unroll") for (int h = 0; h < WN; h++)                                                                  \
       acc[g][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][h].c, fa[j][g].c, acc[g][h], 0, 0, 0);
-
+    auto step = [&](int kt, auto Sc) {
+      constexpr int S = decltype(Sc)::value, S1 = (S + 1) % 3, S2 = (S + 2) % 3;
+      fread(S, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      GP_MMA(0, x) GP_MMA(0, y)
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = kt + 2 < nkt;              // wave-uniform
+      if (more) stage(kt + 2, S2);                 // buffer S2 held tile kt - 1: every wave is past the barrier behind its reads
+      __builtin_amdgcn_sched_barrier(0);
+      GP_MMA(0, z) GP_MMA(0, w)
+      __builtin_amdgcn_sched_barrier(0);
+      wait_tiles_in_flight(more);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      fread(S1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      GP_MMA(1, x) GP_MMA(1, y) GP_MMA(1, z) GP_MMA(1, w)
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+    wait_tiles_in_flight(nkt > 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fread(0, 0);
+    const std::integral_constant<int, 0> c0;
+    const std::integral_constant<int, 1> c1;
+    const std::integral_constant<int, 2> c2;
+    for (int kt = 0; kt < nkt; kt += 3) {
+      step(kt, c0);
+      if (kt + 1 >= nkt) break;
+      step(kt + 1, c1);
+      if (kt + 2 >= nkt) break;
+      step(kt + 2, c2);
+    }
+#undef GP_MMA
+  }
+#else
+#define GP_MMA(j, c)                                                                                              \
+  _Pragma("unroll") for (int g = 0; g < WM; g++)                                                                  \
+  _Pragma("unroll") for (int h = 0; h < WN; h++)                                                                  \
+      acc[g][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][h].c, fa[j][g].c, acc[g][h], 0, 0, 0);
   // software pipeline: tile kt in LDS buffer kt & 1, tile kt + 1 in register stage (kt + 1) & 1, tile kt + 2 in
   // flight into stage kt & 1.  Loads past the end of the chunk are clamped (never staged).  ONE barrier per
   // k-tile, in the middle of its matrix instructions: before it a wave stages tile kt + 1 and reads the second
@@ -180,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_p(int M, int N, int K, float al
     step(kt + 1, 1);
   }
 #undef GP_MMA
+#endif
 
   // epilogue: lane (q, i) of accumulator (g, h) holds C[m][n .. n + 3], m = .. + i, n = .. + 4 q
   const bool split = nz > 1;
@@ -221,7 +314,7 @@ struct GemmPCfg {
   int tiles_m, tiles_n;
 };
 
-static inline size_t gemm_p_lds_bytes(int wm, int wn) { return (size_t)2 * 32 * (wm + wn) * GP_LD * sizeof(float); }
+static inline size_t gemm_p_lds_bytes(int wm, int wn) { return (size_t)GP_NB * 32 * (wm + wn) * GP_LD * sizeof(float); }
 
 // the instantiations the library carries
 #define GP_FOR_EACH_TILE(X) X(4, 4) X(4, 3) X(4, 2) X(2, 4) X(2, 3) X(2, 2) X(3, 3) X(3, 2)
