@@ -174,7 +174,9 @@ __device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, 
 // a 16-pixel tile row whose first pixel is in range needs no wrap test per lane (the one-pass
 // frame kernel wraps once per tile -- once per PAIR of tiles, 32 pixels, when it fetches whole 128-byte row
 // pieces -- on the scalar unit); the extrusion scatter keeps the mirror up to date.
+#ifndef RING_PAD
 #define RING_PAD 32
+#endif
 __device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
   int px = x + ox;
   px -= (px >= n) ? n : 0;
