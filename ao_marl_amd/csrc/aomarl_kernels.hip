@@ -2608,7 +2608,8 @@ template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 // voltages instantiations).  A load instruction that covers 16 rows x 64 B (the compute layout: lane (q, c) = row c,
 // pixels 4q .. 4q + 3) makes the memory pipeline handle every 128-byte line twice, half a line at a time; as
 // 8 rows x 128 contiguous bytes the same bytes arrive 25 % faster (tools/dmabench.hip: 3.9 -> 4.9 TB/s on this access
-// pattern alone) and the second fetch of a line two neighbouring tiles share disappears.  The pieces are written by
+// pattern alone).  (HBM-side bytes do not go down -- a 128-byte run at a 4-byte-aligned start straddles two lines 7
+// times out of 8: 1.6 GB per launch against 1.47 -- the number of requests does.)  The pieces are written by
 // buffer_load_dwordx4 ... lds -- no vector registers in flight -- into the wave's own LDS image: per layer two blocks of
 // 8 rows x 8 chunks of 16 bytes in LANE order (what that instruction can write), the second block 128 bytes further,
 // the chunk a lane fetches XOR-ed with its row (lane = 8 row + (chunk ^ row)): the compute layout's ds_read_b128
