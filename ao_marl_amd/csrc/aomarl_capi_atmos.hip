@@ -397,7 +397,8 @@ static int reset_small(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint
     stage_n = st->nenv;
   }
   HIPCHK(hipMemcpyAsync(stage, seeds, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_reset_env, dim3(n), dim3(256), 0, s, c->sys, ds, b, n, stage, st->ld_actu);
+  hipLaunchKernelGGL(k_reset_env, dim3(n), dim3(256), 0, s, c->sys, ds, b, n, stage, st->ld_actu,
+                     c->reset_untransposed ? 0 : 1);
   LAUNCHCHK();
   if (!whole_state) return 0;
   hipLaunchKernelGGL(k_fill_f32, dim3(2048), dim3(256), 0, s, st->dm_shape + (size_t)b * c->sys.shape_stride,

@@ -174,8 +174,13 @@ __device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, 
 // a 16-pixel tile row whose first pixel is in range needs no wrap test per lane (the one-pass
 // frame kernel wraps once per tile -- once per PAIR of tiles, 32 pixels, when it fetches whole 128-byte row
 // pieces -- on the scalar unit); the extrusion scatter keeps the mirror up to date.
+// (56, not 32: with the screens of the production files -- 648 and 168 pixels -- the row pitch is then a multiple of
+// 128 bytes, every row of a tile starts at the same offset inside its line; see k_reset_env)
 #ifndef RING_PAD
-#define RING_PAD 32
+#define RING_PAD 56
+#endif
+#ifndef FW_ALIGN_ORIGIN
+#define FW_ALIGN_ORIGIN 1  // 0: a reset starts the rings at origin (0, 0)
 #endif
 __device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
   int px = x + ox;

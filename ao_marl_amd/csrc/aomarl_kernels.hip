@@ -1213,7 +1213,7 @@ __global__ void k_fill_f32(float *p, long long n, float v) {
 }
 
 __global__ void k_reset_env(DevSys sys, DevState st, int env_begin, int env_count,
-                            const uint32_t *__restrict__ seeds_dev, int ld_actu) {
+                            const uint32_t *__restrict__ seeds_dev, int ld_actu, int origin_in_y) {
   // small per-env state: origin, counters, integrator vectors
   const int e = env_begin + blockIdx.x;
   if (threadIdx.x == 0) {
@@ -1221,8 +1221,18 @@ __global__ void k_reset_env(DevSys sys, DevState st, int env_begin, int env_coun
     st.frame[e] = 0u;
   }
   for (int i = threadIdx.x; i < sys.nlayers; i += blockDim.x) {
-    st.origin[(e * sys.nlayers + i) * 2] = 0;
-    st.origin[(e * sys.nlayers + i) * 2 + 1] = 0;
+#if FW_ALIGN_ORIGIN
+    // Where the ring starts is free (the logical screen does not depend on it).  Start it so that the first pupil
+    // pixel of a row sits on a 128-byte line once the reset is through: the frame kernel's 32-pixel pieces of a layer
+    // that does not move along x (ground layers under a wind along y: this ring origin never changes) then ARE whole
+    // lines, for the whole episode.  The reset's 2 dim extrusions bring the origin back to where it started, and its
+    // final transposition exchanges x and y (origin_in_y: start the offset in y).
+    const int a = sys.fused_ok ? (32 - (sys.layers[i].tox & 31)) & 31 : 0;
+#else
+    const int a = 0;
+#endif
+    st.origin[(e * sys.nlayers + i) * 2] = origin_in_y ? 0 : a;
+    st.origin[(e * sys.nlayers + i) * 2 + 1] = origin_in_y ? a : 0;
     st.ext_count[e * sys.nlayers + i] = 0u;
   }
   for (int i = threadIdx.x; i < ld_actu; i += blockDim.x) {
