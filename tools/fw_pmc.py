@@ -11,6 +11,8 @@ s = system.from_system(sysm, strehl_halfwin=8)
 s.cmat = np.zeros((s.nactu, s.nslope), dtype=np.float32)
 sim = HipSim(s, nenv=nenv)
 sim.reset(1234 + 16 * np.arange(nenv))
+for _ in range(37):                      # ring origins off their reset value (a reset starts every ring on a 128-byte line;
+    sim.move_atmos()                     # in a running loop only the layers without wind along x stay there)
 sim.t["voltage"][:, :s.nactu] = torch.randn(nenv, s.nactu, device="cuda") * 0.5
 sim.set_option("fused_debug", dbg)
 for _ in range(6):
