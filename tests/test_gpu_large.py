@@ -247,3 +247,25 @@ def test_quadratic_form_slopes_match_the_image_forming_launch(large):
     sx, sy = qf[:, :s.nvalid], qf[:, s.nvalid:]
     assert np.abs(sx - (cx - s.cog_offset) * s.cog_scale).max() < 3e-5
     assert np.abs(sy - (cy - s.cog_offset) * s.cog_scale).max() < 3e-5
+
+
+def test_reset_leaves_every_ring_on_a_line(large):
+    """A reset starts the ring origins so that the first pupil pixel of a row sits on a 128-byte line (32 floats) once
+    it is through (k_reset_env): the frame kernel's 32-pixel pieces of a layer without wind along x are whole lines for
+    the whole episode.  The logical screens do not depend on where a ring starts: test_large_frames_match_oracle and
+    the 40x40 reset test compare them with the oracle's."""
+    from ao_marl_amd.sim import HipSim
+    _, s, _ = large
+    sim = HipSim(s, nenv=2)
+    sim.reset([7, 8])
+    org = sim.t["origin"].cpu().numpy()
+    for l, off in enumerate(s.tar_atm_off):
+        tox = int(round(off[0]))
+        assert ((org[:, l, 0] + tox) % 32 == 0).all(), (l, org[:, l], tox)
+    pitch = sim.screen_stride // sum(s.screen_dim) if len(set(s.screen_dim)) == 1 else None
+    if pitch is not None:
+        assert pitch % 32 == 0, pitch            # rows a whole number of 128-byte lines apart (648 + 56)
+    for _ in range(3):                           # layer 0 of the production file has no wind along x: it stays there
+        sim.move_atmos()
+    org2 = sim.t["origin"].cpu().numpy()
+    assert (org2[:, 0, 0] == org[:, 0, 0]).all()
