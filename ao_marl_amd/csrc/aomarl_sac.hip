@@ -24,9 +24,16 @@
 //            Adam                                                       one kernel
 //   alpha    dlog_alpha = -mean(log pi + target entropy), Adam, losses  one kernel
 //
-// 16 GEMMs + 13 small kernels for the reference's two-layer actor, no host synchronisation, no
-// allocation; everything between the replay ring and the updated parameters stays in HBM.
+// Round 5: the products run on k_gemm_g (aomarl_gemm_g.h: k_gemm_p's inner loop, the agent as the group, operands
+// in either orientation so that forward, input gradient and weight gradient all read the tensors as they lie); the
+// policy runs ONCE on the stacked rows [x' ; x] (the critic phase's pi(x') and the actor phase's pi(x) use the same
+// weights: one product of 2 B rows per layer instead of two of B); bias + ReLU, the ReLU mask of the input gradients
+// and the bias gradients (column sums) are epilogues of the products; products that do not depend on each other share
+// a launch (k_gemm_g_multi) and the temperature update that of the policy's Adam: ONE stream, no events, 10 product
+// launches + 8 small kernels for the reference's two-layer actor, no host synchronisation, no allocation; everything between the replay ring and the updated parameters stays in HBM.  Shapes whose rows are not
+// 16-byte aligned (hidden or 2 x act_max not a multiple of 4) take round 1's general kernel, k_gemm_batched_gen.
 #include "aomarl_dev.h"
+#include "aomarl_gemm_g.h"
 
 #define SAC_MAX_HIDDEN 8
 #define SAC_EPSILON 1e-5f                 // model_rpc.py:8
@@ -37,13 +44,11 @@ struct aomarl_sac {
   long long poff[2 * SAC_MAX_HIDDEN + 2], coff[4], plen, clen;
   int32_t *sg = nullptr, *ag = nullptr, *nact = nullptr;
   float *te = nullptr;
-  // act / HD: policy activations of the critic phase (on x'); act2 / HD2: of the actor phase (on x)
-  float *XA, *XP, *X2, *act[SAC_MAX_HIDDEN], *act2[SAC_MAX_HIDDEN], *HD, *HD2, *HQ, *HT, *DQ, *R, *MK, *LP2,
+  // XS = [x' ; x] stacked per agent ([A][2 B][ldx]: rows 0 .. B-1 the critic phase's next states, rows B .. 2B-1 the
+  // actor phase's states; the sampled actions land in their action columns); act / HD: the policy's activations on XS
+  float *XA, *XS, *act[SAC_MAX_HIDDEN], *HD, *HQ, *HT, *DQ, *R, *MK, *LP2,
       *LPI, *SQ, *PL, *DPI, *DHD, *dA[SAC_MAX_HIDDEN], *gP, *gC, *gLA;   // gP / gC / gLA: the caller's buffers
-  // side stream: work off the critical path (see aomarl_sac_update)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_hq = nullptr, ev_actor = nullptr, ev_done = nullptr, ev_d[SAC_MAX_HIDDEN + 1] = {};
-  bool serial = false;
+  bool aligned = false;                   // every product's rows start on 16 bytes: k_gemm_g
   std::vector<void *> owned;
 };
 
@@ -82,8 +87,7 @@ __global__ __launch_bounds__(256) void k_sac_gather(
     const int32_t *__restrict__ ag, const float *__restrict__ state, const float *__restrict__ next_state,
     const float *__restrict__ action, const float *__restrict__ reward, const float *__restrict__ mask,
     long long rows, const int64_t *__restrict__ idx, uint32_t seed, uint32_t counter,
-    float *__restrict__ XA, float *__restrict__ XP, float *__restrict__ X2, float *__restrict__ R,
-    float *__restrict__ MK) {
+    float *__restrict__ XA, float *__restrict__ XS, float *__restrict__ R, float *__restrict__ MK) {
   const int b = blockIdx.x, a = blockIdx.y;
   long long r;
   if (idx) {
@@ -96,13 +100,14 @@ __global__ __launch_bounds__(256) void k_sac_gather(
   r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
   const float *s = state + r * S, *s2 = next_state + r * S, *ac = action + r * AD;
   const long long o = ((long long)a * B + b) * ldx;
+  const long long o2 = ((long long)a * 2 * B + b) * ldx, op = o2 + (long long)B * ldx;
   for (int c = threadIdx.x; c < I; c += 256) {
     const int g = sg[a * I + c];
     const bool on = g >= 0 && g < S;
     const float v = on ? s[g] : 0.f;
     XA[o + c] = v;
-    XP[o + c] = v;
-    X2[o + c] = on ? s2[g] : 0.f;
+    XS[op + c] = v;
+    XS[o2 + c] = on ? s2[g] : 0.f;
   }
   for (int c = threadIdx.x; c < Na; c += 256) {
     const int g = ag[a * Na + c];
@@ -114,17 +119,22 @@ __global__ __launch_bounds__(256) void k_sac_gather(
   }
 }
 
-// GaussianPolicy.sample (model_rpc.py:140-160): one wave per (agent, row); the action goes straight
-// into the action columns of the critic's input matrix.
+// GaussianPolicy.sample (model_rpc.py:140-160) on the stacked rows [x' ; x]: one wave per (agent, row); rows of the
+// first half draw from random stream 12 / eps_next and log into LP2, rows of the second half from stream 13 / eps_pi
+// into LPI; the action goes straight into the action columns of the row (the critics' input).
 __global__ __launch_bounds__(256) void k_sac_sample(
     int B, int I, int Na, int ldx, int ldhd, const int32_t *__restrict__ nact, const float *__restrict__ HD,
-    const float *__restrict__ eps_in, uint32_t seed, uint32_t counter, uint32_t stream, float ls_min,
-    float ls_max, float scale, float bias, float *__restrict__ X, float *__restrict__ LOGP) {
+    const float *__restrict__ eps_next, const float *__restrict__ eps_pi, uint32_t seed, uint32_t counter,
+    float ls_min, float ls_max, float scale, float bias, float *__restrict__ XS, float *__restrict__ LP2,
+    float *__restrict__ LPI) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), a = blockIdx.y;
-  if (row >= B) return;
+  if (row >= 2 * B) return;
+  const int half = row >= B ? 1 : 0;
   const int na = nact[a];
-  const long long ar = (long long)a * B + row;
-  const float *hd = HD + ar * ldhd;
+  const long long ar = (long long)a * B + (row - half * B), sr = (long long)a * 2 * B + row;
+  const float *hd = HD + sr * ldhd;
+  const float *eps_in = half ? eps_pi : eps_next;
+  const uint32_t stream = half ? 13u : 12u;
   float lp = 0.f;
   for (int j = lane; j < Na; j += 64) {
     float act = 0.f;
@@ -136,10 +146,10 @@ __global__ __launch_bounds__(256) void k_sac_sample(
       lp += -0.5f * eps * eps - ls - 0.91893853320467274178f -
             logf(scale * (1.f - fminf(y * y, 1.f)) + SAC_EPSILON);
     }
-    X[ar * ldx + I + j] = act;
+    XS[sr * ldx + I + j] = act;
   }
   lp = wave_sum(lp);
-  if (lane == 0) LOGP[ar] = lp;
+  if (lane == 0) (half ? LPI : LP2)[ar] = lp;
 }
 
 // q_k = h[kH:(k+1)H] . Wout_k + bout_k for one row; valid in every lane
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256) void k_sac_actor_head(int B, int H, float *__r
 // backward of GaussianPolicy.sample + the alpha log pi term of the actor loss.
 // DPI = dL/d(action) from the critics; out DHD = dL/d(mean | log_std) (pre-clamp)
 __global__ __launch_bounds__(256) void k_sac_sample_bwd(
-    int B, int Na, int ldhd, int ldna, const int32_t *__restrict__ nact, const float *__restrict__ HD,
+    int B, int Na, int ldhd, long long sHD, int ldna, const int32_t *__restrict__ nact, const float *__restrict__ HD,
     const float *__restrict__ DPI, const float *__restrict__ eps_in, uint32_t seed, uint32_t counter,
     uint32_t stream, const float *__restrict__ alpha, float ls_min, float ls_max, float scale,
     float *__restrict__ DHD) {
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256) void k_sac_sample_bwd(
   if (row >= B) return;
   const int na = nact[a];
   const long long ar = (long long)a * B + row;
-  const float *hd = HD + ar * ldhd;
+  const float *hd = HD + (long long)a * sHD + (long long)row * ldhd;
   const float aB = alpha[a] / (float)B;
   for (int j = lane; j < Na; j += 64) {
     float dm = 0.f, dls = 0.f;
@@ -268,20 +278,21 @@ __global__ __launch_bounds__(256) void k_sac_sample_bwd(
 }
 
 // out[a][c] = sum_b X[a][b][c]      (bias gradients)
-__global__ __launch_bounds__(1024) void k_sac_colsum(int B, int N, int ld, const float *__restrict__ X,
-                                                     float *__restrict__ out) {
+__global__ __launch_bounds__(1024) void k_sac_colsum(int B, int N, int ld, long long sX,
+                                                     const float *__restrict__ X, float *__restrict__ out,
+                                                     long long sOut) {
   __shared__ float sm[32][33];
   const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5, a = blockIdx.y;
   const int col = blockIdx.x * 32 + cx;
   float acc = 0.f;
   if (col < N)
-    for (int b = rg; b < B; b += 32) acc += X[((long long)a * B + b) * ld + col];
+    for (int b = rg; b < B; b += 32) acc += X[(long long)a * sX + (long long)b * ld + col];
   sm[rg][cx] = acc;
   __syncthreads();
   if (rg == 0 && col < N) {
     float t = 0.f;
     for (int r = 0; r < 32; r++) t += sm[r][cx];
-    out[(long long)a * N + col] = t;
+    out[(long long)a * sOut + col] = t;
   }
 }
 
@@ -295,34 +306,15 @@ __device__ __forceinline__ float adam_one(float p, float g, float &m, float &v, 
   return p - k.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void k_sac_adam(long long n4, float4 *__restrict__ p,
-                                                  const float4 *__restrict__ g, float4 *__restrict__ m,
-                                                  float4 *__restrict__ v, float4 *__restrict__ tgt, AdamK k,
-                                                  float tau) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  float4 P = p[i], M = m[i], V = v[i];
-  const float4 G = g[i];
-  P.x = adam_one(P.x, G.x, M.x, V.x, k); P.y = adam_one(P.y, G.y, M.y, V.y, k);
-  P.z = adam_one(P.z, G.z, M.z, V.z, k); P.w = adam_one(P.w, G.w, M.w, V.w, k);
-  p[i] = P; m[i] = M; v[i] = V;
-  if (tgt) {                                         // soft_update, train_rpc.py:1128-1129
-    float4 T = tgt[i];
-    T.x = T.x * (1.f - tau) + P.x * tau; T.y = T.y * (1.f - tau) + P.y * tau;
-    T.z = T.z * (1.f - tau) + P.z * tau; T.w = T.w * (1.f - tau) + P.w * tau;
-    tgt[i] = T;
-  }
-}
-
 // update_alpha (train_rpc.py:1070-1084) + the per-agent loss log; one block per agent
-__global__ __launch_bounds__(256) void k_sac_alpha(int B, int A, const float *__restrict__ LPI,
-                                                   const float *__restrict__ SQ, const float *__restrict__ PL,
-                                                   const float *__restrict__ te, float *__restrict__ la,
-                                                   float *__restrict__ la_m, float *__restrict__ la_v,
-                                                   float *__restrict__ alpha, float *__restrict__ gla, AdamK k,
-                                                   int tune, float *__restrict__ losses) {
+__device__ __forceinline__ void sac_alpha_block(int a, int B, int A, const float *__restrict__ LPI,
+                                                const float *__restrict__ SQ, const float *__restrict__ PL,
+                                                const float *__restrict__ te, float *__restrict__ la,
+                                                float *__restrict__ la_m, float *__restrict__ la_v,
+                                                float *__restrict__ alpha, float *__restrict__ gla, AdamK k,
+                                                int tune, float *__restrict__ losses) {
   __shared__ float sm[4][4];
-  const int a = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int b = threadIdx.x; b < B; b += 256) {
     const long long ar = (long long)a * B + b;
@@ -359,15 +351,45 @@ __global__ __launch_bounds__(256) void k_sac_alpha(int B, int A, const float *__
   }
 }
 
+struct SacAlphaArgs {
+  int on, B, A, tune;
+  const float *LPI, *SQ, *PL, *te;
+  float *la, *la_m, *la_v, *alpha, *gla, *losses;
+};
+
+// torch.optim.Adam over a flat parameter buffer (+ soft_update of the target, train_rpc.py:1128-1129); with
+// `al.on` the grid carries A more blocks that run the temperature update (nothing of it depends on this Adam).
+__global__ __launch_bounds__(256) void k_sac_adam(long long n4, float4 *__restrict__ p,
+                                                  const float4 *__restrict__ g, float4 *__restrict__ m,
+                                                  float4 *__restrict__ v, float4 *__restrict__ tgt, AdamK k,
+                                                  float tau, unsigned nb, SacAlphaArgs al) {
+  if (blockIdx.x >= nb) {                            // block-uniform
+    if (al.on)
+      sac_alpha_block((int)(blockIdx.x - nb), al.B, al.A, al.LPI, al.SQ, al.PL, al.te, al.la, al.la_m, al.la_v,
+                      al.alpha, al.gla, k, al.tune, al.losses);
+    return;
+  }
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 P = p[i], M = m[i], V = v[i];
+  const float4 G = g[i];
+  P.x = adam_one(P.x, G.x, M.x, V.x, k); P.y = adam_one(P.y, G.y, M.y, V.y, k);
+  P.z = adam_one(P.z, G.z, M.z, V.z, k); P.w = adam_one(P.w, G.w, M.w, V.w, k);
+  p[i] = P; m[i] = M; v[i] = V;
+  if (tgt) {                                         // soft_update, train_rpc.py:1128-1129
+    float4 T = tgt[i];
+    T.x = T.x * (1.f - tau) + P.x * tau; T.y = T.y * (1.f - tau) + P.y * tau;
+    T.z = T.z * (1.f - tau) + P.z * tau; T.w = T.w * (1.f - tau) + P.w * tau;
+    tgt[i] = T;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int aomarl_sac_destroy(aomarl_sac *s) {
   if (!s) return 0;
   for (void *p : s->owned) (void)hipFree(p);
-  if (s->side) (void)hipStreamDestroy(s->side);
-  for (hipEvent_t e : {s->ev_fork, s->ev_hq, s->ev_actor, s->ev_done}) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : s->ev_d) if (e) (void)hipEventDestroy(e);
   delete s;
   return 0;
 }
@@ -416,23 +438,19 @@ int aomarl_sac_create(const aomarl_sac_desc *d, aomarl_sac **out) {
   s->nact = (int32_t *)upload(d->n_act, sizeof(int32_t) * A);
   s->te = (float *)upload(d->target_entropy, sizeof(float) * A);
   const size_t AB = (size_t)A * B;
-  s->XA = alloc(AB * s->ldx); s->XP = alloc(AB * s->ldx); s->X2 = alloc(AB * s->ldx);
+  s->XA = alloc(AB * s->ldx); s->XS = alloc(2 * AB * s->ldx);
   for (int l = 0; l < SAC_MAX_HIDDEN; l++) {
-    s->act[l] = l < s->L ? alloc(AB * H) : nullptr;
-    s->act2[l] = l < s->L ? alloc(AB * H) : nullptr;
+    s->act[l] = l < s->L ? alloc(2 * AB * H) : nullptr;
     s->dA[l] = l < s->L ? alloc(AB * H) : nullptr;
   }
-  s->HD = alloc(AB * s->ldhd); s->HD2 = alloc(AB * s->ldhd); s->DHD = alloc(AB * s->ldhd);
+  s->HD = alloc(2 * AB * s->ldhd); s->DHD = alloc(AB * s->ldhd);
+  // k_gemm_g wants every operand row on a 16-byte boundary: the weights' rows are H, 2 Na and 2 Hc floats long
+  s->aligned = !(H & 3) && !((2 * Na) & 3) && !((2 * Hc) & 3);
+  { const char *e = getenv("AOMARL_SAC_GEMM"); if (e && e[0] == 'g' && e[1] == 'e') s->aligned = false; }   // "gen": round 1's kernel (A/B)
   s->HQ = alloc(AB * 2 * Hc); s->HT = alloc(AB * 2 * Hc);
   s->DQ = alloc(AB * 2); s->SQ = alloc(AB * 2);
   s->R = alloc(AB); s->MK = alloc(AB); s->LP2 = alloc(AB); s->LPI = alloc(AB); s->PL = alloc(AB);
   s->DPI = alloc(AB * s->ldna);
-  if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) ok = false;
-  for (hipEvent_t *e : {&s->ev_fork, &s->ev_hq, &s->ev_actor, &s->ev_done})
-    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) ok = false;
-  for (int l = 0; l <= s->L; l++)
-    if (hipEventCreateWithFlags(&s->ev_d[l], hipEventDisableTiming) != hipSuccess) ok = false;
-  { const char *e = getenv("AOMARL_SAC_SERIAL"); s->serial = e && e[0] == '1'; }
   s->gP = d->policy_grad; s->gC = d->critic_grad; s->gLA = d->log_alpha_grad;
   if (!ok) { aomarl_sac_destroy(s); return fail("sac_create: device allocation failed"); }
   *out = s;
@@ -448,28 +466,52 @@ static AdamK sac_adam_consts(const aomarl_sac_desc &d, int step) {
   return k;
 }
 
-// policy forward on the state columns of X: act[0..L-1] (ReLU) and HD = (mean | log_std)
-static int sac_policy_forward(aomarl_sac *s, const float *X, float *const *act, float *HD, hipStream_t st) {
-  const int A = s->A, B = s->B, I = s->I, H = s->H, Na = s->Na, L = s->L;
-  const float *P = s->d.policy;
-  if (gemm_batched_launch(A, 0, 1, B, H, I, X, s->ldx, (long long)B * s->ldx, P + s->poff[0], H,
-                          (long long)I * H, P + s->poff[1], H, act[0], H, (long long)B * H, 1, 0, nullptr,
-                          0, 0, st)) return 1;
-  for (int l = 1; l < L; l++)
-    if (gemm_batched_launch(A, 0, 1, B, H, H, act[l - 1], H, (long long)B * H, P + s->poff[2 * l], H,
-                            (long long)H * H, P + s->poff[2 * l + 1], H, act[l], H, (long long)B * H, 1, 0,
-                            nullptr, 0, 0, st)) return 1;
-  return gemm_batched_launch(A, 0, 1, B, 2 * Na, H, act[L - 1], H, (long long)B * H, P + s->poff[2 * L],
-                             2 * Na, (long long)H * 2 * Na, P + s->poff[2 * L + 1], 2 * Na, HD, s->ldhd,
-                             (long long)B * s->ldhd, 0, 0, nullptr, 0, 0, st);
+// One product of the update for every agent: C[a] = opA(A[a]) . opB(B[a]) (+ bias, ReLU | masked by `mask` > 0), and
+// optionally colsum[a][n] = sum_k B[a][k][n] (the bias gradient beside a weight gradient).  tA: A is [K][M]; tB: B is
+// [N][K].
+struct SacProb { GemmGArgs g; bool ak, bk; };
+static SacProb sac_prob(int tA, int tB, int M, int N, int K, const float *A, int lda, long long sA, const float *B,
+                        int ldb, long long sB, const float *bias, long long sBias, float *C, int ldc, long long sC,
+                        int relu, const float *mask, int ldm, long long sM, float *colsum, long long sCs) {
+  SacProb p;
+  memset(&p, 0, sizeof(p));
+  GemmGArgs &g = p.g;
+  g.M = M; g.N = N; g.K = K;
+  g.A = A; g.lda = lda; g.sA = sA; g.B = B; g.ldb = ldb; g.sB = sB; g.C = C; g.ldc = ldc; g.sC = sC;
+  g.bias = bias; g.sBias = sBias; g.relu = relu; g.mask = mask; g.ldm = ldm; g.sM = sM;
+  g.colsum = colsum; g.sCs = sCs;
+  p.ak = !tA; p.bk = tB != 0;
+  return p;
 }
 
-// hidden layer of the twin critics: Hout = relu(X Win + bin), [A][B][2H]
-static int sac_critic_hidden(aomarl_sac *s, const float *X, const float *C, float *Hout, hipStream_t st) {
-  const int A = s->A, B = s->B, H = s->Hc, NA = s->NA;
-  return gemm_batched_launch(A, 0, 1, B, 2 * H, NA, X, s->ldx, (long long)B * s->ldx, C + s->coff[0], 2 * H,
-                             (long long)NA * 2 * H, C + s->coff[1], 2 * H, Hout, 2 * H, (long long)B * 2 * H, 1,
-                             0, nullptr, 0, 0, st);
+// n independent products: one launch of k_gemm_g_multi; rows that are not 16-byte aligned: round 1's kernel, one
+// launch per product (+ the column sums)
+static int sac_run(aomarl_sac *s, int n, const SacProb *pr, hipStream_t st) {
+  if (s->aligned) {
+    GemmGArgs g[GG_MAXP];
+    bool ak[GG_MAXP], bk[GG_MAXP];
+    for (int i = 0; i < n; i++) { g[i] = pr[i].g; ak[i] = pr[i].ak; bk[i] = pr[i].bk; }
+    if (gemm_g_launch_multi(s->A, n, g, ak, bk, st)) return fail("sac_update: k_gemm_g_multi launch failed");
+    return 0;
+  }
+  for (int i = 0; i < n; i++) {
+    const GemmGArgs &g = pr[i].g;
+    if (gemm_batched_launch(s->A, !pr[i].ak, !pr[i].bk, g.M, g.N, g.K, g.A, g.lda, g.sA, g.B, g.ldb, g.sB, g.bias, g.sBias,
+                            g.C, g.ldc, g.sC, g.relu, 0, g.mask, g.ldm, g.sM, st)) return 1;
+    if (g.colsum) {
+      hipLaunchKernelGGL(k_sac_colsum, dim3((g.N + 31) / 32, s->A), dim3(1024), 0, st, g.K, g.N, g.ldb, g.sB, g.B,
+                         g.colsum, g.sCs);
+      LAUNCHCHK();
+    }
+  }
+  return 0;
+}
+
+// hidden layer of the twin critics on B rows per agent: Hout = relu(X Win + bin), [A][B][2H]
+static SacProb sac_critic_hidden(aomarl_sac *s, const float *X, long long sX, const float *C, float *Hout) {
+  const int B = s->B, H = s->Hc, NA = s->NA;
+  return sac_prob(0, 0, B, 2 * H, NA, X, s->ldx, sX, C + s->coff[0], 2 * H, (long long)NA * 2 * H, C + s->coff[1], 2 * H,
+                  Hout, 2 * H, (long long)B * 2 * H, 1, nullptr, 0, 0, nullptr, 0);
 }
 
 int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state, const float *action,
@@ -482,41 +524,43 @@ int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state
   if (adam_step < 1) return fail("sac_update: adam_step is 1-based");
   hipStream_t st = (hipStream_t)stream;
   const aomarl_sac_desc &d = s->d;
-  const int A = s->A, B = s->B, I = s->I, Na = s->Na, H = s->H, Hc = s->Hc, L = s->L, NA = s->NA;
-  const dim3 rows4((B + 3) / 4, A), w256(256);
+  const int A = s->A, B = s->B, B2 = 2 * s->B, I = s->I, Na = s->Na, H = s->H, Hc = s->Hc, L = s->L, NA = s->NA;
+  const dim3 rows4((B + 3) / 4, A), rows8((B2 + 3) / 4, A), w256(256);
   const AdamK ak = sac_adam_consts(d, adam_step);
   float *C = d.critic, *P = d.policy;
-  const long long sH = (long long)B * H;
+  const long long sH = (long long)B * H, sH2 = 2 * sH;           // dA rows; the stacked activations' agent stride
+  const long long sXS = (long long)B2 * s->ldx, sHD2 = (long long)B2 * s->ldhd;
+  const float *XP = s->XS + (long long)B * s->ldx;               // the actor phase's half of the stacked rows
+  const float *HDP = s->HD + (long long)B * s->ldhd;
+  SacAlphaArgs no_alpha;
+  memset(&no_alpha, 0, sizeof(no_alpha));
+  SacProb pr[GG_MAXP];
 
-  // Two streams: `st` carries the critical path, `sd` everything that does not feed the next kernel
-  // on it -- the critic's own hidden layer (needs only the gathered batch), the actor-phase policy
-  // forward (the policy does not change during the critic update) and all weight / bias gradients
-  // of the policy.  These launches are 224 .. 448 tiles of one wave per SIMD with a few
-  // microseconds of fixed cost each: the two queues fill each other's gaps.
-  hipStream_t sd = s->serial ? st : s->side;
-#define SAC_REC(ev, q) do { if (!s->serial) HIPCHK(hipEventRecord(ev, q)); } while (0)
-#define SAC_WAIT(q, ev) do { if (!s->serial) HIPCHK(hipStreamWaitEvent(q, ev, 0)); } while (0)
+  // ONE stream, no events: products that do not depend on each other share a launch (k_gemm_g_multi).
   hipLaunchKernelGGL(k_sac_gather, dim3(B, A), w256, 0, st, B, I, Na, s->ldx, d.state_dim, d.action_dim, A,
                      s->sg, s->ag, state, next_state, action, reward, mask, replay_rows, idx, seed, counter,
-                     s->XA, s->XP, s->X2, s->R, s->MK);
+                     s->XA, s->XS, s->R, s->MK);
   LAUNCHCHK();
-  SAC_REC(s->ev_fork, st);
-  SAC_WAIT(sd, s->ev_fork);
-  // ---- side: Q(x, a) hidden layer, then pi(x) for the actor phase
-  if (sac_critic_hidden(s, s->XA, C, s->HQ, sd)) return 1;
-  SAC_REC(s->ev_hq, sd);
-  if (sac_policy_forward(s, s->XP, s->act2, s->HD2, sd)) return 1;
-  hipLaunchKernelGGL(k_sac_sample, rows4, w256, 0, sd, B, I, Na, s->ldx, s->ldhd, s->nact, s->HD2, eps_pi, seed,
-                     counter, 13u, d.log_sig_min, d.log_sig_max, d.action_scale, d.action_bias, s->XP, s->LPI);
-  LAUNCHCHK();
-  SAC_REC(s->ev_actor, sd);
   // ---------------- critic ----------------
-  if (sac_policy_forward(s, s->X2, s->act, s->HD, st)) return 1;
-  hipLaunchKernelGGL(k_sac_sample, rows4, w256, 0, st, B, I, Na, s->ldx, s->ldhd, s->nact, s->HD, eps_next, seed,
-                     counter, 12u, d.log_sig_min, d.log_sig_max, d.action_scale, d.action_bias, s->X2, s->LP2);
+  // pi(x') and pi(x) in one pass on the stacked rows (the policy does not change before the end of the update);
+  // beside its first layer: the critics' hidden layer on (x, a)
+  pr[0] = sac_prob(0, 0, B2, H, I, s->XS, s->ldx, sXS, P + s->poff[0], H, (long long)I * H, P + s->poff[1], H, s->act[0],
+                   H, sH2, 1, nullptr, 0, 0, nullptr, 0);
+  pr[1] = sac_critic_hidden(s, s->XA, (long long)B * s->ldx, C, s->HQ);
+  if (sac_run(s, 2, pr, st)) return 1;
+  for (int l = 1; l < L; l++) {
+    pr[0] = sac_prob(0, 0, B2, H, H, s->act[l - 1], H, sH2, P + s->poff[2 * l], H, (long long)H * H, P + s->poff[2 * l + 1],
+                     H, s->act[l], H, sH2, 1, nullptr, 0, 0, nullptr, 0);
+    if (sac_run(s, 1, pr, st)) return 1;
+  }
+  pr[0] = sac_prob(0, 0, B2, 2 * Na, H, s->act[L - 1], H, sH2, P + s->poff[2 * L], 2 * Na, (long long)H * 2 * Na,
+                   P + s->poff[2 * L + 1], 2 * Na, s->HD, s->ldhd, sHD2, 0, nullptr, 0, 0, nullptr, 0);
+  if (sac_run(s, 1, pr, st)) return 1;
+  hipLaunchKernelGGL(k_sac_sample, rows8, w256, 0, st, B, I, Na, s->ldx, s->ldhd, s->nact, s->HD, eps_next, eps_pi,
+                     seed, counter, d.log_sig_min, d.log_sig_max, d.action_scale, d.action_bias, s->XS, s->LP2, s->LPI);
   LAUNCHCHK();
-  if (sac_critic_hidden(s, s->X2, d.critic_target, s->HT, st)) return 1;
-  SAC_WAIT(st, s->ev_hq);
+  pr[0] = sac_critic_hidden(s, s->XS, sXS, d.critic_target, s->HT);
+  if (sac_run(s, 1, pr, st)) return 1;
   hipLaunchKernelGGL(k_sac_critic_head, rows4, w256, 0, st, B, Hc, s->HQ, s->HT, C + s->coff[2], C + s->coff[3],
                      d.critic_target + s->coff[2], d.critic_target + s->coff[3], s->R, s->MK, s->LP2, d.alpha,
                      d.gamma, s->DQ, s->SQ);
@@ -525,68 +569,60 @@ int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state
                      C + s->coff[2], s->gC + s->coff[2], s->gC + s->coff[3], s->gC + s->coff[1]);
   LAUNCHCHK();
   // dWin = XA^T dh
-  if (gemm_batched_launch(A, 1, 1, NA, 2 * Hc, B, s->XA, s->ldx, (long long)B * s->ldx, s->HQ, 2 * Hc,
-                          (long long)B * 2 * Hc, nullptr, 0, s->gC + s->coff[0], 2 * Hc, (long long)NA * 2 * Hc, 0, 0,
-                          nullptr, 0, 0, st)) return 1;
-  hipLaunchKernelGGL(k_sac_adam, dim3((unsigned)((s->clen / 4 + 255) / 256)), w256, 0, st, s->clen / 4,
-                     (float4 *)C, (const float4 *)s->gC, (float4 *)d.critic_m, (float4 *)d.critic_v,
-                     (flags & AOMARL_SAC_SOFT_UPDATE) ? (float4 *)d.critic_target : (float4 *)nullptr, ak, d.tau);
-  LAUNCHCHK();
+  pr[0] = sac_prob(1, 0, NA, 2 * Hc, B, s->XA, s->ldx, (long long)B * s->ldx, s->HQ, 2 * Hc, (long long)B * 2 * Hc, nullptr,
+                   0, s->gC + s->coff[0], 2 * Hc, (long long)NA * 2 * Hc, 0, nullptr, 0, 0, nullptr, 0);
+  if (sac_run(s, 1, pr, st)) return 1;
+  {
+    const unsigned nb = (unsigned)((s->clen / 4 + 255) / 256);
+    hipLaunchKernelGGL(k_sac_adam, dim3(nb), w256, 0, st, s->clen / 4, (float4 *)C, (const float4 *)s->gC,
+                       (float4 *)d.critic_m, (float4 *)d.critic_v,
+                       (flags & AOMARL_SAC_SOFT_UPDATE) ? (float4 *)d.critic_target : (float4 *)nullptr, ak, d.tau, nb,
+                       no_alpha);
+    LAUNCHCHK();
+  }
   // ---------------- actor ----------------
-  SAC_WAIT(st, s->ev_actor);
-  if (sac_critic_hidden(s, s->XP, C, s->HQ, st)) return 1;
+  pr[0] = sac_critic_hidden(s, XP, sXS, C, s->HQ);
+  if (sac_run(s, 1, pr, st)) return 1;
   hipLaunchKernelGGL(k_sac_actor_head, rows4, w256, 0, st, B, Hc, s->HQ, C + s->coff[2], C + s->coff[3], s->LPI,
                      d.alpha, s->PL);
   LAUNCHCHK();
   // dpi = dh Win[action rows]^T   (sums the two critics: K runs over both hidden halves)
-  if (gemm_batched_launch(A, 0, 0, B, Na, 2 * Hc, s->HQ, 2 * Hc, (long long)B * 2 * Hc,
-                          C + s->coff[0] + (long long)I * 2 * Hc, 2 * Hc, (long long)NA * 2 * Hc, nullptr, 0, s->DPI,
-                          s->ldna, (long long)B * s->ldna, 0, 0, nullptr, 0, 0, st)) return 1;
-  hipLaunchKernelGGL(k_sac_sample_bwd, rows4, w256, 0, st, B, Na, s->ldhd, s->ldna, s->nact, s->HD2, s->DPI, eps_pi,
-                     seed, counter, 13u, d.alpha, d.log_sig_min, d.log_sig_max, d.action_scale, s->DHD);
+  pr[0] = sac_prob(0, 1, B, Na, 2 * Hc, s->HQ, 2 * Hc, (long long)B * 2 * Hc, C + s->coff[0] + (long long)I * 2 * Hc, 2 * Hc,
+                   (long long)NA * 2 * Hc, nullptr, 0, s->DPI, s->ldna, (long long)B * s->ldna, 0, nullptr, 0, 0, nullptr, 0);
+  if (sac_run(s, 1, pr, st)) return 1;
+  hipLaunchKernelGGL(k_sac_sample_bwd, rows4, w256, 0, st, B, Na, s->ldhd, sHD2, s->ldna, s->nact, HDP, s->DPI,
+                     eps_pi, seed, counter, 13u, d.alpha, d.log_sig_min, d.log_sig_max, d.action_scale, s->DHD);
   LAUNCHCHK();
-  SAC_REC(s->ev_d[L], st);
-  // main: the chain of activation gradients;  side: dW = act^T d, db = colsum(d) of every layer
-  SAC_WAIT(sd, s->ev_d[L]);
-  if (gemm_batched_launch(A, 1, 1, H, 2 * Na, B, s->act2[L - 1], H, sH, s->DHD, s->ldhd, (long long)B * s->ldhd,
-                          nullptr, 0, s->gP + s->poff[2 * L], 2 * Na, (long long)H * 2 * Na, 0, 0, nullptr, 0, 0,
-                          sd)) return 1;
-  hipLaunchKernelGGL(k_sac_colsum, dim3((2 * Na + 31) / 32, A), dim3(1024), 0, sd, B, 2 * Na, s->ldhd, s->DHD,
-                     s->gP + s->poff[2 * L + 1]);
-  LAUNCHCHK();
-  if (gemm_batched_launch(A, 0, 0, B, H, 2 * Na, s->DHD, s->ldhd, (long long)B * s->ldhd, P + s->poff[2 * L],
-                          2 * Na, (long long)H * 2 * Na, nullptr, 0, s->dA[L - 1], H, sH, 0, 0, s->act2[L - 1], H, sH,
-                          st)) return 1;
-  SAC_REC(s->ev_d[L - 1], st);
+  // policy backward: a layer's input gradient (ReLU-masked) and its weight + bias gradient share a launch
+  const float *actP[SAC_MAX_HIDDEN];                              // the x half of the stacked activations
+  for (int l = 0; l < L; l++) actP[l] = s->act[l] + sH;
+  pr[0] = sac_prob(0, 1, B, H, 2 * Na, s->DHD, s->ldhd, (long long)B * s->ldhd, P + s->poff[2 * L], 2 * Na,
+                   (long long)H * 2 * Na, nullptr, 0, s->dA[L - 1], H, sH, 0, actP[L - 1], H, sH2, nullptr, 0);
+  pr[1] = sac_prob(1, 0, H, 2 * Na, B, actP[L - 1], H, sH2, s->DHD, s->ldhd, (long long)B * s->ldhd, nullptr, 0,
+                   s->gP + s->poff[2 * L], 2 * Na, (long long)H * 2 * Na, 0, nullptr, 0, 0, s->gP + s->poff[2 * L + 1],
+                   2 * Na);
+  if (sac_run(s, 2, pr, st)) return 1;
   for (int l = L - 1; l >= 1; l--) {
-    // d(layer l pre-activation) = dA[l] is ready on st
-    SAC_WAIT(sd, s->ev_d[l]);
-    if (gemm_batched_launch(A, 1, 1, H, H, B, s->act2[l - 1], H, sH, s->dA[l], H, sH, nullptr, 0,
-                            s->gP + s->poff[2 * l], H, (long long)H * H, 0, 0, nullptr, 0, 0, sd)) return 1;
-    hipLaunchKernelGGL(k_sac_colsum, dim3((H + 31) / 32, A), dim3(1024), 0, sd, B, H, H, s->dA[l],
-                       s->gP + s->poff[2 * l + 1]);
-    LAUNCHCHK();
-    if (gemm_batched_launch(A, 0, 0, B, H, H, s->dA[l], H, sH, P + s->poff[2 * l], H, (long long)H * H, nullptr, 0,
-                            s->dA[l - 1], H, sH, 0, 0, s->act2[l - 1], H, sH, st)) return 1;
-    SAC_REC(s->ev_d[l - 1], st);
+    pr[0] = sac_prob(0, 1, B, H, H, s->dA[l], H, sH, P + s->poff[2 * l], H, (long long)H * H, nullptr, 0, s->dA[l - 1], H,
+                     sH, 0, actP[l - 1], H, sH2, nullptr, 0);
+    pr[1] = sac_prob(1, 0, H, H, B, actP[l - 1], H, sH2, s->dA[l], H, sH, nullptr, 0, s->gP + s->poff[2 * l], H,
+                     (long long)H * H, 0, nullptr, 0, 0, s->gP + s->poff[2 * l + 1], H);
+    if (sac_run(s, 2, pr, st)) return 1;
   }
-  SAC_WAIT(sd, s->ev_d[0]);
-  if (gemm_batched_launch(A, 1, 1, I, H, B, s->XP, s->ldx, (long long)B * s->ldx, s->dA[0], H, sH, nullptr, 0,
-                          s->gP + s->poff[0], H, (long long)I * H, 0, 0, nullptr, 0, 0, sd)) return 1;
-  hipLaunchKernelGGL(k_sac_colsum, dim3((H + 31) / 32, A), dim3(1024), 0, sd, B, H, H, s->dA[0], s->gP + s->poff[1]);
-  LAUNCHCHK();
-  SAC_REC(s->ev_done, sd);
-  SAC_WAIT(st, s->ev_done);
-#undef SAC_REC
-#undef SAC_WAIT
-  hipLaunchKernelGGL(k_sac_adam, dim3((unsigned)((s->plen / 4 + 255) / 256)), w256, 0, st, s->plen / 4,
-                     (float4 *)P, (const float4 *)s->gP, (float4 *)d.policy_m, (float4 *)d.policy_v,
-                     (float4 *)nullptr, ak, 0.f);
-  LAUNCHCHK();
-  // ---------------- temperature + log ----------------
-  hipLaunchKernelGGL(k_sac_alpha, dim3(A), w256, 0, st, B, A, s->LPI, s->SQ, s->PL, s->te, d.log_alpha,
-                     d.log_alpha_m, d.log_alpha_v, d.alpha, s->gLA, ak, (flags & AOMARL_SAC_TUNE_ALPHA) ? 1 : 0,
-                     losses);
-  LAUNCHCHK();
+  pr[0] = sac_prob(1, 0, I, H, B, XP, s->ldx, sXS, s->dA[0], H, sH, nullptr, 0, s->gP + s->poff[0], H, (long long)I * H, 0,
+                   nullptr, 0, 0, s->gP + s->poff[1], H);
+  if (sac_run(s, 1, pr, st)) return 1;
+  // ---------------- policy Adam; temperature + log in the same launch ----------------
+  {
+    const unsigned nb = (unsigned)((s->plen / 4 + 255) / 256);
+    SacAlphaArgs al;
+    al.on = 1; al.B = B; al.A = A; al.tune = (flags & AOMARL_SAC_TUNE_ALPHA) ? 1 : 0;
+    al.LPI = s->LPI; al.SQ = s->SQ; al.PL = s->PL; al.te = s->te;
+    al.la = d.log_alpha; al.la_m = d.log_alpha_m; al.la_v = d.log_alpha_v; al.alpha = d.alpha; al.gla = s->gLA;
+    al.losses = losses;
+    hipLaunchKernelGGL(k_sac_adam, dim3(nb + (unsigned)A), w256, 0, st, s->plen / 4, (float4 *)P, (const float4 *)s->gP,
+                       (float4 *)d.policy_m, (float4 *)d.policy_v, (float4 *)nullptr, ak, 0.f, nb, al);
+    LAUNCHCHK();
+  }
   return 0;
 }

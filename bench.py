@@ -281,10 +281,11 @@ def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
     t0 = time.perf_counter()
     for _ in range(n_updates):
         sac.update_from_memory(batch)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n_updates * 1e3
-    return {"ms_per_update": ms, "agents": layout.n_agents, "batch_per_agent": batch,
-            "updates_per_s": 1e3 / ms, "kernel": "aomarl_sac_update"}
+    return {"ms_per_update": ms, "host_enqueue_ms_per_update": t_enq / n_updates * 1e3, "agents": layout.n_agents,
+            "batch_per_agent": batch, "updates_per_s": 1e3 / ms, "kernel": "aomarl_sac_update"}
 
 
 # ------------------------------------------------------------------------------------ one workload
