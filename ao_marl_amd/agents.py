@@ -290,7 +290,7 @@ class BatchedGaussianPolicy(object):
     def reset_output_ring(self):
         self._ring_i = 0
 
-    def _select_action_one_call(self, state, eval_mode, eps):
+    def _select_action_one_call(self, state, eval_mode, eps, out=None):
         """TrainerRPC.choose_action for all agents in ONE library call (aomarl_actor_forward): the
         same kernels as _native_head + policy_sample, issued from C."""
         from . import libaomarl as la
@@ -311,6 +311,13 @@ class BatchedGaussianPolicy(object):
         else:
             a = torch.empty(nenv, self.layout.action_dim, dtype=torch.float32, device=self.device)
             m = torch.empty_like(a)
+        if out is not None:                 # the caller's buffer for what is returned first (a trajectory's row)
+            if out.shape != a.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device:
+                raise ValueError("select_action: out must be a contiguous float32 [nenv, action_dim] tensor on the policy's device")
+            if eval_mode:
+                m = out
+            else:
+                a = out
         if eps is not None:
             eps = eps.to(torch.float32).contiguous()
         la.check(la.load().aomarl_actor_forward(
@@ -337,13 +344,18 @@ class BatchedGaussianPolicy(object):
         # [A, nenv, act_max] -> [nenv, action_dim]
         return per_agent[self.sc_agent, :, self.sc_local].T.contiguous()
 
-    def select_action(self, state, eval_mode=False, eps=None):
+    def select_action(self, state, eval_mode=False, eps=None, out=None):
         """See _select_action: the one-call native path goes straight to the library (no autograd context to
-        enter -- nothing there is a torch operation -- and a host-bound step notices the 3 us)."""
+        enter -- nothing there is a torch operation -- and a host-bound step notices the 3 us).  out: where the
+        returned action goes (no copy on the one-call path)."""
         if self.use_native and self.native_forward and state.dtype == torch.float32 and \
                 state.dim() == 2 and state.shape[1] == self.layout.state_dim:
-            return self._select_action_one_call(state if state.is_contiguous() else state.contiguous(), eval_mode, eps)
-        return self._select_action(state, eval_mode, eps)
+            return self._select_action_one_call(state if state.is_contiguous() else state.contiguous(), eval_mode, eps, out)
+        a, m = self._select_action(state, eval_mode, eps)
+        if out is not None:
+            out.copy_(a)
+            a = out
+        return a, m
 
     @torch.no_grad()
     def _select_action(self, state, eval_mode=False, eps=None):

@@ -326,6 +326,9 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
     const aomarl_layer_desc &L = d->layers[l];
     DevLayer &D = s.layers[l];
     if (L.dim <= 0 || L.dim > 65535 || L.nstencil <= 0) { aomarl_destroy(c); return fail("bad layer %d", l); }
+    // the mirror columns repeat the row's first RING_PAD pixels: a narrower screen would mirror pixels it is
+    // writing (k_refresh_mirror, k_set_screen, the scatter's px < RING_PAD)
+    if (L.dim < RING_PAD) { aomarl_destroy(c); return fail("layer %d: a screen of %d pixels is narrower than the ring's %d mirror columns", l, L.dim, RING_PAD); }
     D.dim = L.dim; D.ns = L.nstencil; D.screen_off = off; off += (long long)L.dim * (L.dim + RING_PAD);
     c->dim[l] = L.dim; c->ns[l] = L.nstencil; c->deltax[l] = L.deltax; c->deltay[l] = L.deltay;
     if (L.dim > c->maxdim) c->maxdim = L.dim;

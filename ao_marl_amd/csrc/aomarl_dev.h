@@ -179,6 +179,7 @@ __device__ __forceinline__ float philox_uniform(uint32_t seed, uint32_t stream, 
 #ifndef RING_PAD
 #define RING_PAD 56
 #endif
+static_assert(RING_PAD >= 32 && RING_PAD % 4 == 0, "the frame kernel's pair fetch reads 32 consecutive pixels in 16-byte pieces");
 #ifndef FW_ALIGN_ORIGIN
 #define FW_ALIGN_ORIGIN 1  // 0: a reset starts the rings at origin (0, 0)
 #endif

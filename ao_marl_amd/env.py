@@ -12,6 +12,7 @@ sequencing + state bookkeeping on device tensors.  States are float32 (the refer
 float64 NumPy vectors, ao_env.py:909).
 """
 import os
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -75,11 +76,20 @@ class VecRlSupervisor(object):
         # against the reference's traces on a GPU-less box.)
         make = sim_factory if sim_factory is not None else HipSim
         # calibration through the backend (imat_geom, correct_dm, imat, Btt, filtered cmat)
-        cal_sim = make(self.s, nenv=min(512, 2048), device=device, keep_phase=True)
+        # (memoised per geometry / nfilt / backend arithmetic, in the process and on disk: modal.calibrate; the
+        # calibration simulator is only built when the calibration really runs)
         self.n_reverse_filtered_from_cmat = int(self.config_rl["n_reverse_filtered_from_cmat"])
-        self.cal = modal.calibrate(self.s, self.sysm, cal_sim,
-                                   nfilt=max(self.n_reverse_filtered_from_cmat, 0))
-        del cal_sim
+        t_cal = time.perf_counter()
+        if sim_factory is None:
+            from .sim import hip_calibration_id
+            cal_id = hip_calibration_id()
+        else:
+            cal_id = getattr(sim_factory, "calibration_id", None)
+            cal_id = cal_id() if callable(cal_id) else None
+        self.cal = modal.calibrate(self.s, self.sysm,
+                                   lambda: make(self.s, nenv=min(512, 2048), device=device, keep_phase=True),
+                                   nfilt=max(self.n_reverse_filtered_from_cmat, 0), backend_id=cal_id)
+        self.calibration_seconds = time.perf_counter() - t_cal
         self.modes2volts, self.volts2modes = self.cal.modes2volts, self.cal.volts2modes
         self.nmodes = self.volts2modes.shape[0]
         self.n_modes_start_end = list(self.config_rl["n_zernike_start_end"])
@@ -361,7 +371,27 @@ class VecRlSupervisor(object):
                 self.sim.do_control()
         if self.geo is not None and do_control:
             self.geo.next_part_one_geo()            # next_part_one_geo, after controller 0 (:1038-1049)
+        if self.keep_wfs_phase:
+            self._snap_wfs_phase()
         self.iter += 1
+
+    # The phase the sensor saw in the frame just imaged = what COMPASS leaves in d_gs.d_phase behind next_part_one's
+    # raytrace (atmosphere of frame t + the mirrors as the PREVIOUS next_part_two left them); next_part_two only
+    # re-traces the target (rlSupervisor.py:900-947), so wfs.get_wfs_phase(0) read by the rewards behind it
+    # (ao_env.py:736-760) is still that phase.  The one-pass frame kernel never materialises it: with keep_wfs_phase
+    # it is ray-traced once more right behind the frame (screens and mirror shapes are still the frame's) and kept.
+    keep_wfs_phase = False
+    _wfs_phase_frame = None
+
+    def _snap_wfs_phase(self):
+        if self.prefetch_atmos or getattr(self.sim, "pending_atmos", False):
+            raise RuntimeError("keep_wfs_phase: the screens run one frame ahead (prefetch_atmos); build the "
+                               "supervisor with prefetch_atmos=False")
+        self.sim.raytrace_wfs(atm=True, dms=True, reset=True)
+        ph = self.sim.t["wfs_phase"]
+        if self._wfs_phase_frame is None or self._wfs_phase_frame.shape != ph.shape:
+            self._wfs_phase_frame = torch.empty_like(ph)
+        self._wfs_phase_frame.copy_(ph)
 
     def _move_or_keep(self, move_atmos):
         if move_atmos:
@@ -414,10 +444,14 @@ class VecRlSupervisor(object):
         return self.sim.target_image()
 
     def get_wfs_phase(self):
-        """wfsCompass.get_wfs_phase(0): the phase the sensor sees, atmosphere + mirrors, [nenv, n, n] (ray-traced from
-        the state as it stands)."""
-        self.sim.raytrace_wfs(atm=True, dms=True, reset=True)
-        return self.sim.t["wfs_phase"]
+        """wfsCompass.get_wfs_phase(0) (wfsCompass.py:366-372): the phase the sensor saw in the last next_part_one --
+        atmosphere of that frame + the mirrors as they stood THEN, [nenv, n, n].  A command applied since
+        (next_part_two) is not in it, exactly as in the reference, whose next_part_two re-traces the target only.
+        Needs `keep_wfs_phase = True` before the frame (VecAoEnv sets it for the rewards that read it)."""
+        if not self.keep_wfs_phase or self._wfs_phase_frame is None:
+            raise RuntimeError("get_wfs_phase: the frame's sensor phase was not kept (set supervisor.keep_wfs_phase "
+                               "= True before next_part_one; VecAoEnv does for the projection rewards)")
+        return self._wfs_phase_frame
 
     _projector_phase2modes = None
 
@@ -468,8 +502,13 @@ class VecAoEnv(object):
     def __init__(self, parameters_telescope, nenv, config_rl=None, *, normalization_bool=True,
                  initial_seed=1234, seed_stride=16, n_agents_modal=None, device="cuda:0",
                  strehl_halfwin=8, norm=None, zn_norm=None, sim_factory=None, autoencoder=None,
-                 geo=False, prefetch_atmos=True, frame_pipeline="auto", dead_columns="mask",
+                 geo=False, prefetch_atmos=True, frame_pipeline=False, dead_columns="mask",
                  reset_prefetch=None):
+        # frame_pipeline: False (default: the reference's call order; every call-by-call piece -- rl_step,
+        # linear_step, step(linear_control=True), the supervisor's getters -- can be mixed with step() freely),
+        # True (a frame in flight wherever the loop is eligible), or "auto" (True unless a probe of both orders
+        # behind the first reset finds it slower on this process's streams).  bench.py and throughput-minded
+        # trainers opt in; while a frame is in flight the state accepts step() and a full reset() only.
         cfg = dict(DEFAULT_ENV_RL)
         cfg.update(config_rl or {})
         self.config_rl = cfg
@@ -490,6 +529,8 @@ class VecAoEnv(object):
                                           autoencoder=autoencoder, geo=geo,
                                           prefetch_atmos=prefetch_atmos)
         sup = self.supervisor
+        if cfg["reward_type"] in _R.PROJECTION:
+            sup.keep_wfs_phase = True                # these read wfs.get_wfs_phase(0): the frame's sensor phase
         # the next reset's screens grown beside the running episode: None, "same" or the number of seed blocks the
         # trainer moves on by per episode (VecRlSupervisor.reset_prefetch; train_agent sets it)
         sup.reset_prefetch = reset_prefetch
@@ -700,6 +741,7 @@ class VecAoEnv(object):
         zero = torch.zeros(self.nenv, self.action_dim, device=self.device)
         res = {}
         self._probing = True
+        keep_rp, self.supervisor.reset_prefetch = self.supervisor.reset_prefetch, None   # no shadow resets for the probe's resets
         try:
             for name, on in (("plain", False), ("pipelined", True)):      # (the twin of the second pass stays)
                 self.frame_pipeline, self._pipe_checked = on, False
@@ -714,6 +756,7 @@ class VecAoEnv(object):
                 state = self.reset()
         finally:
             self._probing = False
+            self.supervisor.reset_prefetch = keep_rp
         slower = res["pipelined"] > margin * res["plain"]
         res["chosen"] = "plain" if slower else "pipelined"
         if slower:
@@ -837,6 +880,7 @@ class VecAoEnv(object):
         return (self.native_step and self._native_glue and self._default_state_layout and
                 self.modal_shortcut and self._modal_valid and not linear_control and
                 not self.residual_shortcut and sup.geo is None and sup.gain is not None and
+                not sup.keep_wfs_phase and       # (the frame's sensor phase is snapped behind the Python next_part_one)
                 sup.freedom_vector is not None and not sup.next_part_one_split and
                 not sup._control_pending and hasattr(sup.sim, "env_step") and
                 (sup.autoencoder is None or (getattr(sup.autoencoder, "use_native", False) and
@@ -866,7 +910,7 @@ class VecAoEnv(object):
     _out_ring, _out_pos = None, 0
     _pipe_checked = False
 
-    def _step_native(self, action):
+    def _step_native(self, action, out=None):
         sup = self.supervisor
         std = sup.config_rl["normalization_std_inside_environment"]
         mean = sup.config_rl["normalization_mean_inside_environment"]
@@ -893,6 +937,15 @@ class VecAoEnv(object):
                 self._out_pos = 0
             state, r = self._out_ring[self._out_pos]
             self._out_pos = (self._out_pos + 1) % self.OUT_RING
+        elif out is not None:
+            state, r = out
+            ok = lambda t, d: (t.shape == (self.nenv, d) and t.dtype == torch.float32 and t.is_contiguous() and  # noqa: E731
+                               t.device == self.device)
+            if not ok(state, self.state_dim) or (self.layout is not None and not ok(r, self.layout.n_agents)):
+                raise ValueError("step: out = (state [nenv, state_dim], reward [nenv, n_agents]), contiguous float32 on the "
+                                 "environment's device")
+            if self.layout is None:
+                r = None
         else:
             state = torch.empty(self.nenv, self.state_dim, dtype=torch.float32, device=self.device)
             r = None
@@ -1000,15 +1053,23 @@ class VecAoEnv(object):
             return la.agent_rewards(r, self._lohi_i32, self._reward_factor)
         return (r * r) @ self._reward_mat
 
-    def step(self, action, linear_control=False):
-        """TrainerRPC.env_step (train_rpc.py:633-648): (s_next, per-agent reward, done, info)."""
+    def step(self, action, linear_control=False, out=None):
+        """TrainerRPC.env_step (train_rpc.py:633-648): (s_next, per-agent reward, done, info).
+        out = (state [nenv, state_dim], reward [nenv, n_agents]): contiguous float32 device tensors the step writes
+        its results into (rows of a trajectory buffer: a training episode then needs no copy per step)."""
         if self._native_step_ok(linear_control):
-            return self._step_native(action)
+            return self._step_native(action, out)
         _, done, info = self.rl_step(action, linear_control)
         r = self.divide_rewards_for_agents() if self.layout is not None else None
         s_next = self.linear_step()
         if self.supervisor.reset_prefetch is not None:
             self.supervisor.step_done()
+        if out is not None:
+            out[0].copy_(s_next)
+            s_next = out[0]
+            if r is not None and out[1] is not None:
+                out[1].copy_(r)
+                r = out[1]
         return s_next, r, done, info
 
 

@@ -214,9 +214,196 @@ class Calibration(object):
     pass
 
 
-def calibrate(s, sysm, backend, nfilt=0, verbose=False):
+# ------------------------------------------------------------------------------------ calibration cache
+# One calibration of the 40x40 system is 1430 geometric + 2 x 1286 diffractive pushes, a 1284^2 solve + SVD and a
+# 2400 x 1284 least-squares fit: seconds, repeated by every VecRlSupervisor of a process (a test session builds
+# dozens) and by every rank of a multi-GPU job.  The result is a pure function of the system's geometry, the number
+# of filtered modes and the backend's arithmetic, so it is memoised -- in the process, and on disk under a lock (of N
+# ranks started together one calibrates, the others load its file).  A hit replays what calibrate() does to `s` /
+# `sysm` (correct_dm's actuator selection, s.cmat) and returns copies of the same arrays, bit for bit.
+#   AOMARL_CALIB_CACHE=0       no cache at all          AOMARL_CALIB_CACHE=mem   process only
+#   AOMARL_CALIB_CACHE=<dir>   the directory            (default: <tempdir>/ao_marl_amd_calib_<uid>)
+_CAL_MEMO = {}
+_CAL_VERSION = "1"
+cache_stats = {"hit_mem": 0, "hit_disk": 0, "miss": 0, "seconds": 0.0}
+
+
+def _hash_obj(h, name, v, depth=0):
+    import numbers
+    h.update(name.encode())
+    if isinstance(v, np.ndarray):
+        h.update(str((v.dtype.str, v.shape)).encode())
+        h.update(np.ascontiguousarray(v).tobytes())
+    elif isinstance(v, (str, bytes, numbers.Number, type(None), np.generic)):
+        h.update(repr(v).encode())
+    elif isinstance(v, (list, tuple)):
+        for i, x in enumerate(v):
+            _hash_obj(h, "%s[%d]" % (name, i), x, depth + 1)
+    elif isinstance(v, dict):
+        for k in sorted(v):
+            _hash_obj(h, "%s.%s" % (name, k), v[k], depth + 1)
+    elif hasattr(v, "__dict__") and depth < 3:
+        for k in sorted(vars(v)):
+            _hash_obj(h, "%s.%s" % (name, k), getattr(v, k), depth + 1)
+    else:
+        h.update(repr(type(v)).encode())
+
+
+def calibration_key(s, sysm, backend, nfilt, backend_id=None):
+    """sha256 over everything calibrate() reads: pupils, the sensor's maps, every DM, the offsets of the DMs in the
+    sensor's path, nfilt and the backend's identity (`backend_id` or `backend.calibration_id()`: None = not
+    cacheable)."""
+    import hashlib
+    bid = backend_id
+    if bid is None:
+        bid = getattr(backend, "calibration_id", None)
+        bid = bid() if callable(bid) else None
+    if bid is None:
+        return None
+    h = hashlib.sha256()
+    _hash_obj(h, "version", _CAL_VERSION)
+    _hash_obj(h, "backend", bid)
+    _hash_obj(h, "nfilt", int(nfilt))
+    for k in ("n", "pupdiam", "mpupil", "spupil", "nvalid", "pdiam", "nfft", "npix", "nrebin", "nxsub", "phasemap", "halfxy",
+              "binmap", "flux", "nphot", "wfs_lambda", "validsubsx", "validsubsy", "subapd", "cog_offset", "cog_scale",
+              "nslope", "wfs_dm_off", "nactu"):
+        _hash_obj(h, k, getattr(s, k))
+    for i, d in enumerate(s.dms):
+        _hash_obj(h, "dm%d" % i, d)
+    _hash_obj(h, "ipupil", sysm.geom.ipupil)
+    return h.hexdigest()
+
+
+def _cache_dir():
+    import os
+    import tempfile
+    v = os.environ.get("AOMARL_CALIB_CACHE", "")
+    if v in ("0", "mem"):
+        return None
+    if v:
+        return v
+    uid = os.getuid() if hasattr(os, "getuid") else 0
+    return os.path.join(tempfile.gettempdir(), "ao_marl_amd_calib_%d" % uid)
+
+
+_CAL_FIELDS = ("imat_geom", "imat", "Btt", "P", "cmat")
+
+
+def _pack(c):
+    d = {k: getattr(c, k) for k in _CAL_FIELDS}
+    IF = sp.csc_matrix(c.IF)
+    d.update(IF_data=IF.data, IF_indices=IF.indices, IF_indptr=IF.indptr, IF_shape=np.asarray(IF.shape, dtype=np.int64))
+    d["nkept"] = np.asarray(len(c.kept), dtype=np.int64)
+    for i, k in enumerate(c.kept):
+        d["kept%d" % i] = np.asarray(k, dtype=np.int64)
+    return d
+
+
+def _unpack(d):
+    c = Calibration()
+    for k in _CAL_FIELDS:
+        setattr(c, k, np.array(d[k]))
+    c.IF = sp.csc_matrix((np.array(d["IF_data"]), np.array(d["IF_indices"]), np.array(d["IF_indptr"])),
+                         shape=tuple(int(x) for x in d["IF_shape"]))
+    c.kept = [np.array(d["kept%d" % i]) for i in range(int(d["nkept"]))]
+    c.modes2volts, c.volts2modes = c.Btt, c.P
+    return c
+
+
+def _replay(c, s, sysm, backend):
+    """What calibrate() leaves behind in `s` / `sysm` / the backend: the stack-array mirrors reduced to their kept
+    actuators (correct_dm) and the command matrix."""
+    for k, d in enumerate(s.dms):
+        if d.type == "pzt":
+            G.pzt_select(d, sysm.geom, c.kept[k])
+    system.refresh_dms(s)
+    if backend is not None:
+        backend.reload_dms()
+    s.cmat = np.ascontiguousarray(c.cmat)
+    return c
+
+
+class _LazyBackend(object):
+    """A backend built on first use: a cache hit never allocates the calibration simulator."""
+
+    def __init__(self, factory):
+        self.factory, self.obj = factory, None
+
+    def get(self):
+        if self.obj is None:
+            self.obj = self.factory()
+        return self.obj
+
+    def dm_response(self, commands, geometric):
+        return self.get().dm_response(commands, geometric)
+
+    def reload_dms(self):
+        if self.obj is not None:
+            self.obj.reload_dms()
+
+
+def calibrate(s, sysm, backend, nfilt=0, verbose=False, cache=True, backend_id=None):
     """Full init sequence of the controller path; fills s.cmat and returns a Calibration with
-    imat_geom, kept actuators, imat, Btt (= modes2volts), P (= volts2modes), cmat."""
+    imat_geom, kept actuators, imat, Btt (= modes2volts), P (= volts2modes), cmat.  `backend`: an object with
+    dm_response / reload_dms, or a zero-argument factory of one (built only when the calibration really runs).
+    Memoised (see above) when the backend's arithmetic is named (`backend_id`, or `backend.calibration_id()`)."""
+    import os
+    import time
+    t0 = time.perf_counter()
+    if not hasattr(backend, "dm_response"):
+        backend = _LazyBackend(backend)
+    key = None
+    if cache and os.environ.get("AOMARL_CALIB_CACHE", "") != "0":
+        key = calibration_key(s, sysm, backend, nfilt, backend_id)
+    try:
+        if key is None:
+            return _calibrate_now(s, sysm, backend, nfilt, verbose)
+        if key in _CAL_MEMO:
+            cache_stats["hit_mem"] += 1
+            return _replay(_unpack(_CAL_MEMO[key]), s, sysm, backend)
+        cdir = _cache_dir()
+        if cdir is None:
+            c = _calibrate_now(s, sysm, backend, nfilt, verbose)
+            cache_stats["miss"] += 1
+            _CAL_MEMO[key] = _pack(c)
+            return c
+        os.makedirs(cdir, exist_ok=True)
+        path = os.path.join(cdir, key + ".npz")
+        lock = open(os.path.join(cdir, key + ".lock"), "w")
+        try:
+            try:
+                import fcntl
+                fcntl.flock(lock, fcntl.LOCK_EX)        # of N ranks one calibrates, the others wait here and load
+            except ImportError:                         # pragma: no cover
+                pass
+            if os.path.exists(path):
+                try:
+                    with np.load(path) as z:
+                        d = {k: z[k] for k in z.files}
+                    _CAL_MEMO[key] = d
+                    cache_stats["hit_disk"] += 1
+                    return _replay(_unpack(d), s, sysm, backend)
+                except Exception:                       # a damaged file: calibrate and replace it
+                    pass
+            c = _calibrate_now(s, sysm, backend, nfilt, verbose)
+            cache_stats["miss"] += 1
+            d = _pack(c)
+            _CAL_MEMO[key] = d
+            tmp = path + ".tmp%d" % os.getpid()
+            try:
+                with open(tmp, "wb") as f:
+                    np.savez(f, **d)
+                os.replace(tmp, path)
+            except OSError:                             # a read-only cache directory is not an error
+                pass
+            return c
+        finally:
+            lock.close()
+    finally:
+        cache_stats["seconds"] += time.perf_counter() - t0
+
+
+def _calibrate_now(s, sysm, backend, nfilt=0, verbose=False):
     c = Calibration()
     c.imat_geom = imat_geom(s, backend)
     c.kept = correct_dm(s, sysm, c.imat_geom, backend)

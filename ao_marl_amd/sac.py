@@ -142,6 +142,42 @@ class BatchedReplay(object):
                              device=self.device)
 
 
+class TrajectoryReplay(object):
+    """One episode's transitions WITHOUT a copy per step: the environment writes every state and reward, the policy
+    every action, straight into trajectory buffers S [T + 1][nenv][state_dim], A [T][nenv][action_dim],
+    R [T][nenv][n_agents]; the delayed-MDP tuple stored at step t >= n (environment/delayed_mdp.py:5-58,
+    manage_memory train_rpc.py:734-757: state and action of step t - n, next state and reward of step t, n = delay +
+    not modification_online) is then four VIEWS of those buffers n rows of the batch apart.  Offers what
+    BatchedSAC.update_parameters reads of a master memory: len(), rows(begin, count), reset().
+    Why: on the stepping stream every extra launch joins the control / agent chain of the frame in flight and waits
+    tens of microseconds for wave slots beside the frame kernel (0.49 -> 0.65 ms per step with the four slice copies
+    and the return accumulation in line, tools/episode_probe.py)."""
+
+    def __init__(self, state_dim, action_dim, n_agents, max_steps, nenv, lag, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.T, self.nenv, self.lag = int(max_steps), int(nenv), int(lag)
+        self.S = torch.empty(self.T + 1, nenv, state_dim, **f32)
+        self.A = torch.empty(self.T, nenv, action_dim, **f32)
+        self.R = torch.empty(self.T, nenv, n_agents, **f32)
+        self._ones = torch.ones(self.T * nenv, 1, **f32)
+        self.t = 0                          # steps taken
+
+    def __len__(self):
+        return max(0, self.t - self.lag) * self.nenv
+
+    def reset(self):
+        self.t = 0
+
+    def rows(self, begin, count):
+        n, k = self.nenv, self.lag * self.nenv
+        flat = lambda x: x.reshape(-1, x.shape[-1])      # noqa: E731
+        S, A, R = flat(self.S), flat(self.A), flat(self.R)
+        if begin < 0 or begin + count > len(self):
+            raise IndexError("rows [%d, %d) of %d" % (begin, begin + count, len(self)))
+        return (S[begin:begin + count], A[begin:begin + count], R[begin + k:begin + k + count],
+                S[begin + k:begin + k + count], self._ones[begin:begin + count])
+
+
 class _StackedLinearHip(torch.autograd.Function):
     """act(x W + b) for all agents at once on the library's batched GEMM (aomarl_gemm_batched):
     x [A, B, in], W [A, in, out], b [A, 1, out].  Backward: dx = dy W^T, dW = x^T dy, db = sum dy,
@@ -701,23 +737,44 @@ class BatchedSAC(object):
 
 
 def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_control=False,
-                master=None, n_updates=None, batch_size=None):
+                master=None, n_updates=None, batch_size=None, timing=None):
     """TrainerRPC.episode (train=True) / test_episode (train=False), batched over env.nenv
     environments (train_rpc.py:503-547, 549-603).  Returns a dict of device tensors:
-    r_total [nenv], r_per_agent [nenv, A], sr_le [nenv], sr_se_mean [nenv] (+ updates done)."""
+    r_total [nenv], r_per_agent [nenv, A], sr_le [nenv], sr_se_mean [nenv] (test episodes: the training episode
+    reads the Strehl once, at its end, like the reference's :546-549) (+ updates done).
+    timing: a dict that receives `steps_s` / `updates_s` (one extra device synchronisation between the phases)."""
+    import time as _time
+    t_begin = _time.perf_counter()
     from .env import DelayedMDP
     cfg = env.config_rl
     max_steps = max_steps or cfg["max_steps_per_episode"]
     s = env.reset()
     mdp = DelayedMDP(cfg["delayed_assignment"], cfg["modification_online"])
-    if train and master is None:
-        master = BatchedReplay(env.layout.state_dim, env.layout.action_dim, env.layout.n_agents,
-                               max_steps * env.nenv, env.device)
     r_agents = torch.zeros(env.nenv, env.layout.n_agents, device=env.device)
     sr_se = torch.zeros(env.nenv, device=env.device)
     geo = getattr(env.supervisor, "geo", None) if not train else None
     geo_prev, geo_sq = None, None
-    for _ in range(max_steps):
+    # A training episode on the GPU keeps its transitions in trajectory buffers the step writes into directly
+    # (TrajectoryReplay: no launch per step beyond the actor and the environment); episodes with a caller's master
+    # memory, on the CPU stand-in or with the integrator alone take the reference's bookkeeping step by step.
+    traj = None
+    if train and master is None and not linear_control and env.device.type == "cuda" and \
+            not getattr(env.supervisor.sim, "graph_step", False):
+        traj = TrajectoryReplay(env.layout.state_dim, env.layout.action_dim, env.layout.n_agents, max_steps, env.nenv,
+                                mdp._n, env.device)
+        traj.S[0].copy_(s)
+        s = traj.S[0]
+        master = traj
+    elif train and master is None:
+        master = BatchedReplay(env.layout.state_dim, env.layout.action_dim, env.layout.n_agents,
+                               max_steps * env.nenv, env.device)
+    for t in range(max_steps):
+        if traj is not None:
+            a, mu = sac.policy.select_action(s, eval_mode=eval_mode, out=traj.A[t])
+            s_next, r, done, _ = env.step(a, out=(traj.S[t + 1], traj.R[t]))
+            traj.t = t + 1
+            s = s_next
+            continue
         if linear_control:
             a = None
         else:
@@ -729,7 +786,8 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
                 master.push(s0, a0, r, s2, float(not done))
             mdp.save(s, a, s_next)                                 # manage_delayed_mdp
         r_agents += r
-        sr_se += env.supervisor.get_strehl()[:, 0]
+        if not train:                       # test_episode's per-step short-exposure Strehl (:583-584)
+            sr_se += env.supervisor.get_strehl()[:, 0]
         if geo is not None:                 # test_episode: v2m . rtc.get_command(1) per step
             gm = env.supervisor.sim.volts2modes(env.supervisor.get_command(1))
             if geo_prev is not None:
@@ -737,6 +795,8 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
                 geo_sq = d * d if geo_sq is None else geo_sq + d * d
             geo_prev = gm
         s = s_next
+    if traj is not None:
+        r_agents = traj.R[:traj.t].sum(dim=0)
     out = dict(r_total=r_agents.sum(dim=1), r_per_agent=r_agents,
                sr_le=env.supervisor.get_strehl()[:, 1].clone(), sr_se_mean=sr_se / max_steps)
     if geo is not None and geo_sq is not None:
@@ -750,9 +810,15 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
     from .dist import gather_episode_returns
     out["r_total_all"] = gather_episode_returns(out["r_total"])
     out["sr_le_all"] = gather_episode_returns(out["sr_le"])
+    if timing is not None:
+        torch.cuda.synchronize(env.device)
+        timing["steps_s"] = _time.perf_counter() - t_begin
     if train:
         out["updates"] = sac.update_parameters(master, batch_size=batch_size, n_updates=n_updates)
         master.reset()
+        if timing is not None:
+            torch.cuda.synchronize(env.device)
+            timing["updates_s"] = _time.perf_counter() - t_begin - timing["steps_s"]
     return out
 
 

@@ -23,6 +23,14 @@ def _ld4(n):
     return (n + 3) & ~3
 
 
+def hip_calibration_id():
+    """What names the arithmetic of a calibration through this backend (modal.calibrate's cache key): the library
+    file (path, size, modification time) and its precision mode."""
+    import os
+    st = os.stat(la.LIB_PATH)
+    return ("hip", os.path.abspath(la.LIB_PATH), int(st.st_size), int(st.st_mtime_ns), str(la.get_precision()))
+
+
 class HipSim(object):
     def __init__(self, s, nenv, device="cuda:0", keep_bincube=False, keep_phase=False):
         if not torch.cuda.is_available():
@@ -303,6 +311,10 @@ class HipSim(object):
         la.check(self.lib.aomarl_set_modal(self.ctx, nm, la.fptr(v2m), la.fptr(m2v), la.fptr(fr),
                                            int(am.size), la.iptr(am) if am.size else None))
         self.nmodes, self.nact = nm, int(am.size)
+
+    @staticmethod
+    def calibration_id():
+        return hip_calibration_id()
 
     def reload_dms(self):
         """After actuator filtering changed s.dms: rebuild the static description + state."""

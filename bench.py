@@ -60,7 +60,7 @@ SMALL = "production_sh_10x10_2m"
 NOISY = "production_sh_40x40_8m_3layers_d0_noise"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
-PMC_FILE = "r04_pmc_frame_kernel.json"
+PMC_FILE = None              # default: the newest profiles/r*_pmc_frame_kernel.json (by round tag)
 
 
 def parse_args():
@@ -110,7 +110,13 @@ def parse_args():
     ap.add_argument("--precision", default="f32", choices=("f32", "split_f16"),
                     help="arithmetic of the MAIN timed pass (libaomarl.set_precision); f32 is the reference's")
     ap.add_argument("--pmc", default=PMC_FILE,
-                    help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes")
+                    help="profiles/<file> with the HBM bytes per launch from rocprofv3 --pmc passes (default: the newest "
+                         "profiles/r*_pmc_frame_kernel.json)")
+    ap.add_argument("--random-actor", action="store_true",
+                    help="actors with a random last layer (rounds 1-4's bench policy: state-dependent actions at full scale, "
+                         "the loop does not stay closed) instead of SURVEY 8(d)'s policy (Xavier, seed 1234, last layer zero)")
+    ap.add_argument("--no-episode-end-to-end", action="store_true",
+                    help="skip the measured training episode (reset + episode_len steps + episode_len SAC updates)")
     return ap.parse_args()
 
 
@@ -288,12 +294,49 @@ def sac_update_rate(layout, device, n_updates=100, batch=256, rows=20000):
             "batch_per_agent": batch, "updates_per_s": 1e3 / ms, "kernel": "aomarl_sac_update"}
 
 
+def episode_end_to_end(env, layout, device, episode_len, batch=256):
+    """The episode a trainer sees, as the reference runs and prints it (train_rpc.py:503-549: env.reset, max_steps x
+    (choose_action, env_step, replay bookkeeping), then update_all_agents = `updates_per_episode_rpc` SAC updates per
+    agent, :1084-1133; wall time printed at :546-549): ao_marl_amd.sac.run_episode on this environment -- reset +
+    episode_len steps with sampled actions and the delayed-MDP replay writes + episode_len updates of every agent on
+    batches of `batch` -- between two device synchronisations."""
+    import torch
+    from ao_marl_amd.sac import BatchedSAC, run_episode
+    rows = env.nenv * episode_len
+    sac = BatchedSAC(layout, dict(memory_size=rows), device=device)
+    run_episode(env, sac, max_steps=12, train=True, n_updates=12, batch_size=batch)     # allocations, first launches
+    gc.collect()
+    gc.disable()
+    try:
+        tm = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run_episode(env, sac, max_steps=episode_len, train=True, n_updates=episode_len, batch_size=batch, timing=tm)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    res = {"seconds": dt, "steps": episode_len, "updates": int(out["updates"]), "envs": env.nenv,
+           "agents": layout.n_agents, "batch_per_agent": batch,
+           "reset_and_steps_s": tm.get("steps_s"), "updates_s": tm.get("updates_s"),
+           "env_steps_per_s": env.nenv * episode_len / dt,
+           "mean_strehl_le": float(out["sr_le"].mean()), "mean_return": float(out["r_total"].mean()),
+           "what": "reset + %d x (actor forward with sampled actions, env step, delayed-MDP replay write) + %d SAC updates "
+                   "of %d agents (batch %d each) between two synchronisations: the reference's printed episode time "
+                   "(train_rpc.py:503-549, 1084-1133)" % (episode_len, episode_len, layout.n_agents, batch)}
+    del sac
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return res
+
+
 # ------------------------------------------------------------------------------------ one workload
 class Workload(object):
     """A VecAoEnv + random-init batched SAC actors for one BASELINE configuration."""
 
     def __init__(self, config, envs, rank, world, device, denoiser=None, prefetch=True, pipeline="auto",
-                 reset_prefetch=None, agents=None):
+                 reset_prefetch=None, agents=None, random_actor=False):
         import torch
         from ao_marl_amd.agents import BatchedGaussianPolicy
         from ao_marl_amd.env import VecAoEnv, load_norm
@@ -327,11 +370,16 @@ class Workload(object):
                             prefetch_atmos=prefetch, frame_pipeline=pipeline if prefetch else False,
                             reset_prefetch=reset_prefetch, **norm_kw)
         self.layout = self.env.layout
-        # random-init actors (last layer NOT zeroed, so actions are non-trivial): the cost of a step
-        # does not depend on the weights; the loop is not expected to converge (Strehl is reported
-        # only to show the numbers are finite)
-        self.policy = BatchedGaussianPolicy(self.layout, last_layer_zero=False, seed=1234 + rank,
+        # SURVEY 8(d)'s policy = the reference's at the start of training: Xavier-uniform weights, seed 1234, last
+        # layer zero (model_rpc.py:10-14,103-106, `initialize_last_layer_0: True`), actions SAMPLED as the trainer
+        # does (mean 0, log_std 0: a = tanh(N(0, 1)) x freedom vector) -- exploration noise on top of the closed
+        # integrator loop.  random_actor: the last layer random too (rounds 1-4), state-dependent actions at full scale
+        self.init_s = 0.0
+        self.policy = BatchedGaussianPolicy(self.layout, last_layer_zero=not random_actor, seed=1234 + rank,
                                             device=device)
+        self.policy_name = ("random-init actors, last layer random (--random-actor)" if random_actor else
+                            "Xavier-uniform, seed 1234, last layer zero, sampled actions (the reference's policy at the "
+                            "start of training, model_rpc.py:10-14,103-106)")
         self.sim = self.env.supervisor.sim
         self.state = None
         self.torch = torch
@@ -343,14 +391,19 @@ class Workload(object):
         a, _ = self.policy.select_action(self.state)
         self.state, self.last_r, _, _ = self.env.step(a)
 
+    def one_step_integrator(self):
+        # TrainerRPC.env_step(a=None, linear_control=True): the integrator alone (train_rpc.py:577-578)
+        self.state, self.last_r, _, _ = self.env.step(None, linear_control=True)
+
     def reset(self):
         self.state = self.env.reset()
 
-    def timed(self, steps, warmup, dist=None, backend="nccl", time_frame=True, settle=0):
+    def timed(self, steps, warmup, dist=None, backend="nccl", time_frame=True, settle=0, step=None):
         """`settle` untimed steps (timed on their own: self.settle_s), W untimed warm-up steps, then exactly K timed
         steps between barriers + synchronisations.  Returns (elapsed s -- MAX over ranks --, host enqueue s,
         frame-kernel ms per launch from the library's events)."""
         torch = self.torch
+        one_step = step or self.one_step
         # no cyclic-garbage collection inside the timed region: a collection that frees an earlier
         # configuration's device buffers (hipFree synchronises the device) would be charged to this one
         gc.collect()
@@ -361,11 +414,11 @@ class Workload(object):
                 torch.cuda.synchronize()
                 ts = time.perf_counter()
                 for _ in range(settle):
-                    self.one_step()
+                    one_step()
                 torch.cuda.synchronize()
                 self.settle_s = time.perf_counter() - ts
             for _ in range(warmup):
-                self.one_step()
+                one_step()
             torch.cuda.synchronize()
             if time_frame:
                 self.sim.set_option("time_frame_kernel", steps)
@@ -375,7 +428,7 @@ class Workload(object):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
-                self.one_step()
+                one_step()
             t_enq = time.perf_counter() - t0
             torch.cuda.synchronize()
             if dist is not None:
@@ -570,10 +623,14 @@ def main():
     if denoiser == "golden":                # the old spelling
         denoiser = "shipped"
     libaomarl.set_precision(args.precision)
+    t_init = time.perf_counter()
     w = Workload(args.config, args.envs, rank, world, device, denoiser=denoiser,
                  prefetch=not args.no_prefetch,
                  pipeline=False if args.no_frame_pipeline else (True if args.frame_pipeline_always else "auto"),
-                 reset_prefetch="same" if (args.reset_prefetch and not args.no_prefetch) else None)
+                 reset_prefetch="same" if (args.reset_prefetch and not args.no_prefetch) else None,
+                 random_actor=args.random_actor)
+    torch.cuda.synchronize()
+    init_s = time.perf_counter() - t_init
     env, sim, layout = w.env, w.sim, w.layout
     env.residual_shortcut = bool(args.residual_shortcut)
     if args.unfused:
@@ -608,9 +665,14 @@ def main():
     # (here: the reward of the last step summed over agents, and the long-exposure Strehl)
     ret_all = gather_episode_returns(w.last_r.sum(dim=1))
     sr_all = gather_episode_returns(sim.strehl[:, 1].contiguous())
+    from ao_marl_amd import modal as _modal
     shards = [dict(rank=rank, first_seed=int(w.first_seed), envs=args.envs,
                    ms_per_step=w.local_elapsed / args.steps * 1e3, frame_kernel_ms=fk_ms,
-                   device=torch.cuda.get_device_name(dev_index))]
+                   device=torch.cuda.get_device_name(dev_index),
+                   # start-up of this rank: geometry + calibration (memoised on disk under a lock: of N ranks one
+                   # calibrates, the others load) + simulator state
+                   init_s=init_s, calibration_s=float(getattr(w.env.supervisor, "calibration_seconds", 0.0)),
+                   calibration_cache=dict(_modal.cache_stats))]
     if dist is not None:
         got = [None] * world
         dist.all_gather_object(got, shards[0])
@@ -630,21 +692,9 @@ def main():
                                                                 "screens grown beside that episode" if rp_on else "")}
         if rp_on:
             reset_s = rs
-    elif rp_on:
-        reset_s = 0.0 if args.timed_only else reset_open_s
+    # (reset prefetch on but no whole episode measured: the prefetched reset's cost is unknown -- amortise the reset in
+    # the open, an upper bound, rather than nothing)
     value = amortised(envs_total, args.steps, elapsed, reset_s + transient_s, args.episode_len)
-    # side figure: the same whole episode with the NEXT reset's rounds hidden beside it (single-GPU runs)
-    rp_side = None
-    if whole is not None and not rp_on and dist is None and not args.no_prefetch:
-        try:
-            env.supervisor.reset_prefetch = "same"
-            w.time_episode(args.episode_len)             # (begins the prefetch, runs it to its end)
-            ep2, rs2 = w.time_episode(args.episode_len, split_reset=True)
-            rp_side = {"whole_episode_value": envs_total * args.episode_len / ep2, "ms_per_step": ep2 / args.episode_len * 1e3,
-                       "reset_ms": rs2 * 1e3, "prefetched_resets": int(getattr(sim, "prefetched_resets", 0))}
-        finally:
-            env.supervisor.reset_prefetch = None
-            w.reset()
     # the same steps in the plain call order (frame kernel alone on the GPU, the chains behind it): what the
     # pipeline buys, and the frame kernel's duration without the chains' kernels beside it
     plain = None
@@ -663,6 +713,42 @@ def main():
         sim.set_option("frame_pipeline", 1)
         if not (plain["frame_kernel_ms"] and pipe_state[0]):
             plain = None                    # (this rank ran in the plain order anyway)
+    # the integrator alone (a=None, linear_control=True: train_rpc.py:577-578; the reference's evaluation baseline and
+    # its normalisation runs), plain call order (the call-by-call step), from a reset: a closed loop's Strehl beside
+    # the policy's
+    integ = None
+    if not args.timed_only and denoiser is None:
+        if pipe_state[0]:
+            sim.set_option("frame_pipeline", 0)
+        try:
+            w.reset()
+            k_i = min(args.steps, 40)
+            e_i, _, fk_i = w.timed(k_i, min(args.warmup, 5), dist, backend, settle=args.settle, step=w.one_step_integrator)
+            integ = {"ms_per_step_no_reset": e_i / k_i * 1e3, "value_no_reset": envs_total * k_i / e_i, "steps": k_i,
+                     "frame_kernel_ms": fk_i, "mean_strehl_le": float(sim.strehl[:, 1].mean()),
+                     "mean_strehl_se": float(sim.strehl[:, 0].mean()),
+                     "frames_behind_reset": args.settle + min(args.warmup, 5) + k_i,
+                     "what": "TrainerRPC.env_step(a=None, linear_control=True): no actor, no rl_control; call-by-call "
+                             "(plain order); Strehl: long exposure over all frames since the reset (the closing "
+                             "transient included) and the last frame's short exposure"}
+        except Exception as e:                      # side figure
+            integ = {"error": str(e)[:200]}
+        finally:
+            w.reset()
+            if pipe_state[0]:
+                sim.set_option("frame_pipeline", 1)
+    # side figure: the same whole episode with the NEXT reset's rounds hidden beside it (single-GPU runs)
+    rp_side = None
+    if whole is not None and not rp_on and dist is None and not args.no_prefetch:
+        try:
+            env.supervisor.reset_prefetch = "same"
+            w.time_episode(args.episode_len)             # (begins the prefetch, runs it to its end)
+            ep2, rs2 = w.time_episode(args.episode_len, split_reset=True)
+            rp_side = {"whole_episode_value": envs_total * args.episode_len / ep2, "ms_per_step": ep2 / args.episode_len * 1e3,
+                       "reset_ms": rs2 * 1e3, "prefetched_resets": int(getattr(sim, "prefetched_resets", 0))}
+        finally:
+            env.supervisor.reset_prefetch = None
+            w.reset()
     # diagnostic pass (outside `value`): every stage with its own event pair (call by call: behind a reset
     # when the timed steps left a pipelined frame in flight)
     if pipe_state[0] and args.timed_only:
@@ -692,7 +778,7 @@ def main():
                        "envs_per_gpu": args.envs, "agents": layout.n_agents,
                        "state_dims": layout.state_shapes()[:1] + layout.state_shapes()[-1:],
                        "action_dim": layout.action_dim, "episode_len": args.episode_len,
-                       "policy": "random-init actors (step cost does not depend on the weights)",
+                       "policy": w.policy_name,
                        "parallelism": "independent env shards x%d" % world},
             "value_no_reset": envs_total * args.steps / elapsed,
             "ms_per_step_no_reset": elapsed / args.steps * 1e3,
@@ -719,6 +805,7 @@ def main():
                                        "chains beside them (aomarl_set_frame_pipeline)"},
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "mean_strehl_le": sr,
+            "integrator_only": integ,
             "gathered": {"n": int(ret_all.numel()), "mean_last_step_reward": float(ret_all.mean()),
                          "mean_strehl_le": float(sr_all.mean())},
             "shards": shards,
@@ -750,6 +837,11 @@ def main():
             out["sac_update"] = sac_update_rate(layout, device) if main_is_headline else None
         except Exception as e:                      # secondary figure: never fail the bench line
             out["sac_update"] = {"error": str(e)[:200]}
+        if main_is_headline and not args.no_episode_end_to_end and not args.timed_only:
+            try:
+                out["episode_end_to_end"] = episode_end_to_end(env, layout, device, args.episode_len)
+            except Exception as e:
+                out["episode_end_to_end"] = {"error": str(e)[:300]}
         s_main = env.supervisor.s
         del w, env, sim
         gc.collect()
@@ -818,6 +910,14 @@ def pmc_traffic(fname, kernel_name, envs, config):
     tools/fw_pmc.sh + tools/fw_pmc.py).  None unless the file was measured on the kernel instantiation and the
     configuration this run launched."""
     try:
+        if not fname:
+            import glob
+            import re
+            cands = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_frame_kernel.json"))
+            if not cands:
+                return None
+            tag = lambda f: re.match(r"r(\d+)([a-z]*)_", os.path.basename(f))      # noqa: E731
+            fname = os.path.basename(max(cands, key=lambda f: (int(tag(f).group(1)), tag(f).group(2))))
         pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
         if pmc.get("_config") != config:
             return None

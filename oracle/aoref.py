@@ -119,7 +119,9 @@ class OracleSim(object):
         self.voltage = np.zeros(n, dtype=np.float32)
 
     # ---------------------------------------------------------------- reset (A1)
-    def reset(self, seed):
+    def reset(self, seed, grown=None):
+        """grown = (screens, ext_count) of an earlier reset with this seed: restored instead of extruded again (a test
+        session resets the same 40x40 seeds many times; 3 x 1296 extrusions each)."""
         s = self.s
         self.seed = int(seed)
         self.accumx = np.zeros(s.nscreens, dtype=np.float32)
@@ -127,6 +129,10 @@ class OracleSim(object):
         self.ext_count = [0] * s.nscreens
         self.frame = 0
         for l in range(s.nscreens):
+            if grown is not None:
+                self.screens[l][:] = grown[0][l]
+                self.ext_count[l] = int(grown[1][l])
+                continue
             self.screens[l][:] = 0
             d = 1 if s.deltax[l] > 0 else -1
             for _ in range(2 * s.screen_dim[l]):

@@ -48,3 +48,14 @@ def calibrated(name="production_sh_10x10_2m", nfilt=5, hw=8):
 def uncalibrated(name="production_sh_10x10_2m", hw=8):
     sysm = G.build_system(params.builtin(name))
     return sysm, system.from_system(sysm, strehl_halfwin=hw)
+
+
+def calibrated_hip(name, nfilt=5, hw=8):
+    """(sysm, SimArrays, Calibration) calibrated through the HIP backend (GPU tests of the large system: the oracle
+    backend needs minutes for its 1286 actuators; memoised by modal.calibrate)."""
+    from ao_marl_amd.sim import HipSim
+    sysm = G.build_system(params.builtin(name))
+    s = system.from_system(sysm, strehl_halfwin=hw)
+    cal = modal.calibrate(s, sysm, lambda: HipSim(s, nenv=512, keep_phase=True), nfilt=nfilt,
+                          backend_id=HipSim.calibration_id())
+    return sysm, s, cal

@@ -12,7 +12,7 @@ class _Sim(aoref.OracleSim):
         self._lazy = lazy
         aoref.OracleSim.__init__(self, s, seed=0)
 
-    def reset(self, seed):
+    def reset(self, seed, grown=None):
         if self._lazy:              # construction: no screen generation yet
             self.seed, self.frame = int(seed), 0
             self.accumx = np.zeros(self.s.nscreens, dtype=np.float32)
@@ -22,7 +22,7 @@ class _Sim(aoref.OracleSim):
             self.reset_strehl()
             self._lazy = False
             return
-        aoref.OracleSim.reset(self, seed)
+        aoref.OracleSim.reset(self, seed, grown)
 
 
 class OracleVecSim(object):
@@ -142,6 +142,22 @@ class OracleVecSim(object):
 
     def volts2modes(self, vec):
         return torch.from_numpy(np.asarray(vec, dtype=np.float32) @ self.v2m.T)
+
+    # the sensor's phase, as HipSim exposes it: raytrace_wfs fills t["wfs_phase"]
+    def raytrace_wfs(self, atm=True, dms=True, reset=True, env_begin=0, env_count=None):
+        n = self.nenv if env_count is None else env_count
+        for o in self.sims[env_begin:env_begin + n]:
+            o.raytrace_wfs(atm=atm, dms=dms, reset=reset)
+
+    @property
+    def t(self):
+        return {"wfs_phase": self._stack("wfs_phase")}
+
+    def comp_dm_shape(self, volts, env_begin=0, env_count=None):
+        v = np.asarray(volts, dtype=np.float32)
+        n = self.nenv if env_count is None else env_count
+        for i, o in enumerate(self.sims[env_begin:env_begin + n]):
+            o.comp_shapes(v[i])
 
     def dm_response(self, commands, geometric):
         return self.sims[0].dm_response(np.ascontiguousarray(commands, dtype=np.float32), geometric)

@@ -734,7 +734,7 @@ def test_small_chain_equals_the_general_chain_to_rounding():
 
 
 def test_default_call_order_is_probed_and_falls_back_loudly():
-    """VecAoEnv() default, frame_pipeline='auto': behind the first reset of an eligible environment both call orders
+    """VecAoEnv(frame_pipeline='auto') (opt-in; the constructor's default is the plain order): behind the first reset of an eligible environment both call orders
     are timed on the caller's stream and the pipelined one is kept unless it is the slower one; the fallback (forced
     here through the probe's margin) warns, drops the twin and runs the plain order.  Either way the episode is the
     plain order's, bit for bit; an environment that is not eligible (noisy sensor) never probes."""
@@ -742,7 +742,9 @@ def test_default_call_order_is_probed_and_falls_back_loudly():
     rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
     VecAoEnv._ORDER_CACHE.clear()
     ref = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1, frame_pipeline=False)
-    auto = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1)
+    assert ref.frame_pipeline is False
+    assert VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1).frame_pipeline is False   # the default
+    auto = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1, frame_pipeline="auto")
     assert auto.frame_pipeline == "auto" and auto.order_probe is None
     s0, s1 = ref.reset(), auto.reset()
     assert ref.order_probe is None
@@ -758,12 +760,12 @@ def test_default_call_order_is_probed_and_falls_back_loudly():
     if auto.frame_pipeline:
         assert auto.supervisor.sim.frame_pipeline_state()[2] >= 10         # pipelined steps were taken
     # a second environment on the same stream reuses the decision
-    again = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1)
+    again = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1, frame_pipeline="auto")
     again.reset()
     assert again.order_probe.get("cached") and again.frame_pipeline is auto.frame_pipeline
     # the fallback, forced: nothing is 'not more than 0 x slower'
     VecAoEnv._ORDER_CACHE.clear()
-    fb = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1)
+    fb = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1, frame_pipeline="auto")
     fb.frame_pipeline = False
     s2 = fb.reset()
     fb.frame_pipeline = "auto"
@@ -780,7 +782,8 @@ def test_default_call_order_is_probed_and_falls_back_loudly():
     VecAoEnv._ORDER_CACHE.clear()
     # not eligible: no probe, plain order
     noisy = VecAoEnv("production_sh_40x40_8m_3layers_d1_noise", 2,
-                     dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5), n_agents_modal=13)
+                     dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5), n_agents_modal=13,
+                     frame_pipeline="auto")
     noisy.reset()
     assert noisy.frame_pipeline is False and noisy.order_probe is None
 
@@ -793,7 +796,7 @@ def test_prefetched_reset_is_the_plain_reset_bit_for_bit(name, nenv):
     disturbed; a reset that comes before the rounds are through runs what is left; other seeds drop the prefetch.
     32 environments of the 40x40 system: the reset walks its rounds in two parts of the batch (reset_streams)."""
     from ao_marl_amd.sim import HipSim
-    _, s, cal = helpers.calibrated(name)
+    _, s, cal = helpers.calibrated(name) if "10x10" in name else helpers.calibrated_hip(name)
     sims = []
     for _ in range(2):
         sim = HipSim(s, nenv=nenv)

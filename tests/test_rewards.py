@@ -195,14 +195,51 @@ def test_full_frame_image_and_projection_rewards_on_the_device():
         blk = slice(0, sup.nmodes - 2) if mode < sup.nmodes - 2 else slice(sup.nmodes - 2, sup.nmodes)
         e = np.zeros(sup.nmodes); e[mode] = 1.0
         assert np.abs(got[blk] - e[blk]).max() < 2e-3, (mode, np.abs(got[blk] - e[blk]).max())
-    env.reset()
-    env.step(torch.zeros(2, env.action_dim, device="cuda:0"))
-    ph = sup.get_wfs_phase().clone()
-    ph = (ph - ph.mean(dim=(1, 2), keepdim=True)).reshape(2, -1).cpu().numpy().astype(np.float64)[:, pup]
-    proj = -(ph @ P.T)
-    cur = sup.get_voltages().cpu().numpy().astype(np.float64) @ np.asarray(sup.volts2modes, dtype=np.float64).T
-    rng = np.asarray(sup.obtain_action_range_modal())
-    np.testing.assert_allclose(env.calculate_reward("projection_comparison").cpu().numpy(),
-                               -np.linalg.norm(proj[:, rng] - cur[:, rng], axis=1), rtol=2e-3)
-    np.testing.assert_allclose(env.calculate_reward("weighted_projection_comparison").cpu().numpy(),
-                               -np.linalg.norm((proj[:, rng] - cur[:, rng]) * np.asarray(sup.freedom_vector)[rng], axis=1), rtol=2e-3)
+    # The two projection rewards read wfs.get_wfs_phase(0) BEHIND next_part_two (ao_env.py:736-760 called from rl_step,
+    # :911-939): COMPASS's d_gs.d_phase as next_part_one's raytrace left it -- atmosphere of the frame + the mirrors
+    # of the PREVIOUS command; next_part_two re-traces the target only.  The oracle holds exactly that buffer
+    # (OracleSim.wfs_phase, written by its next_part_one, never by next_part_two), the environment under test is
+    # the HIP one, and the current modes come from the voltages the new command produced.
+    assert sup.keep_wfs_phase is False
+    with pytest.raises(RuntimeError, match="keep_wfs_phase"):
+        sup.get_wfs_phase()
+    rl2 = dict(rl, reward_type="projection_comparison")
+    env2 = VecAoEnv("production_sh_10x10_2m", 2, rl2, initial_seed=21)
+    assert env2.supervisor.keep_wfs_phase and env2.supervisor.prefetch_atmos is False and env2.frame_pipeline is False
+    sup2 = env2.supervisor
+    sup2._projector_phase2modes = sup.projector_phase2modes            # (built above on an idle simulator)
+    env2.reset(); oenv.reset()
+    g = torch.Generator().manual_seed(8)
+    rng = np.asarray(sup2.obtain_action_range_modal())
+    v2m = np.asarray(sup2.volts2modes, dtype=np.float64)
+    for it in range(3):
+        a = torch.rand(2, env2.action_dim, generator=g) * 2 - 1
+        env2.step(a.cuda()); oenv.step(a)
+        osims = oenv.supervisor.sim.sims
+        ph = np.stack([o.wfs_phase for o in osims]).astype(np.float64)             # left by the ORACLE's next_part_one
+        # the kept phase IS that buffer (fp32 round-off of two closed loops a few frames on, microns)
+        assert np.abs(sup2.get_wfs_phase().cpu().numpy().astype(np.float64) - ph).max() < 1e-3
+        ph = (ph - ph.mean(axis=(1, 2), keepdims=True)).reshape(2, -1)[:, pup]
+        proj = -(ph @ P.T)
+        # rl_step's reward is computed behind next_part_two and before the next linear_step; step() has already run
+        # that linear_step, so restate it: the phase of the frame just imaged against the voltages now on the mirrors
+        cur = np.stack([o.voltage for o in osims]).astype(np.float64) @ v2m.T
+        want = -np.linalg.norm(proj[:, rng] - cur[:, rng], axis=1)
+        got = env2.calculate_reward("projection_comparison").cpu().numpy()
+        # (the reward is a norm of DIFFERENCES of two mode vectors several times larger: 1e-3 um of phase shows up as
+        # ~1 % of it; a re-trace with the new mirror shapes -- round 4's reading -- is off by the whole increment)
+        np.testing.assert_allclose(got, want, rtol=3e-2)
+        wantw = -np.linalg.norm((proj[:, rng] - cur[:, rng]) * np.asarray(sup2.freedom_vector)[rng], axis=1)
+        np.testing.assert_allclose(env2.calculate_reward("weighted_projection_comparison").cpu().numpy(), wantw, rtol=3e-2)
+    # and the order the reference computes it in: next_part_two (new command on the mirrors), THEN the reward -- the
+    # sensor phase must still be the one of the last next_part_one, not a re-trace with the new mirror shapes
+    before = sup2.get_wfs_phase().clone()
+    a = torch.rand(2, env2.action_dim, generator=g) * 2 - 1
+    env2.rl_step(a.cuda())                                              # next_part_two only
+    assert torch.equal(sup2.get_wfs_phase(), before)
+    sup2.sim.raytrace_wfs(atm=True, dms=True, reset=True)               # what round 4 returned: the NEW shapes in it
+    assert not torch.equal(sup2.sim.t["wfs_phase"], before)
+    r_after = env2.calculate_reward("projection_comparison").cpu().numpy()
+    ph = (before - before.mean(dim=(1, 2), keepdim=True)).reshape(2, -1).cpu().numpy().astype(np.float64)[:, pup]
+    cur = sup2.get_voltages().cpu().numpy().astype(np.float64)[:, :v2m.shape[1]] @ v2m.T
+    np.testing.assert_allclose(r_after, -np.linalg.norm((-(ph @ P.T))[:, rng] - cur[:, rng], axis=1), rtol=2e-3)

@@ -204,6 +204,48 @@ def test_load_model_accepts_the_three_actor_file_layouts(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pipe", [False, True])
+def test_trajectory_resident_episode_is_the_step_by_step_bookkeeping(pipe):
+    """run_episode on the GPU writes states, actions and rewards straight into trajectory buffers (TrajectoryReplay:
+    no copy per step) -- the transitions the agents then learn from are the ones the reference's delayed-MDP
+    bookkeeping (DelayedMDP + manage_memory: one replay push per step) stores, row for row and bit for bit, and so
+    are the episode's returns and the learner it leaves behind."""
+    from ao_marl_amd.env import VecAoEnv
+    from ao_marl_amd.sac import BatchedReplay, TrajectoryReplay, run_episode
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    T, E = 14, 6
+    got = {}
+    for mode in ("steps", "traj"):
+        torch.manual_seed(11)
+        env = VecAoEnv("production_sh_10x10_2m", E, rl, n_agents_modal=1, initial_seed=77, frame_pipeline=pipe)
+        sac = BatchedSAC(env.layout, dict(memory_size=4096, batch_size=32), seed=5)
+        lay = env.layout
+        seen = []
+
+        def record(m, **kw):                # (the episode's master memory as the learner would receive it)
+            assert isinstance(m, TrajectoryReplay if mode == "traj" else BatchedReplay)
+            assert len(m) == (T - 2) * E                          # delay 1, no online modification: tuples from step 2 on
+            seen.append([t.clone() for t in m.rows(0, len(m))])
+            return 0
+        sac.update_parameters = record
+        master = BatchedReplay(lay.state_dim, lay.action_dim, lay.n_agents, T * E, "cuda:0") if mode == "steps" else None
+        out = run_episode(env, sac, max_steps=T, train=True, master=master, n_updates=4)
+        got[mode] = (seen[0], out["r_total"].clone(), out["r_per_agent"].clone(), out["sr_le"].clone())
+    for a, b in zip(got["steps"][0], got["traj"][0]):
+        assert a.shape == b.shape and torch.equal(a, b.reshape(a.shape))
+    assert torch.allclose(got["steps"][1], got["traj"][1], rtol=1e-6) and torch.equal(got["steps"][3], got["traj"][3])
+    assert torch.allclose(got["steps"][2], got["traj"][2], rtol=1e-6)  # (sums of the same rewards in another order)
+    # rows() in pieces, as update_parameters walks them, and its bounds
+    tr = TrajectoryReplay(3, 2, 1, 5, 2, 2, "cuda:0")
+    tr.S.copy_(torch.arange(6 * 2 * 3, dtype=torch.float32).reshape(6, 2, 3)); tr.t = 5
+    s0, a0, r0, s2, mk = tr.rows(2, 3)
+    assert len(tr) == 6 and torch.equal(s0, tr.S.reshape(-1, 3)[2:5]) and torch.equal(s2, tr.S.reshape(-1, 3)[6:9])
+    assert torch.equal(r0, tr.R.reshape(-1, 1)[6:9]) and torch.equal(a0, tr.A.reshape(-1, 2)[2:5]) and bool((mk == 1).all())
+    with pytest.raises(IndexError):
+        tr.rows(4, 3)
+
+
+@pytest.mark.gpu
 def test_training_episode_on_the_gpu_and_update_rate():
     """End-to-end on the HIP path: rollout with the native batched GEMM actors, replay in HBM,
     batched SAC updates through autograd; prints the production-size update rate."""
