@@ -69,6 +69,11 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "small_move")) { c->small_move = value != 0; return 0; }
   if (!strcmp(name, "small_chain")) { c->small_chain = value != 0; return 0; }
+  if (!strcmp(name, "residual_shortcut")) {
+    if (value && (!c->s2m || c->s2m_nmodes < 1)) return fail("residual_shortcut: no v2m . cmat matrix (aomarl_set_slopes2modes)");
+    c->residual_shortcut = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "reset_streams")) { c->reset_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }

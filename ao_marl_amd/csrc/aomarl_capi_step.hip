@@ -321,9 +321,16 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
   return 0;
 }
 
+// the residual shortcut applies: the matrix is there for these modes and the integrator gain is one scalar
+static bool env_step_shortcut(const aomarl_ctx *c, const aomarl_env_glue *g) {
+  return c->residual_shortcut && c->s2m && c->s2m_nmodes == g->nmodes && !c->env_gain;
+}
+
 // ---- the rest of AoEnv.linear_step behind do_control: v2m . err, the state blocks
+// s2m_view: the residual shortcut -- the caller has NOT run do_control; the residual modes come from that state's slopes
+// in one product with -(v2m . cmat) (the integrator lives in the Btt coordinates, the next head rebuilds the command)
 static int env_step_tail(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, bool fused, float *state_out, void *stream,
-                         const aomarl_state *slopes_view = nullptr) {
+                         const aomarl_state *slopes_view = nullptr, const aomarl_state *s2m_view = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   const int n = st->nenv, nm = g->nmodes, R = g->nhist + 1, na = c->sys.nactu;
   const size_t slot = (size_t)n * nm;
@@ -363,7 +370,16 @@ static int env_step_tail(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, bo
     return 0;
   }
   AssemblePart part = {nullptr, 0, 0, 1.f, nullptr};
-  if (fused) {
+  if (s2m_view) {
+    int nsp = 0;
+    float alpha = -1.f;
+    const int nsl = c->sys.nslope;
+    launch_gemm_nt(n, nm, nsl, -1.0f, s2m_view->slopes, nsl, c->s2m, c->ld_cmat, 0.0f, g->res_modes, nm, s,
+                   st->work + w.GEMM, w.gemm_floats, nullptr, &nsp, /* slopes (arcsec), unscaled */ true, 1.f, c->s2m_scale,
+                   &alpha, 288);
+    LAUNCHCHK();
+    if (nsp > 0) { part.part = st->work + w.GEMM; part.nsplit = nsp; part.pn = nm; part.alpha = alpha; part.sum_out = g->res_modes; }
+  } else if (fused) {
     int nsp = 0;
     float alpha = 1.f;
     launch_gemm_nt(n, nm, na, 1.0f, st->err, st->ld_actu, c->v2m, c->ld_v2m, 0.0f, g->res_modes, nm, s,
@@ -447,11 +463,13 @@ static int env_step_body(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, co
     rc = aomarl_do_control(c, st, 0, n, stream);
   } else {
     const bool small = fused && small_chain_ok(c, g);
-    c->skip_do_control = small;                  // the small chain's tail kernel does it
+    const bool shortcut = !small && fused && env_step_shortcut(c, g);
+    c->skip_do_control = small || shortcut;      // the small chain's tail kernel does it; the shortcut needs none
     rc = aomarl_next_part_one(c, st, 0, n, accumx, accumy, 0, stream);
     c->skip_do_control = false;
     if (rc) return rc;
     if (small) return env_step_tail(c, st, g, fused, state_out, stream, st);
+    if (shortcut) return env_step_tail(c, st, g, fused, state_out, stream, nullptr, st);
   }
   if (rc) return rc;
   return env_step_tail(c, st, g, fused, state_out, stream);
@@ -607,6 +625,7 @@ static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *
   // ---- reduce frame p
   if (!rc && hipStreamWaitEvent(s, P.ev_done_cur[p], 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
   if (!rc && small_chain_ok(c, g)) rc = env_step_tail(c, st, g, true, state_out, stream, &vp);
+  else if (!rc && env_step_shortcut(c, g)) rc = env_step_tail(c, st, g, true, state_out, stream, nullptr, &vp);
   else {
     if (!rc) rc = aomarl_do_control(c, &vp, 0, n, stream);
     if (!rc) rc = env_step_tail(c, st, g, true, state_out, stream);
@@ -681,6 +700,11 @@ static bool step_plan_uniform(const aomarl_ctx *c, int n, const float *accumx, c
   return true;
 }
 
+int aomarl_env_step_shortcut(aomarl_ctx *c, const aomarl_env_glue *g) {
+  if (!c || !g) return 0;
+  return (!g->denoiser && env_step_fusable(c, g, nullptr) && !small_chain_ok(c, g) && env_step_shortcut(c, g)) ? 1 : 0;
+}
+
 int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const float *action, float gain,
                     float *accumx, float *accumy, float *state_out, float *reward_out, void *stream) {
   if (!c || !st || !g || !state_out) return fail("env_step: null argument");
@@ -729,7 +753,7 @@ int aomarl_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const f
   kp(g->sel); kp(g->mean_dm); kp(g->std_dm); kp(g->mean_res); kp(g->std_res); kp(g->lohi); kp(g->modes_ring); kp(g->res_modes);
   kp(g->denoiser); kp(c->cmat); kp(c->v2m); kp(c->m2v); kp(c->freedom); kp(c->amode_inv);
   key.push_back(n); key.push_back(g_precision); key.push_back(g_gemm_split_f16 ? 1 : 0); key.push_back(c->dft_mode);
-  key.push_back(pf ? 1 : 0); key.push_back(c->small_move); key.push_back(c->small_chain);
+  key.push_back(pf ? 1 : 0); key.push_back(c->small_move); key.push_back(c->small_chain); key.push_back(c->residual_shortcut);
   key.push_back(c->defer_dm_shape ? 1 : 0); key.push_back(g_gemm_target_blocks); key.push_back(c->fused_debug);
   { int gi; memcpy(&gi, &c->gain, sizeof(gi)); key.push_back(gi); }
   key.push_back((long long)c->cfg_epoch); key.push_back((long long)g_cfg_epoch);

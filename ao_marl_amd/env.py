@@ -11,6 +11,7 @@ Every per-frame arithmetic step runs in libaomarl_hip.so (ao_marl_amd/sim.py); t
 sequencing + state bookkeeping on device tensors.  States are float32 (the reference concatenates
 float64 NumPy vectors, ao_env.py:909).
 """
+import ctypes
 import os
 import time
 from collections import OrderedDict
@@ -65,9 +66,14 @@ class VecRlSupervisor(object):
         self.config_rl.update(config_rl or {})
         if self.config_rl["level"] != "correction" or self.config_rl["basis"] != "zernike_space":
             raise NotImplementedError                       # rlSupervisor.py:728-731, 831-834
+        # modification_online = the reference's `pure_delay_0` (rlSupervisor.py:145): the science target is ray-traced
+        # behind apply_control in next_part_two (:938-939) -- it sees THIS frame's atmosphere with the command just
+        # applied -- and not in next_part_one (:964-965).  Call-by-call order, screens on the current frame.
         self.pure_delay_0 = bool(self.config_rl["modification_online"])
         if self.pure_delay_0:
-            raise NotImplementedError("modification_online (pure delay 0) is not on the hot path")
+            if geo:
+                raise NotImplementedError("modification_online with the geometric controller's twin")
+            prefetch_atmos = False
         self.nenv, self.device = nenv, torch.device(device)
         self.sysm = G.build_system(self.config)
         self.s = system.from_system(self.sysm, ncontrol=0, strehl_halfwin=strehl_halfwin)
@@ -245,6 +251,9 @@ class VecRlSupervisor(object):
         if self.geo is not None:
             self.geo.reset()
         self._control_pending, self._err_stale = False, False
+        self._tar_image_se, self._le_count = None, 0      # target.reset_strehl: the long exposure starts over
+        if self._tar_image_le_sum is not None:
+            self._tar_image_le_sum.zero_()
         self.iter = 0
 
     def check_range(self):
@@ -315,6 +324,11 @@ class VecRlSupervisor(object):
         (aomarl_rl_control_modes) and the coordinates after the action come back in
         `self.last_modes` (written into `modes_out` when given)."""
         self.last_modes = None
+        snap = (self.keep_tar_image or self.keep_le_image) and compute_tar_psf
+        if snap and not self.pure_delay_0:
+            # comp_tar_image (:945-946) forms the image of the phase raytrace_target left in next_part_one: the
+            # atmosphere of the frame + the mirrors BEFORE this call's apply_control -- the state as it stands now
+            self._snap_tar_image()
         if not linear_control and modes_pair is not None and hasattr(self.sim, "rl_control_modes"):
             std = self.config_rl["normalization_std_inside_environment"]
             mean = self.config_rl["normalization_mean_inside_environment"]
@@ -335,7 +349,11 @@ class VecRlSupervisor(object):
         if apply_control:
             # the stack-array shapes are left to the one-pass frame kernel when it can evaluate
             # them from the voltages (any other consumer materialises them on demand)
-            self.sim.apply_control(defer_shape=getattr(self.sim, "defer_shape", False))
+            self.sim.apply_control(defer_shape=getattr(self.sim, "defer_shape", False) and not self.pure_delay_0)
+            if self.pure_delay_0:
+                self.sim.target_psf()           # raytrace_target behind apply_control (rlSupervisor.py:938-939)
+        if snap and self.pure_delay_0:
+            self._snap_tar_image()              # ... and the image is that trace's
         if compute_tar_psf:
             self.sim.comp_strehl()
             if self.geo is not None:
@@ -349,6 +367,8 @@ class VecRlSupervisor(object):
         if defer_control and do_control:
             do_control = False
             self._control_pending = True
+        if self.autoencoder is not None and self.pure_delay_0:
+            raise NotImplementedError("modification_online with the denoiser in the sensor path")
         if self.autoencoder is not None:
             # rlSupervisor.py:975-984 with the denoiser between image formation and centroiding;
             # the bincube never leaves the device (the reference copies it to the host and back)
@@ -358,6 +378,12 @@ class VecRlSupervisor(object):
             if self.prefetch_atmos and move_atmos:      # beside centroids / control, not the denoiser
                 self.sim.prefetch_atmos()
             self.sim.do_centroids()
+            if do_control:
+                self.sim.do_control()
+        elif self.pure_delay_0:
+            # no target trace here (:964-965): the sensor's path alone
+            self._move_or_keep(move_atmos)
+            self.sim.comp_image(noise=True, write_bincube=False, cog=True)
             if do_control:
                 self.sim.do_control()
         elif move_atmos and do_control and self.geo is None and not self.next_part_one_split:
@@ -433,15 +459,46 @@ class VecRlSupervisor(object):
     def get_voltages(self):
         return self.sim.voltage
 
+    # Full-frame target images (targetCompass.py:71-92).  The hot path forms the PSF on the Strehl window only; with
+    # keep_tar_image every next_part_two also forms the whole npsf x npsf short exposure of the phase the reference's
+    # comp_tar_image sees (aomarl_target_image: two DFT passes per environment), with keep_le_image it is summed into
+    # the long exposure too (d_image_le; [nenv, npsf, npsf] floats: 4.3 GB for 256 environments of the 40x40 system).
+    keep_tar_image = False
+    keep_le_image = False
+    _tar_image_se, _tar_image_le_sum, _le_count = None, None, 0
+
+    def _snap_tar_image(self):
+        if self.prefetch_atmos or getattr(self.sim, "pending_atmos", False):
+            raise RuntimeError("keep_tar_image / keep_le_image: the screens run one frame ahead (prefetch_atmos); build "
+                               "the supervisor with prefetch_atmos=False")
+        img = self.sim.target_image()
+        self._tar_image_se = img
+        if self.keep_le_image:
+            if self._tar_image_le_sum is None or self._tar_image_le_sum.shape != img.shape:
+                self._tar_image_le_sum = torch.zeros_like(img)
+                self._le_count = 0
+            self._tar_image_le_sum += img
+            self._le_count += 1
+
     def get_tar_image(self, tar_index=0, expo_type="se"):
-        """targetCompass.py:71-92: the full-frame short-exposure PSF of every environment, [nenv, npsf, npsf], centred
-        (formed on demand: aomarl_target_image).  The long-exposure sum is only kept on the Strehl window."""
+        """targetCompass.py:71-92, [nenv, npsf, npsf], centred.  "se": d_image_se, the image comp_tar_image formed in
+        the last next_part_two (of the phase next_part_one's raytrace_target left: a command applied in that
+        next_part_two is not in it; with modification_online it is).  "le": d_image_le / strehl_counter, the mean of
+        those images since the reset.  Needs keep_tar_image (VecAoEnv sets it for the rewards that read the image) /
+        keep_le_image = True before the frames in question."""
         if tar_index != 0:
             raise NotImplementedError("get_tar_image: target 0 only")
-        if expo_type != "se":
-            raise NotImplementedError("get_tar_image: only the short-exposure image exists full-frame (the long "
-                                      "exposure is accumulated on the Strehl window)")
-        return self.sim.target_image()
+        if expo_type == "se":
+            if not (self.keep_tar_image or self.keep_le_image) or self._tar_image_se is None:
+                raise RuntimeError("get_tar_image: no image was kept (set supervisor.keep_tar_image = True before "
+                                   "next_part_two; VecAoEnv does for the rewards that read it)")
+            return self._tar_image_se
+        if expo_type == "le":
+            if not self.keep_le_image or not self._le_count:
+                raise RuntimeError("get_tar_image(expo_type='le'): the full-frame long exposure is accumulated only when "
+                                   "asked (set supervisor.keep_le_image = True before the episode)")
+            return self._tar_image_le_sum / float(self._le_count)
+        raise ValueError("Unknown exposure type")
 
     def get_wfs_phase(self):
         """wfsCompass.get_wfs_phase(0) (wfsCompass.py:366-372): the phase the sensor saw in the last next_part_one --
@@ -520,8 +577,9 @@ class VecAoEnv(object):
                 parameters_telescope
             config = name
         from . import rewards as _R
-        if cfg["reward_type"] in _R.NEEDS_CURRENT_SCREENS:
-            # these rewards read the image / phase of THIS frame: the screens must not run ahead
+        if cfg["reward_type"] in _R.NEEDS_CURRENT_SCREENS or cfg["modification_online"]:
+            # these rewards read the image / phase of THIS frame, and the pure-delay-0 order traces the target behind
+            # apply_control: the screens must not run ahead
             prefetch_atmos, frame_pipeline = False, False
         self.supervisor = VecRlSupervisor(config, cfg, nenv, initial_seed=initial_seed,
                                           seed_stride=seed_stride, device=device,
@@ -531,6 +589,8 @@ class VecAoEnv(object):
         sup = self.supervisor
         if cfg["reward_type"] in _R.PROJECTION:
             sup.keep_wfs_phase = True                # these read wfs.get_wfs_phase(0): the frame's sensor phase
+        if cfg["reward_type"] in _R.IMAGE:
+            sup.keep_tar_image = True                # these read target.get_tar_image(0): comp_tar_image's frame
         # the next reset's screens grown beside the running episode: None, "same" or the number of seed blocks the
         # trainer moves on by per episode (VecRlSupervisor.reset_prefetch; train_agent sets it)
         sup.reset_prefetch = reset_prefetch
@@ -879,10 +939,13 @@ class VecAoEnv(object):
         sup = self.supervisor
         return (self.native_step and self._native_glue and self._default_state_layout and
                 self.modal_shortcut and self._modal_valid and not linear_control and
-                not self.residual_shortcut and sup.geo is None and sup.gain is not None and
-                not sup.keep_wfs_phase and       # (the frame's sensor phase is snapped behind the Python next_part_one)
+                sup.geo is None and sup.gain is not None and not sup.pure_delay_0 and
+                not sup.keep_wfs_phase and not sup.keep_tar_image and not sup.keep_le_image and       # (the frame's sensor phase is snapped behind the Python next_part_one)
                 sup.freedom_vector is not None and not sup.next_part_one_split and
-                not sup._control_pending and hasattr(sup.sim, "env_step") and
+                # (a do_control left pending by the residual shortcut is dropped by the step: its head rebuilds the
+                # command from the Btt coordinates, the integrator included)
+                (not sup._control_pending or (self.residual_shortcut and sup.autoencoder is None)) and
+                hasattr(sup.sim, "env_step") and
                 (sup.autoencoder is None or (getattr(sup.autoencoder, "use_native", False) and
                                              sup.autoencoder.input_bound is not None)))
 
@@ -909,6 +972,7 @@ class VecAoEnv(object):
     OUT_RING = 6        # a multiple of the command ring's period (number_of_previous_dm + 1 = 3)
     _out_ring, _out_pos = None, 0
     _pipe_checked = False
+    _native_shortcut = False
 
     def _step_native(self, action, out=None):
         sup = self.supervisor
@@ -958,13 +1022,22 @@ class VecAoEnv(object):
             self._pipe_checked = True
             if self._pipe_eligible():
                 sup.sim.enable_frame_pipeline()
+        shortcut = bool(self.residual_shortcut) and ae is None
+        if shortcut != self._native_shortcut:
+            if shortcut:
+                sup.ensure_slopes2modes()
+            sup.sim.set_option("residual_shortcut", int(shortcut))
+            self._native_shortcut = shortcut
+        if shortcut:        # (a small system's tail kernel runs do_control itself: nothing is left pending there)
+            shortcut = bool(sup.sim.lib.aomarl_env_step_shortcut(sup.sim.ctx, g._ref if hasattr(g, "_ref") else ctypes.byref(g)))
         sup.sim.env_step(g, action, sup.gain, state, r)
         if sup.reset_prefetch is not None:
             sup.step_done()
         self._ring_pos = g.ring_pos
         self._last_res_modes = self._res_modes
         sup.last_modes = None
-        sup._err_stale, sup._control_pending = False, False
+        # (shortcut: the frame's slopes are measured, the integrator has not run in actuator space: do_control on demand)
+        sup._err_stale, sup._control_pending = False, shortcut
         sup.iter += 1
         return state, r, False, ""
 

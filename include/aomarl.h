@@ -497,6 +497,16 @@ typedef struct {
 int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, const float *action_dev,
                     float gain, float *accumx, float *accumy, float *state_out, float *reward_out,
                     void *stream);
+/* aomarl_set_option(ctx, "residual_shortcut", 1) (needs aomarl_set_slopes2modes): aomarl_env_step takes the residual
+ * modes v2m . err of a frame from ONE product of its slopes with -(v2m . cmat) instead of aomarl_do_control (cmat . s,
+ * integrate) + v2m . err: the integrator then lives in the Btt coordinates alone (the next call's head rebuilds the
+ * command from them, as the reference's rl_control does every step: rlSupervisor.py:784-818), st->err is not formed and
+ * st->com is not integrated in actuator space -- aomarl_do_control on the same slopes gives both afterwards.  Same
+ * mathematics, another order of the fp32 sums (states within 3e-3 relative of the default's over 10 steps of the 40x40
+ * system, tests/test_gpu_glue.py).  Returns 1 when a call with this glue would take the shortcut (the option is on, the
+ * matrix matches the glue's modes, the chain is fusable and the system is not a small one, whose tail kernel does
+ * do_control itself), else 0: a host that defers do_control must know (VecAoEnv._step_native). */
+int aomarl_env_step_shortcut(aomarl_ctx *ctx, const aomarl_env_glue *glue);
 /* aomarl_set_option(ctx, "graph_step", 1): aomarl_env_step replays a HIP graph captured from its own launch
  * sequence (one per distinct extrusion plan x ring position x buffer addresses; captured the first time a
  * combination occurs): one hipGraphLaunch instead of ~25 launches + ~8 event operations per step, for the

@@ -299,11 +299,14 @@ class OracleSim(object):
         return [self.strehl_se, self.strehl_le, self.phase_var, avg]
 
     # ---------------------------------------------------------------- composite frames
+    # rlSupervisor.py:145: `modification_online` -- the target is traced behind apply_control (:938-939), not in
+    # next_part_one (:964-965)
+    pure_delay_0 = False
+
     def next_part_one(self):
         """rlSupervisor.py:1015-1051 + :954-987 for the integrator controller."""
         self.move_atmos()
-        if self.s.delay != 0 or True:
-            # pure_delay_0 ("modification_online") is False in every shipped config
+        if not self.pure_delay_0:
             self.raytrace_target()
         self.raytrace_wfs(atm=True, dms=False, reset=True)
         self.raytrace_wfs(atm=False, dms=True, reset=False)
@@ -316,6 +319,8 @@ class OracleSim(object):
         if com_rl is not None:
             self.set_com(com_rl)
         self.apply_control()
+        if self.pure_delay_0:
+            self.raytrace_target()
         self.comp_strehl()
 
     # ---------------------------------------------------------------- calibration backend

@@ -76,13 +76,15 @@ class OracleVecSim(object):
     def strehl(self):
         return torch.tensor([o.get_strehl() for o in self.sims], dtype=torch.float32)
 
-    def target_image(self):
-        """Target.get_tar_image("se") of every environment from the oracle: the full |FFT2|^2 of the science phase
-        as it stands (atmosphere + mirrors), centred."""
+    def target_image(self, retrace=True):
+        """Target.get_tar_image("se") of every environment from the oracle: the full |FFT2|^2 of the science phase,
+        centred.  retrace: of the state as it stands (atmosphere + mirrors, like aomarl_target_image); False: of the
+        phase the oracle's last raytrace_target left (COMPASS's d_phase, what comp_tar_image sees)."""
         import ctypes as C
         out = []
         for o in self.sims:
-            o.raytrace_target()
+            if retrace:
+                o.raytrace_target()
             s = o.s
             full = np.zeros((s.npsf, s.npsf), dtype=np.float32)
             pf, pw = C.c_float(0), C.c_float(0)

@@ -19,15 +19,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAR = os.path.join(ROOT, "tools", "par", "production_aomarl_sh_10x10_2m_single.py")
 
 
-def _run(golden_dir, sim_factory, device, tol_scale=1.0, stock=False, geo=False):
+def _run(golden_dir, sim_factory, device, tol_scale=1.0, stock=False, geo=False, online=False):
     """stock: the trace of the reference on its UNMODIFIED production_sh_10x10_2m.py (2 WFS, 4 DMs,
     LS + GEO controllers; tests/golden/trace_10x10_stock.npz) against this package's built-in
     restatement of that file; geo: with the geometric controller's twin (command and Strehl of
     target 1 are compared too)."""
-    z = np.load(os.path.join(golden_dir, "trace_10x10_%s.npz" % ("stock" if stock else "single")))
+    z = np.load(os.path.join(golden_dir, "trace_10x10_%s%s.npz" % ("stock" if stock else "single", "_online" if online else "")))
+    assert bool(z["modification_online"]) is online if "modification_online" in z.files else not online
     ps = params.builtin("production_sh_10x10_2m") if stock else params.load_param_file(PAR)
     norm, zn = load_norm("production_sh_10x10_2m")      # the data the reference run used
-    env = VecAoEnv(ps, 2, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5),
+    env = VecAoEnv(ps, 2, dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, modification_online=online),
                    initial_seed=int(z["seed"]), seed_stride=0, n_agents_modal=1, device=device,
                    norm=norm, zn_norm=zn, sim_factory=sim_factory, geo=geo, frame_pipeline=False,
                    dead_columns="keep")     # the reference divides by whatever it recorded
@@ -100,6 +101,19 @@ def test_env_host_logic_matches_reference_trace_cpu(golden_dir):
     _run(golden_dir, OracleVecSim, "cpu")
 
 
+def test_env_host_logic_matches_the_pure_delay_0_trace_cpu(golden_dir):
+    """`modification_online` (rlSupervisor.py:145, 938-939, 964-965): the reference's RlSupervisor run with its
+    pure-delay-0 call order (tools/gen_golden_trace.py --online) -- the target is traced behind apply_control, so the
+    Strehl of a step already sees the command that step applied."""
+    from tests.oracle_vecsim import OracleVecSim
+    env = _run(golden_dir, OracleVecSim, "cpu", online=True)
+    assert env.supervisor.pure_delay_0 and not env.supervisor.prefetch_atmos and env.frame_pipeline is False
+    # the two call orders differ where they should: the same actions, another Strehl trace
+    a = np.load(os.path.join(golden_dir, "trace_10x10_single.npz"))["strehl"]
+    b = np.load(os.path.join(golden_dir, "trace_10x10_single_online.npz"))["strehl"]
+    assert np.abs(a[5:, 0] - b[5:, 0]).max() > 1e-3
+
+
 def test_env_host_logic_matches_the_stock_file_trace_cpu(golden_dir):
     """Controller 0 of the stock two-controller file == the reduced single-controller file (the
     reference's second controller path shares nothing with the first but the atmosphere)."""
@@ -110,6 +124,12 @@ def test_env_host_logic_matches_the_stock_file_trace_cpu(golden_dir):
 @pytest.mark.gpu
 def test_env_product_path_matches_reference_trace_gpu(golden_dir):
     _run(golden_dir, None, "cuda:0", tol_scale=8.0)
+
+
+@pytest.mark.gpu
+def test_env_product_path_matches_the_pure_delay_0_trace_gpu(golden_dir):
+    env = _run(golden_dir, None, "cuda:0", tol_scale=8.0, online=True)
+    assert env.supervisor.pure_delay_0 and not env._native_step_ok(False)
 
 
 @pytest.mark.gpu

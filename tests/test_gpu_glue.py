@@ -383,7 +383,10 @@ def test_residual_modes_from_slopes_equals_do_control_path():
         scale = (sb * std).abs().max().item()
         assert ((sa - sb) * std).abs().max().item() < 2e-5 * scale, it
         assert torch.allclose(ra, rb, rtol=2e-4, atol=1e-6), it
-    assert deferred == 10
+    # (the one-call step of this SMALL system runs do_control in its tail kernel -- aomarl_env_step_shortcut is 0 there --;
+    # the two call-by-call steps defer it.  The 40x40 system's one-call step defers it too: see
+    # test_residual_shortcut_inside_the_one_call_step)
+    assert deferred == 2
     # actuator-space quantities on demand: err of the last frame, the integrated command, voltages
     eb = b.supervisor.get_err()
     assert (a.supervisor.get_err() - eb).abs().max().item() < 2e-5 * eb.abs().max().item()
@@ -884,3 +887,43 @@ def test_environment_with_prefetched_resets_gives_the_same_episodes(pipe):
         assert len(ra) == len(rb) and all(torch.equal(x, y) for x, y in zip(ra, rb)), (rp, schedule)
         want = 1 if schedule == "surprise" else 2          # the surprise episode's reset ran in the open
         assert getattr(b.supervisor.sim, "prefetched_resets", 0) == want and getattr(a.supervisor.sim, "prefetched_resets", 0) == 0
+
+
+def test_residual_shortcut_inside_the_one_call_step():
+    """VecAoEnv.residual_shortcut in aomarl_env_step ("residual_shortcut"): the residual modes from ONE product of the
+    slopes with v2m . cmat instead of do_control (cmat . s, integrate) + v2m . err -- the integrator lives in the Btt
+    coordinates, the head of the next step rebuilds the command from them.  Same mathematics, another order of the
+    fp32 sums: states, rewards and commands agree with the reference order to round-off of 2400-term dot products;
+    with a frame in flight the shortcut step is the plain shortcut step bit for bit; err / com in actuator space
+    appear on demand (do_control on the frame's slopes)."""
+    from ao_marl_amd.env import VecAoEnv
+    name = "production_sh_40x40_8m_3layers"
+    rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5, window_n_zernike=20, include_tip_tilt_windowed=True)
+    mk = lambda pipe: VecAoEnv(name, 4, rl, initial_seed=5, seed_stride=16, n_agents_modal=13, frame_pipeline=pipe)   # noqa: E731
+    ref, cut, cutp = mk(False), mk(False), mk(True)
+    cut.residual_shortcut = cutp.residual_shortcut = True
+    s0, s1, s2 = ref.reset(), cut.reset(), cutp.reset()
+    assert torch.allclose(s0, s1, rtol=0, atol=2e-3) and torch.equal(s1, s2)
+    g = torch.Generator(device="cuda:0").manual_seed(12)
+    worst = 0.0
+    for it in range(10):
+        a = torch.rand(4, ref.action_dim, device="cuda:0", generator=g) * 2 - 1
+        (sa, ra, _, _), (sb, rb, _, _), (sc, rc, _, _) = ref.step(a), cut.step(a), cutp.step(a)
+        assert cut._native_step_ok(False) and cut._native_shortcut and cutp._native_shortcut and not ref._native_shortcut
+        assert torch.equal(sb, sc) and torch.equal(rb, rc), it            # a frame in flight changes nothing
+        live = torch.isfinite(sa) & (sa.abs() < 1e3)
+        d = ((sa - sb).abs() / (1.0 + sa.abs()))[live].max().item()
+        worst = max(worst, d)
+        assert d < 3e-3, (it, d)
+        assert torch.allclose(ra, rb, rtol=5e-3, atol=1e-3)
+    assert cutp.supervisor.sim.frame_pipeline_state()[2] >= 8
+    # actuator space on demand: the integrated command and err of the last frame
+    ca, cb = ref.supervisor.get_command().clone(), cut.supervisor.get_command().clone()
+    assert (ca - cb).abs().max().item() < 2e-3 * ca.abs().max().item()
+    ea, eb = ref.supervisor.get_err().clone(), cut.supervisor.get_err().clone()
+    assert (ea - eb).abs().max().item() < 5e-3 * ea.abs().max().item() + 1e-5
+    # ... and the loop goes on from there
+    a = torch.zeros(4, ref.action_dim, device="cuda:0")
+    (sa, _, _, _), (sb, _, _, _) = ref.step(a), cut.step(a)
+    assert ((sa - sb).abs() / (1.0 + sa.abs()))[torch.isfinite(sa) & (sa.abs() < 1e3)].max().item() < 3e-3
+    print("residual shortcut: worst relative state difference over 10 steps %.2e" % worst)

@@ -15,7 +15,10 @@ With --record-calls the whole Appendix-B call sequence the reference makes (cons
 loads, per-frame calls, reads) is logged through tools/record_calls.py ->
 tests/golden/calls_10x10_<run>.npz: the input of the facade replay tests.
 
-Usage: python tools/gen_golden_trace.py [single|stock] [--record-calls]
+With --online the run sets `modification_online` (the reference's pure-delay-0 call order, rlSupervisor.py:145,
+938-939, 964-965) -> tests/golden/trace_10x10_<run>_online.npz.
+
+Usage: python tools/gen_golden_trace.py [single|stock] [--record-calls] [--online]
 """
 import os
 import shutil
@@ -53,7 +56,7 @@ def stage(tmp, NAME, src_dir):
     os.makedirs(os.path.join(tmp, "output/debug"))
 
 
-def main(run="single", nframes=30, seed=1234, record=False):
+def main(run="single", nframes=30, seed=1234, record=False, online=False):
     NAME, src_dir = RUNS[run]
     sw, cw = ref_facade.install()
     rec = None
@@ -74,7 +77,10 @@ def main(run="single", nframes=30, seed=1234, record=False):
     cfg.env_rl.update({"parameters_telescope": NAME + ".py", "n_zernike_start_end": [0, 80],
                        "n_reverse_filtered_from_cmat": 5, "include_tip_tilt": "True",
                        "verbose": False})
+    if online:
+        cfg.env_rl["modification_online"] = "True"
     cfg.strings_to_bools()
+    assert cfg.env_rl["modification_online"] is bool(online)
     cfg.autoencoder["path"] = None
     env = AoEnv(config_rl=cfg, normalization_bool=True, initial_seed=seed)
     env.supervisor.set_sim_seed(seed)
@@ -119,10 +125,12 @@ def main(run="single", nframes=30, seed=1234, record=False):
     out["seed"] = np.array(seed)
     out["agents"] = np.array([agents[w] for w in agents])
     out["nactu"] = np.array(out["com"].shape[1])
-    dst = os.path.join(ROOT, "tests", "golden", "trace_10x10_%s.npz" % run)
+    out["modification_online"] = np.array(bool(online))
+    assert sup.pure_delay_0 is bool(online)
+    dst = os.path.join(ROOT, "tests", "golden", "trace_10x10_%s%s.npz" % (run, "_online" if online else ""))
     np.savez_compressed(dst, **out)
     if rec_ is not None:
-        rec_.save(os.path.join(ROOT, "tests", "golden", "calls_10x10_%s.npz" % run))
+        rec_.save(os.path.join(ROOT, "tests", "golden", "calls_10x10_%s%s.npz" % (run, "_online" if online else "")))
     print("wrote", dst, {k: v.shape for k, v in out.items()})
     print("SR se/le last:", out["strehl"][-1][:2], "state absmax", np.abs(out["state"]).max())
     os.chdir(ROOT)
@@ -131,4 +139,4 @@ def main(run="single", nframes=30, seed=1234, record=False):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    main(run=args[0] if args else "single", record="--record-calls" in sys.argv)
+    main(run=args[0] if args else "single", record="--record-calls" in sys.argv, online="--online" in sys.argv)
