@@ -238,3 +238,67 @@ def test_bench_batch_through_env_step_with_the_frame_pipeline():
     st = big.supervisor.get_strehl().cpu().numpy()
     assert np.isfinite(st).all() and st[:, 0].min() > 0.0
     print("256 x 14 agents, %d pipelined steps: batch against batch-of-8 worst %.2e (standardised states)" % (steps, worst))
+
+
+@pytest.mark.parametrize("pipe", [True, False])
+def test_configs1_batch_through_the_small_system_path(pipe):
+    """BASELINE configs[1] at ITS batch -- production_sh_10x10_2m, 64 environments, 2 agents (80 modes + tip-tilt) --
+    through what bench.py times there: k_actor_fused at 64 x 2, aomarl_env_step on the small-system kernels
+    (k_move_small, k_small_head / k_small_tail), with and without a frame in flight.  Properties that do not depend
+    on the size: twin environments (same seed, same actions) stay equal bit for bit, the batch agrees with its own
+    first 8 environments stepped as a batch of 8 and with the GENERAL chain ("small_chain" / "small_move" = 0: the
+    kernels the 40x40 system runs) to fp32 round-off, the pipelined order is the plain order bit for bit, different
+    seeds decorrelate, the loop closes."""
+    from ao_marl_amd.agents import BatchedGaussianPolicy
+    from ao_marl_amd.env import VecAoEnv
+    name, rl = "production_sh_10x10_2m", dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    n, small_n, steps = 64, 8, 40
+
+    def make(nenv, pipeline, general=False):
+        env = VecAoEnv(name, nenv, rl, initial_seed=1234, seed_stride=16, n_agents_modal=1, device="cuda:0",
+                       frame_pipeline=pipeline)
+        seeds = env.supervisor.env_seeds().copy()
+        seeds[1] = seeds[0]                                  # twin environments
+        env.supervisor.env_seeds = lambda: seeds
+        if general:
+            env.supervisor.sim.set_option("small_chain", 0)
+            env.supervisor.sim.set_option("small_move", 0)
+        return env
+    big, small, gen = make(n, pipe), make(small_n, pipe), make(n, False, general=True)
+    other = make(n, not pipe)
+    lay = big.layout
+    assert lay.n_agents == 2 and lay.action_dim == 82 and lay.state_shapes() == [320, 8]
+    pol = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=7, device="cuda:0")
+    sb, ss, sg, so = big.reset(), small.reset(), gen.reset(), other.reset()
+    assert torch.equal(sb[0], sb[1]) and torch.equal(sb, so)
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    live = torch.cat([torch.isfinite(big.norm["dm"][1])] * 3 + [torch.isfinite(big.norm["dm_residual"][1])])
+    worst = dict(sub=0.0, general=0.0)
+    for it in range(steps):
+        eps = torch.randn(n, lay.action_dim, device="cuda:0", generator=g) * 0.3
+        eps[1] = eps[0]
+        a, _ = pol.select_action(sb, eps=eps)
+        assert torch.equal(a[0], a[1]) and big._native_step_ok(False)
+        sb, rb, _, _ = big.step(a)
+        ss, rs, _, _ = small.step(a[:small_n].contiguous())
+        sg, rg, _, _ = gen.step(a)
+        so, ro, _, _ = other.step(a)
+        assert torch.isfinite(sb).all() and torch.isfinite(rb).all() and rb.shape == (n, 2)
+        assert torch.equal(sb[0], sb[1]) and torch.equal(rb[0], rb[1])          # twins: same bits
+        assert torch.equal(sb, so) and torch.equal(rb, ro), it                   # frame in flight or not: same bits
+        scale = max(1.0, sb[:, live].abs().max().item())
+        d1 = (sb[:small_n] - ss)[:, live].abs().max().item() / scale
+        d2 = (sb - sg)[:, live].abs().max().item() / scale
+        worst["sub"], worst["general"] = max(worst["sub"], d1), max(worst["general"], d2)
+        assert d1 < 1e-6 and d2 < 1e-4, (it, d1, d2)    # (one workgroup per environment: the sub-batch is the batch bit for bit; general chain: 1e-5 measured)
+        assert torch.allclose(rb, rg, rtol=5e-3, atol=1e-4)
+    if pipe:
+        flying, _, piped, _ = big.supervisor.sim.frame_pipeline_state()
+        assert flying and piped >= steps - 1
+    sl = big.supervisor.get_slopes() if not pipe else other.supervisor.get_slopes()
+    assert torch.isfinite(sl).all() and torch.equal(sl[0], sl[1])
+    assert abs(np.corrcoef(sl[2].cpu().numpy(), sl[3].cpu().numpy())[0, 1]) < 0.4     # different seeds decorrelate
+    st = (big if not pipe else other).supervisor.get_strehl().cpu().numpy()
+    assert np.isfinite(st).all() and st[:, 0].min() > 0.0
+    print("64 x 2 agents, %d steps (%s): batch against batch-of-8 worst %.2e, small-system kernels against the general chain "
+          "%.2e (standardised states)" % (steps, "pipelined" if pipe else "plain order", worst["sub"], worst["general"]))
