@@ -1,3 +1,4 @@
+#include "aomarl_gemm_g.h"
 // aomarl_capi_composites.hip -- part of the C ABI implementation (included by aomarl_capi.hip, one translation unit):
 // composites (frame_fused, next_part_one / two), the stand-alone GEMM entry points, the SAC update.
 // ---------------------------------------------------------------- composites
@@ -226,28 +227,6 @@ int aomarl_gemm_nt_split(int M, int N, int K, float alpha, const float *A, int l
   return 0;
 }
 
-int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int lda, long long strideA,
-                           const float *B, int ldb, long long strideB, const float *bias,
-                           long long strideBias, float *C, int ldc, long long strideC, int relu,
-                           void *stream) {
-  if (!A || !B || !C) return fail("gemm_nt_batched: null pointer");
-  if (batch < 0 || M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) return fail("gemm_nt_batched: bad sizes");
-  if (batch == 0 || M == 0 || N == 0) return 0;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return fail("gemm_nt_batched: A and B must be 16-byte aligned");
-  const bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0);
-  if (al)
-    hipLaunchKernelGGL(k_gemm_nt_batched2, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0,
-                       (hipStream_t)stream, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias,
-                       C, ldc, strideC, relu);
-  else
-    hipLaunchKernelGGL(k_gemm_nt_batched, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0,
-                       (hipStream_t)stream, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias,
-                       C, ldc, strideC, relu);
-  LAUNCHCHK();
-  return 0;
-}
-
-
 template <bool TA, bool TB, int G>
 static int gemm_batched_launch_g(dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
                                  long long strideA, const float *B, int ldb, long long strideB,
@@ -290,6 +269,28 @@ static int gemm_batched_launch(int batch, int transA, int transB, int M, int N, 
 #undef GG
 }
 
+// Every batched product of the C ABI: the grouped kernel of the learner (aomarl_gemm_g.h: operands in either
+// orientation, bias / ReLU epilogue) when every operand row starts on 16 bytes, round 1's general kernel otherwise
+// (odd leading dimensions, accumulation into C).  transA: A is [K][M]; transB: B is [K][N] (else [N][K]).
+static int gemm_batched_any(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
+                            long long strideA, const float *B, int ldb, long long strideB, const float *bias,
+                            long long strideBias, float *C, int ldc, long long strideC, int relu, int accumulate,
+                            hipStream_t s) {
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  const bool al = !((uintptr_t)A & 15) && !((uintptr_t)B & 15) && !(lda & 3) && !(ldb & 3) && !(strideA & 3) && !(strideB & 3);
+  if (al && !accumulate && K > 0 && !g_gemm_kgroups) {
+    GemmGArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.sA = strideA; g.B = B; g.ldb = ldb; g.sB = strideB; g.C = C; g.ldc = ldc; g.sC = strideC;
+    g.bias = bias; g.sBias = strideBias; g.relu = relu;
+    if (gemm_g_launch(batch, !transA, !transB, g, 0, 0, s)) return fail("gemm_batched: k_gemm_g launch failed");
+    return 0;
+  }
+  return gemm_batched_launch(batch, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc,
+                             strideC, relu, accumulate, nullptr, 0, 0, s);
+}
+
 int aomarl_gemm_batched(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
                         long long strideA, const float *B, int ldb, long long strideB, const float *bias,
                         long long strideBias, float *C, int ldc, long long strideC, int relu,
@@ -297,8 +298,19 @@ int aomarl_gemm_batched(int batch, int transA, int transB, int M, int N, int K, 
   if (!A || !B || !C) return fail("gemm_batched: null pointer");
   if (batch < 0 || M < 0 || N < 0 || K < 0 || ldc < N) return fail("gemm_batched: bad sizes");
   if (lda < (transA ? M : K) || ldb < (transB ? N : K)) return fail("gemm_batched: leading dimension too small");
-  return gemm_batched_launch(batch, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias,
-                             C, ldc, strideC, relu, accumulate, nullptr, 0, 0, (hipStream_t)stream);
+  return gemm_batched_any(batch, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias,
+                          C, ldc, strideC, relu, accumulate, (hipStream_t)stream);
+}
+
+// C[b] = act(A[b] . B[b]^T + bias[b]): B in nn.Linear's [out][in] layout (the actors' layer-by-layer path)
+int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int lda, long long strideA,
+                           const float *B, int ldb, long long strideB, const float *bias,
+                           long long strideBias, float *C, int ldc, long long strideC, int relu,
+                           void *stream) {
+  if (!A || !B || !C) return fail("gemm_nt_batched: null pointer");
+  if (batch < 0 || M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) return fail("gemm_nt_batched: bad sizes");
+  return gemm_batched_any(batch, 0, 0, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc, strideC,
+                          relu, 0, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- multi-agent SAC update (section 8f)

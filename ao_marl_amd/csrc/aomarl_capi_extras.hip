@@ -106,15 +106,13 @@ int aomarl_geo_control(aomarl_ctx *c, aomarl_state *st, int b, int n, float *wor
   const float *phi = st->tar_phase + (size_t)b * pd * pd;
   float *T = work + g.T, *LAT = work + g.LAT, *R3 = work + g.R3, *R = work + g.R;
   // T[e][j][y] = sum_x UxT[j][x] phi[e][y][x]
-  hipLaunchKernelGGL(k_gemm_nt_batched2, dim3((pd + 63) / 64, (gw + 63) / 64, n), dim3(256), 0, s, gw, pd, pd,
-                     c->geoUx, pd, (long long)0, phi, pd, (long long)pd * pd, (const float *)nullptr,
-                     (long long)0, T, pd, (long long)gw * pd, 0);
-  LAUNCHCHK();
+  rc = aomarl_gemm_nt_batched(n, gw, pd, pd, c->geoUx, pd, 0, phi, pd, (long long)pd * pd, nullptr, 0, T, pd,
+                              (long long)gw * pd, 0, stream);
+  if (rc) return rc;
   // LAT[e][j][i] = sum_y T[e][j][y] UyT[i][y]
-  hipLaunchKernelGGL(k_gemm_nt_batched2, dim3((gh + 63) / 64, (gw + 63) / 64, n), dim3(256), 0, s, gw, gh, pd,
-                     T, pd, (long long)gw * pd, c->geoUy, pd, (long long)0, (const float *)nullptr,
-                     (long long)0, LAT, gh, (long long)gw * gh, 0);
-  LAUNCHCHK();
+  rc = aomarl_gemm_nt_batched(n, gw, gh, pd, T, pd, (long long)gw * pd, c->geoUy, pd, 0, nullptr, 0, LAT, gh,
+                              (long long)gw * gh, 0, stream);
+  if (rc) return rc;
   // R3[e][k] = sum_p phi[e][p] planes[k][p]   (TT0, TT1, 1)
   launch_gemm_nt(n, 3, pd * pd, 1.0f, phi, pd * pd, c->geoPlanes, pd * pd, 0.0f, R3, 4, s, work + g.GEMM,
                  g.gemm_floats);

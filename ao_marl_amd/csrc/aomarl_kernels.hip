@@ -144,77 +144,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(int M, int N, int K, float alph
   }
 }
 
-// Batched variant for the SAC MLPs: C[b] = act(A[b] . B[b]^T + bias[b]) ; blockIdx.z = batch
-// (agent).  A [batch][M][lda], B [batch][N][ldb] (nn.Linear weight layout: [out][in]),
-// bias [batch][N] or NULL, C [batch][M][ldc]; relu != 0 applies max(., 0).
-__global__ __launch_bounds__(256) void k_gemm_nt_batched(int M, int N, int K,
-                                                         const float *__restrict__ A, int lda, long long sA,
-                                                         const float *__restrict__ B, int ldb, long long sB,
-                                                         const float *__restrict__ bias, long long sBias,
-                                                         float *__restrict__ C, int ldc, long long sC,
-                                                         int relu) {
-  __shared__ float As[64][17];
-  __shared__ float Bs[64][17];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  const int lr = tid >> 2, lc = (tid & 3) * 4;
-  const int gm = m0 + lr, gn = n0 + lr;
-  const float *pa = A + (long long)gm * lda;
-  const float *pb = B + (long long)gn * ldb;
-  const bool al = ((lda | ldb) & 3) == 0 && ((sA | sB) & 3) == 0;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
-    const int gk = k0 + lc;
-    if (gm < M) {
-      if (al && gk + 3 < K) {
-        float4 t = *reinterpret_cast<const float4 *>(pa + gk);
-        va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (gk + j < K) va[j] = pa[gk + j];
-      }
-    }
-    if (gn < N) {
-      if (al && gk + 3 < K) {
-        float4 t = *reinterpret_cast<const float4 *>(pb + gk);
-        vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (gk + j < K) vb[j] = pb[gk + j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      As[lr][lc + j] = va[j];
-      Bs[lr][lc + j] = vb[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      float a = As[wm * 32 + (lane & 31)][2 * ks + (lane >> 5)];
-      float b = Bs[wn * 32 + (lane & 31)][2 * ks + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  const int col = n0 + wn * 32 + (lane & 31);
-  const float bv = (bias && col < N) ? bias[(long long)blockIdx.z * sBias + col] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < M && col < N) {
-      float v = acc[r] + bv;
-      if (relu) v = fmaxf(v, 0.f);
-      C[(long long)row * ldc + col] = v;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Pipelined variant (operands 16-byte aligned, lda / ldb multiples of 4): block tile 64 x 64 x 32,
@@ -225,77 +154,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_batched(int M, int N, int K,
 // a 128-bit read pass hit 64 distinct banks.
 // ---------------------------------------------------------------------------------------------
 #define G2_LD 36
-__device__ __forceinline__ float4 g2_load4(const float *p, int k, int ke, bool row_ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row_ok) {
-    if (k + 3 < ke) v = *reinterpret_cast<const float4 *>(p + k);
-    else {
-      if (k < ke) v.x = p[k];
-      if (k + 1 < ke) v.y = p[k + 1];
-      if (k + 2 < ke) v.z = p[k + 2];
-    }
-  }
-  return v;
-}
 
-// acc += A[m0.., kb..ke) . B[n0.., kb..ke)^T for the 32 x 32 sub-tile (wm, wn) of this wave.
-// Rows past M / N are clamped to the last valid row (their products land in output rows the
-// epilogue drops), so only the K tail needs guarded, zero-filling loads: every full k-tile is
-// four unconditional 128-bit loads per thread.
-__device__ __forceinline__ void g2_mainloop(const float *__restrict__ A, int lda,
-                                            const float *__restrict__ B, int ldb, int M, int N,
-                                            int m0, int n0, int kb, int ke, float *As, float *Bs,
-                                            f32x16 &acc) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-  const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const float *pa0 = A + (long long)min(m0 + lr, M - 1) * lda + lc;
-  const float *pa1 = A + (long long)min(m0 + lr + 32, M - 1) * lda + lc;
-  const float *pb0 = B + (long long)min(n0 + lr, N - 1) * ldb + lc;
-  const float *pb1 = B + (long long)min(n0 + lr + 32, N - 1) * ldb + lc;
-  float4 ra0, ra1, rb0, rb1;
-  auto gload_full = [&](int k0) {
-    ra0 = *reinterpret_cast<const float4 *>(pa0 + k0); ra1 = *reinterpret_cast<const float4 *>(pa1 + k0);
-    rb0 = *reinterpret_cast<const float4 *>(pb0 + k0); rb1 = *reinterpret_cast<const float4 *>(pb1 + k0);
-  };
-  auto gload_tail = [&](int k0) {
-    ra0 = g2_load4(pa0 - lc, k0 + lc, ke, true); ra1 = g2_load4(pa1 - lc, k0 + lc, ke, true);
-    rb0 = g2_load4(pb0 - lc, k0 + lc, ke, true); rb1 = g2_load4(pb1 - lc, k0 + lc, ke, true);
-  };
-  auto lstore = [&](int buf) {
-    float *as = As + buf * 64 * G2_LD, *bs = Bs + buf * 64 * G2_LD;
-    *reinterpret_cast<float4 *>(as + lr * G2_LD + lc) = ra0;
-    *reinterpret_cast<float4 *>(as + (lr + 32) * G2_LD + lc) = ra1;
-    *reinterpret_cast<float4 *>(bs + lr * G2_LD + lc) = rb0;
-    *reinterpret_cast<float4 *>(bs + (lr + 32) * G2_LD + lc) = rb1;
-  };
-  const int ro = (lane & 31) * G2_LD + 16 * (lane >> 5);
-  if (kb + 32 <= ke) gload_full(kb); else gload_tail(kb);
-  lstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kb; k0 < ke; k0 += 32, buf ^= 1) {
-    const int kn = k0 + 32;
-    if (kn + 32 <= ke) gload_full(kn);            // wave-uniform branches
-    else if (kn < ke) gload_tail(kn);
-    const float *as = As + buf * 64 * G2_LD + wm * 32 * G2_LD + ro;
-    const float *bs = Bs + buf * 64 * G2_LD + wn * 32 * G2_LD + ro;
-    float4 a4[4], b4[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      a4[j] = *reinterpret_cast<const float4 *>(as + 4 * j);
-      b4[j] = *reinterpret_cast<const float4 *>(bs + 4 * j);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
-    }
-    if (kn < ke) lstore(buf ^ 1);
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // The same GEMM on the f16 matrix pipe with SPLIT operands: every fp32 value v is carried as
@@ -468,33 +327,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h(int M, int N, int K, float al
   }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
-                                                          const float *__restrict__ A, int lda, long long sA,
-                                                          const float *__restrict__ B, int ldb, long long sB,
-                                                          const float *__restrict__ bias, long long sBias,
-                                                          float *__restrict__ C, int ldc, long long sC,
-                                                          int relu) {
-  __shared__ __attribute__((aligned(16))) float As[2 * 64 * G2_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * 64 * G2_LD];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  g2_mainloop(A, lda, B, ldb, M, N, m0, n0, 0, K, As, Bs, acc);
-  const int col = n0 + wn * 32 + (lane & 31);
-  const float bv = (bias && col < N) ? bias[(long long)blockIdx.z * sBias + col] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < M && col < N) {
-      float v = acc[r] + bv;
-      if (relu) v = fmaxf(v, 0.f);
-      C[(long long)row * ldc + col] = v;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // General batched GEMM for the SAC networks' forward AND backward passes:
@@ -504,7 +336,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_batched2(int M, int N, int K,
 // The three products of a linear layer y = x W (W stored [in][out]) are
 //     forward  y  = x . W        TA = 0, TB = 1        backward dx = dy . W^T     TA = 0, TB = 0
 //     weights  dW = x^T . dy     TA = 1, TB = 1
-// Same tile / LDS image / MFMA loop as k_gemm_nt_batched2 (g2_mainloop); a k-strided operand is read with 128-bit loads
+// 64 x 64 tile, LDS rows of 36 floats, one 32x32x2 accumulator per wave; a k-strided operand is read with 128-bit loads
 // along its contiguous (row) direction and transposed on the way into LDS.
 // ---------------------------------------------------------------------------------------------
 template <bool T>
