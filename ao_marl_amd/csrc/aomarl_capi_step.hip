@@ -700,6 +700,17 @@ static bool step_plan_uniform(const aomarl_ctx *c, int n, const float *accumx, c
   return true;
 }
 
+int aomarl_do_control_reduced(aomarl_ctx *c, aomarl_state *st, void *stream) {
+  if (!c || !st) return fail("do_control_reduced: null argument");
+  auto &P = c->pipe;
+  if (!(P.active && P.owner_screens == st->screens)) return aomarl_do_control(c, st, 0, st->nenv, stream);
+  aomarl_state v = pipe_view(c, st, 1 - P.par);       // the frame the last call reduced (the other parity is in flight)
+  c->pipe_internal = true;
+  const int rc = aomarl_do_control(c, &v, 0, st->nenv, stream);
+  c->pipe_internal = false;
+  return rc;
+}
+
 int aomarl_env_step_shortcut(aomarl_ctx *c, const aomarl_env_glue *g) {
   if (!c || !g) return 0;
   return (!g->denoiser && env_step_fusable(c, g, nullptr) && !small_chain_ok(c, g) && env_step_shortcut(c, g)) ? 1 : 0;

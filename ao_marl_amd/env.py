@@ -671,11 +671,15 @@ class VecAoEnv(object):
         # Btt coordinates of the command carried from frame to frame by linearity instead of two
         # v2m GEMMs per step (aomarl_rl_control_modes); fp32 round-off apart, the same numbers
         self.modal_shortcut = True
-        # v2m . err straight from the slopes (see _linear_step_fused).  Off by default: it replaces the
-        # reference's order of operations (cmat . s on the device, then v2m . err) by one product with
-        # v2m . cmat -- same mathematics, but the end-to-end trace recorded from the reference's own
-        # Python (tests/test_env_vs_reference_trace.py) is then met only within 2x its tolerance on the
-        # tip-tilt residual, for 1.5 % of step time.
+        # v2m . err straight from the slopes: ONE product with v2m . cmat instead of the reference's do_control
+        # (cmat . s on the device, integrate) + v2m . err -- same mathematics, another order of the fp32 sums (states
+        # within 1.3e-5 relative of the reference order's over 10 steps of the 40x40 system,
+        # tests/test_gpu_glue.py::test_residual_shortcut_inside_the_one_call_step; the end-to-end trace recorded from
+        # the reference's own Python, tests/test_env_vs_reference_trace.py, is met within 2x its tolerance on the
+        # tip-tilt residual).  Off by default (the reference's order; the pipelined step then IS the plain step bit
+        # for bit); bench.py switches it on for its throughput pass: one product and two launches less in the control
+        # chain (0.489 -> 0.482 ms per step at 256 environments).  Works inside the one-call step (aomarl_env_step,
+        # "residual_shortcut") and call by call; err / com in actuator space appear on demand.
         self.residual_shortcut = False
         # one library call per environment step (aomarl_env_step) when the configuration is the one it
         # covers (see _native_step_ok); the same launches in the same order as the call-by-call path
@@ -1028,9 +1032,10 @@ class VecAoEnv(object):
                 sup.ensure_slopes2modes()
             sup.sim.set_option("residual_shortcut", int(shortcut))
             self._native_shortcut = shortcut
-        if shortcut:        # (a small system's tail kernel runs do_control itself: nothing is left pending there)
-            shortcut = bool(sup.sim.lib.aomarl_env_step_shortcut(sup.sim.ctx, g._ref if hasattr(g, "_ref") else ctypes.byref(g)))
         sup.sim.env_step(g, action, sup.gain, state, r)
+        if shortcut:        # (a small system's tail kernel runs do_control itself: nothing is left pending there; asked
+            #                  BEHIND the call: it is the call that switches the deferred mirror shapes on)
+            shortcut = bool(sup.sim.lib.aomarl_env_step_shortcut(sup.sim.ctx, g._ref if hasattr(g, "_ref") else ctypes.byref(g)))
         if sup.reset_prefetch is not None:
             sup.step_done()
         self._ring_pos = g.ring_pos

@@ -497,6 +497,11 @@ class HipSim(object):
 
     def do_control(self, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
+        if getattr(self, "_twin", None) is not None and (b, n) == (0, self.nenv):
+            # (frame pipeline: the last REDUCED frame's slopes live in the state or in its twin by parity -- the library
+            # picks the view: a do_control the residual shortcut left to be run on demand)
+            la.check(self.lib.aomarl_do_control_reduced(self.ctx, C.byref(self.st), self._stream()))
+            return
         la.check(self.lib.aomarl_do_control(self.ctx, C.byref(self.st), b, n, self._stream()))
 
     def set_com(self, com, env_begin=0, env_count=None):

@@ -85,8 +85,10 @@ def parse_args():
                     help="WFS-image denoiser in the loop: 'shipped' (the reference's trained network, "
                          "ao_marl_amd/data) or a state_dict file: BASELINE configs[4] as the workload")
     ap.add_argument("--residual-shortcut", action="store_true",
-                    help="residual modes from one product with v2m.cmat instead of do_control + "
-                         "volts2modes (VecAoEnv.residual_shortcut; off in the product default)")
+                    help="residual modes from one product with v2m.cmat instead of do_control + volts2modes "
+                         "(VecAoEnv.residual_shortcut, an opt-in of the package: this bench's default together with the frame pipeline)")
+    ap.add_argument("--no-residual-shortcut", action="store_true",
+                    help="the reference's order (do_control, then v2m . err) also with the frame pipeline")
     ap.add_argument("--frame-pipeline-always", action="store_true",
                     help="VecAoEnv(frame_pipeline=True): pipelined whenever eligible, without the package's probe of "
                          "both call orders behind the first reset (the default, frame_pipeline='auto')")
@@ -632,7 +634,9 @@ def main():
     torch.cuda.synchronize()
     init_s = time.perf_counter() - t_init
     env, sim, layout = w.env, w.sim, w.layout
-    env.residual_shortcut = bool(args.residual_shortcut)
+    # throughput configuration: like the frame pipeline, the residual shortcut is an opt-in of the package that the
+    # bench takes (states within 1.3e-5 relative of the reference order's)
+    env.residual_shortcut = not args.no_residual_shortcut and (not args.no_frame_pipeline or args.residual_shortcut)
     if args.unfused:
         sim.set_option("force_unfused_frame", 1)
     if args.no_defer:
@@ -803,6 +807,7 @@ def main():
                                "what": "frame t+1 launched before frame t is reduced (loop delay = 1 frame): same kernels, "
                                        "same values, frame kernels back to back with the control / agent and extrusion "
                                        "chains beside them (aomarl_set_frame_pipeline)"},
+            "residual_shortcut": bool(env.residual_shortcut),
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "mean_strehl_le": sr,
             "integrator_only": integ,

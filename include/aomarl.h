@@ -507,6 +507,13 @@ int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, co
  * matrix matches the glue's modes, the chain is fusable and the system is not a small one, whose tail kernel does
  * do_control itself), else 0: a host that defers do_control must know (VecAoEnv._step_native). */
 int aomarl_env_step_shortcut(aomarl_ctx *ctx, const aomarl_env_glue *glue);
+/* Rtc.do_control (rtcCompass.py:547) for the whole batch on the slopes of the frame the last aomarl_env_step REDUCED:
+ * with a frame in flight (aomarl_set_frame_pipeline) those live in the state or in its twin by parity, and the call-by-
+ * call aomarl_do_control is refused; this one picks the view itself (err and com are not parity buffers, the next
+ * call's head rebuilds com from the Btt coordinates before the delay line takes it).  Without a frame in flight:
+ * aomarl_do_control of the whole batch.  What a host that runs with "residual_shortcut" calls when somebody asks for
+ * err / the integrated command in actuator space (rtc.get_err / rtc.get_command, rtcCompass.py:114-142). */
+int aomarl_do_control_reduced(aomarl_ctx *ctx, aomarl_state *st, void *stream);
 /* aomarl_set_option(ctx, "graph_step", 1): aomarl_env_step replays a HIP graph captured from its own launch
  * sequence (one per distinct extrusion plan x ring position x buffer addresses; captured the first time a
  * combination occurs): one hipGraphLaunch instead of ~25 launches + ~8 event operations per step, for the
