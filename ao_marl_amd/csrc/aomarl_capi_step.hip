@@ -123,13 +123,13 @@ static int env_step_validate(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g
 // Same formulas as the kernels they stand for; the sums of the products run in one thread each, in index order
 // (the split-K GEMM sums tiles): fp32 round-off apart, the same numbers ("small_chain" = 0: the general chain).
 constexpr int SMALL_NM = 512, SMALL_NA = 512, SMALL_NSL = 1024;
-// y[o] = sum_k x[k] W[o][k] for o < no, x in LDS, by a 256-thread block: FOUR threads per output (they read 16
-// consecutive bytes of the row per step, two accumulators each, then two xor-shuffles), 64 outputs per pass.
+// y[o] = sum_k x[k] W[o][k] for o < no, x in LDS, by the whole block: FOUR threads per output (they read 16
+// consecutive bytes of the row per step, two accumulators each, then two xor-shuffles), blockDim.x / 4 outputs per pass.
 // done(o, y) runs in the first thread of each quad.
 template <class F>
 __device__ __forceinline__ void small_gemv(const float *__restrict__ W, int ldw, int no, int K, const float *xs, F done) {
-  const int tid = threadIdx.x, q = tid & 3;
-  for (int o0 = 0; o0 < no; o0 += 64) {
+  const int tid = threadIdx.x, q = tid & 3, per = blockDim.x >> 2;
+  for (int o0 = 0; o0 < no; o0 += per) {
     const int o = o0 + (tid >> 2);
     float a0 = 0.f, a1 = 0.f;
     if (o < no) {
@@ -698,6 +698,22 @@ static bool step_plan_uniform(const aomarl_ctx *c, int n, const float *accumx, c
       else if (p.kx[l] != kx || p.ky[l] != ky) return false;
     }
   return true;
+}
+
+// choose_action + env_step from C: one host round trip instead of two.  (A workgroup-per-environment kernel that ran
+// the actors as matrix-vector products inside the small systems' head launch was built and measured in round 5: 64
+// workgroups streaming the same megabyte of weights in lock-step took 130 us against 23 + 11 us for k_actor_fused +
+// k_small_head -- the 16-environment matrix tiles of k_actor_fused read every weight four times, not sixty-four;
+// LAB_NOTEBOOK section 11.)
+int aomarl_policy_env_step(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *g, const aomarl_actor_desc *d,
+                           const float *state, const float *eps, uint32_t seed, uint32_t counter, float gain,
+                           float *accumx, float *accumy, float *action, float *mean, float *state_out,
+                           float *reward_out, void *stream) {
+  if (!c || !st || !g || !d || !state || !action || !mean || !state_out) return fail("policy_env_step: null argument");
+  if (d->nenv != st->nenv) return fail("policy_env_step: the actors are set up for %d environments, the state has %d", d->nenv, st->nenv);
+  int rc = aomarl_actor_forward(d, state, eps, seed, counter, action, mean, stream);
+  if (rc) return rc;
+  return aomarl_env_step(c, st, g, action, gain, accumx, accumy, state_out, reward_out, stream);
 }
 
 int aomarl_do_control_reduced(aomarl_ctx *c, aomarl_state *st, void *stream) {

@@ -3696,14 +3696,18 @@ __device__ __forceinline__ void strehl_commit_body(const DevSys &sys, const DevS
   float *le = st.le_img + (long long)e * W * W;
   float mse = 0.f, mle = 0.f;
   int arg = 0, argl = 0;
-  for (int o = threadIdx.x; o < W * W; o += blockDim.x) {
-    const float p = pend[o];
-    const float l = le[o] + p;
-    le[o] = l;
-    if (p > mse) { mse = p; arg = o; }
-    if (l > mle) { mle = l; argl = o; }
+  // (the first 256 threads of the block do the work: blocks of 256 -- every caller but k_small_actor_head -- all of them)
+  const int nthr = min((int)blockDim.x, 256);
+  if ((int)threadIdx.x < nthr) {
+    for (int o = threadIdx.x; o < W * W; o += nthr) {
+      const float p = pend[o];
+      const float l = le[o] + p;
+      le[o] = l;
+      if (p > mse) { mse = p; arg = o; }
+      if (l > mle) { mle = l; argl = o; }
+    }
+    r0[threadIdx.x] = mse; r1[threadIdx.x] = mle; ri[threadIdx.x] = arg; rl[threadIdx.x] = argl;
   }
-  r0[threadIdx.x] = mse; r1[threadIdx.x] = mle; ri[threadIdx.x] = arg; rl[threadIdx.x] = argl;
   __syncthreads();
   // (ties go to the lower index, like the scans of the oracle: the sinc fit reads the neighbours of THAT pixel)
   for (int o = 128; o >= 1; o >>= 1) {

@@ -978,13 +978,47 @@ class VecAoEnv(object):
     _pipe_checked = False
     _native_shortcut = False
 
-    def _step_native(self, action, out=None):
+    def policy_step(self, policy, state, eps=None, out=None, action_out=None):
+        """TrainerRPC.choose_action + TrainerRPC.env_step (train_rpc.py:650-675, 633-648) in ONE library call
+        (aomarl_policy_env_step): a = policy.select_action(state) (sampled), then step(a).  Returns
+        (action, s_next, per-agent reward, done, info): the same launches as select_action followed by step, issued by
+        one call (a host-bound step of a small system saves a host round trip); whenever the one-call step does not
+        apply, this IS select_action followed by step.  out = (state, reward) / action_out: the caller's buffers."""
+        sup = self.supervisor
+        std = sup.config_rl["normalization_std_inside_environment"]
+        mean = sup.config_rl["normalization_mean_inside_environment"]
+        ok = (self._native_step_ok(False) and std == 1.0 and mean == 0.0 and getattr(policy, "use_native", False) and
+              getattr(policy, "native_forward", False) and not getattr(policy, "out_ring", 0) and
+              isinstance(state, torch.Tensor) and state.dtype == torch.float32 and state.dim() == 2 and
+              state.shape == (self.nenv, policy.layout.state_dim) and state.device == self.device and
+              hasattr(sup.sim, "policy_env_step") and not getattr(sup.sim, "graph_step", False))
+        if not ok:
+            a, _ = policy.select_action(state, eps=eps, out=action_out)
+            s_next, r, done, info = self.step(a, out=out)
+            return a, s_next, r, done, info
+        if not state.is_contiguous():
+            state = state.contiguous()
+        d = policy._actor_desc(self.nenv)
+        policy._draws += 1
+        a = action_out if action_out is not None else torch.empty(self.nenv, self.action_dim, dtype=torch.float32, device=self.device)
+        if a.shape != (self.nenv, self.action_dim) or a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            raise ValueError("policy_step: action_out must be a contiguous float32 [nenv, action_dim] tensor on the environment's device")
+        if self._mean_buf is None or self._mean_buf.shape != a.shape:
+            self._mean_buf = torch.empty_like(a)
+        if eps is not None:
+            eps = eps.to(torch.float32).contiguous()
+        s_next, r, done, info = self._step_native(a, out, policy=(d, state, eps, policy.seed, policy._draws, self._mean_buf))
+        return a, s_next, r, done, info
+
+    _mean_buf = None
+
+    def _step_native(self, action, out=None, policy=None):
         sup = self.supervisor
         std = sup.config_rl["normalization_std_inside_environment"]
         mean = sup.config_rl["normalization_mean_inside_environment"]
         if not (isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.device == self.device):
             action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
-        if std != 1.0 or mean != 0.0:
+        if policy is None and (std != 1.0 or mean != 0.0):
             action = action * std + mean
         if not action.is_contiguous():
             action = action.contiguous()
@@ -1032,7 +1066,11 @@ class VecAoEnv(object):
                 sup.ensure_slopes2modes()
             sup.sim.set_option("residual_shortcut", int(shortcut))
             self._native_shortcut = shortcut
-        sup.sim.env_step(g, action, sup.gain, state, r)
+        if policy is not None:      # (the action is an OUTPUT here: the actors run inside the call)
+            d, s_in, eps, seed, counter, mean_buf = policy
+            sup.sim.policy_env_step(g, d, s_in, eps, seed, counter, sup.gain, action, mean_buf, state, r)
+        else:
+            sup.sim.env_step(g, action, sup.gain, state, r)
         if shortcut:        # (a small system's tail kernel runs do_control itself: nothing is left pending there; asked
             #                  BEHIND the call: it is the call that switches the deferred mirror shapes on)
             shortcut = bool(sup.sim.lib.aomarl_env_step_shortcut(sup.sim.ctx, g._ref if hasattr(g, "_ref") else ctypes.byref(g)))

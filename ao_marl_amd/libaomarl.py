@@ -136,6 +136,8 @@ SYMBOLS = [
     ("aomarl_actor_tile_weights", _i, [_i, _i, _i, _vp, _vp, _vp]),
     ("aomarl_actor_forward", _i, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     ("aomarl_env_step", _i, [_vp, C.POINTER(State), _vp, _vp, _f, _fp, _fp, _vp, _vp, _vp]),
+    ("aomarl_policy_env_step", _i, [_vp, C.POINTER(State), _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _f, _fp, _fp,
+                                    _vp, _vp, _vp, _vp, _vp]),
     ("aomarl_env_step_shortcut", _i, [_vp, _vp]),
     ("aomarl_do_control_reduced", _i, [_vp, C.POINTER(State), _vp]),
     ("aomarl_graph_stats", _i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),

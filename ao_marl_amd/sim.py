@@ -236,6 +236,23 @@ class HipSim(object):
         if self.prefetch and not self.pending_atmos:
             self.pending_atmos, self._pending_range = True, (0, self.nenv)
 
+    def policy_env_step(self, glue, desc, state, eps, seed, counter, gain, action, mean, state_out, reward_out=None):
+        """aomarl_policy_env_step: the actors on `state` and the environment step with their action in ONE library call."""
+        want = self.defer_shape and (self._defer_on or self.dm_from_voltage_available())
+        if want != self._defer_on:
+            self._set_defer(want)
+        ptrs = self.__dict__.get("_accum_ptrs")
+        if ptrs is None or ptrs[0] is not self.accumx or ptrs[1] is not self.accumy:
+            ptrs = self._accum_ptrs = (self.accumx, self.accumy, la.fptr(self.accumx), la.fptr(self.accumy))
+        la.check(self.lib.aomarl_policy_env_step(
+                self.ctx, self._st_ref, glue._ref if hasattr(glue, "_ref") else C.byref(glue), C.byref(desc),
+                state.data_ptr(), eps.data_ptr() if eps is not None else None, seed & 0xFFFFFFFF, counter & 0xFFFFFFFF,
+                gain, ptrs[2], ptrs[3], action.data_ptr(), mean.data_ptr(), state_out.data_ptr(),
+                reward_out.data_ptr() if reward_out is not None else None, self._stream()))
+        self._stale = self._defer_on
+        if self.prefetch and not self.pending_atmos:
+            self.pending_atmos, self._pending_range = True, (0, self.nenv)
+
     def graph_stats(self):
         """(graphs captured, graphs replayed) by aomarl_env_step under set_option("graph_step", 1)."""
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)

@@ -390,8 +390,9 @@ class Workload(object):
         self.launched, self.local_elapsed = {}, None
 
     def one_step(self):
-        a, _ = self.policy.select_action(self.state)
-        self.state, self.last_r, _, _ = self.env.step(a)
+        # choose_action + env_step as ONE library call (aomarl_policy_env_step): the launches of policy.select_action
+        # followed by env.step, one host round trip
+        _, self.state, self.last_r, _, _ = self.env.policy_step(self.policy, self.state)
 
     def one_step_integrator(self):
         # TrainerRPC.env_step(a=None, linear_control=True): the integrator alone (train_rpc.py:577-578)

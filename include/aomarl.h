@@ -497,6 +497,14 @@ typedef struct {
 int aomarl_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, const float *action_dev,
                     float gain, float *accumx, float *accumy, float *state_out, float *reward_out,
                     void *stream);
+/* TrainerRPC.choose_action + TrainerRPC.env_step (train_rpc.py:650-675, 633-648) in ONE call: action = the actors on
+ * `state` (aomarl_actor_forward's arguments), then aomarl_env_step with that action -> state_out (the next state),
+ * reward_out: the two entry points one behind the other, from C -- one host round trip per step instead of two (a
+ * host-bound step of a small system notices: BASELINE configs[1]).  action / mean: [nenv][action_dim] outputs. */
+int aomarl_policy_env_step(aomarl_ctx *ctx, aomarl_state *st, aomarl_env_glue *glue, const aomarl_actor_desc *d,
+                           const float *state_dev, const float *eps_dev, uint32_t seed, uint32_t counter, float gain,
+                           float *accumx, float *accumy, float *action_dev, float *mean_dev, float *state_out,
+                           float *reward_out, void *stream);
 /* aomarl_set_option(ctx, "residual_shortcut", 1) (needs aomarl_set_slopes2modes): aomarl_env_step takes the residual
  * modes v2m . err of a frame from ONE product of its slopes with -(v2m . cmat) instead of aomarl_do_control (cmat . s,
  * integrate) + v2m . err: the integrator then lives in the Btt coordinates alone (the next call's head rebuilds the

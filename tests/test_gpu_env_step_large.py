@@ -266,11 +266,16 @@ def test_configs1_batch_through_the_small_system_path(pipe):
         return env
     big, small, gen = make(n, pipe), make(small_n, pipe), make(n, False, general=True)
     other = make(n, not pipe)
+    one, two = make(n, pipe), make(n, pipe)                  # choose_action + env_step as ONE call (aomarl_policy_env_step)
     lay = big.layout
     assert lay.n_agents == 2 and lay.action_dim == 82 and lay.state_shapes() == [320, 8]
     pol = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=7, device="cuda:0")
     sb, ss, sg, so = big.reset(), small.reset(), gen.reset(), other.reset()
-    assert torch.equal(sb[0], sb[1]) and torch.equal(sb, so)
+    s1, s2 = one.reset(), two.reset()
+    assert torch.equal(sb[0], sb[1]) and torch.equal(sb, so) and torch.equal(sb, s1)
+    pol1 = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=7, device="cuda:0")     # the same weights, its own draw counter
+    pol2 = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=7, device="cuda:0")
+    worst1 = 0.0
     g = torch.Generator(device="cuda:0").manual_seed(9)
     live = torch.cat([torch.isfinite(big.norm["dm"][1])] * 3 + [torch.isfinite(big.norm["dm_residual"][1])])
     worst = dict(sub=0.0, general=0.0)
@@ -292,6 +297,20 @@ def test_configs1_batch_through_the_small_system_path(pipe):
         worst["sub"], worst["general"] = max(worst["sub"], d1), max(worst["general"], d2)
         assert d1 < 1e-6 and d2 < 1e-4, (it, d1, d2)    # (one workgroup per environment: the sub-batch is the batch bit for bit; general chain: 1e-5 measured)
         assert torch.allclose(rb, rg, rtol=5e-3, atol=1e-4)
+        # choose_action + env_step as one library call: the same launches, the same numbers
+        a_same, _ = pol.select_action(s1, eps=eps)
+        a1, s1n, r1, _, _ = one.policy_step(pol1, s1, eps=eps)
+        assert torch.equal(a1, a_same), it
+        assert torch.equal(a1[0], a1[1]) and torch.equal(s1n[0], s1n[1]) and torch.equal(r1[0], r1[1]), it
+        s1 = s1n
+        worst1 = max(worst1, (s1 - sb)[:, live].abs().max().item() / max(1.0, sb[:, live].abs().max().item()))
+        # ... and on the policy's own Philox draws (keyed by seed, number of calls, environment, action index: what
+        # select_action draws with the same counter)
+        pol2._draws = 100 + it
+        a_ref, _ = pol2.select_action(s2)
+        pol2._draws = 100 + it
+        a2, s2, _, _, _ = two.policy_step(pol2, s2)
+        assert torch.equal(a2, a_ref), it
     if pipe:
         flying, _, piped, _ = big.supervisor.sim.frame_pipeline_state()
         assert flying and piped >= steps - 1
@@ -300,5 +319,8 @@ def test_configs1_batch_through_the_small_system_path(pipe):
     assert abs(np.corrcoef(sl[2].cpu().numpy(), sl[3].cpu().numpy())[0, 1]) < 0.4     # different seeds decorrelate
     st = (big if not pipe else other).supervisor.get_strehl().cpu().numpy()
     assert np.isfinite(st).all() and st[:, 0].min() > 0.0
+    assert worst1 == 0.0, worst1                          # the same launches: the same bits
+    assert torch.isfinite(s1).all() and one.supervisor.sim.frame_pipeline_state()[0] == bool(pipe)
     print("64 x 2 agents, %d steps (%s): batch against batch-of-8 worst %.2e, small-system kernels against the general chain "
-          "%.2e (standardised states)" % (steps, "pipelined" if pipe else "plain order", worst["sub"], worst["general"]))
+          "%.2e, one-call policy step against select_action + step %.2e (standardised states)" %
+          (steps, "pipelined" if pipe else "plain order", worst["sub"], worst["general"], worst1))
