@@ -770,8 +770,11 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
                                max_steps * env.nenv, env.device)
     for t in range(max_steps):
         if traj is not None:
-            a, mu = sac.policy.select_action(s, eval_mode=eval_mode, out=traj.A[t])
-            s_next, r, done, _ = env.step(a, out=(traj.S[t + 1], traj.R[t]))
+            if eval_mode or not hasattr(env, "policy_step"):
+                a, mu = sac.policy.select_action(s, eval_mode=eval_mode, out=traj.A[t])
+                s_next, r, done, _ = env.step(a, out=(traj.S[t + 1], traj.R[t]))
+            else:           # choose_action + env_step in one library call, every output straight into the trajectory
+                a, s_next, r, done, _ = env.policy_step(sac.policy, s, out=(traj.S[t + 1], traj.R[t]), action_out=traj.A[t])
             traj.t = t + 1
             s = s_next
             continue
