@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <type_traits>
 
 #ifndef GP_TYPES
 #define GP_TYPES
@@ -48,7 +49,7 @@ template <> struct gg_vec<2> { typedef float2 t; };
 template <> struct gg_vec<4> { typedef float4 t; };
 
 // one workgroup = tile `w` of the problem's (group-major) tile list
-template <int WM, int WN, bool AK, bool BK>
+template <int WM, int WN, bool AK, bool BK, bool CS = false>
 __device__ __forceinline__ void gemm_g_body(const GemmGArgs &a, const int w) {
   static_assert((WM == 2 || WM == 4) && (WN == 2 || WN == 4), "wave tiles of 32 or 64 rows / columns");
   constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -113,10 +114,12 @@ __device__ __forceinline__ void gemm_g_body(const GemmGArgs &a, const int w) {
         rb[st][p] = *reinterpret_cast<const float4 *>(pb[p] + (long long)min(kt * GG_KT + krb + (32 / WN) * p, K - 1) * a.ldb);
     }
   };
-  const bool want_cs = !BK && a.colsum != nullptr && tm == 0;   // block-uniform
+  const bool want_cs = CS && !BK && a.colsum != nullptr && tm == 0;   // block-uniform (CS: instantiations without the sums carry no code for them)
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto lstore = [&](int buf, int st, int kt) {
-    const bool tail = (kt + 1) * GG_KT > K;        // wave-uniform: the tile crosses the end of K
+  // TAILc: the tile crosses the end of K (only ever the last one): its own instantiation of the step, so that the
+  // k-tiles in front of it carry no masks (as selects they cost 27 vector instructions per k-tile of 32 matrix ones)
+  auto lstore = [&](int buf, int st, int kt, auto TAILc) {
+    constexpr bool tail = decltype(TAILc)::value;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     if (AK) {
       float *as = As + buf * SA + lr * PA + lcs;
@@ -209,12 +212,14 @@ __device__ __forceinline__ void gemm_g_body(const GemmGArgs &a, const int w) {
       acc[g][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ob[j][c][h], oa[j][c][g], acc[g][h], 0, 0, 0);
   // software pipeline of aomarl_gemm_p.h: tile kt in LDS buffer kt & 1, tile kt + 1 in register stage (kt + 1) & 1,
   // tile kt + 2 in flight into stage kt & 1; one barrier per k-tile between its two halves.
-  auto step = [&](int kt, int S) {
+  const std::integral_constant<bool, false> full_c;
+  const std::integral_constant<bool, true> tail_c;
+  auto step = [&](int kt, int S, auto TAILc) {
     fread(S, 1);
     __builtin_amdgcn_sched_barrier(0);
     GG_MMA(0, 0) GG_MMA(0, 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nkt) lstore(S ^ 1, S ^ 1, kt + 1);   // wave-uniform
+    if (kt + 1 < nkt) lstore(S ^ 1, S ^ 1, kt + 1, TAILc);   // wave-uniform
     gload(kt + 3, S ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     GG_MMA(0, 2) GG_MMA(0, 3)
@@ -225,17 +230,19 @@ __device__ __forceinline__ void gemm_g_body(const GemmGArgs &a, const int w) {
     GG_MMA(1, 0) GG_MMA(1, 1) GG_MMA(1, 2) GG_MMA(1, 3)
     __builtin_amdgcn_sched_barrier(0);
   };
+  const bool ktail = (K & (GG_KT - 1)) != 0;        // the last k-tile is a partial one
   gload(0, 0);
   gload(1, 1);
   __builtin_amdgcn_sched_barrier(0);
-  lstore(0, 0, 0);
+  if (ktail && nkt == 1) lstore(0, 0, 0, tail_c); else lstore(0, 0, 0, full_c);
   gload(2, 0);
   __syncthreads();
   fread(0, 0);
+  // (the step that STAGES tile nkt - 1 is step nkt - 2)
   for (int kt = 0; kt < nkt; kt += 2) {
-    step(kt, 0);
+    if (ktail && kt + 2 == nkt) step(kt, 0, tail_c); else step(kt, 0, full_c);
     if (kt + 1 >= nkt) break;
-    step(kt + 1, 1);
+    if (ktail && kt + 3 == nkt) step(kt + 1, 1, tail_c); else step(kt + 1, 1, full_c);
   }
 #undef GG_MMA
 
@@ -310,7 +317,8 @@ template <int WM, int WN, bool AK, bool BK>
 __global__ __launch_bounds__(256, 2) void k_gemm_g(const GemmGArgs a) {
   const int w = gemm_g_tile_of_block();
   if (w >= a.ntile) return;
-  gemm_g_body<WM, WN, AK, BK>(a, w);
+  if (!BK && a.colsum) gemm_g_body<WM, WN, AK, BK, true>(a, w);      // block-uniform
+  else gemm_g_body<WM, WN, AK, BK>(a, w);
 }
 
 // Up to GG_MAXP independent products in ONE launch (64 x 64 tiles), each with its own shapes, operand forms and
@@ -333,7 +341,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_g_multi(const GemmGMulti mp) {
   while (i < mp.np - 1 && w >= mp.tile_end[i]) i++;
   const int wl = w - (i ? mp.tile_end[i - 1] : 0);
   switch (mp.form[i]) {
-    case 0: gemm_g_body<2, 2, false, false>(mp.p[i], wl); break;
+    case 0:
+      if (mp.p[i].colsum) gemm_g_body<2, 2, false, false, true>(mp.p[i], wl);
+      else gemm_g_body<2, 2, false, false>(mp.p[i], wl);
+      break;
     case 1: gemm_g_body<2, 2, false, true>(mp.p[i], wl); break;
     case 2: gemm_g_body<2, 2, true, false>(mp.p[i], wl); break;
     default: gemm_g_body<2, 2, true, true>(mp.p[i], wl); break;
