@@ -48,5 +48,5 @@ for _ in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     run_episode(env, sac, max_steps=N + 20, train=True, n_updates=1, batch_size=256, timing=tm)
     torch.cuda.synchronize()
-    print("run_episode (bookkeeping on its own stream)        %.3f ms per step incl. the reset (46 ms / %d steps = %.3f)" %
+    print("run_episode (trajectory-resident, one call per step) %.3f ms per step incl. the reset (46 ms / %d steps = %.3f)" %
           (tm["steps_s"] / (N + 20) * 1e3, N + 20, 46.0 / (N + 20)), flush=True)
