@@ -991,6 +991,7 @@ class VecAoEnv(object):
               getattr(policy, "native_forward", False) and not getattr(policy, "out_ring", 0) and
               isinstance(state, torch.Tensor) and state.dtype == torch.float32 and state.dim() == 2 and
               state.shape == (self.nenv, policy.layout.state_dim) and state.device == self.device and
+              policy.layout.action_dim == self.action_dim and
               hasattr(sup.sim, "policy_env_step") and not getattr(sup.sim, "graph_step", False))
         if not ok:
             a, _ = policy.select_action(state, eps=eps, out=action_out)

@@ -367,7 +367,7 @@ def calibrate(s, sysm, backend, nfilt=0, verbose=False, cache=True, backend_id=N
             cache_stats["miss"] += 1
             _CAL_MEMO[key] = _pack(c)
             return c
-        os.makedirs(cdir, exist_ok=True)
+        os.makedirs(cdir, mode=0o700, exist_ok=True)     # (arrays only: np.load refuses pickles; the directory is the user's own)
         path = os.path.join(cdir, key + ".npz")
         lock = open(os.path.join(cdir, key + ".lock"), "w")
         try:
