@@ -204,16 +204,19 @@ def test_load_model_accepts_the_three_actor_file_layouts(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipe", [False, True])
-def test_trajectory_resident_episode_is_the_step_by_step_bookkeeping(pipe):
+@pytest.mark.parametrize("pipe,online", [(False, False), (True, False), (False, True)])
+def test_trajectory_resident_episode_is_the_step_by_step_bookkeeping(pipe, online):
     """run_episode on the GPU writes states, actions and rewards straight into trajectory buffers (TrajectoryReplay:
     no copy per step) -- the transitions the agents then learn from are the ones the reference's delayed-MDP
     bookkeeping (DelayedMDP + manage_memory: one replay push per step) stores, row for row and bit for bit, and so
     are the episode's returns and the learner it leaves behind."""
     from ao_marl_amd.env import VecAoEnv
     from ao_marl_amd.sac import BatchedReplay, TrajectoryReplay, run_episode
-    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    # online: `modification_online` -- the delayed-MDP tuple then spans delay + 0 steps (delayed_mdp.py:11-16) and the
+    # environment steps call by call (pure-delay-0 order): the trajectory views must follow both
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, modification_online=online)
     T, E = 14, 6
+    lag = 1 if online else 2
     got = {}
     for mode in ("steps", "traj"):
         torch.manual_seed(11)
@@ -224,7 +227,7 @@ def test_trajectory_resident_episode_is_the_step_by_step_bookkeeping(pipe):
 
         def record(m, **kw):                # (the episode's master memory as the learner would receive it)
             assert isinstance(m, TrajectoryReplay if mode == "traj" else BatchedReplay)
-            assert len(m) == (T - 2) * E                          # delay 1, no online modification: tuples from step 2 on
+            assert len(m) == (T - lag) * E                        # delay 1 (+ 1 without online modification): tuples from step `lag` on
             seen.append([t.clone() for t in m.rows(0, len(m))])
             return 0
         sac.update_parameters = record
