@@ -30,13 +30,14 @@ typedef float f32x4d __attribute__((ext_vector_type(4)));
 
 struct DenoiseW {
   const float *w1;        // [3][64]                 L1: tap 4i+q, channel c
-  const float4 *w2;       // [9][1][2][64]           L2
-  const float4 *w3;       // [9][2][4][64]           L3
-  const float4 *w4;       // [4][4][4][2][64]        D1: class, tap, group, tile
-  const float4 *w5;       // [4][4][2][1][64]        D2
-  // the same four arrays as split-fp16 B operands: per (step, lane) one 16-byte word
-  // [hi(b0..b3) | lo(b0..b3)] (see dup_hl in aomarl_kernels.hip)
-  const float4 *w2h, *w3h, *w4h, *w5h;
+  // fp32 B operands of L2, L3, D1, D2 in ONE allocation (k_denoise4 reads them through one buffer resource), one
+  // float4 per lane per (tap, channel group, channel tile):
+  //   L2 [9][1][2][64] at DN_WOFF2, L3 [9][2][4][64] at DN_WOFF3, D1 [4 classes][4 taps][4][2][64] at DN_WOFF4,
+  //   D2 [4][4][2][1][64] at DN_WOFF5
+  const float4 *wf;
+  // k_denoise4's border table: [5][256] words, two 16-bit LDS byte offsets each (entry e of thread t in word
+  // (e >> 1) * 256 + t, low half first): the zero stores of the six grids' borders, DN_DUMMY for a thread without one
+  const unsigned *border;
   // split-fp16 B operands in 32-channel chunks (k_denoise4c): per (chunk, tile, lane) two 16-byte
   // words, hi then lo, of the lane's 8 consecutive K slots
   const float4 *w2c;      // [5 tap pairs][2 tiles][64][2]
@@ -59,103 +60,9 @@ __device__ __forceinline__ f32x4d dn_mfma(float a, float b, f32x4d c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void dn_zero(float *p, int n, int tid) {
-  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid * 4; i < n; i += 128 * 4) *reinterpret_cast<float4 *>(p + i) = z;
-}
-
 // zero the one-pixel border of an [R][R][S] channel-last grid (S floats per position, S % 4 == 0,
-// or S == 1): 4R - 4 positions; the interior is overwritten by the layer that owns the grid
-template <int R, int S>
-__device__ __forceinline__ void dn_border(float *p, int tid) {
-  constexpr int NP = 4 * R - 4;
-  if (S == 1) {
-    for (int i = tid; i < NP; i += 128) {
-      const int row = i < R ? 0 : (i < 2 * R ? R - 1 : 1 + ((i - 2 * R) >> 1));
-      const int col = i < R ? i : (i < 2 * R ? i - R : (((i - 2 * R) & 1) ? R - 1 : 0));
-      p[row * R + col] = 0.f;
-    }
-  } else {
-    constexpr int V = S / 4;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < NP * V; i += 128) {
-      const int pi = i / V, k = i - pi * V;
-      const int row = pi < R ? 0 : (pi < 2 * R ? R - 1 : 1 + ((pi - 2 * R) >> 1));
-      const int col = pi < R ? pi : (pi < 2 * R ? pi - R : (((pi - 2 * R) & 1) ? R - 1 : 0));
-      *reinterpret_cast<float4 *>(p + (row * R + col) * S + 4 * k) = z;
-    }
-  }
-}
-
-// four MFMAs: A = 4 consecutive channels of this lane's position, B = the matching weights
-__device__ __forceinline__ f32x4d dn_quad(const float4 a, const float4 b, f32x4d acc) {
-  acc = dn_mfma(a.x, b.x, acc);
-  acc = dn_mfma(a.y, b.y, acc);
-  acc = dn_mfma(a.z, b.z, acc);
-  acc = dn_mfma(a.w, b.w, acc);
-  return acc;
-}
-
-// Split-fp16 variant (H): a value v is carried as hi = f16(v), lo = f16(v - hi) (22 mantissa bits).
-// The 16 real terms of a quad (4 channels x 4 lane groups) occupy the K = 32 slots of
-// v_mfma_f32_16x16x32_f16 twice:  A = [hi(a0..a3) | lo(a0..a3)],  B = [hi(b) | hi(b)] then
-// [lo(b) | lo(b)], so two 16-cycle instructions give (a_hi + a_lo)(b_hi + b_lo) in fp32 against four
-// 32-cycle fp32 MFMAs.
-//  * the activations A1..A4 live in LDS ALREADY in that form: the 16 bytes of a (position, 4-channel
-//    group) hold [h0 h1 h2 h3 l0 l1 l2 l3] instead of four floats -- same addresses, same strides,
-//    split once by the layer that produces them (each value is consumed 4 to 18 times), so an A
-//    operand is one ds_read_b128 and no arithmetic;
-//  * the weights stream as [hi(b0..b3) | lo(b0..b3)], 16 bytes per lane like the fp32 operand (the
-//    stream out of L2 is what this kernel is closest to), and are expanded with register moves.
-// Values must stay inside the fp16 range (|v| < 65504): photon counts and the activations of this
-// network do by orders of magnitude; aomarl_denoiser_apply_f32 is the all-fp32 kernel otherwise.
-template <bool H> struct DnWt { float4 b; };         // a streamed B operand, as loaded
-template <bool H>
-__device__ __forceinline__ DnWt<H> dn_ldw(const float4 *__restrict__ p, int idx) {
-  DnWt<H> r; r.b = p[idx]; return r;
-}
-template <bool H> struct DnB;                        // a B operand ready for the matrix instruction(s)
-template <> struct DnB<false> { float4 b; };
-template <> struct DnB<true> { hx8 h, l; };
-__device__ __forceinline__ DnB<false> dn_expand(const DnWt<false> w) { DnB<false> r; r.b = w.b; return r; }
-__device__ __forceinline__ DnB<true> dn_expand(const DnWt<true> w) {
-  const hx2 h01 = __builtin_bit_cast(hx2, w.b.x), h23 = __builtin_bit_cast(hx2, w.b.y);
-  const hx2 l01 = __builtin_bit_cast(hx2, w.b.z), l23 = __builtin_bit_cast(hx2, w.b.w);
-  DnB<true> r;
-  r.h = hx8{h01[0], h01[1], h23[0], h23[1], h01[0], h01[1], h23[0], h23[1]};
-  r.l = hx8{l01[0], l01[1], l23[0], l23[1], l01[0], l01[1], l23[0], l23[1]};
-  return r;
-}
-__device__ __forceinline__ f32x4d dn_quadw(const float4 a, const DnB<false> b, f32x4d acc) {
-  return dn_quad(a, b.b, acc);
-}
-__device__ __forceinline__ f32x4d dn_quadw(const float4 a, const DnB<true> b, f32x4d acc) {
-  const hx8 A = __builtin_bit_cast(hx8, a);
-  acc = mfma_h(A, b.h, acc);
-  return mfma_h(A, b.l, acc);
-}
-// store activation v of channel ch at a position whose channel vector starts at `pos`
-template <bool H>
-__device__ __forceinline__ void dn_store(float *pos, int ch, float v) {
-  if (!H) {
-    pos[ch] = v;
-  } else {
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
-    _Float16 *p = reinterpret_cast<_Float16 *>(pos) + 8 * (ch >> 2) + (ch & 3);
-    p[0] = hi;
-    p[4] = lo;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// FOUR waves per image (four blocks = sixteen waves per CU; a two-wave-per-image version of this
-// kernel was measured at 6.1 ms per 307 200 images against 5.8 ms, profiles/r01h_*, and retired).
-// Work split (wv = 0..3):
-//   L1  M tiles 4 wv .. 4 wv + 3            L2  N tile wv & 1, M tiles 2 (wv >> 1), + 1
-//   L3  N tile wv                           D1  N tile wv & 1, parity classes 2 (wv >> 1), + 1
-//   D2  parity class wv (py = wv >> 1, px = wv & 1), all four M tiles       D3  one pixel per thread
-// ---------------------------------------------------------------------------------------------
+// or S == 1): 4R - 4 positions; the interior is overwritten by the layer that owns the grid (k_denoise4c;
+// the fp32 kernel reads the same positions from a table)
 template <int R, int S>
 __device__ __forceinline__ void dn_border4(float *p, int tid) {
   constexpr int NP = 4 * R - 4;
@@ -177,46 +84,90 @@ __device__ __forceinline__ void dn_border4(float *p, int tid) {
   }
 }
 
-template <bool H>
+// four MFMAs: A = 4 consecutive channels of this lane's position, B = the matching weights
+__device__ __forceinline__ f32x4d dn_quad(const float4 a, const float4 b, f32x4d acc) {
+  acc = dn_mfma(a.x, b.x, acc);
+  acc = dn_mfma(a.y, b.y, acc);
+  acc = dn_mfma(a.z, b.z, acc);
+  acc = dn_mfma(a.w, b.w, acc);
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The all-fp32 kernel (aomarl_denoiser_apply_f32; the library's default arithmetic).  FOUR waves per image (four
+// blocks = sixteen waves per CU; a two-wave-per-image version was measured at 6.1 ms per 307 200 images against
+// 5.8 ms, profiles/r01h_*, and retired).
+// Work split (wv = 0..3):
+//   L1  M tiles 4 wv .. 4 wv + 3            L2  N tile wv & 1, M tiles 2 (wv >> 1), + 1
+//   L3  N tile wv                           D1  N tile wv & 1, parity classes 2 (wv >> 1), + 1
+//   D2  parity class wv (py = wv >> 1, px = wv & 1), all four M tiles       D3  a quad of lanes per pixel
+// fp32 matrix and vector instructions share the SIMD's issue cycles on gfx950 (a matrix instruction is 32 of them,
+// tools/mfmabench.hip): everything here that is not a matrix instruction is paid for in full, so
+//  * the weights come through ONE buffer resource (all four layers in one allocation): lane offset in a register,
+//    step offset a scalar -- no 64-bit vector address arithmetic, and no flat loads whose lgkmcnt the LDS reads
+//    would wait for;
+//  * the one-pixel zero borders of the six grids are a per-thread table of LDS offsets computed on the host (nine
+//    entries, loaded once): a border costs an unpack and a store per entry, not 30 instructions of index arithmetic;
+//  * the bias starts the accumulators;
+//  * LDS banks: a 128-bit read is served in passes of 16 lanes over the 64 banks, so the 16 pixels of an M tile
+//    must fall into 16 different 16-byte groups (mod 16).  With an odd number of groups per pixel (5, 9, 17) that
+//    means 16 pixel indices distinct mod 16: the 4 x 4 grids use a row pitch of 12 (pitch 6 puts two pairs of pixels
+//    16 apart), and the M tiles of the 8 x 8 grids are 8 rows x 2 columns (rows 10 apart: residues 0, 10, 4, 14, 8,
+//    2, 12, 6), not 2 rows x 8 columns.  Every A-operand read is then one pass per 16 lanes.
+// ---------------------------------------------------------------------------------------------
+#define DN_P 12            // row pitch (pixels) of the 6-row grids A2, A3
+#define DN_WOFF2 0         // float4 offsets of the four layers in DenoiseW::wf
+#define DN_WOFF3 1152
+#define DN_WOFF4 5760
+#define DN_WOFF5 13952
+#define DN_WTOTAL 16000
+#define DN_NBORDER 9       // border table entries per thread: IN, A1, A2, A3 x 2, A4 x 2, A5 x 2
+#define DN_DUMMY ((DN_X + DN_Y + 144) * 4)      // LDS byte offset of the 16 bytes idle table entries write to
+
+__device__ __forceinline__ float4 dn_ldw(__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+}
+__device__ __forceinline__ void dn_zero16(unsigned byte_off) {     // 16 zero bytes at an LDS byte offset
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  *reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + byte_off) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
   constexpr int PF = 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer
-  const int tid0 = threadIdx.x, lane0 = tid0 & 63, q0 = lane0 >> 4, c0 = lane0 & 15;
-  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer (+ the dummy slot)
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt2 = wv & 1, hi2 = wv >> 1;
-  for (int i = tid0; i < 144; i += 256) W6[i] = w.w6[i];
+  for (int i = tid; i < 144; i += 256) W6[i] = w.w6[i];
   float b1w[3];
   int t1off[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    b1w[i] = w.w1[i * 64 + lane0];
-    const int tap = 4 * i + q0;
+    b1w[i] = w.w1[i * 64 + lane];
+    const int tap = 4 * i + q;
     t1off[i] = tap < 9 ? (tap / 3 - 1) * 18 + (tap % 3 - 1) : 0;
   }
-  const float bias1 = w.b1[c0], bias2 = w.b2[16 * nt2 + c0], bias3 = w.b3[16 * wv + c0],
-              bias4 = w.b4[16 * nt2 + c0], bias5 = w.b5[c0];
-  const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
+  const float bias1 = w.b1[c], bias2 = w.b2[16 * nt2 + c], bias3 = w.b3[16 * wv + c],
+              bias4 = w.b4[16 * nt2 + c], bias5 = w.b5[c];
+  unsigned bt[(DN_NBORDER + 1) / 2];     // border table: two 16-bit LDS byte offsets per register
+#pragma unroll
+  for (int i = 0; i < (DN_NBORDER + 1) / 2; i++) bt[i] = w.border[i * 256 + tid];
+  auto border = [&](int e) { return (e & 1) ? bt[e >> 1] >> 16 : bt[e >> 1] & 0xffffu; };
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(w.wf), 0, DN_WTOTAL * 16, 0x00020000);
+  const unsigned wvo = 16u * lane;
   __syncthreads();
   float cur = 0.f;                       // this image's pixel of this thread, prefetched
-  if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid0];
+  if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid];
   for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
-    // per-lane indices laundered once per image: every LDS / global address below is recomputed
-    // where it is used instead of living in a register across the whole loop (~80 of them otherwise)
-    int tid = tid0, q = q0, c = c0;
-    asm volatile("" : "+v"(tid), "+v"(q), "+v"(c));
-    const int lane = tid & 63;
     float *tile = cube + (long long)img * 256;
-    const float4 *w2p = H ? w.w2h : w.w2, *w3p = H ? w.w3h : w.w3, *w4p = H ? w.w4h : w.w4,
-                 *w5p = H ? w.w5h : w.w5;
-    asm volatile("" : "+s"(w2p), "+s"(w3p), "+s"(w4p), "+s"(w5p));
-    const float4 *w2l = w2p + (nt2 * 64 + lane);             // step tap: + tap * 2 * 64
-    DnWt<H> rb2[PF];
+    const unsigned so2 = 16u * (DN_WOFF2 + nt2 * 64);        // step tap: + tap * 2 * 64 float4
+    float4 rb2[PF];
 #pragma unroll
-    for (int s = 0; s < PF; s++) rb2[s] = dn_ldw<H>(w2l, s * 2 * 64);
+    for (int s = 0; s < PF; s++) rb2[s] = dn_ldw(wrs, wvo, so2 + s * 2048);
     // ================= input (transposed) -> IN = Y[18][18]
-    dn_border4<18, 1>(Y, tid);
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + border(0)) = 0.f;
     Y[((tid & 15) + 1) * 18 + ((tid >> 4) + 1)] = cur;       // tile[ty][tx] -> net row tx, col ty
     {
       const int nxt = img + gridDim.x;
@@ -224,117 +175,119 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
     }
     __syncthreads();
     // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X [10][10][20]
-    dn_border4<10, DN_S16>(X, tid);
+    dn_zero16(border(1));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int mt = 4 * wv + k;
       const int win = 4 * mt + (c >> 2), r = c & 3;
       const int py = 2 * (win >> 3) + (r >> 1), px = 2 * (win & 7) + (r & 1);
       const float *in = Y + (py + 1) * 18 + (px + 1);
-      f32x4d acc = Z;
+      f32x4d acc = {bias1, bias1, bias1, bias1};
 #pragma unroll
       for (int i = 0; i < 3; i++) acc = dn_mfma(in[t1off[i]], b1w[i], acc);
-      const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
+      const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])), 0.f);
       const int wo = 4 * mt + q;
-      dn_store<H>(X + (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DN_S16, c, v);
+      X[(((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DN_S16 + c] = v;
     }
     __syncthreads();
-    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y [6][6][36]
-    dn_border4<6, DN_S32>(Y, tid);
-    const float4 *wp3 = w3p + (wv * 64 + lane);              // step s = tap * 2 + g: + s * 4 * 64
-    DnWt<H> rb3[PF];
+    // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y [6][12][36]
+    dn_zero16(border(2));
+    const unsigned so3 = 16u * (DN_WOFF3 + wv * 64);         // step s = tap * 2 + g: + s * 4 * 64 float4
+    float4 rb3[PF];
     {
-      f32x4d acc[2] = {Z, Z};
+      f32x4d acc[2] = {{bias2, bias2, bias2, bias2}, {bias2, bias2, bias2, bias2}};
       int abase[2];
 #pragma unroll
       for (int m = 0; m < 2; m++) {
-        const int mt = 2 * hi2 + m;
-        const int win = 4 * mt + (c >> 2), r = c & 3;
-        const int py = 2 * (win >> 2) + (r >> 1), px = 2 * (win & 3) + (r & 1);
+        // M tile mt = the four pooling windows of window COLUMN mt (8 pixel rows x 2 columns):
+        // m = c -> window row c >> 2, pixel r = c & 3 of the window
+        const int mt = 2 * hi2 + m, r = c & 3;
+        const int py = 2 * (c >> 2) + (r >> 1), px = 2 * mt + (r & 1);
         abase[m] = ((py + 1) * 10 + (px + 1)) * DN_S16 + 4 * q;
       }
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
-        const DnB<H> b = dn_expand(rb2[tap % PF]);
-        if (tap + PF < 9) rb2[tap % PF] = dn_ldw<H>(w2l, (tap + PF) * 2 * 64);
+        const float4 b = rb2[tap % PF];
+        if (tap + PF < 9) rb2[tap % PF] = dn_ldw(wrs, wvo, so2 + (tap + PF) * 2048);
         const int toff = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * DN_S16;
 #pragma unroll
         for (int m = 0; m < 2; m++) {
           const float4 a = *reinterpret_cast<const float4 *>(X + abase[m] + toff);
-          acc[m] = dn_quadw(a, b, acc[m]);
+          acc[m] = dn_quad(a, b, acc[m]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int s = 0; s < PF; s++) rb3[s] = dn_ldw<H>(wp3, s * 256);
+      for (int s = 0; s < PF; s++) rb3[s] = dn_ldw(wrs, wvo, so3 + s * 4096);
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         const int mt = 2 * hi2 + m;
-        const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])) + bias2, 0.f);
-        const int wo = 4 * mt + q;                           // window in the 4x4 pooled grid
-        dn_store<H>(Y + (((wo >> 2) + 1) * 6 + (wo & 3) + 1) * DN_S32, 16 * nt2 + c, v);
+        const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])), 0.f);
+        // D: lane group q = window row q of column mt in the 4x4 pooled grid
+        Y[((q + 1) * DN_P + mt + 1) * DN_S32 + 16 * nt2 + c] = v;
       }
     }
     __syncthreads();
-    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X [6][6][68]; wave = channel tile wv
-    dn_border4<6, DN_S64>(X, tid);
-    // D1: step t = (clsl * 4 + tap) * 4 + g of this wave's two classes: + ((2 hi2) * 16 + t) * 2 * 64
-    const float4 *wp4 = w4p + ((2 * hi2 * 16) * 128 + nt2 * 64 + lane);
-    DnWt<H> rb4[PF];
+    // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X [6][12][68]; wave = channel tile wv
+    dn_zero16(border(3));
+    dn_zero16(border(4));
+    // D1: step t = (clsl * 4 + tap) * 4 + g of this wave's two classes: + ((2 hi2) * 16 + t) * 2 * 64 float4
+    const unsigned so4 = 16u * (DN_WOFF4 + (2 * hi2 * 16) * 128 + nt2 * 64);
+    float4 rb4[PF];
     {
-      f32x4d acc = Z;
-      const int abase = (((c >> 2) + 1) * 6 + (c & 3) + 1) * DN_S32 + 4 * q;
+      f32x4d acc = {bias3, bias3, bias3, bias3};
+      const int abase = (((c >> 2) + 1) * DN_P + (c & 3) + 1) * DN_S32 + 4 * q;
 #pragma unroll
       for (int s = 0; s < 18; s++) {
         const int tap = s >> 1, g = s & 1;
-        const int toff = ((tap / 3 - 1) * 6 + (tap % 3 - 1)) * DN_S32;
+        const int toff = ((tap / 3 - 1) * DN_P + (tap % 3 - 1)) * DN_S32;
         const float4 a = *reinterpret_cast<const float4 *>(Y + abase + toff + 16 * g);
-        const DnB<H> b = dn_expand(rb3[s % PF]);
-        if (s + PF < 18) rb3[s % PF] = dn_ldw<H>(wp3, (s + PF) * 256);
-        acc = dn_quadw(a, b, acc);
+        const float4 b = rb3[s % PF];
+        if (s + PF < 18) rb3[s % PF] = dn_ldw(wrs, wvo, so3 + (s + PF) * 4096);
+        acc = dn_quad(a, b, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int s = 0; s < PF; s++) rb4[s] = dn_ldw<H>(wp4, s * 128);
+      for (int s = 0; s < PF; s++) rb4[s] = dn_ldw(wrs, wvo, so4 + s * 2048);
 #pragma unroll
       for (int r = 0; r < 4; r++)                            // D: m = 4q + r -> pixel (q, r)
-        dn_store<H>(X + ((q + 1) * 6 + r + 1) * DN_S64, 16 * wv + c, fmaxf(acc[r] + bias3, 0.f));
+        X[((q + 1) * DN_P + r + 1) * DN_S64 + 16 * wv + c] = fmaxf(acc[r], 0.f);
     }
     __syncthreads();
     // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y [10][10][36]
-    dn_border4<10, DN_S32>(Y, tid);
-    const float4 *w5l = w5p + (wv * 8 * 64 + lane);          // D2: class wv, step s = tap * 2 + g: + s * 64
-    DnWt<H> rb5[PF];
+    dn_zero16(border(5));
+    dn_zero16(border(6));
+    const unsigned so5 = 16u * (DN_WOFF5 + wv * 8 * 64);     // D2: class wv, step s = tap * 2 + g: + s * 64 float4
+    float4 rb5[PF];
     // the output-row parity of this wave (py) is made a compile-time constant by a wave-uniform
     // branch: every tap offset stays an immediate of the LDS instruction (as run-time values they
     // became ~100 hoisted address registers)
     auto d1_body = [&](auto PYc) {
       constexpr int py = decltype(PYc)::value;
       const int a0 = c >> 2, b0 = c & 3;                     // A operand: m = c -> input pixel (a0, b0)
-      const int abase = ((a0 + 1) * 6 + b0 + 1) * DN_S64 + 4 * q;
-      f32x4d acc = Z;
+      const int abase = ((a0 + 1) * DN_P + b0 + 1) * DN_S64 + 4 * q;
+      f32x4d acc = {bias4, bias4, bias4, bias4};
 #pragma unroll
       for (int s = 0; s < 32; s++) {
         const int clsl = s >> 4, tap = (s >> 2) & 3, g = s & 3;
         const int px = clsl;                                 // class 2 py + clsl
         const int ty = tap >> 1, tx = tap & 1;
         const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
-        const int toff = (dy * 6 + dx) * DN_S64;
+        const int toff = (dy * DN_P + dx) * DN_S64;
         const float4 a = *reinterpret_cast<const float4 *>(X + abase + toff + 16 * g);
-        const DnB<H> b = dn_expand(rb4[s % PF]);
-        if (s + PF < 32) rb4[s % PF] = dn_ldw<H>(wp4, (s + PF) * 128);
-        acc = dn_quadw(a, b, acc);
+        const float4 b = rb4[s % PF];
+        if (s + PF < 32) rb4[s % PF] = dn_ldw(wrs, wvo, so4 + (s + PF) * 2048);
+        acc = dn_quad(a, b, acc);
         if ((s & 15) == 15) {
           if (s == 31) {
 #pragma unroll
-            for (int t = 0; t < PF; t++) rb5[t] = dn_ldw<H>(w5l, t * 64);
+            for (int t = 0; t < PF; t++) rb5[t] = dn_ldw(wrs, wvo, so5 + t * 1024);
           }
           // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            dn_store<H>(Y + ((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32, 16 * nt2 + c,
-                        fmaxf(acc[r] + bias4, 0.f));
-          acc = Z;
+            Y[((2 * q + py + 1) * 10 + 2 * r + px + 1) * DN_S32 + 16 * nt2 + c] = fmaxf(acc[r], 0.f);
+          acc = f32x4d{bias4, bias4, bias4, bias4};
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -342,14 +295,17 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
     if (hi2 == 0) d1_body(std::integral_constant<int, 0>{}); else d1_body(std::integral_constant<int, 1>{});
     __syncthreads();
     // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X [18][18][16]; wave = class
-    dn_border4<18, 16>(X, tid);
+    dn_zero16(border(7));
+    dn_zero16(border(8));
     auto d2_body = [&](auto PYc, auto PXc) {
       constexpr int py = decltype(PYc)::value, px = decltype(PXc)::value;
       int abase[4];
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
-        abase[mt] = ((2 * mt + (c >> 3) + 1) * 10 + (c & 7) + 1) * DN_S32 + 4 * q;
-      f32x4d acc[4] = {Z, Z, Z, Z};
+        abase[mt] = (((c >> 1) + 1) * 10 + 2 * mt + (c & 1) + 1) * DN_S32 + 4 * q;   // M tile = columns 2mt, 2mt + 1
+      f32x4d acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) acc[mt] = f32x4d{bias5, bias5, bias5, bias5};
 #pragma unroll
       for (int tap = 0; tap < 4; tap++) {
         const int ty = tap >> 1, tx = tap & 1;
@@ -357,47 +313,61 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
 #pragma unroll
         for (int g = 0; g < 2; g++) {
           const int s = tap * 2 + g;
-          const DnB<H> b = dn_expand(rb5[s % PF]);
-          if (s + PF < 8) rb5[s % PF] = dn_ldw<H>(w5l, (s + PF) * 64);
+          const float4 b = rb5[s % PF];
+          if (s + PF < 8) rb5[s % PF] = dn_ldw(wrs, wvo, so5 + (s + PF) * 1024);
 #pragma unroll
           for (int mt = 0; mt < 4; mt++) {
             const float4 a = *reinterpret_cast<const float4 *>(Y + abase[mt] + toff + 16 * g);
-            acc[mt] = dn_quadw(a, b, acc[mt]);
+            acc[mt] = dn_quad(a, b, acc[mt]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // D: m = 4q + r -> input pixel (2 mt + (q >> 1), 4 (q & 1) + r)
+      // D: m = 4q + r -> input pixel (row 2q + (r >> 1), column 2 mt + (r & 1))
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int a = 2 * mt + (q >> 1), b = 4 * (q & 1) + r;
-          X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r] + bias5, 0.f);
+          const int a = 2 * q + (r >> 1), b = 2 * mt + (r & 1);
+          X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r], 0.f);
         }
     };
     {
-      std::integral_constant<int, 0> c0; std::integral_constant<int, 1> c1;
-      if (wv == 0) d2_body(c0, c0); else if (wv == 1) d2_body(c0, c1); else if (wv == 2) d2_body(c1, c0); else d2_body(c1, c1);
+      std::integral_constant<int, 0> k0; std::integral_constant<int, 1> k1;
+      if (wv == 0) d2_body(k0, k0); else if (wv == 1) d2_body(k0, k1); else if (wv == 2) d2_body(k1, k0); else d2_body(k1, k1);
     }
     __syncthreads();
-    // ================= D3: 3x3 correlation 16 -> 1 on the VALU, write back transposed
+    // ================= D3: 3x3 correlation 16 -> 1 on the vector lanes, write back transposed
+    // Thread t = (pixel group t >> 2, channel group g = t & 3): the four lanes of a quad read the
+    // four 16-byte channel groups of ONE pixel (64 contiguous bytes), a 16-lane pass of the LDS
+    // 256 contiguous bytes -- one thread per pixel reading its 64 bytes was a 4-way bank conflict
+    // on every read.  Each thread accumulates 4 pixels (p = (t >> 2) + 64 j) of its group, the quad
+    // is summed with two DPP adds and lane g writes pixel j = g.
     {
-      const int ry = tid >> 4, rx = tid & 15;                // net pixel (row, col)
-      float s0 = w.b6, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      typedef float f32x2d __attribute__((ext_vector_type(2)));
+      const int g = tid & 3, pg = tid >> 2;                  // pg: 0..63 -> pixels pg + 64 j
+      float res = 0.f;
 #pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        const float *in = X + ((ry + tap / 3) * 18 + rx + tap % 3) * 16;
-        const float *wt = W6 + tap * 16;
+      for (int j = 0; j < 4; j++) {
+        const int p = pg + 64 * j;                           // net pixel (row p >> 4, col p & 15)
+        const float *in = X + ((p >> 4) * 18 + (p & 15)) * 16 + 4 * g;
+        f32x2d s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const float4 a = *reinterpret_cast<const float4 *>(in + 4 * g);
-          const float4 ww = *reinterpret_cast<const float4 *>(wt + 4 * g);
-          s0 += a.x * ww.x; s1 += a.y * ww.y; s2 += a.z * ww.z; s3 += a.w * ww.w;
+        for (int tap = 0; tap < 9; tap++) {
+          const float4 a = *reinterpret_cast<const float4 *>(in + ((tap / 3) * 18 + tap % 3) * 16);
+          const float4 wg = *reinterpret_cast<const float4 *>(W6 + tap * 16 + 4 * g);
+          s01 += f32x2d{a.x, a.y} * f32x2d{wg.x, wg.y};
+          s23 += f32x2d{a.z, a.w} * f32x2d{wg.z, wg.w};
         }
+        const f32x2d s2 = s01 + s23;
+        float sum = s2[0] + s2[1];
+        sum += dpp_f<0xB1>(sum);                             // quad_perm [1,0,3,2]
+        sum += dpp_f<0x4E>(sum);                             // quad_perm [2,3,0,1]
+        if (j == g) res = sum;
         __builtin_amdgcn_sched_barrier(0);
       }
-      tile[rx * 16 + ry] = (s0 + s1) + (s2 + s3);            // tile[ty = net col][tx = net row]
+      const int p = pg + 64 * g;
+      tile[(p & 15) * 16 + (p >> 4)] = res + w.b6;           // tile[ty = net col][tx = net row]
     }
   }
 }
@@ -772,27 +742,51 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
             }
       }
   };
-  std::vector<float4> h4;
-  if (!rc) { conv_pack(wt[1], 32, 16, h4); rc = dn_upload<float4>(d, h4, &d->w.w2); }
-  if (!rc) { conv_pack(wt[2], 64, 32, h4); rc = dn_upload<float4>(d, h4, &d->w.w3); }
-  if (!rc) { convT_pack(wt[3], 64, 32, h4); rc = dn_upload<float4>(d, h4, &d->w.w4); }
-  if (!rc) { convT_pack(wt[4], 32, 16, h4); rc = dn_upload<float4>(d, h4, &d->w.w5); }
-  // split-fp16 B operands of the same four arrays
-  auto split_pack = [&](const std::vector<float4> &src, std::vector<float4> &dst) {
-    dst.resize(src.size());
-    for (size_t i = 0; i < src.size(); i++) {
-      const float v[4] = {src[i].x, src[i].y, src[i].z, src[i].w};
-      _Float16 hl[8];
-      for (int j = 0; j < 4; j++) { hl[j] = (_Float16)v[j]; hl[4 + j] = (_Float16)(v[j] - (float)hl[j]); }
-      memcpy(&dst[i], hl, 16);
-    }
-  };
   {
-    std::vector<float4> hs;
-    if (!rc) { conv_pack(wt[1], 32, 16, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w2h); }
-    if (!rc) { conv_pack(wt[2], 64, 32, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w3h); }
-    if (!rc) { convT_pack(wt[3], 64, 32, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w4h); }
-    if (!rc) { convT_pack(wt[4], 32, 16, h4); split_pack(h4, hs); rc = dn_upload<float4>(d, hs, &d->w.w5h); }
+    std::vector<float4> h4, all;
+    conv_pack(wt[1], 32, 16, h4); all.insert(all.end(), h4.begin(), h4.end());
+    if (all.size() != DN_WOFF3) rc = fail("denoiser: weight layout");
+    conv_pack(wt[2], 64, 32, h4); all.insert(all.end(), h4.begin(), h4.end());
+    if (all.size() != DN_WOFF4) rc = fail("denoiser: weight layout");
+    convT_pack(wt[3], 64, 32, h4); all.insert(all.end(), h4.begin(), h4.end());
+    if (all.size() != DN_WOFF5) rc = fail("denoiser: weight layout");
+    convT_pack(wt[4], 32, 16, h4); all.insert(all.end(), h4.begin(), h4.end());
+    if (all.size() != DN_WTOTAL) rc = fail("denoiser: weight layout");
+    if (!rc) rc = dn_upload<float4>(d, all, &d->w.wf);
+  }
+  if (!rc) {  // k_denoise4's border table (LDS byte offsets; X at 0, Y behind it)
+    struct Grid { int base, rows, pitch, stride, chans; };   // base in floats; chans floats zeroed per border pixel
+    const Grid grids[6] = {{DN_X, 18, 18, 1, 1},             // IN  (entry 0: 4-byte stores)
+                           {0, 10, 10, DN_S16, 16},          // A1
+                           {DN_X, 6, DN_P, DN_S32, 32},      // A2
+                           {0, 6, DN_P, DN_S64, 64},         // A3
+                           {DN_X, 10, 10, DN_S32, 32},       // A4
+                           {0, 18, 18, 16, 16}};             // A5
+    const int nent[6] = {1, 1, 1, 2, 2, 2};
+    std::vector<unsigned> tab((size_t)((DN_NBORDER + 1) / 2) * 256, 0u);
+    int e0 = 0;
+    for (int gi = 0; gi < 6 && !rc; gi++) {
+      const Grid &g = grids[gi];
+      std::vector<unsigned> off;                             // byte offsets of this grid's zero stores
+      for (int r = 0; r < g.rows; r++)
+        for (int cc = 0; cc < g.rows; cc++) {
+          if (r != 0 && r != g.rows - 1 && cc != 0 && cc != g.rows - 1) continue;
+          const int px = (r * g.pitch + cc) * g.stride;
+          if (g.chans == 1) off.push_back(4u * (g.base + px));
+          else for (int k = 0; k < g.chans; k += 4) off.push_back(4u * (g.base + px + k));
+        }
+      if ((int)off.size() > 256 * nent[gi]) rc = fail("denoiser: border table");
+      for (int e = 0; e < nent[gi] && !rc; e++)
+        for (int t = 0; t < 256; t++) {
+          const size_t i = (size_t)e * 256 + t;
+          const unsigned v = i < off.size() ? off[i] : (unsigned)DN_DUMMY;
+          if (v > 0xffffu) { rc = fail("denoiser: border offset"); break; }
+          const int ent = e0 + e;
+          tab[(size_t)(ent >> 1) * 256 + t] |= v << (16 * (ent & 1));
+        }
+      e0 += nent[gi];
+    }
+    if (!rc) rc = dn_upload<unsigned>(d, tab, &d->w.border);
   }
   // ---- 32-channel chunk operands of k_denoise4c: lane (n = lane & 15, kg = lane >> 4) holds K slots
   //      8 kg .. 8 kg + 7 of output channel 16 nt + n, as 8 hi halfs then 8 lo halfs
@@ -891,8 +885,8 @@ static int denoiser_launch(aomarl_denoiser *d, float *cube, long long nimg, bool
     hipLaunchKernelGGL(k_denoise4c, dim3(blocks), dim3(256), smc, (hipStream_t)stream, d->w, cube, (int)nimg);
     g_arith[AR_DENOISE_SPLIT]++;
   } else {
-    const size_t smem = sizeof(float) * (DN_X + DN_Y + 144);
-    hipLaunchKernelGGL(k_denoise4<false>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
+    const size_t smem = sizeof(float) * (DN_X + DN_Y + 144 + 4);
+    hipLaunchKernelGGL(k_denoise4, dim3(blocks), dim3(256), smem, (hipStream_t)stream, d->w, cube, (int)nimg);
     g_arith[AR_DENOISE_F32]++;
   }
   LAUNCHCHK();
