@@ -40,10 +40,10 @@ struct DenoiseW {
   const unsigned *border;
   // split-fp16 B operands in 32-channel chunks (k_denoise4c): per (chunk, tile, lane) two 16-byte
   // words, hi then lo, of the lane's 8 consecutive K slots
-  const float4 *w2c;      // [5 tap pairs][2 tiles][64][2]
-  const float4 *w3c;      // [9 taps][4 tiles][64][2]
-  const float4 *w4c;      // [4 classes][4 taps][2 halves][2 tiles][64][2]
-  const float4 *w5c;      // [4 classes][4 taps][64][2]
+  // in ONE allocation: L2 [5 tap pairs][2 tiles][64][2] at DC_WOFF2, L3 [9 taps][4 tiles][64][2] at DC_WOFF3,
+  // D1 [4 classes][4 taps][2 halves][2 tiles][64][2] at DC_WOFF4, D2 [4 classes][4 taps][64][2] at DC_WOFF5
+  const float4 *wc;
+  const unsigned *border_c;   // k_denoise4c's border table (fp16 planes), same form as `border`
   const float *w6;        // [9][16]                 D3 (taps as a plain correlation)
   const float *b1, *b2, *b3, *b4, *b5;
   float b6;
@@ -137,30 +137,33 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
   constexpr int PF = 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer (+ the dummy slot)
-  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, q0 = lane0 >> 4, c0 = lane0 & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int nt2 = wv & 1, hi2 = wv >> 1;
-  for (int i = tid; i < 144; i += 256) W6[i] = w.w6[i];
+  for (int i = tid0; i < 144; i += 256) W6[i] = w.w6[i];
   float b1w[3];
   int t1off[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    b1w[i] = w.w1[i * 64 + lane];
-    const int tap = 4 * i + q;
+    b1w[i] = w.w1[i * 64 + lane0];
+    const int tap = 4 * i + q0;
     t1off[i] = tap < 9 ? (tap / 3 - 1) * 18 + (tap % 3 - 1) : 0;
   }
-  const float bias1 = w.b1[c], bias2 = w.b2[16 * nt2 + c], bias3 = w.b3[16 * wv + c],
-              bias4 = w.b4[16 * nt2 + c], bias5 = w.b5[c];
+  const float bias1 = w.b1[c0], bias2 = w.b2[16 * nt2 + c0], bias3 = w.b3[16 * wv + c0],
+              bias4 = w.b4[16 * nt2 + c0], bias5 = w.b5[c0];
   unsigned bt[(DN_NBORDER + 1) / 2];     // border table: two 16-bit LDS byte offsets per register
 #pragma unroll
-  for (int i = 0; i < (DN_NBORDER + 1) / 2; i++) bt[i] = w.border[i * 256 + tid];
+  for (int i = 0; i < (DN_NBORDER + 1) / 2; i++) bt[i] = w.border[i * 256 + tid0];
   auto border = [&](int e) { return (e & 1) ? bt[e >> 1] >> 16 : bt[e >> 1] & 0xffffu; };
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(w.wf), 0, DN_WTOTAL * 16, 0x00020000);
-  const unsigned wvo = 16u * lane;
   __syncthreads();
   float cur = 0.f;                       // this image's pixel of this thread, prefetched
-  if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid];
+  if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid0];
   for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+    // (the per-lane LDS addresses of all six layers live in registers across the loop: 20 of them spilled, and still
+    // faster than recomputing them per image -- 7.8 against 8.1 ms; the split-fp16 kernel is the other way round)
+    const int tid = tid0, q = q0, c = c0;
+    const unsigned wvo = 16u * lane0;
     float *tile = cube + (long long)img * 256;
     const unsigned so2 = 16u * (DN_WOFF2 + nt2 * 64);        // step tap: + tap * 2 * 64 float4
     float4 rb2[PF];
@@ -397,10 +400,10 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
 #define DC_Y 4000          // floats of region Y (2 x 4000 halfs)
 
 struct DcB { hx8 h, l; };
-__device__ __forceinline__ DcB dc_ldw(const float4 *__restrict__ p, int idx) {
-  DcB r;
-  r.h = __builtin_bit_cast(hx8, p[2 * idx]);
-  r.l = __builtin_bit_cast(hx8, p[2 * idx + 1]);
+__device__ __forceinline__ DcB dc_ldw(__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) {
+  DcB r;                                 // vo = 32 lane: the lane's hi word, its lo word 16 bytes further
+  r.h = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+  r.l = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16u, so, 0));
   return r;
 }
 __device__ __forceinline__ f32x4d dc_chunk(const _Float16 *__restrict__ hi, const _Float16 *__restrict__ lo,
@@ -417,18 +420,12 @@ __device__ __forceinline__ void dc_store(_Float16 *hi, _Float16 *lo, int off, fl
   lo[off] = (_Float16)(v - (float)h);
 }
 
-// zero the one-pixel border of the 6 x 6 window of a grid with row pitch DC_P (S floats per pixel)
-template <int S>
-__device__ __forceinline__ void dc_border6(float *p, int tid) {
-  constexpr int V = S / 4;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid; i < 20 * V; i += 256) {
-    const int pi = i / V, k = i - pi * V;
-    const int row = pi < 6 ? 0 : (pi < 12 ? 5 : 1 + ((pi - 12) >> 1));
-    const int col = pi < 6 ? pi : (pi < 12 ? pi - 6 : (((pi - 12) & 1) ? 5 : 0));
-    *reinterpret_cast<float4 *>(p + (row * DC_P + col) * S + 4 * k) = z;
-  }
-}
+#define DC_WOFF2 0         // float4 offsets of the four layers in DenoiseW::wc
+#define DC_WOFF3 1280
+#define DC_WOFF4 5888
+#define DC_WOFF5 14080
+#define DC_WTOTAL 16128
+#define DC_DUMMY ((DN_X + DC_Y + 144) * 4)      // LDS byte offset of the 16 bytes idle border-table entries write to
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
@@ -451,25 +448,28 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
   }
   const float bias1 = w.b1[c0], bias2 = w.b2[16 * nt2 + c0], bias3 = w.b3[16 * wv + c0],
               bias4 = w.b4[16 * nt2 + c0], bias5 = w.b5[c0];
-  const f32x4d Z = {0.f, 0.f, 0.f, 0.f};
+  unsigned bt[(DN_NBORDER + 1) / 2];     // border table: two 16-bit LDS byte offsets per register (see k_denoise4)
+#pragma unroll
+  for (int i = 0; i < (DN_NBORDER + 1) / 2; i++) bt[i] = w.border_c[i * 256 + tid0];
+  auto border = [&](int e) { return (e & 1) ? bt[e >> 1] >> 16 : bt[e >> 1] & 0xffffu; };
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(w.wc), 0, DC_WTOTAL * 16, 0x00020000);
   __syncthreads();
   float cur = 0.f;                       // this image's pixel of this thread, prefetched
   float vmax = 0.f;                      // largest activation this thread stored as an fp16 pair
   if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid0];
   for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
-    // per-lane indices laundered once per image (see k_denoise4)
+    // per-lane indices laundered once per image: every LDS address below is recomputed where it is used instead of
+    // living in a register across the whole loop (~80 of them otherwise)
     int tid = tid0, q = q0, c = c0;
     asm volatile("" : "+v"(tid), "+v"(q), "+v"(c));
-    const int lane = tid & 63;
+    const unsigned wvo = 32u * (tid & 63);
     float *tile = cube + (long long)img * 256;
-    const float4 *w2p = w.w2c, *w3p = w.w3c, *w4p = w.w4c, *w5p = w.w5c;
-    asm volatile("" : "+s"(w2p), "+s"(w3p), "+s"(w4p), "+s"(w5p));
-    const float4 *w2l = w2p + 2 * (nt2 * 64 + lane);         // chunk j: + j * 2 tiles * 64 (x 2 words)
+    const unsigned so2 = 16u * DC_WOFF2 + 32u * (nt2 * 64);  // chunk j: + j * 2 tiles * 64 (x 2 words)
     DcB rb2[PF];
 #pragma unroll
-    for (int s = 0; s < PF; s++) rb2[s] = dc_ldw(w2l, s * 128);
+    for (int s = 0; s < PF; s++) rb2[s] = dc_ldw(wrs, wvo, so2 + s * 4096);
     // ================= input (transposed) -> IN = Y[18][18] (fp32)
-    dn_border4<18, 1>(Y, tid);
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + border(0)) = 0.f;
     Y[((tid & 15) + 1) * 18 + ((tid >> 4) + 1)] = cur;       // tile[ty][tx] -> net row tx, col ty
     {
       const int nxt = img + gridDim.x;
@@ -477,29 +477,27 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
     }
     __syncthreads();
     // ================= L1: conv3x3 1->16, ReLU, pool -> A1 = X planes [10][10][24]
-    dn_border4<10, DC_S1 / 2>(reinterpret_cast<float *>(XH), tid);
-    dn_border4<10, DC_S1 / 2>(reinterpret_cast<float *>(XL), tid);
+    dn_zero16(border(1));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int mt = 4 * wv + k;
       const int win = 4 * mt + (c >> 2), r = c & 3;
       const int py = 2 * (win >> 3) + (r >> 1), px = 2 * (win & 7) + (r & 1);
       const float *in = Y + (py + 1) * 18 + (px + 1);
-      f32x4d acc = Z;
+      f32x4d acc = {bias1, bias1, bias1, bias1};
 #pragma unroll
       for (int i = 0; i < 3; i++) acc = dn_mfma(in[t1off[i]], b1w[i], acc);
-      const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bias1, 0.f);
+      const float v = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])), 0.f);
       const int wo = 4 * mt + q;
       dc_store(XH, XL, (((wo >> 3) + 1) * 10 + (wo & 7) + 1) * DC_S1 + c, v, vmax);
     }
     __syncthreads();
     // ================= L2: conv3x3 16->32 on 8x8, ReLU, pool -> A2 = Y planes [6][6][40]
-    dc_border6<DC_S2 / 2>(reinterpret_cast<float *>(YH), tid);
-    dc_border6<DC_S2 / 2>(reinterpret_cast<float *>(YL), tid);
-    const float4 *wp3 = w3p + 2 * (wv * 64 + lane);          // chunk tap: + tap * 4 tiles * 64 (x 2)
+    dn_zero16(border(2));
+    const unsigned so3 = 16u * DC_WOFF3 + 32u * (wv * 64);   // chunk tap: + tap * 4 tiles * 64 (x 2)
     DcB rb3[PF];
     {
-      f32x4d acc[2] = {Z, Z};
+      f32x4d acc[2] = {{bias2, bias2, bias2, bias2}, {bias2, bias2, bias2, bias2}};
       int abase[2];
 #pragma unroll
       for (int m = 0; m < 2; m++) {
@@ -513,7 +511,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
 #pragma unroll
       for (int j = 0; j < 5; j++) {
         const DcB b = rb2[j % PF];
-        if (j + PF < 5) rb2[j % PF] = dc_ldw(w2l, (j + PF) * 128);
+        if (j + PF < 5) rb2[j % PF] = dc_ldw(wrs, wvo, so2 + (j + PF) * 4096);
         const int ta = 2 * j, tb = (2 * j + 1 < 9) ? 2 * j + 1 : 2 * j;
         const int offa = ((ta / 3 - 1) * 10 + (ta % 3 - 1)) * DC_S1, offb = ((tb / 3 - 1) * 10 + (tb % 3 - 1)) * DC_S1;
         const int toff = qt ? offb : offa;
@@ -522,48 +520,48 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int s = 0; s < PF; s++) rb3[s] = dc_ldw(wp3, s * 256);
+      for (int s = 0; s < PF; s++) rb3[s] = dc_ldw(wrs, wvo, so3 + s * 8192);
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         const int mt = 2 * hi2 + m;
-        const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])) + bias2, 0.f);
+        const float v = fmaxf(fmaxf(fmaxf(acc[m][0], acc[m][1]), fmaxf(acc[m][2], acc[m][3])), 0.f);
         // D: lane group q = window row q of column mt in the 4x4 pooled grid
         dc_store(YH, YL, ((q + 1) * DC_P + mt + 1) * DC_S2 + 16 * nt2 + c, v, vmax);
       }
     }
     __syncthreads();
     // ================= L3: conv3x3 32->64 on 4x4, ReLU -> A3 = X planes [6][6][72]; wave = channel tile wv
-    dc_border6<DC_S3 / 2>(reinterpret_cast<float *>(XH), tid);
-    dc_border6<DC_S3 / 2>(reinterpret_cast<float *>(XL), tid);
+    dn_zero16(border(3));
+    dn_zero16(border(4));
     // D1: chunk t = (clsl * 4 + tap) * 2 + h of this wave's two classes: + ((2 hi2) * 8 + t) * 2 tiles * 64
-    const float4 *wp4 = w4p + 2 * ((2 * hi2 * 8) * 128 + nt2 * 64 + lane);
+    const unsigned so4 = 16u * DC_WOFF4 + 32u * ((2 * hi2 * 8) * 128 + nt2 * 64);
     DcB rb4[PF];
     {
-      f32x4d acc = Z;
+      f32x4d acc = {bias3, bias3, bias3, bias3};
       const int abase = (((c >> 2) + 1) * DC_P + (c & 3) + 1) * DC_S2 + 8 * q;
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
         const DcB b = rb3[tap % PF];
-        if (tap + PF < 9) rb3[tap % PF] = dc_ldw(wp3, (tap + PF) * 256);
+        if (tap + PF < 9) rb3[tap % PF] = dc_ldw(wrs, wvo, so3 + (tap + PF) * 8192);
         acc = dc_chunk(YH, YL, abase + ((tap / 3 - 1) * DC_P + (tap % 3 - 1)) * DC_S2, b, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int s = 0; s < PF; s++) rb4[s] = dc_ldw(wp4, s * 128);
+      for (int s = 0; s < PF; s++) rb4[s] = dc_ldw(wrs, wvo, so4 + s * 4096);
 #pragma unroll
       for (int r = 0; r < 4; r++)                            // D: m = 4q + r -> pixel (q, r)
-        dc_store(XH, XL, ((q + 1) * DC_P + r + 1) * DC_S3 + 16 * wv + c, fmaxf(acc[r] + bias3, 0.f), vmax);
+        dc_store(XH, XL, ((q + 1) * DC_P + r + 1) * DC_S3 + 16 * wv + c, fmaxf(acc[r], 0.f), vmax);
     }
     __syncthreads();
     // ================= D1: convT4x4s2 64->32, 4x4 -> 8x8, ReLU -> A4 = Y planes [10][10][40]
-    dn_border4<10, DC_S2 / 2>(reinterpret_cast<float *>(YH), tid);
-    dn_border4<10, DC_S2 / 2>(reinterpret_cast<float *>(YL), tid);
-    const float4 *w5l = w5p + 2 * (wv * 4 * 64 + lane);      // D2: class wv, chunk tap: + tap * 64 (x 2)
+    dn_zero16(border(5));
+    dn_zero16(border(6));
+    const unsigned so5 = 16u * DC_WOFF5 + 32u * (wv * 4 * 64);   // D2: class wv, chunk tap: + tap * 64 (x 2)
     DcB rb5[PF];
     auto d1_body = [&](auto PYc) {
       constexpr int py = decltype(PYc)::value;
       const int abase = (((c >> 2) + 1) * DC_P + (c & 3) + 1) * DC_S3 + 8 * q;   // m = c -> input pixel
-      f32x4d acc = Z;
+      f32x4d acc = {bias4, bias4, bias4, bias4};
 #pragma unroll
       for (int s = 0; s < 16; s++) {
         const int clsl = s >> 3, tap = (s >> 1) & 3, h = s & 1;
@@ -571,19 +569,19 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
         const int ty = tap >> 1, tx = tap & 1;
         const int dy = ty == 0 ? 0 : (py == 0 ? -1 : 1), dx = tx == 0 ? 0 : (px == 0 ? -1 : 1);
         const DcB b = rb4[s % PF];
-        if (s + PF < 16) rb4[s % PF] = dc_ldw(wp4, (s + PF) * 128);
+        if (s + PF < 16) rb4[s % PF] = dc_ldw(wrs, wvo, so4 + (s + PF) * 4096);
         acc = dc_chunk(XH, XL, abase + (dy * DC_P + dx) * DC_S3 + 32 * h, b, acc);
         if ((s & 7) == 7) {
           if (s == 15) {
 #pragma unroll
-            for (int t = 0; t < PF; t++) rb5[t] = dc_ldw(w5l, t * 64);
+            for (int t = 0; t < PF; t++) rb5[t] = dc_ldw(wrs, wvo, so5 + t * 2048);
           }
           // D: m = 4q + r -> input pixel (q, r) -> output pixel (2q + py, 2r + px)
 #pragma unroll
           for (int r = 0; r < 4; r++)
             dc_store(YH, YL, ((2 * q + py + 1) * 10 + 2 * r + px + 1) * DC_S2 + 16 * nt2 + c,
-                     fmaxf(acc[r] + bias4, 0.f), vmax);
-          acc = Z;
+                     fmaxf(acc[r], 0.f), vmax);
+          acc = f32x4d{bias4, bias4, bias4, bias4};
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -591,20 +589,23 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
     if (hi2 == 0) d1_body(std::integral_constant<int, 0>{}); else d1_body(std::integral_constant<int, 1>{});
     __syncthreads();
     // ================= D2: convT4x4s2 32->16, 8x8 -> 16x16, ReLU -> A5 = X [18][18][16] fp32; wave = class
-    dn_border4<18, 16>(X, tid);
+    dn_zero16(border(7));
+    dn_zero16(border(8));
     auto d2_body = [&](auto PYc, auto PXc) {
       constexpr int py = decltype(PYc)::value, px = decltype(PXc)::value;
       int abase[4];
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
         abase[mt] = (((c >> 1) + 1) * 10 + 2 * mt + (c & 1) + 1) * DC_S2 + 8 * q;   // M tile = columns 2mt, 2mt + 1
-      f32x4d acc[4] = {Z, Z, Z, Z};
+      f32x4d acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) acc[mt] = f32x4d{bias5, bias5, bias5, bias5};
 #pragma unroll
       for (int tap = 0; tap < 4; tap++) {
         const int ty = tap >> 1, tx = tap & 1;
         const int toff = ((ty == 0 ? 0 : (2 * py - 1)) * 10 + (tx == 0 ? 0 : (2 * px - 1))) * DC_S2;
         const DcB b = rb5[tap % PF];
-        if (tap + PF < 4) rb5[tap % PF] = dc_ldw(w5l, (tap + PF) * 64);
+        if (tap + PF < 4) rb5[tap % PF] = dc_ldw(wrs, wvo, so5 + (tap + PF) * 2048);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[mt] = dc_chunk(YH, YL, abase[mt] + toff, b, acc[mt]);
         __builtin_amdgcn_sched_barrier(0);
@@ -615,7 +616,7 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int a = 2 * q + (r >> 1), b = 2 * mt + (r & 1);
-          X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r] + bias5, 0.f);
+          X[((2 * a + py + 1) * 18 + 2 * b + px + 1) * 16 + c] = fmaxf(acc[mt][r], 0.f);
         }
     };
     {
@@ -630,22 +631,23 @@ void k_denoise4c(DenoiseW w, float *__restrict__ cube, int nimg) {
     // on every read.  Each thread accumulates 4 pixels (p = (t >> 2) + 64 j) of its group, the quad
     // is summed with two DPP adds and lane g writes pixel j = g.
     {
+      typedef float f32x2d __attribute__((ext_vector_type(2)));
       const int g = tid & 3, pg = tid >> 2;                  // pg: 0..63 -> pixels pg + 64 j
-      float4 wg[9];                                          // this group's weights of the 9 taps
-#pragma unroll
-      for (int tap = 0; tap < 9; tap++) wg[tap] = *reinterpret_cast<const float4 *>(W6 + tap * 16 + 4 * g);
       float res = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int p = pg + 64 * j;                           // net pixel (row p >> 4, col p & 15)
         const float *in = X + ((p >> 4) * 18 + (p & 15)) * 16 + 4 * g;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        f32x2d s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
           const float4 a = *reinterpret_cast<const float4 *>(in + ((tap / 3) * 18 + tap % 3) * 16);
-          s0 += a.x * wg[tap].x; s1 += a.y * wg[tap].y; s2 += a.z * wg[tap].z; s3 += a.w * wg[tap].w;
+          const float4 wg = *reinterpret_cast<const float4 *>(W6 + tap * 16 + 4 * g);
+          s01 += f32x2d{a.x, a.y} * f32x2d{wg.x, wg.y};
+          s23 += f32x2d{a.z, a.w} * f32x2d{wg.z, wg.w};
         }
-        float sum = (s0 + s1) + (s2 + s3);
+        const f32x2d s2 = s01 + s23;
+        float sum = s2[0] + s2[1];
         sum += dpp_f<0xB1>(sum);                             // quad_perm [1,0,3,2]
         sum += dpp_f<0x4E>(sum);                             // quad_perm [2,3,0,1]
         if (j == g) res = sum;
@@ -754,39 +756,54 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
     if (all.size() != DN_WTOTAL) rc = fail("denoiser: weight layout");
     if (!rc) rc = dn_upload<float4>(d, all, &d->w.wf);
   }
-  if (!rc) {  // k_denoise4's border table (LDS byte offsets; X at 0, Y behind it)
-    struct Grid { int base, rows, pitch, stride, chans; };   // base in floats; chans floats zeroed per border pixel
-    const Grid grids[6] = {{DN_X, 18, 18, 1, 1},             // IN  (entry 0: 4-byte stores)
-                           {0, 10, 10, DN_S16, 16},          // A1
-                           {DN_X, 6, DN_P, DN_S32, 32},      // A2
-                           {0, 6, DN_P, DN_S64, 64},         // A3
-                           {DN_X, 10, 10, DN_S32, 32},       // A4
-                           {0, 18, 18, 16, 16}};             // A5
+  // border tables (LDS byte offsets; X at 0, Y behind it): per grid the planes' bases, rows, row pitch (pixels), pixel
+  // stride and the bytes to zero per border pixel (4: one float per store, else 16-byte stores)
+  struct Grid { int base[2], nplanes, rows, pitch, stride, bytes; };
+  auto border_table = [&](const Grid (&grids)[6], unsigned dummy, const unsigned **dev) -> int {
     const int nent[6] = {1, 1, 1, 2, 2, 2};
     std::vector<unsigned> tab((size_t)((DN_NBORDER + 1) / 2) * 256, 0u);
     int e0 = 0;
-    for (int gi = 0; gi < 6 && !rc; gi++) {
+    for (int gi = 0; gi < 6; gi++) {
       const Grid &g = grids[gi];
       std::vector<unsigned> off;                             // byte offsets of this grid's zero stores
-      for (int r = 0; r < g.rows; r++)
-        for (int cc = 0; cc < g.rows; cc++) {
-          if (r != 0 && r != g.rows - 1 && cc != 0 && cc != g.rows - 1) continue;
-          const int px = (r * g.pitch + cc) * g.stride;
-          if (g.chans == 1) off.push_back(4u * (g.base + px));
-          else for (int k = 0; k < g.chans; k += 4) off.push_back(4u * (g.base + px + k));
-        }
-      if ((int)off.size() > 256 * nent[gi]) rc = fail("denoiser: border table");
-      for (int e = 0; e < nent[gi] && !rc; e++)
+      for (int pl = 0; pl < g.nplanes; pl++)
+        for (int r = 0; r < g.rows; r++)
+          for (int cc = 0; cc < g.rows; cc++) {
+            if (r != 0 && r != g.rows - 1 && cc != 0 && cc != g.rows - 1) continue;
+            const int px = g.base[pl] + (r * g.pitch + cc) * g.stride;
+            for (int k = 0; k < g.bytes; k += 16) off.push_back((unsigned)(px + k));
+          }
+      if ((int)off.size() > 256 * nent[gi]) return fail("denoiser: border table");
+      for (int e = 0; e < nent[gi]; e++)
         for (int t = 0; t < 256; t++) {
           const size_t i = (size_t)e * 256 + t;
-          const unsigned v = i < off.size() ? off[i] : (unsigned)DN_DUMMY;
-          if (v > 0xffffu) { rc = fail("denoiser: border offset"); break; }
+          const unsigned v = i < off.size() ? off[i] : dummy;
+          if (v > 0xffffu || (g.bytes >= 16 && (v & 15))) return fail("denoiser: border offset");
           const int ent = e0 + e;
           tab[(size_t)(ent >> 1) * 256 + t] |= v << (16 * (ent & 1));
         }
       e0 += nent[gi];
     }
-    if (!rc) rc = dn_upload<unsigned>(d, tab, &d->w.border);
+    return dn_upload<unsigned>(d, tab, dev);
+  };
+  if (!rc) {  // k_denoise4: fp32 grids
+    const Grid grids[6] = {{{4 * DN_X, 0}, 1, 18, 18, 4, 4},                 // IN
+                           {{0, 0}, 1, 10, 10, 4 * DN_S16, 64},              // A1
+                           {{4 * DN_X, 0}, 1, 6, DN_P, 4 * DN_S32, 128},     // A2
+                           {{0, 0}, 1, 6, DN_P, 4 * DN_S64, 256},            // A3
+                           {{4 * DN_X, 0}, 1, 10, 10, 4 * DN_S32, 128},      // A4
+                           {{0, 0}, 1, 18, 18, 64, 64}};                     // A5
+    rc = border_table(grids, DN_DUMMY, &d->w.border);
+  }
+  if (!rc) {  // k_denoise4c: A1..A4 as two fp16 planes (hi, lo), IN and A5 fp32
+    const int Y0 = 4 * DN_X;
+    const Grid grids[6] = {{{Y0, 0}, 1, 18, 18, 4, 4},                                   // IN
+                           {{0, 2 * DC_PLX}, 2, 10, 10, 2 * DC_S1, 32},                  // A1
+                           {{Y0, Y0 + 2 * DC_PLY}, 2, 6, DC_P, 2 * DC_S2, 64},           // A2
+                           {{0, 2 * DC_PLX}, 2, 6, DC_P, 2 * DC_S3, 128},                // A3
+                           {{Y0, Y0 + 2 * DC_PLY}, 2, 10, 10, 2 * DC_S2, 64},            // A4
+                           {{0, 0}, 1, 18, 18, 64, 64}};                                 // A5
+    rc = border_table(grids, DC_DUMMY, &d->w.border_c);
   }
   // ---- 32-channel chunk operands of k_denoise4c: lane (n = lane & 15, kg = lane >> 4) holds K slots
   //      8 kg .. 8 kg + 7 of output channel 16 nt + n, as 8 hi halfs then 8 lo halfs
@@ -797,6 +814,7 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
     memcpy(&h[2 * idx + 1], lo, 16);
   };
   auto convT_k = [](int py, int ty) { return py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0); };
+  std::vector<float4> allc;
   if (!rc) {  // L2: chunk j = taps 2j, 2j + 1 x 16 channels; slot: tap 2j + (kg >> 1), channel 8 (kg & 1) + i
     std::vector<float4> h((size_t)5 * 2 * 64 * 2);
     for (int j = 0; j < 5; j++)
@@ -807,7 +825,8 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
           for (int i = 0; i < 8; i++) v[i] = tap < 9 ? wt[1][((size_t)co * 16 + 8 * (kg & 1) + i) * 9 + tap] : 0.f;
           put_chunk(h, ((size_t)j * 2 + nt) * 64 + lane, v);
         }
-    rc = dn_upload<float4>(d, h, &d->w.w2c);
+    allc.insert(allc.end(), h.begin(), h.end());
+    if (allc.size() != DC_WOFF3) rc = fail("denoiser: weight layout");
   }
   if (!rc) {  // L3: chunk = tap x 32 channels; slot: channel 8 kg + i
     std::vector<float4> h((size_t)9 * 4 * 64 * 2);
@@ -819,7 +838,8 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
           for (int i = 0; i < 8; i++) v[i] = wt[2][((size_t)co * 32 + 8 * kg + i) * 9 + tap];
           put_chunk(h, ((size_t)tap * 4 + nt) * 64 + lane, v);
         }
-    rc = dn_upload<float4>(d, h, &d->w.w3c);
+    allc.insert(allc.end(), h.begin(), h.end());
+    if (allc.size() != DC_WOFF4) rc = fail("denoiser: weight layout");
   }
   if (!rc) {  // D1: chunk = (class, tap, half of the 64 channels); ConvTranspose2d weight [Cin][Cout][4][4]
     std::vector<float4> h((size_t)4 * 4 * 2 * 2 * 64 * 2);
@@ -834,7 +854,8 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
               for (int i = 0; i < 8; i++) v[i] = wt[3][(((size_t)(32 * hf + 8 * kg + i) * 32 + co) * 4 + ky) * 4 + kx];
               put_chunk(h, ((((size_t)cls * 4 + tap) * 2 + hf) * 2 + nt) * 64 + lane, v);
             }
-    rc = dn_upload<float4>(d, h, &d->w.w4c);
+    allc.insert(allc.end(), h.begin(), h.end());
+    if (allc.size() != DC_WOFF5) rc = fail("denoiser: weight layout");
   }
   if (!rc) {  // D2: chunk = (class, tap) x 32 channels; weight [32][16][4][4]
     std::vector<float4> h((size_t)4 * 4 * 64 * 2);
@@ -847,7 +868,9 @@ int aomarl_denoiser_create(const float *const *wt, const float *const *bs, aomar
           for (int i = 0; i < 8; i++) v[i] = wt[4][(((size_t)(8 * kg + i) * 16 + co) * 4 + ky) * 4 + kx];
           put_chunk(h, ((size_t)cls * 4 + tap) * 64 + lane, v);
         }
-    rc = dn_upload<float4>(d, h, &d->w.w5c);
+    allc.insert(allc.end(), h.begin(), h.end());
+    if (allc.size() != DC_WTOTAL) rc = fail("denoiser: weight layout");
+    if (!rc) rc = dn_upload<float4>(d, allc, &d->w.wc);
   }
   if (!rc) {  // D3: out[oy][ox] = sum in[oy + 1 - ky][ox + 1 - kx] w[ci][0][ky][kx]: tap (ty, tx) = (2 - ky, 2 - kx)
     std::vector<float> h(9 * 16);
@@ -881,7 +904,7 @@ static int denoiser_launch(aomarl_denoiser *d, float *cube, long long nimg, bool
   const int blocks = (int)std::min<long long>(nimg, 256 * 4 * 4);
   if (!f32) {
     // split-fp16 operands in 32-channel chunks, four waves per image
-    const size_t smc = sizeof(float) * (DN_X + DC_Y + 144);
+    const size_t smc = sizeof(float) * (DN_X + DC_Y + 144 + 4);
     hipLaunchKernelGGL(k_denoise4c, dim3(blocks), dim3(256), smc, (hipStream_t)stream, d->w, cube, (int)nimg);
     g_arith[AR_DENOISE_SPLIT]++;
   } else {
