@@ -134,7 +134,7 @@ __device__ __forceinline__ void dn_zero16(unsigned byte_off) {     // 16 zero by
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
-  constexpr int PF = 3;
+  constexpr int PF = 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *X = lds, *Y = lds + DN_X, *W6 = Y + DN_Y;          // W6: 144 weights of the last layer (+ the dummy slot)
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, q0 = lane0 >> 4, c0 = lane0 & 15;
@@ -160,8 +160,9 @@ void k_denoise4(DenoiseW w, float *__restrict__ cube, int nimg) {
   float cur = 0.f;                       // this image's pixel of this thread, prefetched
   if ((int)blockIdx.x < nimg) cur = cube[(long long)blockIdx.x * 256 + tid0];
   for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
-    // (the per-lane LDS addresses of all six layers live in registers across the loop: 20 of them spilled, and still
-    // faster than recomputing them per image -- 7.8 against 8.1 ms; the split-fp16 kernel is the other way round)
+    // (the per-lane LDS addresses of all six layers live in registers across the loop: a few of them spilled, and still
+    // faster than recomputing them per image -- 7.8 against 8.1 ms; the split-fp16 kernel is the other way round.
+    // Weight prefetch depth 2 / 3 / 4: 7.74 / 7.79 / 7.86 ms; three waves per SIMD without spills: 7.81)
     const int tid = tid0, q = q0, c = c0;
     const unsigned wvo = 16u * lane0;
     float *tile = cube + (long long)img * 256;
