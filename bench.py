@@ -604,9 +604,12 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     device = "cuda:%d" % dev_index
     torch.cuda.set_device(device)
-    if world > 1:
+    # AOMARL_DIST_FORCE=1: a one-rank run goes through the process group too (the RCCL leg -- barrier, MAX over ranks,
+    # the gathers -- executed on a one-GPU box; tests/test_bench_launch.py)
+    if world > 1 or os.environ.get("AOMARL_DIST_FORCE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         tmo = datetime.timedelta(seconds=int(os.environ.get("AOMARL_DIST_TIMEOUT_S", "300")))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,

@@ -175,6 +175,26 @@ def test_two_rank_bench_over_rccl():
 
 
 @pytest.mark.gpu
+def test_one_rank_bench_over_rccl():
+    """The RCCL leg of bench.py on ONE card: AOMARL_DIST_FORCE=1 makes a one-rank run initialise the "nccl" process
+    group and take the multi-rank path (barriers around the timed region, MAX over ranks of the elapsed time on a
+    device tensor, gather of shards and episode returns) -- what the scaling runs execute per rank, minus the peers."""
+    env = dict(os.environ, AOMARL_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("AOMARL_DIST_BACKEND", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+           "--envs", "8", "--config", "production_sh_10x10_2m", "--no-cpu-baseline", "--no-side-configs"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["gathered"]["n"] == 8 and out["value"] > 0
+    assert [d["rank"] for d in out["shards"]] == [0]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "split_f16"])
 def test_bench_dtype_follows_the_precision_mode(mode):
     """The label comes from the launch counters of the timed region: an all-fp32 pass launches no
