@@ -117,10 +117,16 @@ struct DevState {
 //  stream}; 4 outputs -> 4 uniforms or 2 Box-Muller pairs)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  // both halves of a 32 x 32 product from ONE instruction (v_mad_u64_u32: 6.5 cycles of the SIMD against 5.2 + 5.5 for
+  // v_mul_hi_u32 + v_mul_lo_u32 with three waves resident, tools/valubench.hip); the multiplier rides in a scalar
+  // register (VOP3 takes no 32-bit literal on this target)
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint64_t m0, m1;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(m0) : "s"(M0), "v"(c0) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(m1) : "s"(M1), "v"(c2) : "vcc");
+    const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u;

@@ -30,6 +30,14 @@ __global__ __launch_bounds__(768) void k(float *out, int iters, float seed) {
       if (KIND == 9) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
       if (KIND == 10) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
       if (KIND == 11) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+      // the integer side of Philox (k_frame_wave's noisy instantiations): 32 x 32 products
+      if (KIND == 12) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (KIND == 13) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (KIND == 14) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "+v"(p[i]) : "v"(b), "v"(c) : "vcc");
+      if (KIND == 15) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (KIND == 16) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
+      if (KIND == 17) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
+      if (KIND == 18) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
     }
   }
   float s = 0.f;
@@ -66,5 +74,10 @@ int main() {
   run<2>("v_sin_f32", out, ghz); run<8>("v_rcp_f32", out, ghz); run<3>("v_rndne_f32", out, ghz);
   run<4>("v_add_f32_dpp quad_perm", out, ghz); run<5>("v_add_f32_dpp row_mirror", out, ghz);
   run<6>("v_add_f32_dpp row_bcast:15", out, ghz); run<7>("v_mfma_f32_16x16x4_f32", out, ghz);
+  for (int w = 1; w <= 3; w += 2) {
+    run<12>("v_mul_lo_u32", out, ghz, w); run<13>("v_mul_hi_u32", out, ghz, w); run<14>("v_mad_u64_u32", out, ghz, w);
+    run<15>("v_xor_b32", out, ghz, w); run<16>("v_log_f32", out, ghz, w); run<17>("v_sqrt_f32", out, ghz, w);
+    run<18>("v_cvt_f32_u32", out, ghz, w); run<8>("v_rcp_f32", out, ghz, w);
+  }
   return 0;
 }
