@@ -117,6 +117,32 @@ def test_split_fp16_and_fp32_denoiser_kernels_agree_with_fp64(golden_dir, peak):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("f32", [True, False])
+def test_fused_denoiser_walking_several_images_per_workgroup(golden_dir, f32):
+    """More images than the launch has workgroups (4096): a workgroup walks 2-3 images and re-uses its two LDS
+    regions with another shape in every layer, so what it must redraw between them -- the one-pixel zero borders of
+    the six grids, from the host-built table of LDS offsets -- decides the SECOND image's values.  Every image against
+    the same image denoised alone in a small launch (one image per workgroup) and against the functional path."""
+    from ao_marl_amd.denoiser import SubapDenoiser
+    g = torch.load(os.path.join(golden_dir, "host_denoiser.pt"), weights_only=True)
+    dn = SubapDenoiser(g["state_dict"], device="cuda:0")
+    n = 2 * 4096 + 37
+    gen = torch.Generator().manual_seed(11)
+    cube = torch.rand(1, n, 256, generator=gen) * 60.0
+    cube[0, ::3] *= 0.05                                        # bright images next to faint ones
+    cube = cube.cuda()
+    got = dn.denoise_bincube_(cube.clone(), f32=f32)
+    alone = torch.empty_like(cube)
+    for b in range(0, n, 2048):                                # launches of at most 2048 workgroups: one image each
+        alone[:, b:b + 2048] = dn.denoise_bincube_(cube[:, b:b + 2048].clone(), f32=f32)
+    assert torch.equal(got, alone)
+    dn.use_native = False
+    want = dn.denoise_bincube_(cube.clone())
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < (2e-5 if f32 else 6e-5) * scale
+
+
+@pytest.mark.gpu
 def test_supervisor_with_denoiser_is_independent_of_the_atmosphere_prefetch(golden_dir):
     """rlSupervisor's autoencoder branch (image -> denoiser -> centroids) with the next frame's
     move_atmos issued on the side stream right behind the image kernel, against the plain order."""
