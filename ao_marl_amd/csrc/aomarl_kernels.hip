@@ -772,8 +772,16 @@ __device__ __forceinline__ void extrude_scatter_col(const DevSys &sys, const Dev
   for (int r = threadIdx.x; r < n; r += blockDim.x) {
     float v = zref;
     if (nsplit > 0) {
+      // the slabs in their fixed order, eight loads in flight at a time (one at a time, the loop waited for every
+      // load in turn: 4 us of a 18 us launch inside the reset, tools/reset_trace.sh)
       float acc = 0.f;
-      for (int z = 0; z < nsplit; z++) acc += P[((long long)z * ncol + col) * pn + r];
+      for (int z0 = 0; z0 < nsplit; z0 += 8) {
+        float pz[8];
+#pragma unroll
+        for (int z = 0; z < 8; z++) pz[z] = P[((long long)min(z0 + z, nsplit - 1) * ncol + col) * pn + r];
+#pragma unroll
+        for (int z = 0; z < 8; z++) acc = (z0 + z < nsplit) ? acc + pz[z] : acc;
+      }
       v += acc * pscale;
     } else {
       v += NEWL[(long long)col * ldn + r];
@@ -845,6 +853,30 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   int *o = st.origin + (e * sys.nlayers + li) * 2;
   const int ox = o[0], oy = o[1];
   const uint32_t cnt = st.ext_count[e * sys.nlayers + li];
+  const DevLayer &L = sys.layers[li];
+  const int n = L.dim, ns = L.ns;
+  const int ni = nx.idx[oi];                     // this column's layer in the next round (-1: it has no operation there)
+  const int col2 = el * nx.nops + (ni < 0 ? 0 : ni);
+  const int dir = nx.dir[ni < 0 ? 0 : ni];
+  // What the next round's gather needs and the scatter does not touch goes FIRST, so that it runs while the scatter's
+  // loads are in flight instead of behind the barrier: the stencil's index list (the gather was a dependent pair of
+  // loads per item) and the noise half of Z (Philox + two Box-Muller pairs per item: nothing but arithmetic).  Z / ZREFN
+  // are the next round's buffers: the product that last read them is a whole round back.
+  constexpr int U = 4;                           // ns <= U * blockDim.x (checked on the host: AOMARL_SG_MAX_NS)
+  uint32_t xy[U];
+  if (ni >= 0) {
+    const uint32_t *ist = nx.tflag[ni] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
+#pragma unroll
+    for (int u = 0; u < U; u++) xy[u] = ist[min((int)threadIdx.x + u * (int)blockDim.x, ns - 1)];
+    const uint32_t seed = st.seeds[e] + (uint32_t)li;
+    for (int g = threadIdx.x; g < (n + 3) / 4; g += blockDim.x) {
+      float z4[4];
+      philox_normal4(seed, 0u, cnt + 1u, 0u, (uint32_t)g, z4);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (4 * g + u < n) Z[(long long)col2 * ldz + ns + 4 * g + u] = L.amp * z4[u];
+    }
+  }
   int nox, noy;
   extrude_scatter_col(sys, st, env_begin, ops, NEWL, ldn, ZREF, P, nsplit, ncol, pn, pscale, col, ox, oy, nox, noy);
   __syncthreads();                               // the new line is in the ring (block-visible); ZREF[col] was read by everyone
@@ -853,37 +885,17 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
     if (st.origin_snap) { st.origin_snap[(e * sys.nlayers + li) * 2] = nox; st.origin_snap[(e * sys.nlayers + li) * 2 + 1] = noy; }
     st.ext_count[e * sys.nlayers + li] = cnt + 1u;
   }
-  // the gather of extrude_gather_item, restated so that one thread's loads are independent of each
-  // other (index loads first, then the screen loads): with one block per column instead of six, a
-  // dependent pair of loads per item was the whole kernel
-  const int ni = nx.idx[oi];
-  if (ni < 0) return;                            // this layer has no operation in the next round
-  const int col2 = el * nx.nops + ni;            // its column there
-  const DevLayer &L = sys.layers[li];
-  const int n = L.dim, ns = L.ns, dir = nx.dir[ni];
+  if (ni < 0) return;
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
   const bool top_right = (dir == 1 || dir == -2);
   const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, nox, noy, n)];
-  const uint32_t *ist = nx.tflag[ni] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
-  constexpr int U = 4;
-  for (int j0 = threadIdx.x; j0 < ns; j0 += U * blockDim.x) {
-    uint32_t xy[U];
-    float v[U];
+  float v[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) xy[u] = ist[min(j0 + u * (int)blockDim.x, ns - 1)];
+  for (int u = 0; u < U; u++) v[u] = base[ring_idx(xy[u] & 0xFFFF, xy[u] >> 16, nox, noy, n)];
 #pragma unroll
-    for (int u = 0; u < U; u++) v[u] = base[ring_idx(xy[u] & 0xFFFF, xy[u] >> 16, nox, noy, n)];
-#pragma unroll
-    for (int u = 0; u < U; u++)
-      if (j0 + u * (int)blockDim.x < ns) Z[(long long)col2 * ldz + j0 + u * blockDim.x] = v[u] - zref;
-  }
-  const uint32_t seed = st.seeds[e] + (uint32_t)li;
-  for (int g = threadIdx.x; g < (n + 3) / 4; g += blockDim.x) {
-    float z4[4];
-    philox_normal4(seed, 0u, cnt + 1u, 0u, (uint32_t)g, z4);
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (4 * g + u < n) Z[(long long)col2 * ldz + ns + 4 * g + u] = L.amp * z4[u];
+  for (int u = 0; u < U; u++) {
+    const int j = (int)threadIdx.x + u * (int)blockDim.x;
+    if (j < ns) Z[(long long)col2 * ldz + j] = v[u] - zref;
   }
   if (threadIdx.x == 0) ZREFN[col2] = zref;
 }

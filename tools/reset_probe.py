@@ -6,10 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+once = len(sys.argv) > 2 and sys.argv[2] == "once"          # one pass with the default (tools/reset_trace.sh)
 w = bench.Workload(bench.WORKLOAD, envs, 0, 1, "cuda:0")
 S = torch.cuda.Stream()
 with torch.cuda.stream(S):
-    for two in (1, 2, 3, 4, 1, 2, 3, 4):
+    for two in ((2,) if once else (1, 2, 3, 4, 1, 2, 3, 4)):
         w.sim.set_option("reset_streams", two)
         w.reset()
         t = min(w.time_reset() for _ in range(2))
