@@ -216,9 +216,7 @@ __global__ void k_assemble_state(int nenv, StateBlocks sb, float *__restrict__ o
   CHAIN_SETPRIO();
   const int e = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
   auto psum = [&](int col) {
-    float s = 0.f;
-    for (int z = 0; z < sb.nsplit; z++) s += sb.part[((long long)z * nenv + e) * sb.pn + col];
-    return sb.alpha * s;
+    return sb.alpha * slab_sum<4>(sb.nsplit, [&](int z) { return sb.part[((long long)z * nenv + e) * sb.pn + col]; });
   };
   if (j >= sb.total) {                       // extra threads: the reduced matrix itself
     const int col = j - sb.total;

@@ -112,6 +112,23 @@ struct DevState {
   int32_t *origin_snap;   // frame pipeline: the kernels that advance a ring origin also write it here (or null)
 };
 
+// Sum of split-K slabs in their fixed order with B loads in flight at a time.  Written as a plain loop over a run-time
+// count, the compiler emits load / wait / add per slab: every slab costs a full load latency (4 us of the 18 us
+// scatter + gather launch inside the reset, one to two microseconds per slab in the chains' consumers beside the
+// frame kernel).  at(z): the z-th slab's element (slabs past the count re-read the last one and are not added).
+template <int B, typename F>
+__device__ __forceinline__ float slab_sum(int nsplit, F at) {
+  float acc = 0.f;
+  for (int z0 = 0; z0 < nsplit; z0 += B) {
+    float pz[B];
+#pragma unroll
+    for (int z = 0; z < B; z++) pz[z] = at(min(z0 + z, nsplit - 1));
+#pragma unroll
+    for (int z = 0; z < B; z++) acc = (z0 + z < nsplit) ? acc + pz[z] : acc;
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------- Philox4x32-10 + normals
 // (same definition as the oracle: key = {seed, "AOMR"}, ctr = {block, counter_lo, counter_hi,
 //  stream}; 4 outputs -> 4 uniforms or 2 Box-Muller pairs)

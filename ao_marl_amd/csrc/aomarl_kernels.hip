@@ -502,8 +502,7 @@ __global__ void k_gemm_reduce(int M, int N, int nsplit, float alpha, const float
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)M * N) return;
   const int row = (int)(i / N), col = (int)(i - (long long)row * N);
-  float s = 0.f;
-  for (int z = 0; z < nsplit; z++) s += P[(long long)z * M * N + i];
+  const float s = slab_sum<4>(nsplit, [&](int z) { return P[(long long)z * M * N + i]; });
   float *c = C + (long long)row * ldc + col;
   float v = alpha * s;
   if (beta != 0.f) v += beta * (*c);
@@ -526,8 +525,7 @@ __global__ void k_gemm_reduce_epi(int M, int N, int nsplit, float alpha, const f
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)M * N) return;
   const int row = (int)(i / N), col = (int)(i - (long long)row * N);
-  float s = 0.f;
-  for (int z = 0; z < nsplit; z++) s += P[(long long)z * M * N + i];
+  const float s = slab_sum<4>(nsplit, [&](int z) { return P[(long long)z * M * N + i]; });
   float *c = C + (long long)row * ldc + col;
   float v = alpha * s;
   if (beta != 0.f) v += beta * (*c);
@@ -772,16 +770,7 @@ __device__ __forceinline__ void extrude_scatter_col(const DevSys &sys, const Dev
   for (int r = threadIdx.x; r < n; r += blockDim.x) {
     float v = zref;
     if (nsplit > 0) {
-      // the slabs in their fixed order, eight loads in flight at a time (one at a time, the loop waited for every
-      // load in turn: 4 us of a 18 us launch inside the reset, tools/reset_trace.sh)
-      float acc = 0.f;
-      for (int z0 = 0; z0 < nsplit; z0 += 8) {
-        float pz[8];
-#pragma unroll
-        for (int z = 0; z < 8; z++) pz[z] = P[((long long)min(z0 + z, nsplit - 1) * ncol + col) * pn + r];
-#pragma unroll
-        for (int z = 0; z < 8; z++) acc = (z0 + z < nsplit) ? acc + pz[z] : acc;
-      }
+      const float acc = slab_sum<8>(nsplit, [&](int z) { return P[((long long)z * ncol + col) * pn + r]; });   // (tools/reset_trace.sh)
       v += acc * pscale;
     } else {
       v += NEWL[(long long)col * ldn + r];
@@ -3038,8 +3027,7 @@ __global__ void k_delay_sum(DevState st, int nactu, int ld, float a, float b, fl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nactu) return;
   const long long o = (long long)e * ld + i;
-  float s = 0.f;
-  for (int z = 0; z < nsplit; z++) s += P[((long long)z * nrows + blockIdx.y) * nactu + i];
+  const float s = slab_sum<4>(nsplit, [&](int z) { return P[((long long)z * nrows + blockIdx.y) * nactu + i]; });
   const float c0 = alpha * s;
   st.com[o] = c0;
   if (comp_voltage) {
@@ -3062,9 +3050,7 @@ __global__ void k_delay_ahead(DevSys sys, DevState st, int nactu, int ld, int n,
   CHAIN_SETPRIO();
   auto newest = [&](int row, int a) -> float {
     if (nsplit > 0) {
-      float s = 0.f;
-      for (int z = 0; z < nsplit; z++) s += P[((long long)z * n + row) * nactu + a];
-      return alpha * s;
+      return alpha * slab_sum<4>(nsplit, [&](int z) { return P[((long long)z * n + row) * nactu + a]; });
     }
     return st.com[(long long)row * ld + a];
   };

@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
   const Shape shapes[] = {
       {"do_control (bench sys)", 256, 1286, 2400}, {"v2m", 256, 1283, 1286}, {"m2v", 256, 1286, 1283},
       {"extrusion 3 layers", 768, 648, 1957},      {"extrusion 2 layers", 512, 648, 1957},
-      {"extrusion 1 layer", 256, 648, 1957},       {"do_control (unfiltered)", 256, 1430, 2400},
+      {"extrusion 1 layer", 256, 648, 1957},       {"reset half (128 envs x 3 layers)", 384, 648, 1957},       {"do_control (unfiltered)", 256, 1430, 2400},
       {"v2m (unfiltered)", 256, 1427, 1430},       {"ragged", 250, 1285, 1283}};
   hipStream_t s;
   CK(hipStreamCreate(&s));
