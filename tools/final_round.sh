@@ -18,8 +18,8 @@ for n in ("1gpu", "driver_args"):
         print(n, "value %.0f ms/step %.4f no_reset %.4f whole_episode %s frame %.4f frac %.3f alone %.4f traffic %s" % (
             d["value"], d["ms_per_step"], d["ms_per_step_no_reset"], (d.get("whole_episode") or {}).get("value"),
             r["avg_launch_ms"], r["frac"], r["alone"]["avg_launch_ms"], r.get("traffic")))
-        for c in d.get("configs", []) or []:
-            print("   ", c.get("workload"), c.get("f32", c).get("value") if isinstance(c.get("f32", c), dict) else c)
+        for name, c in (d.get("configs") or {}).items():
+            print("   ", name, c.get("workload"), "%.0f" % c.get("value", float("nan")))
     except Exception as e:
         print(n, "unreadable:", e)
 PY
