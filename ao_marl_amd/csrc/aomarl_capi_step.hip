@@ -135,6 +135,15 @@ __device__ __forceinline__ void small_gemv(const float *__restrict__ W, int ldw,
     if (o < no) {
       const float *row = W + (long long)o * ldw;
       int k = q;
+      // eight row elements in flight per thread (same accumulators, same order: the plain loop below, which the
+      // compiler runs one load pair at a time -- K / 8 load latencies in a row)
+      for (; k + 28 < K; k += 32) {
+        float r[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) r[u] = row[k + 4 * u];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { a0 = fmaf(xs[k + 4 * u], r[u], a0); a1 = fmaf(xs[k + 4 * u + 4], r[u + 1], a1); }
+      }
       for (; k + 4 < K; k += 8) { a0 = fmaf(xs[k], row[k], a0); a1 = fmaf(xs[k + 4], row[k + 4], a1); }
       if (k < K) a0 = fmaf(xs[k], row[k], a0);
     }
