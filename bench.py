@@ -542,6 +542,40 @@ def roofline_block(model, fk_ms, kernel_name, args_pmc, envs, config):
     return r
 
 
+# the denoiser of one spot image on 16 x 16 x K matrix instructions (csrc/aomarl_denoise.hip): L1 16 tiles x 3
+# (K = 9 taps padded to 12), L2 4 x 2 x 9 x 4, L3 1 x 4 x 9 x 8, D1 4 classes x 2 x 4 taps x 16, D2 4 x 4 x 4 x 8
+DENOISER_MFMA_PER_IMAGE = 48 + 288 + 288 + 512 + 512
+DENOISER_MAC_PER_IMAGE = 1712128
+
+
+def denoiser_roofline(w, f32, reps=5):
+    """The denoiser launch of one step by itself (a copy of the step's spot cube, torch events on the launch stream):
+    fp32: matrix-issue bound -- the time its v_mfma_f32_16x16x4_f32 instructions (32 cycles each, one SIMD per wave)
+    need on 1024 SIMDs at the clock of the quoted fp32 matrix peak against the launch; fast mode: the duration only."""
+    import torch
+    sup = w.env.supervisor
+    cube = sup.sim.t["bincube"].clone()
+    dn = sup.autoencoder
+    for _ in range(2):
+        dn.denoise_bincube_(cube, f32=f32)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dn.denoise_bincube_(cube, f32=f32)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nimg = cube.shape[0] * cube.shape[1]
+    ghz = FP32_MFMA_PEAK_TF * 1e12 / (256 * 256.0) * 1e-9        # the clock the fp32 matrix peak is quoted at (2.4 GHz)
+    out = {"kernel": "k_denoise4" if f32 else "k_denoise4c", "images": nimg, "ms": ms,
+           "tflops": 2.0 * DENOISER_MAC_PER_IMAGE * nimg / (ms * 1e-3) * 1e-12}
+    if f32:
+        floor_ms = nimg * DENOISER_MFMA_PER_IMAGE * 32 / (1024 * ghz * 1e9) * 1e3
+        out.update({"bound": "mfma issue", "matrix_instructions_per_image": DENOISER_MFMA_PER_IMAGE,
+                    "matrix_floor_ms": floor_ms, "frac": floor_ms / ms, "clock_ghz": ghz})
+    return out
+
+
 def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None, settle=100, agents=None):
     """A BASELINE configuration other than the headline one, same loop, same accounting (1 GPU): the
     all-fp32 pass is the figure, the split-fp16 pass rides along as `fast_mode`."""
@@ -565,6 +599,7 @@ def side_config(config, envs, device, steps, warmup, episode_len, denoiser=None,
                    "mean_strehl_le": float(w.sim.strehl[:, 1].mean())}
             if denoiser:
                 w.env.supervisor.autoencoder.check_range()
+                rec["denoiser_kernel"] = denoiser_roofline(w, mode == "f32")
         finally:
             libaomarl.set_precision("f32")
         if mode == "f32":
@@ -825,6 +860,8 @@ def main():
     # ---- everything below is single-GPU side information (rank 0 of an N = 1 run)
     if rank == 0 and world == 1:
         main_is_headline = args.config == WORKLOAD and not denoiser
+        if denoiser:
+            out["denoiser_kernel"] = denoiser_roofline(w, args.precision == "f32")
         if not args.no_side_configs and main_is_headline and args.precision == "f32":
             try:        # the same loop in the fast mode: split-fp16 operand pairs in the DFTs and the GEMMs
                 libaomarl.set_precision("split_f16")
