@@ -54,6 +54,8 @@ struct aomarl_ctx {
   int dft_mode = -1;                   // frame kernel DFTs: -1 follow the library's precision mode, 0 fp32 MFMAs, 1 split-fp16 ("force_f32_dft")
   bool reset_untransposed = false;     // "reset_untransposed": the reset's x extrusions on the row-major screen itself
   int small_chain = 1;                 // "small_chain": small systems run the control / agent chain of aomarl_env_step as two kernels
+  hipEvent_t ride_ev = nullptr;        // frame pipeline: the event a whole-batch one-launch move may carry on its dispatch
+  bool rode = false;                   // ... and whether it did
   int residual_shortcut = 0;           // "residual_shortcut": aomarl_env_step takes the residual modes from ONE product with v2m . cmat (aomarl_set_slopes2modes)
   bool skip_do_control = false;        // (aomarl_env_step's small chain: aomarl_next_part_one leaves do_control to its tail kernel)
   int small_move = 1;                  // "small_move": 1 = one k_move_small launch per frame's move where the screens allow it

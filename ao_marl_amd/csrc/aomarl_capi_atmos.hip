@@ -228,8 +228,11 @@ static int run_plan(aomarl_ctx *c, aomarl_state *st, int b, int n, const Plan &p
     if (s != c->atm_stream) c->screens_dirty_main = true;
     DevState dsm = dev_state(st);
     dsm.origin_snap = c->snap_target;
-    hipLaunchKernelGGL(k_move_small, dim3(n, c->nlayers), dim3(MOVE_SMALL_T), 0, s, c->sys, dsm, b, mp);
+    // (the whole batch in this one launch: the caller's "moved" event rides on the dispatch)
+    hipEvent_t ride = (c->ride_ev && b == 0 && n == st->nenv && !c->capturing) ? c->ride_ev : nullptr;
+    hipExtLaunchKernelGGL(k_move_small, dim3(n, c->nlayers), dim3(MOVE_SMALL_T), 0, s, nullptr, ride, 0, c->sys, dsm, b, mp);
     LAUNCHCHK();
+    if (ride) c->rode = true;
     return 0;
   }
   std::vector<RoundOps> rounds((size_t)maxr);
@@ -292,14 +295,16 @@ static int prefetch_atmos_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, fl
   } else {
     c->frame_wait_pending = true;
   }
+  c->ride_ev = c->ev_moved; c->rode = false;
   rc = move_atmos_now(c, st, b, n, accumx, accumy, (void *)c->atm_stream);
+  c->ride_ev = nullptr;
   if (rc) return rc;
   if (c->frame_wait_pending) {            // nothing was extruded this frame: still order the marker behind the readers
     HIPCHK(hipStreamWaitEvent(c->atm_stream, c->ev_frame_cur, 0));
     c->frame_wait_pending = false;
   }
   c->screens_dirty_main = false;
-  HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
+  if (!c->rode) HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));      // (else the move's one launch carried it)
   c->premoved = true; c->pre_screens = st->screens; c->pre_b = b; c->pre_n = n;
   return 0;
 }

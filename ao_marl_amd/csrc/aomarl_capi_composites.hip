@@ -118,9 +118,10 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
     HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
     if (!c->pipe.cmd_covers_commit)
       HIPCHK(hipStreamWaitEvent(c->psf_stream, c->pipe.ev_commit, 0));   // that parity's pending window has been committed
-    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
+    // (its completion event rides on the dispatch, like the frame kernel's: one runtime call less per step)
+    hipExtLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, nullptr, c->pipe.ev_psf[slot], 0, c->sys, TR,
+                          TP, w.nblk, PEND, st->frame + b);
     LAUNCHCHK();
-    HIPCHK(hipEventRecord(c->pipe.ev_psf[slot], c->psf_stream));
     c->pipe.psf_out[slot] = true;
     return 0;
   }
@@ -130,9 +131,10 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
     c->ev_frame_cur = ev_done; c->frame_marked = true;
     c->side_joined = false;
     HIPCHK(hipStreamWaitEvent(c->psf_stream, ev_done, 0));
-    hipLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, c->sys, TR, TP, w.nblk, PEND, st->frame + b);
+    hipExtLaunchKernelGGL(k_target_finish_mfma, dim3(n), dim3(256), 0, c->psf_stream, nullptr, c->capturing ? nullptr : c->ev_psf, 0,
+                          c->sys, TR, TP, w.nblk, PEND, st->frame + b);
     LAUNCHCHK();
-    HIPCHK(hipEventRecord(c->ev_psf, c->psf_stream));
+    if (c->capturing) HIPCHK(hipEventRecord(c->ev_psf, c->psf_stream));       // (a captured dispatch carries no events)
     c->psf_side = true;
     return 0;
   }

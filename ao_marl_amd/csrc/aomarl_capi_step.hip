@@ -285,11 +285,12 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
     p.PEND = stv->work + w.PEND; p.amode_inv = c->amode_inv; p.lohi = g->lohi; p.modes_out = mnew; p.rew = reward_out;
     if (psf_ev) HIPCHK(hipStreamWaitEvent(s, psf_ev, 0));
     else if (stv == st) { int rc = psf_wait_pending(c, stream); if (rc) return rc; }
-    hipLaunchKernelGGL(k_small_head, dim3(n), dim3(256), 0, s, c->sys, dsv, p);
-    LAUNCHCHK();
     // ONE kernel wrote the voltages and committed the pending window, behind the wait for that parity's PSF finish:
-    // the release of the frame stream covers all three (no separate commit event, no wait of its own on the frame stream)
-    if (ahead) { HIPCHK(hipEventRecord(c->pipe.ev_cmd, s)); c->pipe.cmd_covers_commit = true; }
+    // the release of the frame stream covers all three (no separate commit event, no wait of its own on the frame
+    // stream); the event rides on the dispatch
+    hipExtLaunchKernelGGL(k_small_head, dim3(n), dim3(256), 0, s, nullptr, ahead ? c->pipe.ev_cmd : nullptr, 0, c->sys, dsv, p);
+    LAUNCHCHK();
+    if (ahead) c->pipe.cmd_covers_commit = true;
     return 0;
   }
   float *modes = st->work + w.MODES;
@@ -563,7 +564,9 @@ static int pipe_prefetch(aomarl_ctx *c, aomarl_state *st, float *accumx, float *
   // the kernels that advance the ring origins write them into that frame's snapshot as well (behind the same wait
   // as their ring writes); a copy of all origins only when some ring did not move at all
   c->snap_target = P.snap[older]; c->snap_complete = true;
+  c->ride_ev = c->ev_moved; c->rode = false;
   int rc = move_atmos_now(c, st, 0, st->nenv, accumx, accumy, (void *)c->atm_stream);
+  c->ride_ev = nullptr;
   const bool complete = c->snap_complete;
   c->snap_target = nullptr;
   if (!rc && !complete && c->need_prev && c->frame_wait_pending)   // nothing written yet: the copy overwrites what the older frame reads
@@ -574,7 +577,7 @@ static int pipe_prefetch(aomarl_ctx *c, aomarl_state *st, float *accumx, float *
     HIPCHK(hipMemcpyAsync(P.snap[older], st->origin, sizeof(int32_t) * (size_t)st->nenv * c->nlayers * 2,
                           hipMemcpyDeviceToDevice, c->atm_stream));
   c->screens_dirty_main = false;
-  HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));
+  if (!(c->rode && complete)) HIPCHK(hipEventRecord(c->ev_moved, c->atm_stream));     // (else the move's one launch carried it)
   c->premoved = true; c->pre_screens = st->screens; c->pre_b = 0; c->pre_n = st->nenv;
   return 0;
 }
