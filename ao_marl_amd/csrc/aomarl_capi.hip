@@ -632,6 +632,14 @@ int aomarl_create(const aomarl_desc *d, aomarl_ctx **out) {
         UP(float, twf.data(), twf.size(), devf);
         s.psf_tw_f = devf;
       }
+      {
+        std::vector<float> z(64 * 8, 0.f);
+        float *qt;
+        UP(float, z.data(), z.size(), qt);
+        hipLaunchKernelGGL(k_fill_qf_tab, dim3(1), dim3(128), 0, 0, qt);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { aomarl_destroy(c); return fail("create: quadratic-form constants"); }
+        s.qf_tab = qt;
+      }
       UP(uint16_t, tmask.data(), tmask.size(), s.tile_mask);
       {
         // tip-tilt planes as the frame kernel reads them (k_frame_wave: tvo): pupil pixel (y, 4 g + j)

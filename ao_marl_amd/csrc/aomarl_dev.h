@@ -96,6 +96,7 @@ struct DevSys {
   // sin k X (k = 1..8)], X = 16 t + 4 q + j, j = 0..3
   const void *psf_tw_h;          // [ntiles][64] x 8 halfs: [hi(j = 0..3) | lo(j = 0..3)]  (split-fp16 form)
   const void *psf_tw_f;          // [ntiles][64] x 4 floats                                  (fp32 form)
+  const float *qf_tab;           // [64 lanes][8]: SpotQf of each lane (spot_qf_consts, computed once at create by k_fill_qf_tab)
   // tip-tilt planes in pupil coordinates, 4 pixels of a row at a time: [pupdiam][pupdiam / 4] x [x0 x1 x2 x3 | y0 y1 y2 y3]
   const float *tt_pk;
 };

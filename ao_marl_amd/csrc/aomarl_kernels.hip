@@ -1785,6 +1785,24 @@ __device__ __forceinline__ SpotQf spot_qf_consts(int lane, const float2 *sTw /* 
   return k;
 }
 
+// sys.qf_tab: the constants of every lane, once per context (the frame kernel computed them at the head of every
+// workgroup: a 128-entry twiddle table by two of its waves, a barrier, 64 LDS reads and ~250 vector instructions per
+// wave).  Same table expression, same function: the same bits.
+__global__ __launch_bounds__(128) void k_fill_qf_tab(float *__restrict__ tab) {
+  __shared__ float2 sTw[128];
+  const int tid = threadIdx.x;
+  float sn, cs;
+  sincospif((float)tid * (1.0f / 64.0f), &sn, &cs);
+  sTw[tid] = make_float2(cs, sn);
+  __syncthreads();
+  if (tid < 64) {
+    const SpotQf k = spot_qf_consts(tid, sTw);
+    float *o = tab + 8 * tid;
+    o[0] = k.Ml.x; o[1] = k.Ml.y; o[2] = k.Mh.x; o[3] = k.Mh.y;
+    o[4] = k.Sl.x; o[5] = k.Sl.y; o[6] = k.Sh.x; o[7] = k.Sh.y;
+  }
+}
+
 __device__ __forceinline__ void spot_cog_qf(const DevSys &sys, const DevState &st, int e, int i, int lane,
                                             const SpotQf &K, const float (&er)[4], const float (&ei)[4],
                                             int do_cog, const f32x4 z4) {
@@ -2481,26 +2499,35 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   // shortest ones (longest-processing-time order: smaller tail)
   const int r = sys.stripe_order[blockIdx.y];                // stripe: pupil rows 16 r .. 16 r + 15
   const int el = 4 * blockIdx.x + wv;                        // environment of this wave
-  if (tid < 128) {
-    float sn, cs;
-    sincospif((float)tid * (1.0f / 64.0f), &sn, &cs);
-    sTw[tid] = make_float2(cs, sn);
+  // slopes only, fp32: the moments as quadratic forms of the field (spot_cog_qf): no transform, no Cc / Ss, no
+  // twiddle table -- the lane's constants come from sys.qf_tab
+  constexpr bool QF = FW_QF && OTF && !HP && !NOISE && !WRITE_CUBE;
+  if constexpr (!QF) {
+    if (tid < 128) {
+      float sn, cs;
+      sincospif((float)tid * (1.0f / 64.0f), &sn, &cs);
+      sTw[tid] = make_float2(cs, sn);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const bool active = el < env_count;          // a wave past the last environment repeats it (see the tile)
   const int e = env_begin + (active ? el : env_count - 1);
-  float Cc[4], Ss[4];
+  float Cc[4] = {0.f, 0.f, 0.f, 0.f}, Ss[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (!QF) {
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const float2 w = sTw[((4 * q + s) * (2 * c + 1)) & 127];
-    Cc[s] = w.x; Ss[s] = w.y;
+    for (int s = 0; s < 4; s++) {
+      const float2 w = sTw[((4 * q + s) * (2 * c + 1)) & 127];
+      Cc[s] = w.x; Ss[s] = w.y;
+    }
   }
   SpotTwH twh;
   if (HP) twh = spot_tw_h(Cc, Ss);
-  // slopes only, fp32: the moments as quadratic forms of the field (spot_cog_qf): no transform, no Cc / Ss
-  constexpr bool QF = FW_QF && OTF && !HP && !NOISE && !WRITE_CUBE;
   SpotQf qfk;
-  if constexpr (QF) qfk = spot_qf_consts(lane, sTw);
+  if constexpr (QF) {
+    const float4 ka = reinterpret_cast<const float4 *>(sys.qf_tab)[2 * lane], kb = reinterpret_cast<const float4 *>(sys.qf_tab)[2 * lane + 1];
+    qfk.Ml = f32x2{ka.x, ka.y}; qfk.Mh = f32x2{ka.z, ka.w};
+    qfk.Sl = f32x2{kb.x, kb.y}; qfk.Sh = f32x2{kb.z, kb.w};
+  }
   // shared loads: wave 0 / 1: the two 16-byte halves of the lane's tip-tilt pairs, wave 2 (and 3, a
   // duplicate that hits in the L1): the PSF operand of the lane, [t][64] x 16 B
   unsigned shstep;
