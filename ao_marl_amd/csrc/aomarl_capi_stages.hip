@@ -69,6 +69,19 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
   }
   if (!strcmp(name, "small_move")) { c->small_move = value != 0; return 0; }
   if (!strcmp(name, "small_chain")) { c->small_chain = value != 0; return 0; }
+  if (!strcmp(name, "renew_frame_stream")) {
+    // the frame pipeline's stream, anew: the runtime deals its hardware queues out as streams come, and a frame stream
+    // that shares one with another stream of the step serialises the pipelined order (VecAoEnv's probe asks for this)
+    auto &P = c->pipe;
+    if (P.active) return fail("renew_frame_stream: a frame is in flight (reset first)");
+    if (P.fstream) {
+      HIPCHK(hipStreamSynchronize(P.fstream));
+      HIPCHK(hipStreamDestroy(P.fstream));
+      P.fstream = nullptr;
+      HIPCHK(hipStreamCreateWithFlags(&P.fstream, hipStreamNonBlocking));
+    }
+    return 0;
+  }
   if (!strcmp(name, "residual_shortcut")) {
     if (value && (!c->s2m || c->s2m_nmodes < 1)) return fail("residual_shortcut: no v2m . cmat matrix (aomarl_set_slopes2modes)");
     c->residual_shortcut = value != 0;

@@ -787,7 +787,7 @@ class VecAoEnv(object):
                     sup.s.delay == 1.0 and sup.s.noise < 0 and sup.prefetch_atmos and sup.geo is None and
                     not getattr(sup.sim, "graph_step", False))
 
-    def _probe_order(self, state, steps=28, skip=6, margin=1.15):
+    def _probe_order(self, state, steps=28, skip=6, margin=1.15, alias_ratio=1.3):
         """Behind the first reset of an eligible environment: `steps` steps with zero actions in the pipelined and
         in the plain call order, the period between the states of step `skip` and step `steps` becoming ready on the
         caller's stream (device events).  The pipelined order is kept unless it is more than `margin` times SLOWER
@@ -809,18 +809,30 @@ class VecAoEnv(object):
         res = {}
         self._probing = True
         keep_rp, self.supervisor.reset_prefetch = self.supervisor.reset_prefetch, None   # no shadow resets for the probe's resets
+        def timed_pass(on):
+            self.frame_pipeline, self._pipe_checked = on, False
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for k in range(steps):
+                self.step(zero)
+                if k == skip - 1:
+                    e0.record()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / (steps - skip), self.reset()
         try:
             for name, on in (("plain", False), ("pipelined", True)):      # (the twin of the second pass stays)
-                self.frame_pipeline, self._pipe_checked = on, False
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for k in range(steps):
-                    self.step(zero)
-                    if k == skip - 1:
-                        e0.record()
-                e1.record()
-                e1.synchronize()
-                res[name] = e0.elapsed_time(e1) / (steps - skip)
-                state = self.reset()
+                res[name], state = timed_pass(on)
+            # The signature of a frame stream that shares a hardware queue with another stream of the step is a
+            # pipelined order nearly twice as slow (1.02 against 0.47 ms per step at production size, one process in
+            # fifty on this runtime): the library's frame stream is created anew -- the runtime deals queues out as
+            # streams come -- and the pipelined pass repeated, twice at most, before the plain order is settled for.
+            res["frame_stream_renewed"] = 0
+            while (res["pipelined"] > alias_ratio * res["plain"] and res["frame_stream_renewed"] < 2 and
+                   hasattr(sim, "renew_frame_stream")):
+                sim.renew_frame_stream()
+                res["frame_stream_renewed"] += 1
+                res["pipelined_before_renewal"] = res.get("pipelined_before_renewal", res["pipelined"])
+                res["pipelined"], state = timed_pass(True)
         finally:
             self._probing = False
             self.supervisor.reset_prefetch = keep_rp

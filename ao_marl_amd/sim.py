@@ -253,6 +253,11 @@ class HipSim(object):
         if self.prefetch and not self.pending_atmos:
             self.pending_atmos, self._pending_range = True, (0, self.nenv)
 
+    def renew_frame_stream(self):
+        """aomarl_set_option("renew_frame_stream"): the library's frame stream (frame pipeline) destroyed and created anew
+        -- another hardware queue for it; nothing may be in flight (behind a full reset)."""
+        la.check(self.lib.aomarl_set_option(self.ctx, b"renew_frame_stream", 1))
+
     def graph_stats(self):
         """(graphs captured, graphs replayed) by aomarl_env_step under set_option("graph_step", 1)."""
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)

@@ -315,6 +315,10 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * "small_move" (default 1: screens of <= 256 pixels with stencil + dim <= 4096 -- the 10x10 files -- move in ONE
  * launch per frame, k_move_small, instead of gather / GEMM / scatter rounds; fp32 vector FMAs in both precision
  * modes; 0: the rounds),
+ * "renew_frame_stream" (any value): the frame pipeline's own stream is destroyed and created anew -- the runtime deals
+ *   its hardware queues out as streams come, and a frame stream that shares one with another stream of the step makes
+ *   the pipelined order nearly twice as slow; nothing may be in flight (behind a full-range reset).  VecAoEnv's probe
+ *   of the two call orders asks for it before it settles for the plain order.
  * "small_chain" (default 1: systems with <= 512 actuators / modes, <= 1024 slopes and nactu x nslope <= 65536 run the
  * control / agent chain of aomarl_env_step as two workgroup-per-environment kernels, k_small_head / k_small_tail,
  * instead of three GEMMs and five elementwise kernels; fp32 round-off apart, the same numbers; 0: the general chain),

@@ -766,6 +766,14 @@ def test_default_call_order_is_probed_and_falls_back_loudly():
     again = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1, frame_pipeline="auto")
     again.reset()
     assert again.order_probe.get("cached") and again.frame_pipeline is auto.frame_pipeline
+    # the frame stream created anew behind a reset (what the probe does when the pipelined order looks aliased): same episode
+    s0b, s1b = ref.reset(), auto.reset()
+    if auto.frame_pipeline:
+        auto.supervisor.sim.renew_frame_stream()
+    assert torch.equal(s0b, s1b)
+    for a in acts[:8]:
+        (sa, ra, _, _), (sb, rb, _, _) = ref.step(a), auto.step(a)
+        assert torch.equal(sa, sb) and torch.equal(ra, rb)
     # the fallback, forced: nothing is 'not more than 0 x slower'
     VecAoEnv._ORDER_CACHE.clear()
     fb = VecAoEnv("production_sh_10x10_2m", 8, rl, initial_seed=3, n_agents_modal=1, frame_pipeline="auto")
@@ -773,8 +781,9 @@ def test_default_call_order_is_probed_and_falls_back_loudly():
     s2 = fb.reset()
     fb.frame_pipeline = "auto"
     with pytest.warns(UserWarning, match="plain order"):
-        s2 = fb._probe_order(s2, margin=0.0)
+        s2 = fb._probe_order(s2, margin=0.0, alias_ratio=0.0)
     assert fb.frame_pipeline is False and fb.order_probe["chosen"] == "plain"
+    assert fb.order_probe["frame_stream_renewed"] == 2         # (it tried the frame stream anew, twice, first)
     assert getattr(fb.supervisor.sim, "_twin", None) is None
     assert torch.equal(s2, s0)
     ref.reset()
