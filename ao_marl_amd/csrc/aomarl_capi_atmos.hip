@@ -146,8 +146,13 @@ struct ExtrudeRun {          // one range of environments walking through a sequ
         par ^= 1;
         gathered = true;
       } else {
-        hipLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, c->sys, ds, b, ops, NEWL, w.ldn,
-                           ZREF, WS, nsp, ncol, dimc, pscale);
+        // (the last launch of a whole-batch move carries the caller's "moved" event on its dispatch: no marker packet
+        // of its own between the move and the frame kernel that waits for it)
+        hipEvent_t ride = (c->ride_ev && r + 1 == nrounds && cls + 1 == c->nclass && b == 0 && n == st->nenv && !c->capturing)
+                              ? c->ride_ev : nullptr;
+        hipExtLaunchKernelGGL(k_extrude_scatter, dim3(ncol), dim3(256), 0, s, nullptr, ride, 0, c->sys, ds, b, ops, NEWL, w.ldn,
+                              ZREF, WS, nsp, ncol, dimc, pscale);
+        if (ride) c->rode = true;
         gathered = false;
       }
       LAUNCHCHK();
