@@ -676,3 +676,92 @@ int aomarl_get_screen(aomarl_ctx *c, aomarl_state *st, int b, int n, int layer, 
   LAUNCHCHK();
   return 0;
 }
+
+// ---------------------------------------------------------------- run-time wind and r0 (atmosCompass.py:79-135)
+// Host values of the context (deltax / deltay drive the planning of every later move and the direction of a reset's
+// rounds; amp rides in the kernels' DevSys argument) + the stencil lists on the device.  Rare calls (the trainer's
+// non-stationary experiments change the atmosphere once, train_rpc.py:429-450): they synchronise the device instead of
+// ordering themselves into the streams.
+static int stencil_rewrite(aomarl_ctx *c, int l, int axis, const uint32_t *flat /* null: mirror what is there */, int n) {
+  DevLayer &D = c->sys.layers[l];
+  const int dim = D.dim, ns = D.ns;
+  if (flat && n != ns) return fail("set_stencil: layer %d has %d stencil points, got %d", l, ns, n);
+  uint32_t *dst = const_cast<uint32_t *>(axis == 0 ? D.istx : D.isty);
+  std::vector<uint32_t> pk((size_t)ns);
+  HIPCHK(hipDeviceSynchronize());
+  if (flat) {
+    for (int k = 0; k < ns; k++) {
+      if (flat[k] >= (uint32_t)(dim * dim)) return fail("set_stencil: index out of range");
+      pk[k] = (flat[k] % dim) | ((flat[k] / dim) << 16);
+    }
+  } else {
+    HIPCHK(hipMemcpy(pk.data(), dst, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost));
+    for (int k = 0; k < ns; k++) {                 // n * n - 1 - (y * n + x) = (n - 1 - y) * n + (n - 1 - x)
+      const uint32_t x = pk[k] & 0xFFFFu, y = pk[k] >> 16;
+      pk[k] = (uint32_t)(dim - 1 - (int)x) | ((uint32_t)(dim - 1 - (int)y) << 16);
+    }
+  }
+  HIPCHK(hipMemcpy(dst, pk.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice));
+  if (axis == 0) {                                 // the reset's rounds read the x stencil with x and y exchanged
+    for (int k = 0; k < ns; k++) pk[k] = (pk[k] >> 16) | (pk[k] << 16);
+    HIPCHK(hipMemcpy(const_cast<uint32_t *>(D.istT), pk.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+static int atmos_change_ok(aomarl_ctx *c, const char *who) {
+  if (c->capturing) return fail("%s: inside a graph capture", who);
+  if (c->rp && c->rp->n > 0)
+    return fail("%s: a prefetched reset is in flight (its rounds were planned with the old atmosphere): "
+                "aomarl_reset_prefetch_cancel first", who);
+  return 0;
+}
+
+int aomarl_set_wind(aomarl_ctx *c, int layer, float deltax, float deltay, int mirror_stencils) {
+  if (!c) return fail("set_wind: null ctx");
+  if (layer < 0 || layer >= c->nlayers) return fail("set_wind: layer %d of %d", layer, c->nlayers);
+  if (!(fabsf(deltax) < (float)c->dim[layer]) || !(fabsf(deltay) < (float)c->dim[layer]))
+    return fail("set_wind: layer %d would move by more than its %d pixels per frame (or the value is not finite)", layer, c->dim[layer]);
+  int rc = atmos_change_ok(c, "set_wind");
+  if (rc) return rc;
+  const float oldx = c->deltax[layer], oldy = c->deltay[layer];
+  if (mirror_stencils) {
+    if (oldx * deltax < 0.f && (rc = stencil_rewrite(c, layer, 0, nullptr, 0))) return rc;
+    if (oldy * deltay < 0.f && (rc = stencil_rewrite(c, layer, 1, nullptr, 0))) return rc;
+  }
+  HIPCHK(hipDeviceSynchronize());
+  c->deltax[layer] = deltax; c->deltay[layer] = deltay;
+  g_cfg_epoch++; c->cfg_epoch++;                   // captured step graphs hold plans of the old wind
+  return 0;
+}
+
+int aomarl_set_stencil(aomarl_ctx *c, int layer, int axis, const uint32_t *istencil, int n) {
+  if (!c || !istencil) return fail("set_stencil: null argument");
+  if (layer < 0 || layer >= c->nlayers || (axis != 0 && axis != 1)) return fail("set_stencil: layer %d, axis %d", layer, axis);
+  int rc = atmos_change_ok(c, "set_stencil");
+  if (rc) return rc;
+  g_cfg_epoch++; c->cfg_epoch++;
+  return stencil_rewrite(c, layer, axis, istencil, n);
+}
+
+int aomarl_set_r0(aomarl_ctx *c, const float *amplitude, int nlayers) {
+  if (!c || !amplitude) return fail("set_r0: null argument");
+  if (nlayers != c->nlayers) return fail("set_r0: %d amplitudes for %d layers", nlayers, c->nlayers);
+  for (int l = 0; l < nlayers; l++)
+    if (!(amplitude[l] >= 0.f) || !(amplitude[l] < 1e30f)) return fail("set_r0: amplitude %d is not a finite non-negative number", l);
+  int rc = atmos_change_ok(c, "set_r0");
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  for (int l = 0; l < nlayers; l++) c->sys.layers[l].amp = amplitude[l];
+  g_cfg_epoch++; c->cfg_epoch++;                   // DevSys rides by value in every captured kernel node
+  return 0;
+}
+
+int aomarl_get_layer(const aomarl_ctx *c, int layer, float *deltax, float *deltay, float *amplitude) {
+  if (!c) return fail("get_layer: null ctx");
+  if (layer < 0 || layer >= c->nlayers) return fail("get_layer: layer %d of %d", layer, c->nlayers);
+  if (deltax) *deltax = c->deltax[layer];
+  if (deltay) *deltay = c->deltay[layer];
+  if (amplitude) *amplitude = c->sys.layers[layer].amp;
+  return 0;
+}

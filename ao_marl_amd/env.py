@@ -53,6 +53,79 @@ def load_norm(name):
     return norm, z["zn_norm"].copy()
 
 
+class VecAtmos(object):
+    """AtmosCompass's run-time surface for the whole batch: set_wind / set_r0 (atmosCompass.py:79-135), what the
+    trainer's non-stationary experiments call between episodes (train_rpc.py:429-450).  The new values hold for every
+    move PLANNED after the call.  A move that is already issued -- the next frame's, under prefetch_atmos or with a
+    frame in flight -- keeps the atmosphere it was planned with: the reference would have moved it with the new one,
+    so stepping on from there raises; call these right before reset() (the trainer's use), or build the environment
+    with prefetch_atmos=False to change the atmosphere in mid-episode."""
+
+    def __init__(self, sup):
+        self._sup = sup
+        a = sup.config.p_atmos
+        self.windspeed = np.array(a.windspeed, dtype=np.float32)      # (PATMOS.py: float32 arrays)
+        self.winddir = np.array(a.winddir, dtype=np.float32)
+        self.r0 = float(a.r0)
+
+    def _changed(self, blocked, dropped):
+        sup = self._sup
+        if blocked:
+            sup._atmos_changed_behind = blocked
+        if dropped:
+            sup._rp_left = 0                       # the prefetched reset was grown with the old atmosphere: the next reset runs in the open
+
+    def deltas(self, screen_index):
+        """(deltax, deltay) in pixels per frame of a layer from its wind speed and direction (atmos_init.py:99-102,
+        atmosCompass.py:118-123)."""
+        # (the expression of geometry.atmos_geometry, same types in the same order: a layer set to the wind of a
+        # parameter file moves exactly like the layer of a system built from that file)
+        sup, ps = self._sup, self._sup.config
+        cz = np.cos(ps.p_geom.zenithangle * G.DEG2RAD)
+        lin_delta = sup.sysm.geom.pupdiam / ps.p_tel.diam * self.windspeed * cz * ps.p_loop.ittime
+        deltax = np.asarray(lin_delta * np.sin(G.DEG2RAD * self.winddir + np.pi), dtype=np.float32)
+        deltay = np.asarray(lin_delta * np.cos(G.DEG2RAD * self.winddir + np.pi), dtype=np.float32)
+        return deltax[screen_index], deltay[screen_index]
+
+    def set_wind(self, screen_index, *, windspeed=None, winddir=None):
+        """atmosCompass.py:103-135: new speed [m/s] and / or direction [deg] of one layer, every environment."""
+        sup = self._sup
+        k = int(screen_index)
+        if not 0 <= k < sup.s.nscreens:
+            raise IndexError("screen_index %d of %d" % (k, sup.s.nscreens))
+        if windspeed is not None:
+            self.windspeed[k] = float(windspeed)
+        if winddir is not None:
+            self.winddir[k] = float(winddir)
+        dx, dy = self.deltas(k)
+        blocked = sup.sim.atmos_change_blocked()
+        dropped = sup.sim.set_wind(k, dx, dy)
+        sup.config.p_atmos.windspeed[k], sup.config.p_atmos.winddir[k] = self.windspeed[k], self.winddir[k]
+        self._changed(blocked, dropped)
+
+    def amplitudes(self, r0):
+        """Per-layer noise amplitude [um] of the extrusion for a global r0 @ 0.5 um (atmos_init.py:115,
+        iterkolmo.py:278; ao_marl_amd/system.py)."""
+        sup = self._sup
+        atm = sup.sysm.atm
+        fr = np.asarray(sup.config.p_atmos.frac)
+        frac = fr / np.sum(fr)                              # geometry.atmos_geometry, same types in the same order
+        r0_layers = np.asarray(r0 / (frac**(3. / 5.) * atm.pupixsize), dtype=np.float32)
+        return (r0_layers.astype(np.float64)**(-5. / 6.) * 0.5 / (2 * np.pi)).astype(np.float32)
+
+    def set_r0(self, r0, *, reset_seed=-1):
+        """atmosCompass.py:79-101: r0 @ 0.5 um for all layers; the screens as they stand are kept (reset_seed = -1)."""
+        if reset_seed != -1:
+            raise NotImplementedError("set_r0(reset_seed=...): re-seeding belongs to the episode here -- "
+                                      "set_sim_seed(seed) and reset() (every environment owns a block of seeds)")
+        sup = self._sup
+        blocked = sup.sim.atmos_change_blocked()
+        dropped = sup.sim.set_amplitudes(self.amplitudes(r0))
+        self.r0 = float(r0)
+        sup.config.p_atmos.r0 = float(r0)
+        self._changed(blocked, dropped)
+
+
 class VecRlSupervisor(object):
     """Batched counterpart of shesha's RlSupervisor for the integrator (+RL correction) path."""
 
@@ -130,6 +203,17 @@ class VecRlSupervisor(object):
         self.initial_seed, self.seed_stride = int(initial_seed), int(seed_stride)
         self.current_seed = int(initial_seed)
         self.iter = 0
+        # supervisor.atmos.set_wind / set_r0 (atmosCompass.py:79-135)
+        self.atmos = VecAtmos(self)
+
+    # a change of wind / r0 made while the next frame's atmosphere was already moved (see VecAtmos): why, or None
+    _atmos_changed_behind = None
+
+    def _check_atmos_change(self):
+        if self._atmos_changed_behind:
+            raise RuntimeError("atmos.set_wind / set_r0 was called while %s: that frame keeps the old atmosphere, the "
+                               "reference's would have the new one.  Call them right before reset(), or build the "
+                               "environment with prefetch_atmos=False" % self._atmos_changed_behind)
 
     # ---------------------------------------------------------------- configuration
     def obtain_action_range_modal(self):
@@ -244,6 +328,7 @@ class VecRlSupervisor(object):
             self.autoencoder.check_range()      # a saturated fp16 launch of the last episode is an error
         self.check_range()
         self.sim.reset(self.env_seeds())
+        self._atmos_changed_behind = None
         self._rp_left = 0
         if self.reset_prefetch is not None:
             self._begin_reset_prefetch()
@@ -362,6 +447,7 @@ class VecRlSupervisor(object):
     def next_part_one(self, move_atmos=True, do_control=True, defer_control=False):
         """rlSupervisor.py:1015-1051 -> next_part_one_integrator :954-987.  defer_control: image the
         frame, leave do_control to `materialize_control` (run on demand)."""
+        self._check_atmos_change()
         self.materialize_control()              # a frame still waiting for its do_control
         self._err_stale = False
         if defer_control and do_control:
@@ -1040,6 +1126,7 @@ class VecAoEnv(object):
             action = action.contiguous()
         if action.shape != (self.nenv, self.action_dim):
             raise ValueError("action must be [nenv, %d]" % self.action_dim)
+        sup._check_atmos_change()
         if self._glue is None:
             self._make_glue()
         g = self._glue

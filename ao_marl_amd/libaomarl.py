@@ -100,6 +100,10 @@ SYMBOLS = [
     ("aomarl_reset_adopt", _i, _range + [_up, _fp, _fp, _vp, _vp]),
     ("aomarl_move_atmos", _i, _range + [_fp, _fp, _vp]),
     ("aomarl_prefetch_atmos", _i, _range + [_fp, _fp, _vp]),
+    ("aomarl_set_wind", _i, [_vp, _i, C.c_float, C.c_float, _i]),
+    ("aomarl_set_stencil", _i, [_vp, _i, _i, _up, _i]),
+    ("aomarl_set_r0", _i, [_vp, _fp, _i]),
+    ("aomarl_get_layer", _i, [_vp, _i, _fp, _fp, _fp]),
     ("aomarl_extrude", _i, _range + [_i, _ip, _ip, _vp]),
     ("aomarl_get_screen", _i, _range + [_i, _vp, _vp]),
     ("aomarl_set_screen", _i, _range + [_i, _vp, _vp]),

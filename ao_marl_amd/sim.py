@@ -449,6 +449,52 @@ class HipSim(object):
                                                 self._stream()))
         self.pending_atmos, self._pending_range = True, (b, n)
 
+    # ------------------------------------------------------------------ run-time wind / r0 (atmosCompass.py:79-135)
+    def layer_values(self, layer):
+        """(deltax, deltay, amplitude) of a layer as the library holds them now."""
+        v = [C.c_float(0.) for _ in range(3)]
+        la.check(self.lib.aomarl_get_layer(self.ctx, int(layer), *[C.byref(x) for x in v]))
+        return tuple(float(x.value) for x in v)
+
+    def atmos_change_blocked(self):
+        """Why a change of wind / r0 would not take effect on the NEXT frame, or None: a move that is already issued
+        (prefetch_atmos, a pipelined frame in flight) keeps the atmosphere it was planned with."""
+        if self.pending_atmos:
+            return "the next frame's atmosphere is already moved (prefetch_atmos)"
+        if self.frame_pipeline_state()[0]:
+            return "a frame is in flight (frame pipeline)"
+        return None
+
+    def _cancel_reset_prefetch(self):
+        rp = getattr(self, "_rp", None)
+        if rp is not None and rp["seeds"] is not None:
+            la.check(self.lib.aomarl_reset_prefetch_cancel(self.ctx))
+            rp["seeds"], rp["left"] = None, 0
+            return True
+        return False
+
+    def set_wind(self, layer, deltax, deltay, mirror_stencils=True):
+        """aomarl_set_wind: layer `layer` moves by (deltax, deltay) pixels per frame from the next PLANNED move on;
+        where a component changes sign its stencil is mirrored (atmosCompass.py:124-135).  A prefetched reset (grown
+        along the old sign) is dropped.  Returns True when one was dropped."""
+        dropped = self._cancel_reset_prefetch()
+        la.check(self.lib.aomarl_set_wind(self.ctx, int(layer), float(np.float32(deltax)), float(np.float32(deltay)),
+                                          int(bool(mirror_stencils))))
+        return dropped
+
+    def set_stencil(self, layer, axis, istencil):
+        """aomarl_set_stencil: Tscreen.set_istencilx (axis 0) / set_istencily (axis 1), flat logical indices."""
+        self._cancel_reset_prefetch()
+        ist = np.ascontiguousarray(istencil, dtype=np.uint32)
+        la.check(self.lib.aomarl_set_stencil(self.ctx, int(layer), int(axis), la.uptr(ist), int(ist.size)))
+
+    def set_amplitudes(self, amplitude):
+        """aomarl_set_r0: the noise amplitude of every layer's new lines (um); the screens as they stand are kept."""
+        dropped = self._cancel_reset_prefetch()
+        a = np.ascontiguousarray(amplitude, dtype=np.float32).reshape(-1)
+        la.check(self.lib.aomarl_set_r0(self.ctx, la.fptr(a), int(a.size)))
+        return dropped
+
     def extrude(self, layers, dirs, env_begin=0, env_count=None):
         b, n = self._range(env_begin, env_count)
         l = np.ascontiguousarray(layers, dtype=np.int32)

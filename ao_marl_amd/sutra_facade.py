@@ -255,7 +255,29 @@ class Telescope(object):
 
 # ------------------------------------------------------------------------------ atmosphere
 class _Screen(object):
-    pass
+    """sutra's Tscreen as atmosCompass.py uses it at run time (:103-135): set_deltax / set_deltay, d_istencilx /
+    d_istencily (np.array(...) of them) and set_istencilx / set_istencily -- over aomarl_set_wind (the deltas alone)
+    and aomarl_set_stencil of the engine that moves the atmosphere."""
+
+    def _push(self, fn):
+        if _HUB["engines"]:                       # built: the library holds these values (else they are read at the build)
+            fn(_HUB["engines"][0].sim)
+
+    def set_deltax(self, v):
+        self.deltax = f32(v)
+        self._push(lambda sim: sim.set_wind(self.index, self.deltax, self.deltay, mirror_stencils=False))
+
+    def set_deltay(self, v):
+        self.deltay = f32(v)
+        self._push(lambda sim: sim.set_wind(self.index, self.deltax, self.deltay, mirror_stencils=False))
+
+    def set_istencilx(self, ist):
+        self.istx = _c(ist, np.uint32)
+        self._push(lambda sim: sim.set_stencil(self.index, 0, self.istx))
+
+    def set_istencily(self, ist):
+        self.isty = _c(ist, np.uint32)
+        self._push(lambda sim: sim.set_stencil(self.index, 1, self.isty))
 
 
 class Atmos(object):
@@ -266,6 +288,9 @@ class Atmos(object):
         self.d_screens = []
         for i in range(self.nscreens):
             s = _Screen()
+            s.index = i
+            s.d_istencilx = DevArray(lambda s=s: s.istx.astype(np.int64))
+            s.d_istencily = DevArray(lambda s=s: s.isty.astype(np.int64))
             s.dim = int(dim_screens[i])
             s.deltax, s.deltay = f32(deltax[i]), f32(deltay[i])
             s.amplitude = f32(float(r0_layers[i])**(-5. / 6.) * 0.5 / (2 * np.pi))
@@ -284,6 +309,16 @@ class Atmos(object):
 
     def set_seed(self, k, seed):
         self.d_screens[k].seed = int(seed)
+
+    def set_r0(self, r0):
+        """sutra's Atmos.set_r0 (atmosCompass.py:93): every layer's noise amplitude follows r0^(-5/6); the screens as
+        they stand are kept."""
+        scale = (float(r0) / float(self.r0))**(-5. / 6.)
+        for sc in self.d_screens:
+            sc.amplitude = f32(float(sc.amplitude) * scale)
+        self.r0 = float(r0)
+        if _HUB["engines"]:
+            _HUB["engines"][0].sim.set_amplitudes([sc.amplitude for sc in self.d_screens])
 
     def _base_seed(self):
         base = {sc.seed - k for k, sc in enumerate(self.d_screens)}

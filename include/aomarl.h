@@ -220,6 +220,25 @@ int aomarl_move_atmos(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_
  * screens (the GEO twin).  Results are those of the plain call order, bit for bit. */
 int aomarl_prefetch_atmos(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count,
                           float *accumx, float *accumy, void *stream);
+/* Run-time changes of the atmosphere (AtmosCompass.set_wind / set_r0, atmosCompass.py:79-135; the trainer's
+ * non-stationary experiments, train_rpc.py:429-450).  Host values of the context: every move PLANNED after the call
+ * uses them; a move already issued by aomarl_prefetch_atmos keeps the wind it was planned with (the host side
+ * refuses to step across that: ao_marl_amd/env.py VecAtmos), a prefetched reset in flight must be cancelled by the
+ * caller when a sign of deltax changes (its rounds run along the old sign).  Both calls synchronise the device.
+ *
+ * aomarl_set_wind = Tscreen.set_deltax + set_deltay of layer `layer` (pixels per frame), and -- the rule of
+ * atmosCompass.py:124-135 -- where old * new < 0 along an axis that axis' stencil is mirrored
+ * (istencil -> dim * dim - 1 - istencil: set_istencilx / set_istencily).  mirror_stencils = 0: the deltas alone
+ * (the facade's set_deltax / set_deltay; it mirrors through aomarl_set_stencil).
+ * aomarl_set_stencil = Tscreen.set_istencilx (axis 0) / set_istencily (axis 1): n = the layer's stencil size, flat
+ * logical indices, host memory.
+ * aomarl_set_r0 = Atmos.set_r0: the amplitude of the noise term of every layer's new lines, amplitude[nlayers] =
+ * r0_layer^(-5/6) * 0.5 / (2 pi) in um (atmos_init.py:115, iterkolmo.py:278); the screens as they stand are kept. */
+int aomarl_set_wind(aomarl_ctx *ctx, int layer, float deltax, float deltay, int mirror_stencils);
+int aomarl_set_stencil(aomarl_ctx *ctx, int layer, int axis, const uint32_t *istencil, int n);
+int aomarl_set_r0(aomarl_ctx *ctx, const float *amplitude, int nlayers);
+/* the layer's current host values (deltax, deltay, amplitude); any pointer may be null */
+int aomarl_get_layer(const aomarl_ctx *ctx, int layer, float *deltax, float *deltay, float *amplitude);
 /* one parallel round of extrusions: op i extrudes layer[i] in direction dir[i] (+-1 x, +-2 y) */
 int aomarl_extrude(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count, int nops,
                    const int32_t *layer, const int32_t *dir, void *stream);

@@ -108,7 +108,33 @@ class OracleSim(object):
                 self._influ.append(np.ascontiguousarray(d.influ, dtype=np.float32))
         self._alloc_ctrl()
         self.ref_peak = float(np.sum(s.spupil, dtype=np.float64))**2
+        # the atmosphere's run-time values, this environment's own (set_wind / set_amplitudes change them)
+        self.deltax = np.array(s.deltax, dtype=np.float32)
+        self.deltay = np.array(s.deltay, dtype=np.float32)
+        self.amplitude = np.array(s.amplitude, dtype=np.float32)
+        self.istx = [np.array(a, dtype=np.uint32) for a in s.istx]
+        self.isty = [np.array(a, dtype=np.uint32) for a in s.isty]
         self.reset(seed)
+
+    # ---------------------------------------------------------------- run-time wind / r0
+    def set_wind(self, layer, deltax, deltay, mirror_stencils=True):
+        """Tscreen.set_deltax / set_deltay, and AtmosCompass.set_wind's rule (atmosCompass.py:124-135): where the
+        old and the new value of a component have opposite signs that axis' stencil becomes n * n - 1 - stencil."""
+        n = self.s.screen_dim[layer]
+        ox, oy = self.deltax[layer], self.deltay[layer]
+        dx, dy = np.float32(deltax), np.float32(deltay)
+        if mirror_stencils and ox * dx < 0:
+            self.istx[layer] = (np.int64(n * n - 1) - self.istx[layer].astype(np.int64)).astype(np.uint32)
+        if mirror_stencils and oy * dy < 0:
+            self.isty[layer] = (np.int64(n * n - 1) - self.isty[layer].astype(np.int64)).astype(np.uint32)
+        self.deltax[layer], self.deltay[layer] = dx, dy
+
+    def set_stencil(self, layer, axis, istencil):
+        (self.istx if axis == 0 else self.isty)[layer] = np.array(istencil, dtype=np.uint32)
+
+    def set_amplitudes(self, amplitude):
+        """Atmos.set_r0 (atmosCompass.py:79-101): the noise amplitude of the new lines; the screens are kept."""
+        self.amplitude = np.array(amplitude, dtype=np.float32).reshape(self.s.nscreens)
 
     def _alloc_ctrl(self):
         n = self.s.nactu
@@ -134,7 +160,7 @@ class OracleSim(object):
                 self.ext_count[l] = int(grown[1][l])
                 continue
             self.screens[l][:] = 0
-            d = 1 if s.deltax[l] > 0 else -1
+            d = 1 if self.deltax[l] > 0 else -1
             for _ in range(2 * s.screen_dim[l]):
                 self._extrude(l, d)
         self._alloc_ctrl()
@@ -161,18 +187,18 @@ class OracleSim(object):
     def _extrude(self, l, d):
         s = self.s
         n = s.screen_dim[l]
-        ist = s.istx[l] if abs(d) == 1 else s.isty[l]
+        ist = self.istx[l] if abs(d) == 1 else self.isty[l]
         eps = normals(self.seed + l, 0, self.ext_count[l], n)
         self.ext_count[l] += 1
         tmp = np.empty(ist.size + n, dtype=np.float32)
         self.L.aoref_extrude(self.screens[l].reshape(-1), n, s.A[l], ist.size, s.B[l], ist, d,
-                             float(s.amplitude[l]), eps, tmp)
+                             float(self.amplitude[l]), eps, tmp)
 
     def move_atmos(self):
         s = self.s
         for l in range(s.nscreens):
-            self.accumx[l] = np.float32(self.accumx[l] + s.deltax[l])
-            self.accumy[l] = np.float32(self.accumy[l] + s.deltay[l])
+            self.accumx[l] = np.float32(self.accumx[l] + self.deltax[l])
+            self.accumy[l] = np.float32(self.accumy[l] + self.deltay[l])
             kx, ky = int(self.accumx[l]), int(self.accumy[l])
             for _ in range(abs(kx)):
                 self._extrude(l, 1 if kx > 0 else -1)

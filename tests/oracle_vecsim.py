@@ -103,6 +103,28 @@ class OracleVecSim(object):
         for o, sd in zip(self.sims, seeds):
             o.reset(int(sd))
 
+    # run-time wind / r0 (the HipSim surface of the same names)
+    def layer_values(self, layer):
+        o = self.sims[0]
+        return float(o.deltax[layer]), float(o.deltay[layer]), float(o.amplitude[layer])
+
+    def atmos_change_blocked(self):
+        return None                                                  # call-by-call order: nothing runs ahead
+
+    def set_wind(self, layer, deltax, deltay, mirror_stencils=True):
+        for o in self.sims:
+            o.set_wind(layer, deltax, deltay, mirror_stencils)
+        return False
+
+    def set_stencil(self, layer, axis, istencil):
+        for o in self.sims:
+            o.set_stencil(layer, axis, istencil)
+
+    def set_amplitudes(self, amplitude):
+        for o in self.sims:
+            o.set_amplitudes(amplitude)
+        return False
+
     def rl_control(self, action):
         a = np.asarray(action, dtype=np.float32)
         for e, o in enumerate(self.sims):
