@@ -84,22 +84,27 @@ RL43 = dict(n_zernike_start_end=[0, 1260], n_reverse_filtered_from_cmat=5, windo
             include_tip_tilt_windowed=True)
 
 
-@pytest.mark.parametrize("precision,pipeline,layout", [("f32", False, 14), ("f32", True, 14), ("split_f16", True, 14),
-                                                       ("f32", True, 43)])
-def test_env_step_40x40_windowed_agents_match_the_oracle_env(monkeypatch, precision, pipeline, layout):
+@pytest.mark.parametrize("precision,pipeline,layout,bench", [("f32", False, 14, False), ("f32", True, 14, False),
+                                                             ("split_f16", True, 14, False), ("f32", True, 43, False),
+                                                             ("f32", True, 14, True), ("f32", False, 14, True)])
+def test_env_step_40x40_windowed_agents_match_the_oracle_env(monkeypatch, precision, pipeline, layout, bench):
     """pipeline: the frame pipeline bench.py runs with (frame t+1 in flight while frame t is reduced).
-    layout: the bench's 14 agents, or the reference's published 43."""
+    layout: the bench's 14 agents, or the reference's published 43.
+    bench: the EXACT composition bench.py times and `run_episode` steps with -- `VecAoEnv.policy_step`
+    (aomarl_policy_env_step: the actors inside the call, sampled actions) with `residual_shortcut=True` (v2m . cmat in
+    one product) -- against the oracle environment in the reference's order (do_control, then v2m . err), which gets
+    the actions the call returned."""
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     keep = la.get_precision()
     la.set_precision(precision)
     try:
-        _run(monkeypatch, precision, pipeline, layout)
+        _run(monkeypatch, precision, pipeline, layout, bench)
     finally:
         la.set_precision(keep)
 
 
-def _run(monkeypatch, precision, pipeline, layout=14):
+def _run(monkeypatch, precision, pipeline, layout=14, bench=False):
     from ao_marl_amd import libaomarl as la
     from ao_marl_amd.env import VecAoEnv
     PushedSim = _pushed_sim_class()
@@ -111,6 +116,12 @@ def _run(monkeypatch, precision, pipeline, layout=14):
     lay = env.layout
     assert lay.n_agents == layout and lay.state_shapes()[0] == (552 if layout == 14 else 280) and lay.state_shapes()[-1] == 168
     assert env._native_glue and env._default_state_layout
+    pol = None
+    if bench:
+        from ao_marl_amd.agents import BatchedGaussianPolicy
+        env.residual_shortcut = True
+        # a policy that acts (random last layer, sampled actions: the whole action range is exercised)
+        pol = BatchedGaussianPolicy(lay, last_layer_zero=False, seed=7, device="cuda:0")
     cal = env.supervisor.cal
 
     # the oracle-backed twin takes the GPU side's calibration (an interaction matrix of 1286 actuators
@@ -155,9 +166,16 @@ def _run(monkeypatch, precision, pipeline, layout=14):
         worst["state"] = max(worst["state"], d)
         # standardised Btt coordinates: O(1) columns; fp32 round-off of two differently ordered chains
         assert d < 2e-3, ("state", it, d)
-        a = rng.uniform(-1, 1, size=(NENV, env.action_dim)).astype(np.float32)
         ok = env._native_step_ok(False)
-        sg, rg, done, _ = env.step(torch.from_numpy(a).cuda())
+        if bench:
+            calls = la.arith_launches().get("actor:f32_mfma", 0)
+            a_t, sg, rg, done, _ = env.policy_step(pol, sg)
+            a = a_t.cpu().numpy()
+            assert la.arith_launches().get("actor:f32_mfma", 0) == calls + 1          # the actors ran inside the call
+            assert np.isfinite(a).all() and np.abs(a).max() <= 1.0 and np.abs(a).max() > 0.5
+        else:
+            a = rng.uniform(-1, 1, size=(NENV, env.action_dim)).astype(np.float32)
+            sg, rg, done, _ = env.step(torch.from_numpy(a).cuda())
         used_native += int(ok)
         so_t, ro, _, _ = oenv.step(torch.from_numpy(a))
         so, ro = so_t.numpy(), ro.numpy()
@@ -176,6 +194,8 @@ def _run(monkeypatch, precision, pipeline, layout=14):
         worst["com"] = max(worst["com"], dc)
         assert dc < 5e-4, ("com", it, dc)
     assert used_native == NSTEP                      # every step went through aomarl_env_step
+    if bench:
+        assert env._native_shortcut and env.supervisor._control_pending       # the shortcut ran inside the one-call step
     flying, _, piped, beside = env.supervisor.sim.frame_pipeline_state()
     assert (flying, piped, beside) == ((True, NSTEP - 1, NSTEP) if pipeline else (False, 0, 0))
     launched = {k: v for k, v in la.arith_launches().items() if v}
@@ -194,7 +214,8 @@ def _run(monkeypatch, precision, pipeline, layout=14):
 
 def test_bench_batch_through_env_step_with_the_frame_pipeline():
     """What bench.py times, at ITS batch, with asserts: 256 environments x 14 windowed agents through
-    aomarl_actor_forward + aomarl_env_step with a frame in flight, 32 steps.  Size-independent properties: equal
+    `policy_step` (aomarl_policy_env_step = aomarl_actor_forward + aomarl_env_step in one call) with the residual
+    shortcut and a frame in flight, 32 steps.  Size-independent properties: equal
     seeds with equal actions stay equal bit for bit, different seeds decorrelate, everything is finite, the loop
     closes, and the first environments agree with the same seeds stepped as a batch of 8 (another GEMM tiling:
     fp32 round-off of differently ordered sums, not bits)."""
@@ -205,6 +226,7 @@ def test_bench_batch_through_env_step_with_the_frame_pipeline():
     def make(nenv):
         env = VecAoEnv(NAME, nenv, RL, initial_seed=1234, seed_stride=16, n_agents_modal=13, device="cuda:0",
                        frame_pipeline=True)
+        env.residual_shortcut = True
         seeds = env.supervisor.env_seeds().copy()
         seeds[1] = seeds[0]                                  # twin environments
         env.supervisor.env_seeds = lambda: seeds
@@ -218,10 +240,10 @@ def test_bench_batch_through_env_step_with_the_frame_pipeline():
     for it in range(steps):
         eps = torch.randn(n, big.layout.action_dim, device="cuda:0", generator=g)
         eps[1] = eps[0]
-        a, _ = pol.select_action(sb, eps=eps)                # k_actor_fused on the batch's states
-        assert torch.equal(a[0], a[1])
         assert big._native_step_ok(False)
-        sb, rb, _, _ = big.step(a)
+        a_want, _ = pol.select_action(sb, eps=eps)           # k_actor_fused on the batch's states
+        a, sb, rb, _, _ = big.policy_step(pol, sb, eps=eps)  # ... and inside the one-call step: the same launch, the same bits
+        assert torch.equal(a, a_want) and torch.equal(a[0], a[1])
         ss, rs, _, _ = small.step(a[:small_n].contiguous())
         assert torch.isfinite(sb).all() and torch.isfinite(rb).all() and rb.shape == (n, 14)
         assert torch.equal(sb[0], sb[1]) and torch.equal(rb[0], rb[1])          # same seed, same actions: same bits
@@ -231,6 +253,7 @@ def test_bench_batch_through_env_step_with_the_frame_pipeline():
         assert d < 5e-3, (it, d)                             # batch of 256 against batch of 8, closed loop, 32 steps
     flying, _, piped, beside = big.supervisor.sim.frame_pipeline_state()
     assert flying and piped >= steps - 1 and beside >= steps - 2, (piped, beside)
+    assert big._native_shortcut and small._native_shortcut
     sl = big.supervisor.get_slopes()
     assert torch.isfinite(sl).all() and torch.equal(sl[0], sl[1])
     c = np.corrcoef(sl[2].cpu().numpy(), sl[3].cpu().numpy())[0, 1]

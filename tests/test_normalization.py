@@ -74,8 +74,10 @@ COMPASS_RUNS = ["production_sh_10x10_2m", L40, L40 + "_dir_0_15_30", L40 + "_sam
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", COMPASS_RUNS)
 def test_statistics_match_the_references_recorded_compass_runs(name):
-    """Acceptance of SURVEY section 8c: median ratio of the per-slope and per-mode standard
-    deviations within +-10 %, action bounds (extreme-value statistics) within +-20 %."""
+    """SURVEY section 8c asks for the median ratio of the per-slope and per-mode standard deviations within +-10 % and
+    the action bounds (extreme-value statistics) within +-20 %.  The build measures 0.990 .. 1.001 on the eleven 40x40
+    files (1200 sub-apertures, 1283 modes: the medians are tight) and 1.000 .. 1.023 on the 10x10 file (64
+    sub-apertures); asserted: +-3 % / +-5 % -- a 5 % error in the flow, the noise amplitude or the loop gain fails."""
     ref, zn_ref = load_norm(name)
     norm, zn, sr = N.obtain_normalization(name, modes_filtered=5, episodes=20, frames=1000)
     assert norm["wfs"]["std"].shape == ref["wfs"]["std"].shape
@@ -89,9 +91,10 @@ def test_statistics_match_the_references_recorded_compass_runs(name):
     r_zn = np.median(zn[live] / zn_ref[live])
     print("%s: median std ratio  slopes %.3f  command modes %.3f  residual modes %.3f  zn_norm %.3f  "
           "LE Strehl %.3f" % (name, r_wfs, r_dm, r_res, r_zn, sr.mean()))
-    assert abs(r_wfs - 1) < 0.10
-    assert abs(r_dm - 1) < 0.10
-    assert abs(r_res - 1) < 0.10
+    tol = 0.03 if name.startswith(L40) else 0.05
+    assert abs(r_wfs - 1) < tol, r_wfs
+    assert abs(r_dm - 1) < tol, r_dm
+    assert abs(r_res - 1) < tol, r_res
     assert abs(r_zn - 1) < 0.20
     assert np.abs(norm["wfs"]["mean"]).max() < 0.2 * norm["wfs"]["std"].max()
     # Not only the medians: a mode-number-dependent error (say the high orders 15 % off) would leave a median
