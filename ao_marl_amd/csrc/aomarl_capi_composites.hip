@@ -280,7 +280,12 @@ static int gemm_batched_any(int batch, int transA, int transB, int M, int N, int
                             hipStream_t s) {
   if (batch == 0 || M == 0 || N == 0) return 0;
   const bool al = !((uintptr_t)A & 15) && !((uintptr_t)B & 15) && !(lda & 3) && !(ldb & 3) && !(strideA & 3) && !(strideB & 3);
-  if (al && !accumulate && K > 0 && !g_gemm_kgroups) {
+  // k_gemm_g fetches 16-byte pieces along each operand's contiguous dimension: a row's last piece reaches up to three
+  // floats past its K (M, N) elements -- inside the leading dimension, but past the END of a tightly sized buffer in the
+  // last row of the last matrix.  The public entry points promise nothing beyond (rows - 1) * ld + length floats, so
+  // only whole pieces go there; a ragged inner dimension takes the general kernel (element-wise tail).
+  const bool whole = !((transA ? M : K) & 3) && !((transB ? N : K) & 3);
+  if (al && whole && !accumulate && K > 0 && !g_gemm_kgroups) {
     GemmGArgs g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.N = N; g.K = K;

@@ -249,6 +249,28 @@ def _hash_obj(h, name, v, depth=0):
         h.update(repr(type(v)).encode())
 
 
+_CODE_FP = None
+
+
+def _code_fingerprint():
+    """sha256 of the Python that PRODUCES a calibration -- this module, geometry.py, system.py -- and of the NumPy /
+    SciPy versions behind its linear algebra: an edit to compute_btt / cmat_with_btt / correct_dm or to the geometry
+    invalidates every stored result by itself (nobody has to remember _CAL_VERSION)."""
+    global _CODE_FP
+    if _CODE_FP is None:
+        import hashlib
+        import os
+        import scipy
+        h = hashlib.sha256()
+        here = os.path.dirname(os.path.abspath(__file__))
+        for f in ("modal.py", "geometry.py", "system.py"):
+            with open(os.path.join(here, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+        h.update(("numpy %s scipy %s" % (np.__version__, scipy.__version__)).encode())
+        _CODE_FP = h.hexdigest()
+    return _CODE_FP
+
+
 def calibration_key(s, sysm, backend, nfilt, backend_id=None):
     """sha256 over everything calibrate() reads: pupils, the sensor's maps, every DM, the offsets of the DMs in the
     sensor's path, nfilt and the backend's identity (`backend_id` or `backend.calibration_id()`: None = not
@@ -262,6 +284,7 @@ def calibration_key(s, sysm, backend, nfilt, backend_id=None):
         return None
     h = hashlib.sha256()
     _hash_obj(h, "version", _CAL_VERSION)
+    _hash_obj(h, "code", _code_fingerprint())
     _hash_obj(h, "backend", bid)
     _hash_obj(h, "nfilt", int(nfilt))
     for k in ("n", "pupdiam", "mpupil", "spupil", "nvalid", "pdiam", "nfft", "npix", "nrebin", "nxsub", "phasemap", "halfxy",
@@ -284,6 +307,40 @@ def _cache_dir():
         return v
     uid = os.getuid() if hasattr(os, "getuid") else 0
     return os.path.join(tempfile.gettempdir(), "ao_marl_amd_calib_%d" % uid)
+
+
+def _own_private_dir(cdir):
+    """Create `cdir` (0700) if need be and check that it is what it should be: a real directory (no symbolic link)
+    that belongs to this user and that nobody else can write to.  The default lives in the shared temporary
+    directory under a predictable name: somebody else's directory there (or a link to one) could hold planted
+    matrices, so it is not used -- the caller falls back to the in-process memo."""
+    import os
+    import stat
+    try:
+        os.makedirs(cdir, mode=0o700, exist_ok=True)
+        st = os.lstat(cdir)
+    except OSError:
+        return False
+    if not stat.S_ISDIR(st.st_mode) or stat.S_ISLNK(st.st_mode):
+        return False
+    if hasattr(os, "getuid") and st.st_uid != os.getuid():
+        return False
+    return (st.st_mode & 0o022) == 0
+
+
+def _fits(c, s):
+    """A loaded calibration has the shapes of the system it is replayed into (a file of another system under this
+    key -- a damaged or planted one -- is recalibrated over, not trusted)."""
+    try:
+        nact = int(sum(len(k) for k in c.kept))         # (one entry per DM: the kept stack-array actuators, both tip-tilt axes)
+        ok_dm = len(c.kept) == len(s.dms) and all(
+            (len(k) == 2 if d.type == "tt" else (k.size > 0 and int(k.min()) >= 0))
+            for k, d in zip(c.kept, s.dms))
+        return (ok_dm and c.cmat.ndim == 2 and c.cmat.shape == (nact, s.nslope) and
+                c.imat.shape == (s.nslope, nact) and c.Btt.shape[0] == nact and c.P.shape == c.Btt.shape[::-1] and
+                c.IF.shape[1] == nact and all(np.all(np.isfinite(getattr(c, k))) for k in ("cmat", "Btt", "P")))
+    except Exception:
+        return False
 
 
 _CAL_FIELDS = ("imat_geom", "imat", "Btt", "P", "cmat")
@@ -362,13 +419,17 @@ def calibrate(s, sysm, backend, nfilt=0, verbose=False, cache=True, backend_id=N
             cache_stats["hit_mem"] += 1
             return _replay(_unpack(_CAL_MEMO[key]), s, sysm, backend)
         cdir = _cache_dir()
+        if cdir is not None and not _own_private_dir(cdir):
+            import warnings
+            warnings.warn("calibration cache: %r is not a private directory of this user (a link, another owner, or "
+                          "writable by others): not used, this process keeps its calibrations in memory" % cdir)
+            cdir = None
         if cdir is None:
             c = _calibrate_now(s, sysm, backend, nfilt, verbose)
             cache_stats["miss"] += 1
             _CAL_MEMO[key] = _pack(c)
             return c
-        os.makedirs(cdir, mode=0o700, exist_ok=True)     # (arrays only: np.load refuses pickles; the directory is the user's own)
-        path = os.path.join(cdir, key + ".npz")
+        path = os.path.join(cdir, key + ".npz")     # (arrays only: np.load refuses pickles; the directory is the user's own: checked)
         lock = open(os.path.join(cdir, key + ".lock"), "w")
         try:
             try:
@@ -380,9 +441,12 @@ def calibrate(s, sysm, backend, nfilt=0, verbose=False, cache=True, backend_id=N
                 try:
                     with np.load(path) as z:
                         d = {k: z[k] for k in z.files}
+                    c = _unpack(d)
+                    if not _fits(c, s):
+                        raise ValueError("stored calibration does not fit this system")
                     _CAL_MEMO[key] = d
                     cache_stats["hit_disk"] += 1
-                    return _replay(_unpack(d), s, sysm, backend)
+                    return _replay(c, s, sysm, backend)
                 except Exception:                       # a damaged file: calibrate and replace it
                     pass
             c = _calibrate_now(s, sysm, backend, nfilt, verbose)

@@ -826,7 +826,7 @@ def run_episode(env, sac, max_steps=None, train=True, eval_mode=False, linear_co
 
 
 def train_agent(env, sac, n_episodes, max_steps=None, test_every=50, n_updates=None, batch_size=None,
-                on_episode=None):
+                on_episode=None, throughput=True):
     """TrainerRPC.train_agent (train_rpc.py:452-501), batched: training episodes, every
     `test_every` episodes one RL evaluation and one integrator evaluation on fresh seeds, and after
     EVERY episode (training or test) the simulation moves on to a seed block no environment of no
@@ -838,10 +838,12 @@ def train_agent(env, sac, n_episodes, max_steps=None, test_every=50, n_updates=N
     # several ranks = several collectors feeding ONE learner (BatchedSAC.sync_learners): equal weights
     # at the start, averaged learner state after every episode's updates
     sac.sync_learners(init=True)
-    # (VecAoEnv(reset_prefetch=world) grows the next training episode's screens beside this one,
-    # aomarl_reset_prefetch_*: its seeds are this episode's + one block per rank; an evaluation in between resets on
-    # other seeds, the prefetch is dropped and that reset runs in the open.  Opt-in: on this GPU the loop is bound by
-    # instruction issue, the hidden rounds cost the steps what the reset saved -- DESIGN.md)
+    # throughput (default): the loop bench.py times -- VecAoEnv.throughput_mode: frame pipeline where eligible,
+    # residual shortcut, and the next training episode's screens grown beside this one (aomarl_reset_prefetch_*: its
+    # seeds are this episode's + one block per rank; an evaluation in between resets on other seeds, the prefetch is
+    # dropped and that reset runs in the open).  throughput=False leaves the environment as the caller built it.
+    if throughput and hasattr(env, "throughput_mode"):
+        env.throughput_mode(reset_prefetch=world)
     for ep in range(int(n_episodes)):
         seed = env.supervisor.current_seed
         out = run_episode(env, sac, max_steps=max_steps, train=True, n_updates=n_updates,

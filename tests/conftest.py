@@ -10,9 +10,28 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+_SESSION_CACHE = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
+    # calibrations memoised on disk (ao_marl_amd/modal.py) in a directory of THIS session: tests never replay what an
+    # earlier checkout left in the user's persistent cache, and the ranks a test spawns still share one (inherited)
+    global _SESSION_CACHE
+    if "AOMARL_CALIB_CACHE" not in os.environ:
+        import tempfile
+        _SESSION_CACHE = tempfile.mkdtemp(prefix="aomarl_calib_test_")
+        os.environ["AOMARL_CALIB_CACHE"] = _SESSION_CACHE
+
+
+def pytest_unconfigure(config):
+    global _SESSION_CACHE
+    if _SESSION_CACHE:
+        import shutil
+        shutil.rmtree(_SESSION_CACHE, ignore_errors=True)
+        os.environ.pop("AOMARL_CALIB_CACHE", None)
+        _SESSION_CACHE = None
 
 
 def _gpu_unavailable_reason():

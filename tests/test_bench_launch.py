@@ -152,6 +152,37 @@ def test_two_rank_bench_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_five_rank_bench_on_one_gpu():
+    """More ranks than any box of the pool has cards, on ONE card over gloo: five processes through the calibration
+    cache's lock (one calibrates, four load), five shards of one global seed sequence, the port hand-out of
+    `spawn_ranks`, the gathers at world size 5.  (Five, not eight: a GPU box admits six processes of one user on its
+    card at a time, and the test runner is one of them.)"""
+    import tempfile
+    env = dict(os.environ, AOMARL_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    with tempfile.TemporaryDirectory(prefix="aomarl_calib_5rank_") as cache:
+        env["AOMARL_CALIB_CACHE"] = cache       # empty: exactly one rank must calibrate
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "4", "--warmup", "1", "--settle", "4",
+               "--envs", "8", "--config", "production_sh_10x10_2m", "--no-cpu-baseline", "--no-side-configs",
+               "--episode-len", "20"]
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        assert len([f for f in os.listdir(cache) if f.endswith(".npz")]) == 1
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 5 and out["scaling"] == "weak" and out["gathered"]["n"] == 40
+    sh = sorted(out["shards"], key=lambda d: d["rank"])
+    assert [d["rank"] for d in sh] == list(range(5))
+    seeds = [d["first_seed"] + 16 * i for d in sh for i in range(d["envs"])]
+    assert seeds == [1234 + 16 * i for i in range(40)]
+    stats = [d["calibration_cache"] for d in sh]
+    assert sum(c["miss"] for c in stats) == 1 and sum(c["hit_disk"] for c in stats) == 4, stats
+    assert out["value"] > 0 and all(d["ms_per_step"] > 0 for d in sh)
+
+
+@pytest.mark.gpu
 def test_two_rank_bench_over_rccl():
     """One rank per GPU over RCCL (backend "nccl"), as the driver launches the scaling runs; needs two
     cards (the one-GPU boxes skip it)."""

@@ -66,3 +66,32 @@ def test_cache_can_be_switched_off(monkeypatch):
     _run(built)
     _run(built)
     assert len(built) == 2 and not modal._CAL_MEMO
+
+
+def test_the_key_follows_the_code_and_a_foreign_directory_is_not_trusted(tmp_path, monkeypatch):
+    """The key holds a hash of the modules that produce a calibration (an edit invalidates stored results by itself);
+    a cache directory that is a symbolic link or writable by others is not used; a stored file whose shapes do not fit
+    the system is calibrated over."""
+    import os
+    from ao_marl_amd import modal
+    from tests import helpers
+    sysm, s = helpers.uncalibrated()
+    k0 = modal.calibration_key(s, sysm, None, 5, backend_id="x")
+    monkeypatch.setattr(modal, "_CODE_FP", "another edit of modal.py")
+    assert modal.calibration_key(s, sysm, None, 5, backend_id="x") != k0
+    monkeypatch.setattr(modal, "_CODE_FP", None)
+    assert modal.calibration_key(s, sysm, None, 5, backend_id="x") == k0
+    real = tmp_path / "real"
+    real.mkdir(mode=0o700)
+    link = tmp_path / "link"
+    os.symlink(real, link)
+    assert modal._own_private_dir(str(real)) and not modal._own_private_dir(str(link))
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    assert not modal._own_private_dir(str(loose))
+    # a planted / foreign file under the right name: shapes of another system -> not replayed
+    _, s2, cal = helpers.calibrated()
+    bad = modal._unpack(modal._pack(cal))
+    bad.cmat = bad.cmat[:-1]
+    assert modal._fits(modal._unpack(modal._pack(cal)), helpers.uncalibrated()[1]) and not modal._fits(bad, helpers.uncalibrated()[1])

@@ -107,3 +107,38 @@ def test_two_rank_learners_start_equal_and_are_averaged():
         moved = max(moved, float(np.abs(x0 - x1).max()))
     assert moved > 0                                        # the ranks really learned different things
     assert np.allclose(al0, np.exp(la0)) and np.array_equal(al0, al1)
+
+
+def test_four_rank_learners_and_shards():
+    """World size 4 (the scaling runs go to 8; nothing here is specific to two ranks): one global seed sequence in
+    four disjoint shards, every rank sees all sixteen returns in order, the learners start from rank 0's weights and
+    end on the mean of the four."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q, q2 = ctx.Queue(), ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all_seeds = sum((r[1] for r in res), [])
+    assert all_seeds == (1234 + 16 * np.arange(16)).tolist()
+    assert all(r[2] == [0.5 * s for s in all_seeds] and r[3] == 4.0 for r in res)
+    port = _free_port()
+    ps = [ctx.Process(target=_learner_worker, args=(r, world, port, q2)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q2.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(np.array_equal(res[0][1], r[1]) for r in res[1:])             # rank 0's weights everywhere at the start
+    for k in range(len(res[0][2])):
+        mean = sum(r[2][k].astype(np.float64) for r in res) / world
+        for r in res:
+            assert np.array_equal(r[3][k], res[0][3][k])                    # one learner afterwards
+            assert np.allclose(r[3][k], mean, rtol=0, atol=2e-7)
+    assert max(float(np.abs(res[0][2][k] - res[3][2][k]).max()) for k in range(len(res[0][2]))) > 0

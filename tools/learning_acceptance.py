@@ -9,6 +9,12 @@ production_sh_10x10_2m, 64 environments, 2 agents (80 Btt modes + tip-tilt), eve
 VecAoEnv.step through aomarl_env_step, actors through aomarl_actor_forward, updates through aomarl_sac_update.
 
     python tools/learning_acceptance.py [--episodes 60] [--test-every 10] [--envs 64] [--precision f32]
+
+--config 40x40: the same loop on BASELINE configs[2] -- production_sh_40x40_8m_3layers, 256 environments, 14 agents
+(13 windowed modal agents of 98 modes + the windowed tip-tilt agent, states 552 / 168), the reference's recorded
+statistics file for the standardisation (its five filtered modes masked), the loop bench.py times
+(VecAoEnv.throughput_mode through sac.train_agent: frame pipeline, residual shortcut, prefetched resets):
+profiles/r06_learning_acceptance_40x40.txt.
 Prints one line per evaluation and a verdict line; exit code 1 when the last evaluation's RL reward or LE
 Strehl is not above the integrator's.
 """
@@ -23,9 +29,13 @@ sys.path.insert(0, ROOT)
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="10x10", choices=("10x10", "40x40"))
     ap.add_argument("--episodes", type=int, default=60)
     ap.add_argument("--test-every", type=int, default=10)
-    ap.add_argument("--envs", type=int, default=64)
+    ap.add_argument("--envs", type=int, default=None, help="default: 64 (10x10) / 256 (40x40)")
+    ap.add_argument("--memory", type=int, default=1000000, help="rows of the agents' replay ring (46 KB each at 40x40)")
+    ap.add_argument("--lr", type=float, default=None, help="learning rate of actors, critics and temperature (default: the reference's)")
+    ap.add_argument("--no-throughput", action="store_true", help="train_agent(throughput=False): the environment as built here")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--updates", type=int, default=1000)
     ap.add_argument("--precision", default="f32")
@@ -46,20 +56,33 @@ def main(argv=None):
     from ao_marl_amd.env import VecAoEnv
     from ao_marl_amd.sac import BatchedSAC, train_agent
     la.set_precision(a.precision)
-    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, max_steps_per_episode=a.steps)
+    large = a.config == "40x40"
+    name = "production_sh_40x40_8m_3layers" if large else "production_sh_10x10_2m"
+    if a.envs is None:
+        a.envs = 256 if large else 64
+    if large:
+        rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5, window_n_zernike=20,
+                  include_tip_tilt_windowed=True, max_steps_per_episode=a.steps)
+        n_modal = 13
+    else:
+        rl, n_modal = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, max_steps_per_episode=a.steps), 1
     norm_kw = {}
-    if not a.recorded_normalisation:
+    if not a.recorded_normalisation and not large:
         # the reference's own workflow for a (parameter file, filtered modes) pair: run the normalisation recipe
         # first (obtain_normalization.py:246-300) -- here on the device, 20 seeds x 1000 integrator frames
+        # (the 40x40 file's recorded statistics were made with the README's five filtered modes: used as they are,
+        # the five dead columns masked)
         from ao_marl_amd.normalization import obtain_normalization
-        norm, zn, _ = obtain_normalization("production_sh_10x10_2m", modes_filtered=5)
+        norm, zn, _ = obtain_normalization(name, modes_filtered=5)
         norm_kw = dict(norm=norm, zn_norm=zn)
-    env = VecAoEnv("production_sh_10x10_2m", a.envs, rl, initial_seed=a.seed, seed_stride=16, n_agents_modal=1,
+    env = VecAoEnv(name, a.envs, rl, initial_seed=a.seed, seed_stride=16, n_agents_modal=n_modal,
                    frame_pipeline=a.frame_pipeline, **norm_kw)
-    sac = BatchedSAC(env.layout, dict(updates_per_episode_rpc=a.updates, memory_size=1000000), seed=a.seed,
-                     native=not a.torch_update)
-    print("config production_sh_10x10_2m  envs %d  agents %d (state dims %s, action dims %s)  %d steps + %d updates per "
-          "episode  precision %s" % (a.envs, env.layout.n_agents, env.layout.state_shapes(), env.layout.action_shapes(),
+    cfg = dict(updates_per_episode_rpc=a.updates, memory_size=a.memory)
+    if a.lr is not None:
+        cfg.update(lr=a.lr)
+    sac = BatchedSAC(env.layout, cfg, seed=a.seed, native=not a.torch_update)
+    print("config %s  envs %d  agents %d (state dims %s, action dims %s)  %d steps + %d updates per "
+          "episode  precision %s" % (name, a.envs, env.layout.n_agents, env.layout.state_shapes(), env.layout.action_shapes(),
                                      a.steps, a.updates, la.get_precision()), flush=True)
     t0 = time.time()
     evals = []
@@ -89,8 +112,12 @@ def main(argv=None):
                    ["%.4f" % v for v in sac.last_losses["alpha_value"].reshape(-1).tolist()] if sac.last_losses else "-",
                    ["%.2e" % v for v in sac.last_losses["q1"].reshape(-1).tolist()] if sac.last_losses else "-"),
                   flush=True)
-    train_agent(env, sac, a.episodes, max_steps=a.steps, test_every=a.test_every, n_updates=a.updates, on_episode=on_episode)
+    train_agent(env, sac, a.episodes, max_steps=a.steps, test_every=a.test_every, n_updates=a.updates, on_episode=on_episode,
+                throughput=not a.no_throughput)
     torch.cuda.synchronize()
+    print("environment: frame_pipeline %s (probe %s), residual_shortcut %s, reset_prefetch %s, prefetched resets adopted %d" %
+          (env.frame_pipeline, env.order_probe, env.residual_shortcut, env.supervisor.reset_prefetch,
+           int(getattr(env.supervisor.sim, "prefetched_resets", 0))), flush=True)
     last = evals[-1]
     ok = last["test_r_rl"] > last["test_r_integrator"] and last["test_sr_le_rl"] > last["test_sr_le_integrator"]
     print("verdict after %d training episodes (%.0f s): RL %s the integrator (reward %.2f vs %.2f, LE Strehl %.4f vs %.4f)" %
