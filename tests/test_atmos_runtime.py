@@ -237,10 +237,12 @@ def test_change_then_reset_is_the_environment_built_with_the_new_wind_and_steppi
         sa, ra, _, _ = env.step(a)
         sb, rb, _, _ = want.step(a)
         assert torch.equal(sa, sb) and torch.equal(ra, rb), it
-    assert torch.equal(env.supervisor.sim.screen(0), want.supervisor.sim.screen(0))
     # the prefetched reset starts over with the new atmosphere at the next reset: adopted, same bits again
+    n0 = int(getattr(env.supervisor.sim, "prefetched_resets", 0))
     sa, sb = env.reset(), want.reset()
     assert torch.equal(sa, sb) and env.supervisor.sim.prefetch_reset_pending()
+    assert int(getattr(env.supervisor.sim, "prefetched_resets", 0)) == n0 + 1
+    assert torch.equal(env.supervisor.sim.screen(0), want.supervisor.sim.screen(0))
 
 
 @pytest.mark.gpu
