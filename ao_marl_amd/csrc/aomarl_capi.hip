@@ -17,7 +17,7 @@
 
 static thread_local char g_err[512] = "";
 
-static int fail(const char *fmt, ...) {
+int fail(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -25,18 +25,6 @@ static int fail(const char *fmt, ...) {
   return 1;
 }
 
-#define HIPCHK(x)                                                                            \
-  do {                                                                                       \
-    hipError_t _e = (x);                                                                     \
-    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e),    \
-                                      __FILE__, __LINE__);                                   \
-  } while (0)
-#define LAUNCHCHK()                                                                          \
-  do {                                                                                       \
-    hipError_t _e = hipGetLastError();                                                       \
-    if (_e != hipSuccess) return fail("kernel launch failed: %s (%s:%d)",                    \
-                                      hipGetErrorString(_e), __FILE__, __LINE__);            \
-  } while (0)
 
 struct aomarl_ctx {
   DevSys sys;

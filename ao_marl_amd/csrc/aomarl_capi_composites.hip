@@ -1,4 +1,3 @@
-#include "aomarl_gemm_g.h"
 // aomarl_capi_composites.hip -- part of the C ABI implementation (included by aomarl_capi.hip, one translation unit):
 // composites (frame_fused, next_part_one / two), the stand-alone GEMM entry points, the SAC update.
 // ---------------------------------------------------------------- composites
@@ -250,7 +249,7 @@ static int gemm_batched_launch_g(dim3 grid, hipStream_t s, int M, int N, int K, 
   return 0;
 }
 
-static int gemm_batched_launch(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
+int gemm_batched_launch(int batch, int transA, int transB, int M, int N, int K, const float *A, int lda,
                                long long strideA, const float *B, int ldb, long long strideB,
                                const float *bias, long long strideBias, float *C, int ldc, long long strideC,
                                int relu, int accumulate, const float *mask, int ldm, long long strideM,
@@ -286,13 +285,8 @@ static int gemm_batched_any(int batch, int transA, int transB, int M, int N, int
   // only whole pieces go there; a ragged inner dimension takes the general kernel (element-wise tail).
   const bool whole = !((transA ? M : K) & 3) && !((transB ? N : K) & 3);
   if (al && whole && !accumulate && K > 0 && !g_gemm_kgroups) {
-    GemmGArgs g;
-    memset(&g, 0, sizeof(g));
-    g.M = M; g.N = N; g.K = K;
-    g.A = A; g.lda = lda; g.sA = strideA; g.B = B; g.ldb = ldb; g.sB = strideB; g.C = C; g.ldc = ldc; g.sC = strideC;
-    g.bias = bias; g.sBias = strideBias; g.relu = relu;
-    if (gemm_g_launch(batch, !transA, !transB, g, 0, 0, s)) return fail("gemm_batched: k_gemm_g launch failed");
-    return 0;
+    return gemm_g_batched(batch, !transA, !transB, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc,
+                          strideC, relu, s);
   }
   return gemm_batched_launch(batch, transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, bias, strideBias, C, ldc,
                              strideC, relu, accumulate, nullptr, 0, 0, s);
@@ -320,5 +314,5 @@ int aomarl_gemm_nt_batched(int batch, int M, int N, int K, const float *A, int l
                           relu, 0, (hipStream_t)stream);
 }
 
-// ---------------------------------------------------------------- multi-agent SAC update (section 8f)
-#include "aomarl_sac.hip"
+// (the multi-agent SAC update, section 8f, and the grouped GEMM it runs on are a translation unit of their own:
+// aomarl_sac.hip)

@@ -1,7 +1,6 @@
 // aomarl_capi_extras.hip -- part of the C ABI implementation (included by aomarl_capi.hip, one translation unit):
 // denoiser, geometric controller, full-frame PSF on demand.
-// ---------------------------------------------------------------- WFS-image denoiser (A17)
-#include "aomarl_denoise.hip"
+// (the WFS-image denoiser, A17, is a translation unit of its own: aomarl_denoise.hip)
 
 // ---------------------------------------------------------------- geometric controller
 __global__ void k_geo_assemble(int nactu, int npzt, int ldr, int gwgh, const int32_t *__restrict__ map,

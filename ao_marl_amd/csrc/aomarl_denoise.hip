@@ -23,8 +23,11 @@
 //  * the last layer (16 -> 1) runs on the VALU.
 // The network sees the image transposed ([x][y], the reference feeds COMPASS's first-index-fastest
 // arrays); the transpose happens on the way into and out of LDS.
-#include "aomarl_dev.h"
+#include "aomarl_host.h"
 #include <type_traits>
+#include <vector>
+#include <string.h>
+#include <math.h>
 
 typedef float f32x4d __attribute__((ext_vector_type(4)));
 

@@ -19,6 +19,12 @@
 #define ATM_SETPRIO() do { if (ATM_PRIO) __builtin_amdgcn_s_setprio(ATM_PRIO); } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// split-fp16 operand pairs (the opt-in fast mode): 2 / 8 halfs, and the matrix instruction they feed
+typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_h(hx8 a, hx8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 struct DevLayer {
   int dim, ns;
@@ -213,4 +219,38 @@ __device__ __forceinline__ int ring_idx(int x, int y, int ox, int oy, int n) {
   int py = y + oy;
   py -= (py >= n) ? n : 0;
   return py * (n + RING_PAD) + px;
+}
+
+// ---- cross-lane helpers on the VALU (DPP) instead of the LDS crossbar (ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// v + v[lane ^ 1]
+__device__ __forceinline__ float add_xor1(float v) { return v + dpp_f<0xB1>(v); }   // quad_perm [1,0,3,2]
+// sum over the 64 lanes, result uniform (returned in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x124>(v);     // row_ror:4
+  v += dpp_f<0x128>(v);     // row_ror:8   -> every lane holds its 16-lane row sum
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+}
+
+// sum over the 64 lanes, valid in LANE 63 ONLY: 6 DPP adds, no v_readlane (row_bcast:15 / :31 carry
+// the row sums across the four 16-lane rows)
+__device__ __forceinline__ float wave_sum_last(float v) {
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror -> every lane holds its 16-lane row sum
+  // rows 1, 3 += last lane of the row before; rows 2, 3 += last lane of row 1: ONE instruction each
+  // (dst == src, the rows the mask leaves out keep their value) -- written through update_dpp with a
+  // zero `old` the compiler needs v_mov 0 + v_mov_dpp + v_add per step
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return v;
 }

@@ -1,48 +1,13 @@
 // aomarl_kernels.hip -- CDNA4 (gfx950) kernels of the AO environment hot path.
 // wave = 64 lanes; fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) for the DFT and GEMM work.
-#include "aomarl_dev.h"
+#include "aomarl_host.h"
 #include "aomarl_gemm_p.h"
 #include <type_traits>
 
 #define WAVE 64
 
-// ---- cross-lane helpers on the VALU (DPP) instead of the LDS crossbar (ds_bpermute)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-// v + v[lane ^ 1]
-__device__ __forceinline__ float add_xor1(float v) { return v + dpp_f<0xB1>(v); }   // quad_perm [1,0,3,2]
-// sum over the 64 lanes, result uniform (returned in every lane)
-__device__ __forceinline__ float wave_sum(float v) {
-  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += dpp_f<0x124>(v);     // row_ror:4
-  v += dpp_f<0x128>(v);     // row_ror:8   -> every lane holds its 16-lane row sum
-  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
-          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
-         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
-          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
-}
-
-// sum over the 64 lanes, valid in LANE 63 ONLY: 6 DPP adds, no v_readlane (row_bcast:15 / :31 carry
-// the row sums across the four 16-lane rows)
-__device__ __forceinline__ float wave_sum_last(float v) {
-  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += dpp_f<0x141>(v);     // row_half_mirror
-  v += dpp_f<0x140>(v);     // row_mirror -> every lane holds its 16-lane row sum
-  // rows 1, 3 += last lane of the row before; rows 2, 3 += last lane of row 1: ONE instruction each
-  // (dst == src, the rows the mask leaves out keep their value) -- written through update_dpp with a
-  // zero `old` the compiler needs v_mov 0 + v_mov_dpp + v_add per step
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-  return v;
-}
-
 // ---- split-fp16 helpers (used by the GEMM below and by the frame kernel; see the frame kernel's notes)
-typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
-typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+// (hx2 / hx8 and mfma_h: aomarl_dev.h -- the denoiser's translation unit uses them too)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ hx2 cvt_h2(float a, float b) {
@@ -554,10 +519,10 @@ static float gemm_scale(const float *h, size_t n) {
 // opt-in fast mode: split-fp16 operand pairs (hi + lo, 22-bit mantissa, fp32 accumulation) in the three kernel
 // families that have such a form -- the frame kernel's DFTs, the internal GEMMs, the denoiser.
 static bool g_gemm_split_f16 = false; // "gemm_split_f16": the internal GEMMs (extrusion, command matrix, Btt projections) on k_gemm_nt_h
-static int g_precision = 0;           // process-wide default of every family (aomarl_set_precision)
+int g_precision = 0;                  // process-wide default of every family (aomarl_set_precision)
 // launches per arithmetic family since aomarl_arith_reset (bench.py builds its `dtype` from them)
-enum { AR_FRAME_F32 = 0, AR_FRAME_SPLIT, AR_GEMM_F32, AR_GEMM_SPLIT, AR_DENOISE_F32, AR_DENOISE_SPLIT, AR_ACTOR_F32, AR_N };
-static unsigned long long g_arith[AR_N] = {0, 0, 0, 0, 0, 0, 0};
+// (the AR_* enumeration: aomarl_host.h)
+unsigned long long g_arith[AR_N] = {0, 0, 0, 0, 0, 0, 0};
 static const char *const g_arith_name[AR_N] = {
     "frame_kernel_dft:f32_mfma", "frame_kernel_dft:split_f16_mfma", "gemm:f32_mfma", "gemm:split_f16_mfma",
     "denoiser:f32_mfma", "denoiser:split_f16_mfma", "actor:f32_mfma"};
@@ -1422,9 +1387,6 @@ __device__ __forceinline__ void dup_hl(float a0, float a1, float a2, float a3, h
   const hx2 l23 = cvt_h2(sub_lo(h23, a2), sub_hi(h23, a3));
   H = hx8{h01[0], h01[1], h23[0], h23[1], h01[0], h01[1], h23[0], h23[1]};
   L = hx8{l01[0], l01[1], l23[0], l23[1], l01[0], l01[1], l23[0], l23[1]};
-}
-__device__ __forceinline__ f32x4 mfma_h(hx8 a, hx8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 // twiddle operands of the spot DFT in split-fp16 form (constant per lane)
 struct SpotTwH { hx8 CH, CL, SH, SL; };

@@ -1,5 +1,5 @@
 // aomarl_sac.hip -- one soft actor-critic update of EVERY agent as a fixed sequence of gfx950 kernels
-// ("replay + SAC update").  Included by aomarl_capi.hip.
+// ("replay + SAC update").  A translation unit of its own (aomarl_host.h).
 //
 // Reference (per agent, one process + one torch autograd graph each):
 //   SAC.update_critic   src/reinforcement_learning/rpc_training/train_rpc.py:985-1038
@@ -32,8 +32,12 @@
 // a launch (k_gemm_g_multi) and the temperature update that of the policy's Adam: ONE stream, no events, 10 product
 // launches + 8 small kernels for the reference's two-layer actor, no host synchronisation, no allocation; everything between the replay ring and the updated parameters stays in HBM.  Shapes whose rows are not
 // 16-byte aligned (hidden or 2 x act_max not a multiple of 4) take round 1's general kernel, k_gemm_batched_gen.
-#include "aomarl_dev.h"
+#include "aomarl_host.h"
 #include "aomarl_gemm_g.h"
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <vector>
 
 #define SAC_MAX_HIDDEN 8
 #define SAC_EPSILON 1e-5f                 // model_rpc.py:8
@@ -624,5 +628,18 @@ int aomarl_sac_update(aomarl_sac *s, const float *state, const float *next_state
                        (float4 *)d.policy_m, (float4 *)d.policy_v, (float4 *)nullptr, ak, 0.f, nb, al);
     LAUNCHCHK();
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------- the grouped kernel for the C ABI's batched products
+int gemm_g_batched(int batch, bool ak, bool bk, int M, int N, int K, const float *A, int lda, long long sA,
+                   const float *B, int ldb, long long sB, const float *bias, long long sBias, float *C, int ldc,
+                   long long sC, int relu, hipStream_t s) {
+  GemmGArgs g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.N = N; g.K = K;
+  g.A = A; g.lda = lda; g.sA = sA; g.B = B; g.ldb = ldb; g.sB = sB; g.C = C; g.ldc = ldc; g.sC = sC;
+  g.bias = bias; g.sBias = sBias; g.relu = relu;
+  if (gemm_g_launch(batch, ak, bk, g, 0, 0, s)) return fail("gemm_batched: k_gemm_g launch failed");
   return 0;
 }

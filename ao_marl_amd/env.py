@@ -142,10 +142,10 @@ class VecRlSupervisor(object):
         # modification_online = the reference's `pure_delay_0` (rlSupervisor.py:145): the science target is ray-traced
         # behind apply_control in next_part_two (:938-939) -- it sees THIS frame's atmosphere with the command just
         # applied -- and not in next_part_one (:964-965).  Call-by-call order, screens on the current frame.
+        # (the geometric controller's path, next_part_one_geo, is the same in both orders: rlSupervisor.py:989-1013 does
+        # not read pure_delay_0; the denoiser sits between image formation and centroiding in both, :975-984)
         self.pure_delay_0 = bool(self.config_rl["modification_online"])
         if self.pure_delay_0:
-            if geo:
-                raise NotImplementedError("modification_online with the geometric controller's twin")
             prefetch_atmos = False
         self.nenv, self.device = nenv, torch.device(device)
         self.sysm = G.build_system(self.config)
@@ -336,9 +336,10 @@ class VecRlSupervisor(object):
         if self.geo is not None:
             self.geo.reset()
         self._control_pending, self._err_stale = False, False
-        self._tar_image_se, self._le_count = None, 0      # target.reset_strehl: the long exposure starts over
-        if self._tar_image_le_sum is not None:
-            self._tar_image_le_sum.zero_()
+        self._tar_image_se, self._tar_image_se_geo, self._le_count = None, None, 0      # target.reset_strehl: the long exposure starts over
+        for t in (self._tar_image_le_sum, self._tar_image_le_sum_geo):
+            if t is not None:
+                t.zero_()
         self.iter = 0
 
     def check_range(self):
@@ -453,13 +454,14 @@ class VecRlSupervisor(object):
         if defer_control and do_control:
             do_control = False
             self._control_pending = True
-        if self.autoencoder is not None and self.pure_delay_0:
-            raise NotImplementedError("modification_online with the denoiser in the sensor path")
         if self.autoencoder is not None:
             # rlSupervisor.py:975-984 with the denoiser between image formation and centroiding;
             # the bincube never leaves the device (the reference copies it to the host and back)
             self._move_or_keep(move_atmos)
-            self._target_and_image(write_bincube=True, cog=False)
+            if self.pure_delay_0:               # no target trace here (:964-965): the sensor's path alone
+                self.sim.comp_image(noise=True, write_bincube=True, cog=False)
+            else:
+                self._target_and_image(write_bincube=True, cog=False)
             self.autoencoder.denoise_bincube_(self.sim.t["bincube"])
             if self.prefetch_atmos and move_atmos:      # beside centroids / control, not the denoiser
                 self.sim.prefetch_atmos()
@@ -552,6 +554,7 @@ class VecRlSupervisor(object):
     keep_tar_image = False
     keep_le_image = False
     _tar_image_se, _tar_image_le_sum, _le_count = None, None, 0
+    _tar_image_se_geo, _tar_image_le_sum_geo = None, None
 
     def _snap_tar_image(self):
         if self.prefetch_atmos or getattr(self.sim, "pending_atmos", False):
@@ -559,11 +562,18 @@ class VecRlSupervisor(object):
                                "the supervisor with prefetch_atmos=False")
         img = self.sim.target_image()
         self._tar_image_se = img
+        # target 1 (the geometric controller's, comp_tar_image loops over every target: rlSupervisor.py:943-946): the
+        # image of the phase next_part_one_geo left -- the frame's atmosphere + its own mirrors
+        geo_img = self.geo.target_image() if (self.geo is not None and hasattr(self.geo, "target_image")) else None
+        self._tar_image_se_geo = geo_img
         if self.keep_le_image:
             if self._tar_image_le_sum is None or self._tar_image_le_sum.shape != img.shape:
                 self._tar_image_le_sum = torch.zeros_like(img)
+                self._tar_image_le_sum_geo = torch.zeros_like(img) if geo_img is not None else None
                 self._le_count = 0
             self._tar_image_le_sum += img
+            if geo_img is not None and self._tar_image_le_sum_geo is not None:
+                self._tar_image_le_sum_geo += geo_img
             self._le_count += 1
 
     def get_tar_image(self, tar_index=0, expo_type="se"):
@@ -572,18 +582,22 @@ class VecRlSupervisor(object):
         next_part_two is not in it; with modification_online it is).  "le": d_image_le / strehl_counter, the mean of
         those images since the reset.  Needs keep_tar_image (VecAoEnv sets it for the rewards that read the image) /
         keep_le_image = True before the frames in question."""
-        if tar_index != 0:
-            raise NotImplementedError("get_tar_image: target 0 only")
+        if tar_index not in (0, 1):
+            raise IndexError("get_tar_image: target %d (0: the loop's, 1: the geometric controller's)" % tar_index)
+        if tar_index == 1 and self.geo is None:
+            raise RuntimeError("no geometric controller (VecRlSupervisor(..., geo=True)): target 1 is its target")
+        se = self._tar_image_se if tar_index == 0 else self._tar_image_se_geo
+        le = self._tar_image_le_sum if tar_index == 0 else self._tar_image_le_sum_geo
         if expo_type == "se":
-            if not (self.keep_tar_image or self.keep_le_image) or self._tar_image_se is None:
+            if not (self.keep_tar_image or self.keep_le_image) or se is None:
                 raise RuntimeError("get_tar_image: no image was kept (set supervisor.keep_tar_image = True before "
                                    "next_part_two; VecAoEnv does for the rewards that read it)")
-            return self._tar_image_se
+            return se
         if expo_type == "le":
-            if not self.keep_le_image or not self._le_count:
+            if not self.keep_le_image or not self._le_count or le is None:
                 raise RuntimeError("get_tar_image(expo_type='le'): the full-frame long exposure is accumulated only when "
                                    "asked (set supervisor.keep_le_image = True before the episode)")
-            return self._tar_image_le_sum / float(self._le_count)
+            return le / float(self._le_count)
         raise ValueError("Unknown exposure type")
 
     def get_wfs_phase(self):

@@ -906,3 +906,12 @@ class HipGeoTwin(object):
     def comp_strehl(self, env_begin=0, env_count=None):
         b, n = self.sim._range(env_begin, env_count)
         la.check(self.lib.aomarl_comp_strehl(self.ctx, C.byref(self.st), b, n, self._stream()))
+
+    def target_image(self, env_begin=0, env_count=None):
+        """Target.get_tar_image(1, "se") (targetCompass.py:71-92): the full npsf x npsf image of the geometric
+        controller's target -- the frame's atmosphere (the shared screens) + this twin's mirrors, as next_part_one_geo
+        left them: [env_count, npsf, npsf], centred, raw |FFT2|^2 (aomarl_target_image on the twin's state)."""
+        b, n = self.sim._range(env_begin, env_count)
+        out = torch.empty(n, self.s.npsf, self.s.npsf, dtype=torch.float32, device=self.device)
+        la.check(self.lib.aomarl_target_image(self.ctx, C.byref(self.st), b, n, out.data_ptr(), self._stream()))
+        return out

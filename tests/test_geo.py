@@ -122,3 +122,59 @@ def test_env_with_the_geometric_twin():
     assert env.supervisor.get_command(1).shape == env.supervisor.get_command(0).shape
     with pytest.raises(RuntimeError):
         ref.supervisor.get_strehl(1)
+
+
+@pytest.mark.gpu
+def test_pure_delay_0_order_with_the_geometric_twin_and_the_image_of_target_1():
+    """`modification_online` with the geometric controller's twin (the reference loops over both controllers in either
+    order, rlSupervisor.py:1038-1049; next_part_one_geo does not read pure_delay_0): controller 0 is the twin-less
+    pure-delay-0 environment bit for bit, controller 1 the twin of the plain order bit for bit.  And
+    `get_tar_image(1)`: the full-frame image of the geometric controller's target (comp_tar_image loops over every
+    target, :943-946) against an FFT of the twin's own science phase in float64."""
+    import numpy as np
+    import torch
+    from ao_marl_amd.env import VecAoEnv
+    rl = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5)
+    both = VecAoEnv(NAME, 2, dict(rl, modification_online=True), n_agents_modal=1, geo=True)
+    solo = VecAoEnv(NAME, 2, dict(rl, modification_online=True), n_agents_modal=1)
+    plain = VecAoEnv(NAME, 2, rl, n_agents_modal=1, geo=True)
+    assert both.supervisor.pure_delay_0 and both.supervisor.geo is not None and not both.supervisor.prefetch_atmos
+    both.supervisor.keep_tar_image = True
+    sa, sb, sc = both.reset(), solo.reset(), plain.reset()
+    assert torch.equal(sa, sb)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    s = both.supervisor.s
+    for it in range(6):
+        a = torch.rand(2, both.action_dim, device="cuda:0", generator=g) * 2 - 1
+        (sa, ra, _, _), (sb, rb, _, _), (sc, rc, _, _) = both.step(a), solo.step(a), plain.step(a)
+        assert torch.equal(sa, sb) and torch.equal(ra, rb), it                      # controller 0: the twin changes nothing
+        assert torch.equal(both.supervisor.get_strehl(0), solo.supervisor.get_strehl(0))
+        assert not torch.equal(both.supervisor.get_strehl(0)[:, 0], plain.supervisor.get_strehl(0)[:, 0])   # another order
+    # controller 1 sees the atmosphere only (its own mirrors, its own target): the same in both orders as long as the
+    # atmosphere is -- and that does not depend on controller 0 at all
+    assert torch.equal(both.supervisor.get_command(1), plain.supervisor.get_command(1))
+    assert torch.equal(both.supervisor.get_strehl(1), plain.supervisor.get_strehl(1))
+    # target 1's image: rl_step = next_part_two snaps it (of the phase next_part_one_geo left in the twin)
+    a = torch.zeros(2, both.action_dim, device="cuda:0")
+    both.rl_step(a)
+    img = both.supervisor.get_tar_image(1).double().cpu().numpy()
+    img0 = both.supervisor.get_tar_image(0).double().cpu().numpy()
+    ph = both.supervisor.geo.t["tar_phase"].double().cpu().numpy()
+    pup = np.asarray(s.spupil, dtype=np.float64)
+    npsf = s.npsf
+    for e in range(2):
+        amp = np.zeros((npsf, npsf), dtype=np.complex128)
+        amp[:s.pupdiam, :s.pupdiam] = pup * np.exp(2j * np.pi * ph[e] / float(s.tar_lambda))
+        want = np.fft.fftshift(np.abs(np.fft.fft2(amp))**2)
+        assert img[e].shape == want.shape
+        assert np.unravel_index(np.argmax(img[e]), img[e].shape) == np.unravel_index(np.argmax(want), want.shape)
+        assert np.abs(img[e] - want).max() < 1e-4 * want.max(), np.abs(img[e] - want).max() / want.max()
+        # ... consistent with the Strehl meter of that target, and not the loop's image
+        sr = float(both.supervisor.get_strehl(1, do_fit=False)[e, 0])
+        assert abs(want.max() / float(np.sum(pup))**2 - sr) < 1e-3, (want.max() / float(np.sum(pup))**2, sr)
+        assert np.abs(img[e] - img0[e]).max() > 1e-3 * want.max()
+    both.linear_step()
+    with pytest.raises(IndexError):
+        both.supervisor.get_tar_image(2)
+    with pytest.raises(RuntimeError):
+        solo.supervisor.get_tar_image(1)
