@@ -1765,9 +1765,23 @@ __global__ __launch_bounds__(128) void k_fill_qf_tab(float *__restrict__ tab) {
   }
 }
 
-__device__ __forceinline__ void spot_cog_qf(const DevSys &sys, const DevState &st, int e, int i, int lane,
-                                            const SpotQf &K, const float (&er)[4], const float (&ei)[4],
-                                            int do_cog, const f32x4 z4) {
+// The three moments of one sub-aperture, summed over the wave: returns z with  row 0 (lanes 0 .. 15): sum I,
+// row 1: sum (Y - 7.5) I / 2 (sign: see qf_slopes),  row 2: sum (X - 7.5) I / 2  -- every lane of a row holds the total.
+// Round 6: 10 cross-lane instructions instead of 3 x 7 (tools/permlanebench.hip): gfx950's row swaps fold the four
+// 16-lane rows of TWO registers into one (v_permlane32_swap: the upper half of the first operand against the lower
+// half of the second -- [a_lo | b_lo] + [a_hi | b_hi]; v_permlane16_swap: the odd rows of the first against the even
+// rows of the second), so that one register carries all three sums through the four in-row DPP steps; and the two
+// products that make sum I share an accumulator (two packed instructions less).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  const u32x2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);      // rows 0, 1: a (rows 0 + 2, 1 + 3); rows 2, 3: b
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  const u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);      // rows: a.0 + a.1, b.0 + b.1, a.2 + a.3, b.2 + b.3
+}
+__device__ __forceinline__ float spot_qf_moments(const SpotQf &K, const float (&er)[4], const float (&ei)[4], const f32x4 z4) {
   const float Mc[4] = {K.Ml.x, K.Ml.y, K.Mh.x, K.Mh.y}, Sc[4] = {K.Sl.x, K.Sl.y, K.Sh.x, K.Sh.y};
   f32x4 Wr = z4, Wi = z4, V = z4;
 #pragma unroll
@@ -1776,38 +1790,39 @@ __device__ __forceinline__ void spot_cog_qf(const DevSys &sys, const DevState &s
     Wi = mfma16(Mc[s], ei[s], Wi);               // (M Ei^T)[x'][y]
     V = mfma16(Sc[s], er[s], V);                 // (S Er^T)[x'][y]
   }
-  f32x4 G1a = z4, G1b = z4, G2 = z4, G3 = z4;
+  f32x4 G1 = z4, G2 = z4, G3 = z4;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    G1a = mfma16(er[s], Wr[s], G1a);             // (Er M Er^T)[y'][y]
-    G1b = mfma16(ei[s], Wi[s], G1b);             // (Ei M Ei^T)[y'][y]
+    G1 = mfma16(er[s], Wr[s], G1);               // (Er M Er^T + Ei M Ei^T)[y'][y]: both products into one accumulator
     G2 = mfma16(ei[s], Wr[s], G2);               // (Ei M Er^T)[y'][y]
     G3 = mfma16(ei[s], V[s], G3);                // (Ei S Er^T)[y'][y]
+    G1 = mfma16(ei[s], Wi[s], G1);
   }
   // constants in the result layout: M[4q + r][c] = M[c][4q + r] = Mc[r];  S[(4q + r) - c] = -Sc[r]
   PK_GUARD_MFMA();
-  f32x2 p0 = pk_mul(pk_lo(G1a), K.Ml);
+  f32x2 p0 = pk_mul(pk_lo(G1), K.Ml);
   f32x2 px = pk_mul(pk_lo(G3), K.Ml);
   f32x2 py = pk_mul(pk_lo(G2), K.Sl);
-  pk_acc_fma(p0, pk_hi(G1a), K.Mh);
+  pk_acc_fma(p0, pk_hi(G1), K.Mh);
   pk_acc_fma(px, pk_hi(G3), K.Mh);
   pk_acc_fma(py, pk_hi(G2), K.Sh);
-  pk_acc_fma(p0, pk_lo(G1b), K.Ml);
-  pk_acc_fma(p0, pk_hi(G1b), K.Mh);
-  float s0 = p0.x + p0.y, tx = px.x + px.y, ty = py.x + py.y;
-  s0 = wave_sum_last(s0);
-  tx = wave_sum_last(tx);
-  ty = wave_sum_last(ty);
-  if (do_cog && lane == 63) {
-    float *sl = st.slopes + (long long)e * sys.nslope;
-    if (s0 > 0.f) {
-      const float inv = 2.f * __builtin_amdgcn_rcpf(s0);  // 1 ulp; slopes are compared at 1e-4"
-      sl[i] = (fmaf(tx, inv, 7.5f) - sys.cog_offset) * sys.cog_scale;
-      sl[sys.nvalid + i] = (fmaf(-ty, inv, 7.5f) - sys.cog_offset) * sys.cog_scale;
-    } else {
-      sl[i] = 0.f;
-      sl[sys.nvalid + i] = 0.f;
-    }
+  const float s0 = p0.x + p0.y, tx = px.x + px.y, ty = py.x + py.y;
+  float z = swap16_add(swap32_add(s0, tx), swap32_add(ty, ty));     // rows: s0, ty, tx, ty
+  z += dpp_f<0xB1>(z);      // quad_perm [1,0,3,2]
+  z += dpp_f<0x4E>(z);      // quad_perm [2,3,0,1]
+  z += dpp_f<0x141>(z);     // row_half_mirror
+  z += dpp_f<0x140>(z);     // row_mirror -> every lane holds its 16-lane row sum
+  return z;
+}
+// the two slopes of a sub-aperture from its moments (sum I, sum (X - 7.5) I / 2, -sum (Y - 7.5) I / 2 as
+// spot_qf_moments leaves them)
+__device__ __forceinline__ void qf_slopes(const DevSys &sys, float s0, float tx, float ty, float &sx, float &sy) {
+  if (s0 > 0.f) {
+    const float inv = 2.f * __builtin_amdgcn_rcpf(s0);  // 1 ulp; slopes are compared at 1e-4"
+    sx = (fmaf(tx, inv, 7.5f) - sys.cog_offset) * sys.cog_scale;
+    sy = (fmaf(-ty, inv, 7.5f) - sys.cog_offset) * sys.cog_scale;
+  } else {
+    sx = 0.f; sy = 0.f;
   }
 }
 
@@ -2454,6 +2469,9 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // [2][4][64]; DMA: [2][2][4][64]
   constexpr bool DMA = FW_DMA && OTF && (HP || FW_DMA_F32);
   char *dimg = reinterpret_cast<char *>(shb + 1024) + (DMA ? wv * FWD_WAVE(NL) : 0);            // this wave's layer images
+  // slopes-only fp32 instantiation (QF below): the moments of the stripe's sub-apertures, [tile][s0, ty, tx, ty] per wave,
+  // turned into slopes once per stripe by lane = tile (the per-tile finish was a dozen instructions on ONE lane)
+  float4 *qmom = reinterpret_cast<float4 *>(reinterpret_cast<char *>(shb + 1024) + (DMA ? 4 * FWD_WAVE(NL) : 0)) + wv * ntl;
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
   // blocks are dispatched x-fastest: x = group of 4 environments, y = rank of the stripe by
@@ -2461,7 +2479,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   // shortest ones (longest-processing-time order: smaller tail)
   const int r = sys.stripe_order[blockIdx.y];                // stripe: pupil rows 16 r .. 16 r + 15
   const int el = 4 * blockIdx.x + wv;                        // environment of this wave
-  // slopes only, fp32: the moments as quadratic forms of the field (spot_cog_qf): no transform, no Cc / Ss, no
+  // slopes only, fp32: the moments as quadratic forms of the field (spot_qf_moments): no transform, no Cc / Ss, no
   // twiddle table -- the lane's constants come from sys.qf_tab
   constexpr bool QF = FW_QF && OTF && !HP && !NOISE && !WRITE_CUBE;
   if constexpr (!QF) {
@@ -2683,9 +2701,12 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       if (info & FW_FULL) {
         const f32x2 t01 = pk_mul_s(p01, wil2), t23 = pk_mul_s(p23, wil2);
         const f32x2 b01 = pk_mul_s(p01, til2), b23 = pk_mul_s(p23, til2);
-        pk_acc_add(sdp, p01); pk_acc_fma(sd2p, p01, p01);
+        // (plain vector arithmetic, not the in-place asm forms: behind an asm the allocator copied both accumulators
+        // into fresh registers in front of the full tile and back at the join with the partial tile's path -- four
+        // v_mov_b64 per full tile; the compiler packs these itself)
+        sdp += p01; sd2p = __builtin_elementwise_fma(p01, p01, sd2p);
         const f32x2 r01 = {rintf(t01.x), rintf(t01.y)}, r23 = {rintf(t23.x), rintf(t23.y)};
-        pk_acc_add(sdp, p23); pk_acc_fma(sd2p, p23, p23);
+        sdp += p23; sd2p = __builtin_elementwise_fma(p23, p23, sd2p);
         const f32x2 a01 = pk_fma_nc_s(p01, wil2, r01), a23 = pk_fma_nc_s(p23, wil2, r23);
         wr[0] = __builtin_amdgcn_cosf(a01.x); wi[0] = __builtin_amdgcn_sinf(a01.x);
         wr[1] = __builtin_amdgcn_cosf(a01.y); wi[1] = __builtin_amdgcn_sinf(a01.y);
@@ -2773,8 +2794,10 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         spot_dft_h_v(twh, wr, wi, Z4, v);
         spot_finish_v<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, v, do_cog, flux_i);
       } else if (!NOISE && !WRITE_CUBE) {
-        if constexpr (QF) spot_cog_qf(sys, st, e, info & 0xFFFF, lane, qfk, wr, wi, do_cog, Z4);
-        else if constexpr (PK) spot_cog_f32_pk(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
+        if constexpr (QF) {
+          const float z = spot_qf_moments(qfk, wr, wi, Z4);
+          if (c == 0) reinterpret_cast<float *>(qmom + t)[q] = z;          // lanes 0, 16, 32, 48: the four row totals
+        } else if constexpr (PK) spot_cog_f32_pk(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
         else spot_cog_f32(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
       } else {
         spot_core<NOISE, WRITE_CUBE>(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, flux_i, Z4);
@@ -2890,6 +2913,23 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   }
   }
   if (!active) return;
+  if constexpr (QF) {
+    // ---- slopes of the stripe's sub-apertures: lane t = tile t (the moments were written by this wave: its LDS
+    // accesses complete in order)
+    if (do_cog && !(dbg & 1)) {
+      for (int tt = lane; tt < ntl; tt += 64) {
+        const int ti = sys.tile_info[r * ntl + tt];
+        if (ti & FW_SUB) {
+          const float4 m = qmom[tt];
+          float sx, sy;
+          qf_slopes(sys, m.x, m.z, m.y, sx, sy);
+          float *sl = st.slopes + (long long)e * sys.nslope;
+          sl[ti & 0xFFFF] = sx;
+          sl[sys.nvalid + (ti & 0xFFFF)] = sy;
+        }
+      }
+    }
+  }
   // ---- PSF rows of this stripe.  Register j of lane (q, c): row y = 4q + j, column c of the merged operand
   // (c < 8: cos of k = c + 1; c >= 8: sin of k = c - 7); the other half of a +-k pair sits in lane c ^ 8 of
   // the same 16-lane row (row_ror:8).  Lanes c < 8 write kx = -(c + 1), lanes 8 .. 14 kx = +(c - 7), lane 15

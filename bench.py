@@ -883,6 +883,9 @@ def main():
                 w.reset()
                 rs16 = w.time_reset()
                 e16, _, fk16 = w.timed(args.steps, args.warmup, settle=args.settle)
+                if rp_on:       # (the prefetched reset, like the headline: what an adopting reset costs behind a whole episode)
+                    w.time_episode(args.episode_len)
+                    _, rs16 = w.time_episode(args.episode_len, split_reset=True)
                 out["fast_mode"] = {"dtype": libaomarl.dtype_string(w.launched),
                                     "value": amortised(args.envs, args.steps, e16, rs16 + w.transient_excess(args.steps, e16), args.episode_len),
                                     "value_no_reset": args.envs * args.steps / e16,

@@ -36,6 +36,12 @@ def main(argv=None):
     ap.add_argument("--memory", type=int, default=1000000, help="rows of the agents' replay ring (46 KB each at 40x40)")
     ap.add_argument("--lr", type=float, default=None, help="learning rate of actors, critics and temperature (default: the reference's)")
     ap.add_argument("--no-throughput", action="store_true", help="train_agent(throughput=False): the environment as built here")
+    ap.add_argument("--reward-factor", type=float, default=None,
+                    help="the factor of the per-agent reward -factor x mean(residual modes^2): reward_type "
+                         "avg_squared_modes_<factor> (helper_rewards.py:18 parses any number; the reference's default is 1000)")
+    ap.add_argument("--action-scale", type=float, default=None,
+                    help="norm_scale_zernike_actions (parameters.cfg:43, default 10): the action range of a mode is its "
+                         "recorded maximum / this")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--updates", type=int, default=1000)
     ap.add_argument("--precision", default="f32")
@@ -66,6 +72,10 @@ def main(argv=None):
         n_modal = 13
     else:
         rl, n_modal = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, max_steps_per_episode=a.steps), 1
+    if a.reward_factor is not None:
+        rl["reward_type"] = "avg_squared_modes_%g" % a.reward_factor
+    if a.action_scale is not None:
+        rl["norm_scale_zernike_actions"] = a.action_scale
     norm_kw = {}
     if not a.recorded_normalisation and not large:
         # the reference's own workflow for a (parameter file, filtered modes) pair: run the normalisation recipe
@@ -81,6 +91,7 @@ def main(argv=None):
     if a.lr is not None:
         cfg.update(lr=a.lr)
     sac = BatchedSAC(env.layout, cfg, seed=a.seed, native=not a.torch_update)
+    print("reward_type %s  norm_scale_zernike_actions %s  lr %s" % (env.reward_type, env.config_rl["norm_scale_zernike_actions"], sac.lr))
     print("config %s  envs %d  agents %d (state dims %s, action dims %s)  %d steps + %d updates per "
           "episode  precision %s" % (name, a.envs, env.layout.n_agents, env.layout.state_shapes(), env.layout.action_shapes(),
                                      a.steps, a.updates, la.get_precision()), flush=True)
