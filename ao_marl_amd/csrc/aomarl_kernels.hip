@@ -2587,15 +2587,19 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       Pyr[s] = (ay >= 0 && ay < D0.ss) ? D0.prof[ay] : 0.f;
     }
     const float *volt = st.voltage + (long long)e * st.ld_actu + D0.com_off;
-    for (int idx = lane; idx < 4 * NB * latw; idx += 64) {
-      const int i = idx / latw, jj = idx - i * latw;
-      const int gy = sys.otf_gy0 + r * tpn + i, gx = sys.otf_gx0 + jj;
-      float v = 0.f;
-      if (gx >= 0 && gx < D0.gw && gy >= 0 && gy < D0.gh) {
-        const int a = D0.grid[gy * D0.gw + gx];
-        if (a >= 0) v = volt[a];
+    // (row by row, a lane per column: the flat index over rows x columns cost an integer division per element, a
+    // hundred vector instructions at the head of every wave)
+    for (int i = 0; i < 4 * NB; i++) {
+      const int gy = sys.otf_gy0 + r * tpn + i;
+      for (int jj = lane; jj < latw; jj += 64) {
+        const int gx = sys.otf_gx0 + jj;
+        float v = 0.f;
+        if (gx >= 0 && gx < D0.gw && gy >= 0 && gy < D0.gh) {
+          const int a = D0.grid[gy * D0.gw + gx];
+          if (a >= 0) v = volt[a];
+        }
+        lat[i * latw + jj] = v;
       }
-      lat[idx] = v;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -2701,6 +2705,20 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       if (info & FW_FULL) {
         const f32x2 t01 = pk_mul_s(p01, wil2), t23 = pk_mul_s(p23, wil2);
         const f32x2 b01 = pk_mul_s(p01, til2), b23 = pk_mul_s(p23, til2);
+        if constexpr (QF) {
+          // Slopes only: the sensor's phase goes to v_sin / v_cos as it stands, in revolutions, like the science
+          // path's (the instructions reduce |x| <= 256 themselves; an 8 m pupil sees a few tens of revolutions at
+          // 0.5 um).  The explicit round-and-subtract below keeps one rounding less in the REDUCED argument -- what
+          // the 2e-5 image tolerance of the image-producing instantiations needs; the centre of gravity does not see
+          // it (6e-8 x |revolutions| of phase per pixel, unbiased: 1e-7 pixel of centroid), and the reference itself
+          // takes cos / sin of the unreduced float phase.  Six vector instructions less per tile.
+          sdp += p01; sd2p = __builtin_elementwise_fma(p01, p01, sd2p);
+          sdp += p23; sd2p = __builtin_elementwise_fma(p23, p23, sd2p);
+          wr[0] = __builtin_amdgcn_cosf(t01.x); wi[0] = __builtin_amdgcn_sinf(t01.x);
+          wr[1] = __builtin_amdgcn_cosf(t01.y); wi[1] = __builtin_amdgcn_sinf(t01.y);
+          wr[2] = __builtin_amdgcn_cosf(t23.x); wi[2] = __builtin_amdgcn_sinf(t23.x);
+          wr[3] = __builtin_amdgcn_cosf(t23.y); wi[3] = __builtin_amdgcn_sinf(t23.y);
+        } else {
         // (plain vector arithmetic, not the in-place asm forms: behind an asm the allocator copied both accumulators
         // into fresh registers in front of the full tile and back at the join with the partial tile's path -- four
         // v_mov_b64 per full tile; the compiler packs these itself)
@@ -2712,6 +2730,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         wr[1] = __builtin_amdgcn_cosf(a01.y); wi[1] = __builtin_amdgcn_sinf(a01.y);
         wr[2] = __builtin_amdgcn_cosf(a23.x); wi[2] = __builtin_amdgcn_sinf(a23.x);
         wr[3] = __builtin_amdgcn_cosf(a23.y); wi[3] = __builtin_amdgcn_sinf(a23.y);
+        }
         ar[0] = __builtin_amdgcn_cosf(b01.x); ai[0] = __builtin_amdgcn_sinf(b01.x);
         ar[1] = __builtin_amdgcn_cosf(b01.y); ai[1] = __builtin_amdgcn_sinf(b01.y);
         ar[2] = __builtin_amdgcn_cosf(b23.x); ai[2] = __builtin_amdgcn_sinf(b23.x);

@@ -36,6 +36,9 @@ def main(argv=None):
     ap.add_argument("--memory", type=int, default=1000000, help="rows of the agents' replay ring (46 KB each at 40x40)")
     ap.add_argument("--lr", type=float, default=None, help="learning rate of actors, critics and temperature (default: the reference's)")
     ap.add_argument("--no-throughput", action="store_true", help="train_agent(throughput=False): the environment as built here")
+    ap.add_argument("--agents", type=int, default=14, choices=(14, 43),
+                    help="40x40: 14 = BASELINE configs[2]'s 13 x 98 modes + tip-tilt; 43 = the reference's published 42 x 30 "
+                         "modes + tip-tilt (README.md:116-119), both with the 20-mode window")
     ap.add_argument("--reward-factor", type=float, default=None,
                     help="the factor of the per-agent reward -factor x mean(residual modes^2): reward_type "
                          "avg_squared_modes_<factor> (helper_rewards.py:18 parses any number; the reference's default is 1000)")
@@ -67,9 +70,9 @@ def main(argv=None):
     if a.envs is None:
         a.envs = 256 if large else 64
     if large:
-        rl = dict(n_zernike_start_end=[0, 1274], n_reverse_filtered_from_cmat=5, window_n_zernike=20,
+        rl = dict(n_zernike_start_end=[0, 1274 if a.agents == 14 else 1260], n_reverse_filtered_from_cmat=5, window_n_zernike=20,
                   include_tip_tilt_windowed=True, max_steps_per_episode=a.steps)
-        n_modal = 13
+        n_modal = a.agents - 1
     else:
         rl, n_modal = dict(n_zernike_start_end=[0, 80], n_reverse_filtered_from_cmat=5, max_steps_per_episode=a.steps), 1
     if a.reward_factor is not None:
