@@ -73,8 +73,9 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
   // image of a tile pair's layer rows per wave (FW_DMA: the stack-array-from-voltages instantiations)
   // ... + the moments of a stripe's sub-apertures per wave (the slopes-only fp32 instantiation: 16 bytes per tile)
   const bool qf = FW_QF && otf && !hp && !noise && !cube;
-  const size_t smm = sizeof(float) * (2 * 128 + (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + 16384 + 128 +
-                     (FW_DMA && otf && (hp || FW_DMA_F32) ? 4 * FWD_WAVE(c->nlayers == 1 ? 1 : 3) : 0) +
+  const bool dma = FW_DMA && otf && (hp || FW_DMA_F32);
+  const size_t smm = sizeof(float) * ((qf ? 0 : 2 * 128) + (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + FW_SLOT_BYTES(dma) +
+                     (dma ? 4 * FWD_WAVE(c->nlayers == 1 ? 1 : 3) : 128) +
                      (qf ? 4 * 16 * (size_t)c->sys.ntiles : 0);
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
 // the events ride on the dispatch itself (its start / completion signal): no marker packets of their own

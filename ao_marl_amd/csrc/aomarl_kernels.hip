@@ -1807,7 +1807,9 @@ __device__ __forceinline__ float spot_qf_moments(const SpotQf &K, const float (&
   pk_acc_fma(px, pk_hi(G3), K.Mh);
   pk_acc_fma(py, pk_hi(G2), K.Sh);
   const float s0 = p0.x + p0.y, tx = px.x + px.y, ty = py.x + py.y;
-  float z = swap16_add(swap32_add(s0, tx), swap32_add(ty, ty));     // rows: s0, ty, tx, ty
+  // (the second operand of the second fold is a register that is dead by now: rows 2, 3 of that fold -- row 3 of z --
+  // are never read, and a swap of ty with itself would need a copy first)
+  float z = swap16_add(swap32_add(s0, tx), swap32_add(ty, p0.y));   // rows: s0, ty, tx, (unused)
   z += dpp_f<0xB1>(z);      // quad_perm [1,0,3,2]
   z += dpp_f<0x4E>(z);      // quad_perm [2,3,0,1]
   z += dpp_f<0x141>(z);     // row_half_mirror
@@ -2406,6 +2408,7 @@ struct FrameRaw {
   unsigned mrow;      // 16-bit mask row of the tile (this lane's row)
   float F;
   f4u SH;             // this wave's quarter of the tile's environment-independent data
+  float4 CS;          // the PSF operand of the lane (pair walk: read out of the block's slot by the caller, like T)
 };
 
 // Both arithmetics share one skeleton.  The data of a tile that does not depend on the environment
@@ -2442,6 +2445,16 @@ template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 #ifndef FW_DMA_F32
 #define FW_DMA_F32 1       // 0: the pair walk for the split-fp16 instantiations only
 #endif
+// Round 6: the pair walk's shared-data slots single-buffered, three quarters per tile (2 x 3 KB instead of 2 x 2 x 4 KB),
+// no twiddle table in the slopes-only instantiation: 37.5 KB of LDS per workgroup instead of 49.  Three frame workgroups
+// then leave 46 KB of a CU's 160 -- one workgroup of the chains' products (k_gemm_p<2, 3>: 46 080 B, 156 registers beside
+// 3 x 112) is resident beside them on EVERY CU instead of waiting for a frame workgroup to retire.  The price: the
+// slots are read into registers at the head of a pair, between two barriers (one pair of barriers per pair of tiles
+// instead of one barrier).
+#ifndef FW_SLOTS1
+#define FW_SLOTS1 1
+#endif
+#define FW_SLOT_BYTES(dma) ((dma) ? (FW_SLOTS1 ? 2 * 3 * 1024 : 16384) : 16384)
 // Layer rows of a PAIR of adjacent tiles as whole 128-byte pieces, straight into LDS (FW_DMA, the stack-array-from-
 // voltages instantiations).  A load instruction that covers 16 rows x 64 B (the compute layout: lane (q, c) = row c,
 // pixels 4q .. 4q + 3) makes the memory pipeline handle every 128-byte line twice, half a line at a time; as
@@ -2464,14 +2477,18 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   const int pd = sys.pupdiam, ntl = sys.ntiles;
   const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float2 *sTw = reinterpret_cast<float2 *>(smem);            // [128] WFS twiddles
-  float *lat_all = reinterpret_cast<float *>(sTw + 128);     // [4 waves][4 NB][latw]
-  float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));   // [2][4][64]; DMA: [2][2][4][64]
+  // slopes only, fp32: the moments as quadratic forms of the field (spot_qf_moments): no transform, no Cc / Ss, no
+  // twiddle table -- the lane's constants come from sys.qf_tab
+  constexpr bool QF = FW_QF && OTF && !HP && !NOISE && !WRITE_CUBE;
   constexpr bool DMA = FW_DMA && OTF && (HP || FW_DMA_F32);
-  char *dimg = reinterpret_cast<char *>(shb + 1024) + (DMA ? wv * FWD_WAVE(NL) : 0);            // this wave's layer images
-  // slopes-only fp32 instantiation (QF below): the moments of the stripe's sub-apertures, [tile][s0, ty, tx, ty] per wave,
+  float2 *sTw = reinterpret_cast<float2 *>(smem);            // [128] WFS twiddles (none in the slopes-only instantiation)
+  float *lat_all = reinterpret_cast<float *>(sTw + (QF ? 0 : 128));     // [4 waves][4 NB][latw]
+  // per tile walk: [2][4][64]; pair walk: [2 tiles][3 quarters][64] (FW_SLOTS1) or [2 parities][2 tiles][4][64]
+  float4 *shb = reinterpret_cast<float4 *>(lat_all + 4 * 4 * NB * (OTF ? sys.otf_latw : 0));
+  char *dimg = reinterpret_cast<char *>(shb) + FW_SLOT_BYTES(DMA) + (DMA ? wv * FWD_WAVE(NL) : 0);   // this wave's layer images
+  // slopes-only fp32 instantiation: the moments of the stripe's sub-apertures, [tile][s0, ty, tx, -] per wave,
   // turned into slopes once per stripe by lane = tile (the per-tile finish was a dozen instructions on ONE lane)
-  float4 *qmom = reinterpret_cast<float4 *>(reinterpret_cast<char *>(shb + 1024) + (DMA ? 4 * FWD_WAVE(NL) : 0)) + wv * ntl;
+  float4 *qmom = reinterpret_cast<float4 *>(reinterpret_cast<char *>(shb) + FW_SLOT_BYTES(DMA) + (DMA ? 4 * FWD_WAVE(NL) : 0)) + wv * ntl;
   const int dbg = do_cog >> 8;                               // development switches (kbench)
   do_cog &= 1;
   // blocks are dispatched x-fastest: x = group of 4 environments, y = rank of the stripe by
@@ -2479,9 +2496,6 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
   // shortest ones (longest-processing-time order: smaller tail)
   const int r = sys.stripe_order[blockIdx.y];                // stripe: pupil rows 16 r .. 16 r + 15
   const int el = 4 * blockIdx.x + wv;                        // environment of this wave
-  // slopes only, fp32: the moments as quadratic forms of the field (spot_qf_moments): no transform, no Cc / Ss, no
-  // twiddle table -- the lane's constants come from sys.qf_tab
-  constexpr bool QF = FW_QF && OTF && !HP && !NOISE && !WRITE_CUBE;
   if constexpr (!QF) {
     if (tid < 128) {
       float sn, cs;
@@ -2681,10 +2695,13 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       __syncthreads();
 #endif
     }
-    const float4 t0 = slot[lane], t1 = slot[64 + lane];
-    cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
-    cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
-    const float4 csP = slot[128 + lane];          // HP: [hi | lo] halfs; fp32: the 4 K steps
+    if (!(DM && FW_SLOTS1)) {                      // (pair walk with single-buffered slots: the caller has read them)
+      const float4 t0 = slot[lane], t1 = slot[64 + lane];
+      cur.T[0] = t0.x; cur.T[1] = t0.y; cur.T[2] = t0.z; cur.T[3] = t0.w;
+      cur.T[4] = t1.x; cur.T[5] = t1.y; cur.T[6] = t1.z; cur.T[7] = t1.w;
+      cur.CS = slot[128 + lane];
+    }
+    const float4 csP = cur.CS;                     // HP: [hi | lo] halfs; fp32: the 4 K steps
     // (a wave without an environment of its own -- env_count not a multiple of 4 -- repeats the block's last
     // one: same loads, same arithmetic, same values stored twice.  No branch on `active` in here: a join behind
     // a branch that issues loads makes the compiler wait for ALL loads in flight, vmcnt(0), on both sides)
@@ -2815,7 +2832,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       } else if (!NOISE && !WRITE_CUBE) {
         if constexpr (QF) {
           const float z = spot_qf_moments(qfk, wr, wi, Z4);
-          if (c == 0) reinterpret_cast<float *>(qmom + t)[q] = z;          // lanes 0, 16, 32, 48: the four row totals
+          if (c == 0 && q < 3) reinterpret_cast<float *>(qmom + t)[q] = z;     // lanes 0, 16, 32: the three row totals
         } else if constexpr (PK) spot_cog_f32_pk(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
         else spot_cog_f32(sys, st, e, info & 0xFFFF, lane, Cc, Ss, wr, wi, do_cog, Z4);
       } else {
@@ -2863,11 +2880,22 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(vo), "s"(rs), "s"(lds_addr), "s"(so) : "memory");
     };
-    // (par: parity of the pair the loads are for -- its two shared-data slots are filled in place, one quarter per wave)
-    auto issue = [&](int ia, int ib, int par) {
+    // the block's shared data of a pair, one quarter per wave, filled in place (par: parity of the pair with
+    // double-buffered slots; single-buffered: three quarters per tile, wave 3 -- whose quarter was a duplicate -- idles)
+    auto issue_shared = [&](int ia, int ib, int par) {
       const int ta = (ia >> 24) & 0x7F, tb = (ib >> 24) & 0x7F;
-      dma16(shvo, shrs, shb_lds + (unsigned)par * 8192u, (unsigned)ta << shstep);
-      dma16(shvo, shrs, shb_lds + (unsigned)par * 8192u + 4096u, (unsigned)tb << shstep);
+      if (FW_SLOTS1) {
+        if (wv < 3) {
+          dma16(shvo, shrs, shb_lds, (unsigned)ta << shstep);
+          dma16(shvo, shrs, shb_lds + 3072u, (unsigned)tb << shstep);
+        }
+      } else {
+        dma16(shvo, shrs, shb_lds + (unsigned)par * 8192u, (unsigned)ta << shstep);
+        dma16(shvo, shrs, shb_lds + (unsigned)par * 8192u + 4096u, (unsigned)tb << shstep);
+      }
+    };
+    auto issue = [&](int ia, int ib) {
+      const int ta = (ia >> 24) & 0x7F, tb = (ib >> 24) & 0x7F;
       mrA = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)ta + mvo);
       mrB = *reinterpret_cast<const uint16_t *>(mkb + 2u * (unsigned)tb + mvo);
       fA = cflux[ia & 0xFFFF];
@@ -2881,7 +2909,7 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
       }
     };
     int ia = pinfo[0], ib = pinfo[1];
-    if (np > 0) issue(ia, ib, 0);
+    if (np > 0) { issue_shared(ia, ib, 0); issue(ia, ib); }
     for (int k = 0; k < np; k++) {
       const int ja = pinfo[2 * k + 2], jb = pinfo[2 * k + 3];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this pair's layer images, shared quarters and masks have landed
@@ -2892,13 +2920,35 @@ void k_frame_wave(DevSys sys, DevState st, int env_begin,
         A.L[l][0] = va.x; A.L[l][1] = va.y; A.L[l][2] = va.z; A.L[l][3] = va.w;
         B.L[l][0] = vb.x; B.L[l][1] = vb.y; B.L[l][2] = vb.z; B.L[l][3] = vb.w;
       }
-      float4 *slots = shb + (k & 1) * 512;
       A.mrow = mrA; A.F = fA; B.mrow = mrB; B.F = fB;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the image has been read: the next pair may overwrite it
-      __syncthreads();
-      if (k + 1 < np) issue(ja, jb, (k + 1) & 1);
-      if (ia & FW_LIT) tile(ia, 0, A, A, dm, slots);
-      if (ib & FW_LIT) tile(ib, 0, B, B, dm, slots + 256);
+      if (FW_SLOTS1) {
+        if (k + 1 < np) issue(ja, jb);                         // (the wave's own images, masks, flux: nobody else reads them)
+        __syncthreads();                                       // every wave's quarters of THIS pair have landed
+        float4 *slots = shb;
+        {
+          const float4 a0 = slots[lane], a1 = slots[64 + lane];
+          A.CS = slots[128 + lane];
+          A.T[0] = a0.x; A.T[1] = a0.y; A.T[2] = a0.z; A.T[3] = a0.w; A.T[4] = a1.x; A.T[5] = a1.y; A.T[6] = a1.z; A.T[7] = a1.w;
+        }
+        if (ia & FW_LIT) tile(ia, 0, A, A, dm, slots);
+        {   // (the second tile's slot only now: twelve registers less across the first tile -- the kernel has to stay at
+            //  112, the product's workgroup beside three of its waves needs the other 160 of the SIMD's 512)
+          const float4 b0 = slots[192 + lane], b1 = slots[256 + lane];
+          B.CS = slots[320 + lane];
+          B.T[0] = b0.x; B.T[1] = b0.y; B.T[2] = b0.z; B.T[3] = b0.w; B.T[4] = b1.x; B.T[5] = b1.y; B.T[6] = b1.z; B.T[7] = b1.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                       // ... and everybody has read them: the next pair's may land
+        if (k + 1 < np) issue_shared(ja, jb, 0);
+        if (ib & FW_LIT) tile(ib, 0, B, B, dm, slots);
+      } else {
+        float4 *slots = shb + (k & 1) * 512;
+        __syncthreads();
+        if (k + 1 < np) { issue_shared(ja, jb, (k + 1) & 1); issue(ja, jb); }
+        if (ia & FW_LIT) tile(ia, 0, A, A, dm, slots);
+        if (ib & FW_LIT) tile(ib, 0, B, B, dm, slots + 256);
+      }
       ia = ja; ib = jb;
     }
   } else {

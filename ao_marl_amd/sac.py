@@ -36,7 +36,13 @@ DEFAULT_SAC = dict(alpha=0.2, automatic_entropy_tuning=True, batch_size=256, gam
                    hidden_size_actor=256, hidden_size_critic=256, num_layers_actor=2,
                    lr=3e-4, target_update_interval=1, tau=0.005, memory_size=1000000,
                    gaussian_mu=0.0, gaussian_std=1.0, initialize_last_layer_0=True,
-                   LOG_SIG_MAX=2.0, updates_per_episode_rpc=1000)
+                   LOG_SIG_MAX=2.0, updates_per_episode_rpc=1000,
+                   # NOT in the reference (default off = the reference's learner): every agent's rewards divided by their
+                   # own standard deviation before they enter its replay memory ("auto": measured once, on the first
+                   # training episode behind its closing transient).  Independent learners whose rewards differ by four
+                   # orders of magnitude -- -3.5 per step for the tip-tilt agent, -1e-3 for the highest modes of the 40x40
+                   # system -- all see targets of order one; what an episode reports (rewards, Strehl) is untouched
+                   reward_scale=None)
 
 
 class BatchedReplay(object):
@@ -716,6 +722,28 @@ class BatchedSAC(object):
             self._ag = g
         return self._ag
 
+    _rscale = None
+
+    def _reward_scale(self, master):
+        """cfg["reward_scale"]: None (the reference), a number or [n_agents] numbers, or "auto": 1 / std of every
+        agent's rewards over the first training episode's transitions (the first tenth -- the loop closing behind the
+        reset -- left out), measured once and kept."""
+        rs = self.cfg.get("reward_scale")
+        if rs is None:
+            return None
+        if self._rscale is None:
+            if isinstance(rs, str):
+                if rs != "auto":
+                    raise ValueError("reward_scale: None, numbers or 'auto'")
+                total = len(master)
+                if total < 64:
+                    return None
+                r = master.rows(total // 10, total - total // 10)[2]
+                self._rscale = (1.0 / r.std(dim=0).clamp(min=1e-12)).reshape(1, -1).to(torch.float32)
+            else:
+                self._rscale = torch.as_tensor(rs, dtype=torch.float32, device=self.device).reshape(1, -1)
+        return self._rscale
+
     def update_parameters(self, master, batch_size=None, n_updates=None):
         """SAC.update_parameters_sac: n_updates updates; before each, the next slice of the
         episode's master memory moves into the agents' memory (1 transition per update in the
@@ -723,12 +751,16 @@ class BatchedSAC(object):
         batch_size = batch_size or self.cfg["batch_size"]
         n_updates = n_updates or self.cfg["updates_per_episode_rpc"]
         total, moved = len(master), 0
+        scale = self._reward_scale(master)
         per = -(-total // n_updates) if total else 0
         done = 0
         for _ in range(n_updates):
             if moved < total:
                 n = min(per, total - moved)
-                self.memory.push(*master.rows(moved, n))
+                rows = master.rows(moved, n)
+                if scale is not None:
+                    rows = (rows[0], rows[1], rows[2] * scale) + tuple(rows[3:])
+                self.memory.push(*rows)
                 moved += n
             if len(self.memory) > batch_size:
                 self.update_from_memory(batch_size)

@@ -39,6 +39,9 @@ def main(argv=None):
     ap.add_argument("--agents", type=int, default=14, choices=(14, 43),
                     help="40x40: 14 = BASELINE configs[2]'s 13 x 98 modes + tip-tilt; 43 = the reference's published 42 x 30 "
                          "modes + tip-tilt (README.md:116-119), both with the 20-mode window")
+    ap.add_argument("--reward-scale", default=None,
+                    help="BatchedSAC(reward_scale=...): 'auto' divides every agent's rewards by their own standard deviation "
+                         "before they enter its replay memory (not in the reference; default: off)")
     ap.add_argument("--reward-factor", type=float, default=None,
                     help="the factor of the per-agent reward -factor x mean(residual modes^2): reward_type "
                          "avg_squared_modes_<factor> (helper_rewards.py:18 parses any number; the reference's default is 1000)")
@@ -93,8 +96,11 @@ def main(argv=None):
     cfg = dict(updates_per_episode_rpc=a.updates, memory_size=a.memory)
     if a.lr is not None:
         cfg.update(lr=a.lr)
+    if a.reward_scale is not None:
+        cfg.update(reward_scale=a.reward_scale if a.reward_scale == "auto" else float(a.reward_scale))
     sac = BatchedSAC(env.layout, cfg, seed=a.seed, native=not a.torch_update)
-    print("reward_type %s  norm_scale_zernike_actions %s  lr %s" % (env.reward_type, env.config_rl["norm_scale_zernike_actions"], sac.lr))
+    print("reward_type %s  norm_scale_zernike_actions %s  lr %s  reward_scale %s" %
+          (env.reward_type, env.config_rl["norm_scale_zernike_actions"], sac.lr, cfg.get("reward_scale")))
     print("config %s  envs %d  agents %d (state dims %s, action dims %s)  %d steps + %d updates per "
           "episode  precision %s" % (name, a.envs, env.layout.n_agents, env.layout.state_shapes(), env.layout.action_shapes(),
                                      a.steps, a.updates, la.get_precision()), flush=True)
@@ -129,6 +135,9 @@ def main(argv=None):
     train_agent(env, sac, a.episodes, max_steps=a.steps, test_every=a.test_every, n_updates=a.updates, on_episode=on_episode,
                 throughput=not a.no_throughput)
     torch.cuda.synchronize()
+    if sac._rscale is not None:
+        print("reward scales (1 / std of each agent's rewards, first training episode): %s" %
+              ["%.3g" % v for v in sac._rscale.reshape(-1).tolist()], flush=True)
     print("environment: frame_pipeline %s (probe %s), residual_shortcut %s, reset_prefetch %s, prefetched resets adopted %d" %
           (env.frame_pipeline, env.order_probe, env.residual_shortcut, env.supervisor.reset_prefetch,
            int(getattr(env.supervisor.sim, "prefetched_resets", 0))), flush=True)
