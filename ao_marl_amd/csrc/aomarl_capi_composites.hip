@@ -77,10 +77,13 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
   const size_t smm = sizeof(float) * ((qf ? 0 : 2 * 128) + (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + FW_SLOT_BYTES(dma) +
                      (dma ? 4 * FWD_WAVE(c->nlayers == 1 ? 1 : 3) : 128) +
                      (qf ? 4 * 16 * (size_t)c->sys.ntiles : 0);
+  // (development: AOMARL_FW_LDS_PAD=<bytes> asks for that much more LDS per frame workgroup -- fewer of them per CU, room
+  // for the chains' workgroups beside them; profiles/r06_overlap_experiments.txt)
+  static const size_t lds_pad = [] { const char *e = getenv("AOMARL_FW_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
 // the events ride on the dispatch itself (its start / completion signal): no marker packets of their own
 // on the queue in front of and behind the kernel
-#define FW(NL, NB, OTF, NZ, WC, HP) hipExtLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm, s, ev_start, ev_done, 0, c->sys, ds, b, n, cog, TR, TP, w.nblk)
+#define FW(NL, NB, OTF, NZ, WC, HP) hipExtLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm + lds_pad, s, ev_start, ev_done, 0, c->sys, ds, b, n, cog, TR, TP, w.nblk)
 #define FW_H(NL, NB, OTF, NZ, WC) do { if (hp) FW(NL, NB, OTF, NZ, WC, true); else FW(NL, NB, OTF, NZ, WC, false); } while (0)
 #define FW_NC(NL, NB, OTF)                                                                     \
   do {                                                                                          \

@@ -2445,14 +2445,18 @@ template <int NL, int NB, bool OTF, bool NOISE, bool WRITE_CUBE, bool HP>
 #ifndef FW_DMA_F32
 #define FW_DMA_F32 1       // 0: the pair walk for the split-fp16 instantiations only
 #endif
-// Round 6: the pair walk's shared-data slots single-buffered, three quarters per tile (2 x 3 KB instead of 2 x 2 x 4 KB),
-// no twiddle table in the slopes-only instantiation: 37.5 KB of LDS per workgroup instead of 49.  Three frame workgroups
-// then leave 46 KB of a CU's 160 -- one workgroup of the chains' products (k_gemm_p<2, 3>: 46 080 B, 156 registers beside
-// 3 x 112) is resident beside them on EVERY CU instead of waiting for a frame workgroup to retire.  The price: the
-// slots are read into registers at the head of a pair, between two barriers (one pair of barriers per pair of tiles
-// instead of one barrier).
+// Round 6 experiment (FW_SLOTS1 = 1; built, measured, NOT the default): the pair walk's shared-data slots single-buffered,
+// three quarters per tile (2 x 3 KB instead of 2 x 2 x 4 KB; with no twiddle table in the slopes-only instantiation:
+// 37.5 KB of LDS per workgroup instead of 49).  Three frame workgroups then leave 46 KB of a CU's 160, and one workgroup
+// of the chains' products (k_gemm_p<2, 3>: 46 080 B, 156 registers beside 3 x 112) is resident beside them on EVERY CU
+// instead of starting when a frame workgroup retires.  Price: the slots are read into registers between two barriers.
+// Measured (alternating runs on one box, gpurun_out/r06f_*, r06g_*): the frame kernel in the loop gets FASTER (0.365
+// against 0.386 ms: it always has its three workgroups) and the step SLOWER (0.494 against 0.482 ms, 512 against 524 k):
+// a product's wave beside three frame waves gets a quarter of the SIMD's issue slots, one that took a retired frame
+// workgroup's place a third -- and the step waits for the products' chain, not for the frame kernel.  Wave priorities on
+// top (GP_PRIO / ATM_PRIO / CHAIN_PRIO) change nothing, in either layout.
 #ifndef FW_SLOTS1
-#define FW_SLOTS1 1
+#define FW_SLOTS1 0
 #endif
 #define FW_SLOT_BYTES(dma) ((dma) ? (FW_SLOTS1 ? 2 * 3 * 1024 : 16384) : 16384)
 // Layer rows of a PAIR of adjacent tiles as whole 128-byte pieces, straight into LDS (FW_DMA, the stack-array-from-

@@ -41,7 +41,8 @@ def main(argv=None):
                          "modes + tip-tilt (README.md:116-119), both with the 20-mode window")
     ap.add_argument("--reward-scale", default=None,
                     help="BatchedSAC(reward_scale=...): 'auto' divides every agent's rewards by their own standard deviation "
-                         "before they enter its replay memory (not in the reference; default: off)")
+                         "before they enter its replay memory; 'integrator' by what the integrator alone earns the agent "
+                         "per step (measured in the 200 frames in front of the training); not in the reference, default: off")
     ap.add_argument("--reward-factor", type=float, default=None,
                     help="the factor of the per-agent reward -factor x mean(residual modes^2): reward_type "
                          "avg_squared_modes_<factor> (helper_rewards.py:18 parses any number; the reference's default is 1000)")
@@ -96,7 +97,7 @@ def main(argv=None):
     cfg = dict(updates_per_episode_rpc=a.updates, memory_size=a.memory)
     if a.lr is not None:
         cfg.update(lr=a.lr)
-    if a.reward_scale is not None:
+    if a.reward_scale is not None and a.reward_scale != "integrator":
         cfg.update(reward_scale=a.reward_scale if a.reward_scale == "auto" else float(a.reward_scale))
     sac = BatchedSAC(env.layout, cfg, seed=a.seed, native=not a.torch_update)
     print("reward_type %s  norm_scale_zernike_actions %s  lr %s  reward_scale %s" %
@@ -117,6 +118,11 @@ def main(argv=None):
            lin0["sr_le"].mean(), lin0["sr_se_mean"].mean(), rl0["r_per_agent"].mean(dim=0).tolist(),
            lin0["r_per_agent"].mean(dim=0).tolist()), flush=True)
     env.next_seed_block(1)
+    if a.reward_scale == "integrator":
+        # every agent's rewards in units of what the integrator alone earns it per step (the 200 frames above): all
+        # fourteen learners see rewards of about -1 per step where the loop operates, whatever their modes' amplitudes
+        per_step = (lin0["r_per_agent"].mean(dim=0).abs() / 200.0).clamp(min=1e-12)
+        sac.cfg["reward_scale"] = (1.0 / per_step).tolist()
 
     def on_episode(rec):
         if "test_r_rl" in rec:
