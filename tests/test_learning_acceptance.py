@@ -25,3 +25,38 @@ def test_trained_agents_beat_the_integrator():
     assert last["test_sr_le_rl"] > last["test_sr_le_integrator"] + 0.01, last
     assert all(rl > it for rl, it in zip(last["test_r_agents_rl"], last["test_r_agents_integrator"])), last   # both agents
     assert rc == 0
+
+
+@pytest.mark.gpu
+def test_the_40x40_system_learns_in_its_first_twenty_episodes():
+    """production_sh_40x40_8m_3layers, 256 environments, the reference's published layout (42 windowed agents of 30
+    modes + the windowed tip-tilt agent, README.md:116-119), the loop bench.py times (throughput_mode through
+    train_agent), 2000 native updates per episode, every agent's rewards in units of what the integrator earns it
+    (`--reward-scale integrator`: an opt-in of the learner, see tools/learning_acceptance.py).  The first 21 episodes
+    of profiles/r06_learning_acceptance_40x40.txt (~40 s): measured at episode 20 -- summed reward -3279 against the
+    integrator's -3645, the tip-tilt agent -3005 against -3474, 33 of 43 agents ahead of the integrator, LE Strehl
+    0.837 against 0.881 (it crosses later, see the profile); temperatures 3e-4 .. 0.07."""
+    import math
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import learning_acceptance as LA
+    LA.main(["--config", "40x40", "--agents", "43", "--episodes", "21", "--test-every", "10", "--updates", "2000",
+             "--reward-scale", "integrator"])
+    ev = LA.main.evals
+    assert [e["episode"] for e in ev] == [0, 10, 20]
+    first, last = ev[0], ev[-1]
+    for e in ev:
+        vals = [e["r_total"], e["sr_le"], e["test_r_rl"], e["test_sr_le_rl"], e["test_r_integrator"]] + \
+            list(e["test_r_agents_rl"]) + list(e["test_r_agents_integrator"])
+        assert all(math.isfinite(v) for v in vals), e
+    # the training reward climbs out of the exploration of episode 0 by more than an order of magnitude
+    assert last["r_total"] > first["r_total"] / 10.0 and last["sr_le"] > first["sr_le"] + 0.3, (first["r_total"], last["r_total"])
+    # the evaluation (mean actions, fresh seeds) is ahead of the integrator in the summed per-agent reward ...
+    assert last["test_r_rl"] > last["test_r_integrator"] + 100, last
+    # ... the tip-tilt agent by itself, and most of the modal agents
+    assert last["test_r_agents_rl"][-1] > last["test_r_agents_integrator"][-1] + 100, last
+    ahead = sum(1 for a, b in zip(last["test_r_agents_rl"], last["test_r_agents_integrator"]) if a > b)
+    assert ahead >= 25, ahead
+    # the loop stays closed under the learned policy (LE Strehl within 0.1 of the integrator's; it starts 0.065 below)
+    assert last["test_sr_le_rl"] > last["test_sr_le_integrator"] - 0.1, last
+    al = LA.main.alphas
+    assert len(al) == 43 and all(math.isfinite(a) and a > 0 for a in al), al

@@ -153,6 +153,7 @@ def main(argv=None):
           (a.episodes, time.time() - t0, "BEATS" if ok else "does NOT beat", last["test_r_rl"], last["test_r_integrator"],
            last["test_sr_le_rl"], last["test_sr_le_integrator"]))
     main.evals = evals
+    main.alphas = sac.last_losses["alpha_value"].reshape(-1).tolist() if sac.last_losses else []   # per-agent temperatures at the end
     return 0 if ok else 1
 
 
