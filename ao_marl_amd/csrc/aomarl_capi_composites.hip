@@ -77,9 +77,20 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
   const size_t smm = sizeof(float) * ((qf ? 0 : 2 * 128) + (otf ? 4 * 4 * nb * c->sys.otf_latw : 0)) + FW_SLOT_BYTES(dma) +
                      (dma ? 4 * FWD_WAVE(c->nlayers == 1 ? 1 : 3) : 128) +
                      (qf ? 4 * 16 * (size_t)c->sys.ntiles : 0);
-  // (development: AOMARL_FW_LDS_PAD=<bytes> asks for that much more LDS per frame workgroup -- fewer of them per CU, room
-  // for the chains' workgroups beside them; profiles/r06_overlap_experiments.txt)
-  static const size_t lds_pad = [] { const char *e = getenv("AOMARL_FW_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+  // Frames in flight beside the chains (frame pipeline, slot >= 0), slopes-only fp32 instantiation of a large system: the
+  // workgroup asks for so much LDS that TWO of them fit a CU (3 x request > 160 KB) and what is left takes a workgroup of
+  // the chains' products (46 KB) or of the actors (52.7 KB at 14 agents) at any time, instead of three frame workgroups
+  // that leave 13 KB and a chain that starts where one of them retires.  Round 6, with the lighter frame kernel: the
+  // frame kernel in the loop 0.39 -> 0.44 ms, the step 0.482 -> 0.473 ms (profiles/r06_overlap_experiments.txt; round 5
+  // measured the opposite with the heavier kernel).  Not in the plain order (the frame kernel alone on the GPU wants its
+  // three workgroups: 0.292 against 0.317 ms).  AOMARL_FW_LDS_PAD=<bytes> overrides (0: off).
+  static const long lds_pad_env = [] { const char *e = getenv("AOMARL_FW_LDS_PAD"); return e ? atol(e) : -1L; }();
+  size_t lds_pad = 0;
+  if (qf && slot >= 0 && smm >= 40 * 1024) {
+    const size_t two_per_cu = (160 * 1024) / 3 + 64;          // 3 x this does not fit a CU's 160 KB
+    lds_pad = lds_pad_env >= 0 ? (size_t)lds_pad_env : (smm < two_per_cu ? (two_per_cu - smm + 63) / 64 * 64 : 0);
+    if (smm + lds_pad > 64 * 1024) lds_pad = 0;               // (beyond 64 KB the launch would need the opt-in attribute)
+  }
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
 // the events ride on the dispatch itself (its start / completion signal): no marker packets of their own
 // on the queue in front of and behind the kernel

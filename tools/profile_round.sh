@@ -23,6 +23,7 @@ for MODE in f32 split_f16 f32_plain_order; do
   K=$(python3 -c "import json;print(json.load(open('$R/gpurun_out/${TAG}_bench_line_under_rocprofv3_$MODE.json'))['roofline']['kernel'])")
   python3 $R/tools/queue_gaps.py $D "$K" > $R/gpurun_out/${TAG}_main_queue_gaps_$MODE.txt
   python3 $R/tools/pipe_gaps.py $T > $R/gpurun_out/${TAG}_frame_pipeline_waits_$MODE.txt
+  python3 $R/tools/queue_busy.py $T 40 > $R/gpurun_out/${TAG}_queue_busy_$MODE.txt
   rm -rf $D
 done
 cd $R
