@@ -142,8 +142,8 @@ def main(argv=None):
                 throughput=not a.no_throughput)
     torch.cuda.synchronize()
     if sac._rscale is not None:
-        print("reward scales (1 / std of each agent's rewards, first training episode): %s" %
-              ["%.3g" % v for v in sac._rscale.reshape(-1).tolist()], flush=True)
+        print("reward scales per agent (%s): %s" % ("1 / |what the integrator earns the agent per step|" if a.reward_scale == "integrator" else "BatchedSAC(reward_scale=%r)" % (a.reward_scale,),
+              ["%.3g" % v for v in sac._rscale.reshape(-1).tolist()]), flush=True)
     print("environment: frame_pipeline %s (probe %s), residual_shortcut %s, reset_prefetch %s, prefetched resets adopted %d" %
           (env.frame_pipeline, env.order_probe, env.residual_shortcut, env.supervisor.reset_prefetch,
            int(getattr(env.supervisor.sim, "prefetched_resets", 0))), flush=True)
