@@ -818,6 +818,11 @@ def main():
         s = env.supervisor.s
         model = frame_kernel_model(s, args.envs)
         roof = roofline_block(model, fk_ms, kernel_name, args.pmc, args.envs, args.config)
+        if roof is not None and pipe_state[0] and os.environ.get("AOMARL_FW_LDS_PAD") != "0":
+            roof["in_the_timed_region"] = ("pipelined launches of this instantiation ask for 54.7 KB of LDS: TWO frame workgroups per "
+                                           "CU (three when the kernel runs alone) so that a workgroup of the chains' products or "
+                                           "actors fits beside them at any time -- the frame kernel 0.39 -> 0.44 ms, the step 0.482 "
+                                           "-> 0.473 ms (profiles/r06_overlap_experiments.txt); `alone` is the kernel by itself")
         if plain is not None and plain["frame_kernel_ms"]:
             # `achieved` / `frac` above: the launches of the timed region, which share the GPU with the kernels of
             # the control / agent and extrusion chains (the frame pipeline).  The kernel by itself:
