@@ -722,7 +722,7 @@ __device__ __forceinline__ void extrude_scatter_col(const DevSys &sys, const Dev
                                                     const RoundOps &ops, const float *__restrict__ NEWL, int ldn,
                                                     const float *__restrict__ ZREF, const float *__restrict__ P,
                                                     int nsplit, int ncol, int pn, float pscale, int col, int ox,
-                                                    int oy, int &nox, int &noy) {
+                                                    int oy, int &nox, int &noy, float *__restrict__ snew = nullptr) {
   // nsplit > 0: the new lines are still split-K partial tiles P[z][ncol][pn] of the extrusion GEMM
   // (times 1 / pscale when the split-f16 kernel produced them from scaled operands)
   const int e = env_begin + col / ops.nops, op = col % ops.nops;
@@ -756,6 +756,7 @@ __device__ __forceinline__ void extrude_scatter_col(const DevSys &sys, const Dev
     }
     base[py * stride + px] = v;
     if (px < RING_PAD) base[py * stride + n + px] = v;     // mirror columns
+    if (snew) snew[r] = v;                                 // (k_extrude_sg: the next stencil's points on this line)
   }
   nox = ox; noy = oy;
   if (dir == 1) nox = (ox + 1 >= n) ? 0 : ox + 1;
@@ -794,12 +795,17 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
 // The next round may hold fewer layers (a frame's rounds thin out as the slower layers finish) and other
 // directions: `nx` says where this column's layer sits in it; its Z / ZREF are a second pair of buffers
 // (ZN / ZREFN: the next round numbers its columns anew, another block may still need this round's ZREF entry).
+#define SG_MAX_N 1024                            // longest line k_extrude_sg keeps in LDS (checked on the host)
+#ifndef SG_EARLY
+#define SG_EARLY 1                               // 0 (A/B builds): every stencil value read back from the ring behind the barrier, as before round 6
+#endif
 __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int env_begin, RoundOps ops,
                                                     const float *__restrict__ NEWL, int ldn,
                                                     const float *__restrict__ ZREF, const float *__restrict__ P,
                                                     int nsplit, int ncol, int pn, float pscale,
                                                     float *__restrict__ Z, int ldz, float *__restrict__ ZREFN,
                                                     RoundNext nx) {
+  __shared__ float snew[SG_MAX_N];               // the line this block writes, for the next stencil's points on it
   ATM_SETPRIO();
   const int col = blockIdx.x;
   const int el = col / ops.nops, oi = col % ops.nops;
@@ -812,16 +818,54 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   const int ni = nx.idx[oi];                     // this column's layer in the next round (-1: it has no operation there)
   const int col2 = el * nx.nops + (ni < 0 ? 0 : ni);
   const int dir = nx.dir[ni < 0 ? 0 : ni];
+  // the origin as this round's scatter leaves it (the same arithmetic as extrude_scatter_col's)
+  const int cdir = ops.dir[oi];
+  int eox = ox, eoy = oy;
+  if (cdir == 1) eox = (ox + 1 >= n) ? 0 : ox + 1;
+  else if (cdir == -1) eox = (ox - 1 < 0) ? n - 1 : ox - 1;
+  else if (cdir == 2) eoy = (oy + 1 >= n) ? 0 : oy + 1;
+  else eoy = (oy - 1 < 0) ? n - 1 : oy - 1;
+  // Is the logical point (x, y) of the ADVANCED screen on the line this block is about to write, and which of its
+  // elements is it?  (dir +1: the new column is x = n - 1, element y; -1: x = 0, element n - 1 - y; +2: the row y = n - 1,
+  // element x; -2: y = 0, element n - 1 - x -- the placement rules of extrude_scatter_col)
+  auto on_new = [&](int x, int y, int &r) {
+    if (cdir == 1) { r = y; return x == n - 1; }
+    if (cdir == -1) { r = n - 1 - y; return x == 0; }
+    if (cdir == 2) { r = x; return y == n - 1; }
+    r = n - 1 - x; return y == 0;
+  };
   // What the next round's gather needs and the scatter does not touch goes FIRST, so that it runs while the scatter's
   // loads are in flight instead of behind the barrier: the stencil's index list (the gather was a dependent pair of
-  // loads per item) and the noise half of Z (Philox + two Box-Muller pairs per item: nothing but arithmetic).  Z / ZREFN
-  // are the next round's buffers: the product that last read them is a whole round back.
+  // loads per item), the noise half of Z (Philox + two Box-Muller pairs per item: nothing but arithmetic) and -- round
+  // 6 -- the stencil's VALUES off the new line: half of the stencil (its second full line and the far points) is older
+  // data that this block does not write, and the other half IS the line it writes, which it keeps in LDS: no value is
+  // read back from the ring behind the barrier, one dependent round trip to memory less per launch.  Z / ZREFN are the
+  // next round's buffers: the product that last read them is a whole round back.
   constexpr int U = 4;                           // ns <= U * blockDim.x (checked on the host: AOMARL_SG_MAX_NS)
-  uint32_t xy[U];
+  const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
+  float v[U] = {0.f, 0.f, 0.f, 0.f};
+  int rr[U] = {0, 0, 0, 0};
+  bool nw[U] = {false, false, false, false};
+  float zref = 0.f;
+  int zr = 0;
+  bool znew = false;
   if (ni >= 0) {
     const uint32_t *ist = nx.tflag[ni] ? L.istT : ((dir == 1 || dir == -1) ? L.istx : L.isty);
+    uint32_t xy[U];
 #pragma unroll
     for (int u = 0; u < U; u++) xy[u] = ist[min((int)threadIdx.x + u * (int)blockDim.x, ns - 1)];
+    const bool top_right = (dir == 1 || dir == -2);
+    const int zx = top_right ? n - 1 : 0, zy = top_right ? 0 : n - 1;
+    znew = on_new(zx, zy, zr);
+    if (SG_EARLY && !znew) zref = base[ring_idx(zx, zy, eox, eoy, n)];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int x = xy[u] & 0xFFFF, y = xy[u] >> 16;
+      nw[u] = on_new(x, y, rr[u]);
+      if (SG_EARLY && !nw[u]) v[u] = base[ring_idx(x, y, eox, eoy, n)];
+      if (!SG_EARLY) rr[u] = ring_idx(x, y, eox, eoy, n);
+    }
+    if (!SG_EARLY) zr = ring_idx(zx, zy, eox, eoy, n);
     const uint32_t seed = st.seeds[e] + (uint32_t)li;
     for (int g = threadIdx.x; g < (n + 3) / 4; g += blockDim.x) {
       float z4[4];
@@ -832,23 +876,24 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
     }
   }
   int nox, noy;
-  extrude_scatter_col(sys, st, env_begin, ops, NEWL, ldn, ZREF, P, nsplit, ncol, pn, pscale, col, ox, oy, nox, noy);
-  __syncthreads();                               // the new line is in the ring (block-visible); ZREF[col] was read by everyone
+  extrude_scatter_col(sys, st, env_begin, ops, NEWL, ldn, ZREF, P, nsplit, ncol, pn, pscale, col, ox, oy, nox, noy, snew);
+  __syncthreads();                               // the new line is in the ring and in LDS; ZREF[col] was read by everyone
   if (threadIdx.x == 0) {
     o[0] = nox; o[1] = noy;
     if (st.origin_snap) { st.origin_snap[(e * sys.nlayers + li) * 2] = nox; st.origin_snap[(e * sys.nlayers + li) * 2 + 1] = noy; }
     st.ext_count[e * sys.nlayers + li] = cnt + 1u;
   }
   if (ni < 0) return;
-  const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-  const bool top_right = (dir == 1 || dir == -2);
-  const float zref = base[ring_idx(top_right ? n - 1 : 0, top_right ? 0 : n - 1, nox, noy, n)];
-  float v[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) v[u] = base[ring_idx(xy[u] & 0xFFFF, xy[u] >> 16, nox, noy, n)];
+  if (SG_EARLY) {
+    if (znew) zref = snew[zr];
+  } else {
+    zref = base[zr];
+  }
 #pragma unroll
   for (int u = 0; u < U; u++) {
     const int j = (int)threadIdx.x + u * (int)blockDim.x;
+    if (SG_EARLY) { if (nw[u]) v[u] = snew[rr[u]]; }
+    else v[u] = base[rr[u]];
     if (j < ns) Z[(long long)col2 * ldz + j] = v[u] - zref;
   }
   if (threadIdx.x == 0) ZREFN[col2] = zref;
