@@ -121,6 +121,43 @@ def test_update_parameters_trickles_the_episode_into_memory():
     assert torch.isfinite(sac.last_losses["q1"]).all()
 
 
+def test_reward_scale_is_an_opt_in_that_only_touches_what_the_learner_stores():
+    """BatchedSAC(reward_scale=...): not in the reference, off by default.  Numbers per agent (or "auto" = 1 / std of every
+    agent's rewards over the first episode's transitions, its first tenth left out, measured once) multiply the rewards on
+    their way from the episode's master memory into the agents' replay ring -- the master memory (what the episode
+    reports) is untouched, states / actions / next states are stored as they are."""
+    lay = _layout()
+    S, A = torch.randn(120, lay.state_dim), torch.rand(120, lay.action_dim)
+    R = -torch.rand(120, lay.n_agents) * torch.tensor([[1e-3, 5.0] + [1.0] * (lay.n_agents - 2)])[:, :lay.n_agents]
+
+    def fill(cfg):
+        sac = BatchedSAC(lay, dict(hidden_size_actor=16, hidden_size_critic=16, memory_size=1000, batch_size=16, **cfg),
+                         device="cpu")
+        master = BatchedReplay(lay.state_dim, lay.action_dim, lay.n_agents, 200, "cpu")
+        master.push(S, A, R.clone(), S.flip(0), 1.0)
+        sac.update_parameters(master, n_updates=40)
+        assert torch.equal(master.reward[:120], R)                       # the episode's own record: as reported
+        return sac
+    plain = fill({})
+    assert plain._reward_scale(None) is None and torch.equal(plain.memory.reward[:120], R)
+    fixed = fill(dict(reward_scale=[2.0] * lay.n_agents))
+    assert torch.allclose(fixed.memory.reward[:120], 2.0 * R) and torch.equal(fixed.memory.state[:120], S)
+    auto = fill(dict(reward_scale="auto"))
+    want = 1.0 / R[12:].std(dim=0)
+    assert torch.allclose(auto._rscale.reshape(-1), want, rtol=1e-5)
+    stored = auto.memory.reward[:120]
+    assert torch.allclose(stored, R * want, rtol=1e-5)
+    assert torch.allclose(stored[12:].std(dim=0), torch.ones(lay.n_agents), rtol=1e-4)     # every agent: rewards of order one
+    # measured once: a second episode with other rewards keeps the scale
+    master = BatchedReplay(lay.state_dim, lay.action_dim, lay.n_agents, 200, "cpu")
+    master.push(S, A, 100.0 * R, S, 1.0)
+    keep = auto._rscale.clone()
+    auto.update_parameters(master, n_updates=10)
+    assert torch.equal(auto._rscale, keep)
+    with pytest.raises(ValueError):
+        fill(dict(reward_scale="median"))
+
+
 def test_training_episode_on_the_oracle_backed_env():
     from tests.oracle_vecsim import OracleVecSim
     from ao_marl_amd.env import VecAoEnv
