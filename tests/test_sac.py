@@ -174,6 +174,14 @@ def test_training_episode_on_the_oracle_backed_env():
     assert (out["r_total"] <= 0).all() and torch.isfinite(out["sr_le"]).all()
     ev = run_episode(env, sac, max_steps=3, train=False, eval_mode=True)
     assert "updates" not in ev
+    # train_agent takes the package's throughput configuration by default (VecAoEnv.throughput_mode); on a simulator
+    # without an atmosphere prefetch (this CPU stand-in) that leaves the call order alone and only asks for the one-product
+    # residual, which the stage-by-stage path ignores: the loop runs as before, evaluations included
+    from ao_marl_amd.sac import train_agent
+    log = train_agent(env, sac, 2, max_steps=5, test_every=1, n_updates=3)
+    assert env.residual_shortcut and env.frame_pipeline is False and env.supervisor.reset_prefetch is None
+    assert len(log) == 2 and all("test_r_rl" in r and "test_r_integrator" in r for r in log)
+    assert log[1]["seed"] > log[0]["test_seed"] > log[0]["seed"]          # a fresh block of seeds per episode and evaluation
 
 
 def test_checkpoints_use_the_references_container(tmp_path):
