@@ -246,6 +246,13 @@ def load():
                 "libaomarl_hip.so is missing (%s). Build it with `python -c 'import "
                 "__graft_entry__ as g; g.build()'` or `make -C ao_marl_amd/csrc`. There is no CPU "
                 "fallback for the product path." % LIB_PATH)
+    # PyTorch first, when it is there: it ships a HIP runtime of its own, and the library must resolve its HIP calls
+    # to the runtime the tensors live in -- loaded the other way round (build() then smoke() in one process) the library
+    # binds the system's runtime and its first hipMalloc finds "no ROCm-capable device" beside torch's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:                                     # a pure C-ABI user: the system's runtime is the only one
+        pass
     L = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         try:
