@@ -49,6 +49,7 @@ struct aomarl_ctx {
   int small_move = 1;                  // "small_move": 1 = one k_move_small launch per frame's move where the screens allow it
   bool small_ok = false;               // every layer has dim <= MOVE_SMALL_DIM, ns + dim <= MOVE_SMALL_K (transposed [A|B] uploaded)
   int reset_streams = 2;               // "reset_streams": a batch reset in that many parts side by side, one stream each (1..4)
+  bool reset_prefetch_whole = true;    // "reset_prefetch_whole": the prefetched reset as ONE range with the parts' tile and k split
   hipEvent_t ev_reset = nullptr, ev_reset2[3] = {nullptr, nullptr, nullptr};
   bool no_extrude_sg = false;          // "extrude_unfused": scatter and gather of consecutive rounds as separate launches
   bool defer_dm_shape = false;         // composites: stack-array phase from st->voltage on the fly

@@ -88,6 +88,7 @@ static bool next_round(const RoundOps &a, const RoundOps &b, RoundNext &nx) {
 struct ExtrudeRun {          // one range of environments walking through a sequence of rounds on one stream
   aomarl_ctx *c; aomarl_state *st; int b, n; hipStream_t s; bool ordered;
   Work w; DevState ds; float *Zb[2], *NEWL, *ZREFb[2], *WS; size_t ws_floats; bool gathered; int par;
+  int pick_n = 0;            // > 0: the products take the tile and k split a range of pick_n environments would get
   // ordered = false: the caller has ordered the stream behind every reader of the screens (reset)
   ExtrudeRun(aomarl_ctx *c_, aomarl_state *st_, int b_, int n_, void *stream, bool ordered_ = true)
       : c(c_), st(st_), b(b_), n(n_), s((hipStream_t)stream), ordered(ordered_), gathered(false), par(0) {
@@ -133,7 +134,8 @@ struct ExtrudeRun {          // one range of environments walking through a sequ
       float pscale = 1.f;
       launch_gemm_nt(ncol, dimc, K, 1.0f, Z, w.ldz, c->sys.layers[ref].AB, c->sys.layers[ref].ldab,
                      0.0f, NEWL, w.ldn, s, WS, ws_floats, nullptr, &nsp,
-                     /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale);
+                     /* split-f16: stencil values (um) and N(0,1) draws x 2^8 */ true, 256.f, c->ab_scale[cls], &pscale,
+                     128, pick_n > 0 && pick_n < n ? pick_n * ops.nops : 0);
       LAUNCHCHK();
       if (ordered) {
         int wrc = first_write_wait(c, s);
@@ -522,8 +524,8 @@ int aomarl_reset(aomarl_ctx *c, aomarl_state *st, int b, int n, const uint32_t *
 // reset is 2 x 648 DEPENDENT extrusion rounds per layer -- 45 ms for 256 environments, mostly latency.  So the next
 // episode's screens are grown in a SHADOW state (own screens, ring origins, counters, seeds, workspace) on a stream
 // of the caller's, a few rounds per step of the running episode, beside its kernels; aomarl_reset_adopt then
-// copies them in (1.3 GB device to device: < 1 ms) and does the rest of the reset.  Same kernels, same partition
-// of the batch, same columns, same split-K order as aomarl_reset: the same screens, bit for bit.
+// copies them in (1.3 GB device to device: < 1 ms) and does the rest of the reset.  Same kernels, same columns,
+// same split-K order as aomarl_reset (whose partition of the batch fixes it): the same screens, bit for bit.
 struct ResetPrefetch {
   aomarl_state shadow;                 // a copy of the caller's struct (its buffers stay the caller's)
   int b = 0, n = 0, next_round = 0;
@@ -580,11 +582,19 @@ int aomarl_reset_prefetch_begin(aomarl_ctx *c, const aomarl_state *shadow, int b
   reset_rounds_plan(c, rp->rounds);
   rp->runs.clear();
   const int parts = reset_parts(c, n);
-  int e0 = b;
-  for (int k = 0; k < parts; k++) {         // the plain reset's partition, all parts on the one stream
-    const int nk = (b + n - e0) / (parts - k);
-    rp->runs.emplace_back(c, &rp->shadow, e0, nk, stream, false);
-    e0 += nk;
+  if (c->reset_prefetch_whole && parts > 1 && n % parts == 0) {
+    // One range whose products take the tile and the k split of a part's (launch_gemm_nt's pick_M): every sum in the
+    // plain reset's order, so the same screens bit for bit, with half the launches beside the running episode
+    // (256 environments: the rounds alone 47 ms instead of 60, the step beside them 2.7 % shorter).
+    rp->runs.emplace_back(c, &rp->shadow, b, n, stream, false);
+    rp->runs.back().pick_n = n / parts;
+  } else {
+    int e0 = b;
+    for (int k = 0; k < parts; k++) {         // the plain reset's partition, all parts on the one stream
+      const int nk = (b + n - e0) / (parts - k);
+      rp->runs.emplace_back(c, &rp->shadow, e0, nk, stream, false);
+      e0 += nk;
+    }
   }
   HIPCHK(hipEventRecord(rp->ev, s));
   return 0;

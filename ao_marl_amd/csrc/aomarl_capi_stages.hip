@@ -88,6 +88,7 @@ int aomarl_set_option(aomarl_ctx *c, const char *name, int value) {
     return 0;
   }
   if (!strcmp(name, "reset_streams")) { c->reset_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return 0; }
+  if (!strcmp(name, "reset_prefetch_whole")) { c->reset_prefetch_whole = value != 0; return 0; }
   if (!strcmp(name, "extrude_unfused")) { c->no_extrude_sg = value != 0; return 0; }
   if (!strcmp(name, "reset_untransposed")) { c->reset_untransposed = value != 0; return 0; }
   if (!strcmp(name, "time_frame_kernel")) {

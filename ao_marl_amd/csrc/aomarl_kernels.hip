@@ -559,16 +559,20 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
                     int ldb, float beta, float *C, int ldc, hipStream_t s, float *ws = nullptr,
                     size_t ws_floats = 0, const GemmEpi *epi = nullptr, int *nsplit_out = nullptr,
                     bool fast = false, float sa = 1.f, float sb = 1.f, float *alpha_out = nullptr,
-                    int min_chunk = 128) {
+                    int min_chunk = 128, int pick_M = 0) {
   // alpha_out: the factor the caller must apply to the partial tiles when it sums them itself
+  // pick_M > 0: tile and split-K as a product of pick_M rows would get them (a sum's order depends on the k split
+  //             alone: M rows at once then give, bit for bit, what M / pick_M products of pick_M rows give)
   if (nsplit_out) *nsplit_out = 0;
   if (alpha_out) *alpha_out = alpha;
   if (M <= 0 || N <= 0) return false;
-  const int bx = (N + 63) / 64, by = (M + 63) / 64;
+  const int Mp = pick_M > 0 ? pick_M : M;
+  const size_t wsp = pick_M > 0 ? (size_t)((double)ws_floats * Mp / M) : ws_floats;     // the part's share of the workspace
+  const int bx = (N + 63) / 64, by = (M + 63) / 64, byp = (Mp + 63) / 64;
   int nsplit = 1;
   bool al = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
             (((uintptr_t)B & 15) == 0);
-  if (ws && bx * by < 384) {
+  if (ws && bx * byp < 384) {
     // Split K so that the launch is as short as its slowest CU: blocks go round-robin over the 256 CUs, a CU
     // that gets one block more than the others sets the duration (528 blocks = 2.06 per CU took as long as 768
     // would: 132 tiles x 4 chunks lost to 132 x 3 = 396).  Cost model per candidate: blocks per CU (rounded
@@ -576,15 +580,15 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     // min_chunk: the control chain's products ask for at least three groups of three k-tiles per block
     // (288): below that the fill / drain of the load pipeline and the wider reduce cost more than the
     // extra blocks bring (round-2 script gemm_split_time.py, since removed).
-    const int ncu = 256, tiles = bx * by;
+    const int ncu = 256, tiles = bx * byp;
     if (g_gemm_target_blocks > 0) {              // "gemm_target_blocks" > 0: the plain rule (about that many blocks)
       nsplit = (g_gemm_target_blocks + tiles - 1) / tiles;
       if (nsplit > 8) nsplit = 8;
-      while (nsplit > 1 && (K / nsplit < min_chunk || (size_t)nsplit * M * N > ws_floats)) nsplit--;
+      while (nsplit > 1 && (K / nsplit < min_chunk || (size_t)nsplit * Mp * N > wsp)) nsplit--;
     } else {
       long long best = -1;
       for (int ns = 1; ns <= 8; ns++) {
-        if (ns > 1 && (K / ns < min_chunk || (size_t)ns * M * N > ws_floats)) break;
+        if (ns > 1 && (K / ns < min_chunk || (size_t)ns * Mp * N > wsp)) break;
         const int chunk = al ? ((K + ns - 1) / ns + 95) / 96 * 96 : (((K + ns - 1) / ns + 31) & ~31);
         const int nz = (K + chunk - 1) / chunk;
         const long long per_cu = ((long long)tiles * nz + ncu - 1) / ncu;
@@ -599,16 +603,19 @@ bool launch_gemm_nt(int M, int N, int K, float alpha, const float *A, int lda, c
     struct Memo { int M, N, K; size_t ws; GemmPCfg c; };
     static thread_local Memo memo[16];
     static thread_local int memo_n = 0;
-    const size_t wsf = ws ? ws_floats : 0;
+    const size_t wsf = ws ? wsp : 0;
     const GemmPCfg *cfg = nullptr;
     for (int i = 0; i < memo_n; i++)
-      if (memo[i].M == M && memo[i].N == N && memo[i].K == K && memo[i].ws == wsf) { cfg = &memo[i].c; break; }
+      if (memo[i].M == Mp && memo[i].N == N && memo[i].K == K && memo[i].ws == wsf) { cfg = &memo[i].c; break; }
     if (!cfg) {
       Memo &m = memo[memo_n < 16 ? memo_n++ : (memo_n = 1, 0)];
-      m.M = M; m.N = N; m.K = K; m.ws = wsf;
-      m.c = gemm_p_pick(M, N, K, wsf, ws ? 16 : 1);
+      m.M = Mp; m.N = N; m.K = K; m.ws = wsf;
+      m.c = gemm_p_pick(Mp, N, K, wsf, ws ? 16 : 1);
       cfg = &m.c;
     }
+    GemmPCfg mine = *cfg;                        // (pick_M: the part's tile and k split over this product's rows)
+    if (mine.wm > 0) mine.tiles_m = (M + 32 * mine.wm - 1) / (32 * mine.wm);
+    cfg = &mine;
     if (cfg->wm > 0 && gemm_p_launch(*cfg, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ws, g_gemm_xcd, s)) {
       g_arith[AR_GEMM_F32]++;
       nsplit = cfg->nz;

@@ -198,8 +198,8 @@ int aomarl_reset(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int env_count
  * alias the live state's: they are not touched), aomarl_reset_prefetch_advance runs `nrounds` more rounds (< 0: all
  * that are left) -- both on a stream of the caller's choice, beside the live episode --, and aomarl_reset_adopt is
  * aomarl_reset with the screens COPIED from the shadow (it first runs whatever rounds are left, on
- * prefetch_stream).  Same kernels on the same columns in the same partition of the batch as aomarl_reset: the
- * screens are the plain reset's, bit for bit (tests/test_gpu_glue.py).  The seeds must be those of the begin call.
+ * prefetch_stream).  Same kernels on the same columns with the k split aomarl_reset's partition of the batch gives
+ * its products ("reset_prefetch_whole" below): the screens are the plain reset's, bit for bit (tests/test_gpu_glue.py).  The seeds must be those of the begin call.
  * `*remaining` = rounds still to run.  aomarl_reset_prefetch_cancel forgets a begun prefetch. */
 int aomarl_reset_prefetch_begin(aomarl_ctx *ctx, const aomarl_state *shadow, int env_begin, int env_count,
                                 const uint32_t *seeds, void *stream);
@@ -331,6 +331,10 @@ int aomarl_get_dm_shape(aomarl_ctx *ctx, aomarl_state *st, int env_begin, int en
  * halves of the batch side by side, the second on the library's extrusion stream, each half's kernels filling the
  * other's latency -- 59 -> 51 ms per 256 environments; 1: one chain on the caller's stream; same kernels on the same
  * columns, the split-K rule of a product sees its half's columns; only with "prefetch_atmos" on),
+ * "reset_prefetch_whole" (default 1: aomarl_reset_prefetch_* walks the rounds as ONE range whose products take the
+ * tile and the k split a half's product gets -- a sum's order depends on the k split alone, so the screens are the
+ * plain reset's bit for bit, with half the launches beside the running episode: 47 instead of 60 ms of rounds per 256
+ * environments, the step beside them 2.7 % shorter; 0: the plain reset's halves one after the other),
  * "small_move" (default 1: screens of <= 256 pixels with stencil + dim <= 4096 -- the 10x10 files -- move in ONE
  * launch per frame, k_move_small, instead of gather / GEMM / scatter rounds; fp32 vector FMAs in both precision
  * modes; 0: the rounds),

@@ -800,13 +800,15 @@ def test_default_call_order_is_probed_and_falls_back_loudly():
     assert noisy.frame_pipeline is False and noisy.order_probe is None
 
 
-@pytest.mark.parametrize("name,nenv", [("production_sh_10x10_2m", 6), ("production_sh_40x40_8m_3layers", 32)])
-def test_prefetched_reset_is_the_plain_reset_bit_for_bit(name, nenv):
+@pytest.mark.parametrize("name,nenv,whole", [("production_sh_10x10_2m", 6, 1), ("production_sh_40x40_8m_3layers", 32, 1),
+                                             ("production_sh_40x40_8m_3layers", 32, 0)])
+def test_prefetched_reset_is_the_plain_reset_bit_for_bit(name, nenv, whole):
     """aomarl_reset_prefetch_begin / _advance / aomarl_reset_adopt: the next episode's screens grown in a shadow state
     beside the running episode (a few rounds per step, on a stream of their own) are the plain reset's -- screens,
     ring origins, extrusion counters, and the frames that follow -- bit for bit; the running episode is not
     disturbed; a reset that comes before the rounds are through runs what is left; other seeds drop the prefetch.
-    32 environments of the 40x40 system: the reset walks its rounds in two parts of the batch (reset_streams)."""
+    32 environments of the 40x40 system: the reset walks its rounds in two parts of the batch (reset_streams); the
+    prefetched one as one range with the parts' k split ("reset_prefetch_whole", the default) or in the same parts."""
     from ao_marl_amd.sim import HipSim
     _, s, cal = helpers.calibrated(name) if "10x10" in name else helpers.calibrated_hip(name)
     sims = []
@@ -814,6 +816,7 @@ def test_prefetched_reset_is_the_plain_reset_bit_for_bit(name, nenv):
         sim = HipSim(s, nenv=nenv)
         sim.set_modal(cal.volts2modes, cal.modes2volts)
         sim.set_option("prefetch_atmos", 1)
+        sim.set_option("reset_prefetch_whole", whole)
         sims.append(sim)
     a, b = sims
     s1, s2, s3 = 100 + 16 * np.arange(nenv), 9000 + 16 * np.arange(nenv), 555 + 16 * np.arange(nenv)
