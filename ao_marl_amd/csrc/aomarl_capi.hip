@@ -112,6 +112,7 @@ struct aomarl_ctx {
     hipEvent_t ev_done_cur[2] = {nullptr, nullptr};  // the event each parity's last frame launch carries (ev_done[], or a timing event)
     bool psf_out[2] = {false, false};              // a PSF finish of that parity may still run
     bool cmd_covers_commit = false;                // ev_cmd was recorded behind the Strehl commit and the PSF-finish wait as well
+    bool cmd_covers_psf = false;                   // ev_cmd was recorded behind the PSF-finish wait (not the commit)
     int32_t *snap[2] = {nullptr, nullptr};         // ring origins as of each parity's frame
     size_t snap_ints = 0;
     unsigned long long steps = 0, overlapped = 0, behind = 0;

@@ -295,6 +295,11 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
   }
   float *modes = st->work + w.MODES;
   const int cx = (nm + 255) / 256;
+  // (frame pipeline: the wait for that parity's last PSF finish -- two frames old, long over -- HERE, in front of the
+  // chain's first kernel, so that the command event covers it and the frame stream has one cross-queue wait less
+  // between two frame kernels)
+  bool psf_waited = false;
+  if (ahead && psf_ev) { HIPCHK(hipStreamWaitEvent(s, psf_ev, 0)); psf_waited = true; }
   hipLaunchKernelGGL(k_compose_rewards, dim3(cx + (reward_out ? g->n_agents : 0), n), dim3(256), 0, s, nm, newest,
                      g->res_modes, gain, action, c->nact, c->amode_inv, c->freedom, modes, w.ldm, mnew, cx,
                      g->n_agents, g->lohi, g->reward_factor, reward_out);
@@ -310,10 +315,11 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
   if (ahead) {
     // delay == 1 (the pipeline's condition): v(t+1) = c(t); the tip-tilt slot in the same launch, and the frame
     // stream released right behind it -- the Strehl commit below is not on the frame kernel's path
-    hipLaunchKernelGGL(k_delay_ahead, dim3((na + 255) / 256, 2 * n), dim3(256), 0, s, c->sys, dsv, na, st->ld_actu, n,
-                       nsp > 0 ? st->work + w.GEMM : nullptr, nsp, alpha, ktt);
+    // (the command event rides on the dispatch, like the frame kernel's and the move's: no marker packet behind it)
+    hipExtLaunchKernelGGL(k_delay_ahead, dim3((na + 255) / 256, 2 * n), dim3(256), 0, s, nullptr, c->pipe.ev_cmd, 0, c->sys, dsv, na,
+                          st->ld_actu, n, nsp > 0 ? st->work + w.GEMM : nullptr, nsp, alpha, ktt);
     LAUNCHCHK();
-    HIPCHK(hipEventRecord(c->pipe.ev_cmd, s));
+    c->pipe.cmd_covers_psf = psf_waited;
   } else {
     if (nsp > 0)
       hipLaunchKernelGGL(k_delay_sum, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1,
@@ -322,7 +328,7 @@ static int env_step_head_fused(aomarl_ctx *c, aomarl_state *st, aomarl_state *st
       hipLaunchKernelGGL(k_delay, dim3((na + 255) / 256, n), dim3(256), 0, s, dsv, na, st->ld_actu, wa, wb, wc, 0, 1);
     LAUNCHCHK();
   }
-  if (psf_ev) HIPCHK(hipStreamWaitEvent(s, psf_ev, 0));
+  if (psf_ev) { if (!psf_waited) HIPCHK(hipStreamWaitEvent(s, psf_ev, 0)); }
   else if (stv == st) { int rc = psf_wait_pending(c, stream); if (rc) return rc; }
   hipLaunchKernelGGL(k_post_delay, dim3(ahead ? n : 2 * n), dim3(256), 0, s, c->sys, dsv, 0, n, stv->work + w.PEND, 1, ktt,
                      stv->voltage, st->ld_actu);
@@ -629,10 +635,11 @@ static int env_step_pipelined(aomarl_ctx *c, aomarl_state *st, aomarl_env_glue *
   aomarl_state vq = pipe_view(c, st, q), vp = pipe_view(c, st, p);
   hipEvent_t pe = P.psf_out[q] ? P.ev_psf[q] : nullptr;     // the PSF finish of the last frame of parity q
   if (!rc) rc = env_step_head_fused(c, st, &vq, g, action, gain, reward_out, ktt, true, pe, stream);
-  // the frame stream is released behind k_delay_ahead, in front of the Strehl commit that waits for that finish:
-  // the frame kernel overwrites the PSF rows it reads, so the frame stream waits for it itself
-  if (!rc && pe && !P.cmd_covers_commit && hipStreamWaitEvent(P.fstream, pe, 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
-  if (!rc) { P.psf_out[q] = false; rc = pipe_launch_frame(c, st, q, stream); }
+  // the frame stream is released behind k_delay_ahead, in front of the Strehl commit.  The frame kernel overwrites the
+  // PSF rows that parity's last PSF finish reads: the chain waited for that finish in front of its first kernel
+  // (cmd_covers_psf; the small chain's one kernel waits for it too: cmd_covers_commit), else the frame stream does
+  if (!rc && pe && !P.cmd_covers_commit && !P.cmd_covers_psf && hipStreamWaitEvent(P.fstream, pe, 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
+  if (!rc) { P.psf_out[q] = false; P.cmd_covers_psf = false; rc = pipe_launch_frame(c, st, q, stream); }
   if (!rc) rc = pipe_prefetch(c, st, accumx, accumy, p, q);
   // ---- reduce frame p
   if (!rc && hipStreamWaitEvent(s, P.ev_done_cur[p], 0) != hipSuccess) rc = fail("frame pipeline: hipStreamWaitEvent failed");
