@@ -4,15 +4,20 @@ t + 2 (the frame that needs the command computed from frame t's measurement).  F
 per step, times relative to the END of a frame kernel of: start / end of each kernel of the chain's queue that
 follows it (tail product, k_assemble_state, k_actor_fused, k_compose_rewards, head product, k_delay_ahead,
 k_post_delay), and the start of the next two frame kernels; averaged over the steps.
-    python tools/chain_path.py trace.csv [first] [count]"""
+    python tools/chain_path.py trace.csv [--first -45] [--count 40] [--raw N]   (--raw: N steps kernel by kernel)"""
+import argparse
 import csv
-import sys
 from collections import defaultdict
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+ap = argparse.ArgumentParser()
+ap.add_argument("trace")
+ap.add_argument("--first", type=int, default=-45, help="index of the first frame kernel looked at (negative: from the end)")
+ap.add_argument("--count", type=int, default=40)
+ap.add_argument("--raw", type=int, default=0)
+args = ap.parse_args()
+rows = list(csv.DictReader(open(args.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].lstrip("-").isdigit() else -45
-count = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].lstrip("-").isdigit() else 40
+first, count = args.first, args.count
 fr = [i for i, r in enumerate(rows) if "k_frame_wave" in r["Kernel_Name"]]
 qcol = "Queue_Id" if "Queue_Id" in rows[0] else "Queue_ID"
 chain_q = None
@@ -52,8 +57,8 @@ order.sort(key=lambda k: mean(acc[k + " start"]))
 for key in order:
     s, e = acc[key + " start"], acc[key + " end"]
     print("%-34s n=%3d  start %8.1f [%7.1f .. %7.1f]   end %8.1f   dur %6.1f" % (key, len(s), mean(s), min(s), max(s), mean(e), mean(e) - mean(s)))
-if "--raw" in sys.argv:
-    nraw = int(sys.argv[sys.argv.index("--raw") + 1])
+if args.raw:
+    nraw = args.raw
     i0 = sel[len(sel) // 2]
     t0 = int(rows[i0]["Start_Timestamp"])
     print("\n# raw: %d steps from a frame kernel's start (us): kernel, queue, start -> end (duration)" % nraw)
