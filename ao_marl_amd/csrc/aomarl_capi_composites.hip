@@ -92,11 +92,9 @@ static int frame_fused_impl(aomarl_ctx *c, aomarl_state *st, int b, int n, int f
     if (smm + lds_pad > 64 * 1024) lds_pad = 0;               // (beyond 64 KB the launch would need the opt-in attribute)
   }
   dim3 grid((n + 3) / 4, c->sys.ntiles), blk(256);
-  static const int anyorder = []{ const char *e = getenv("AOMARL_FW_ANYORDER"); return e && atoi(e) ? 1 : 0; }();
-  const int fw_flags = (anyorder && slot >= 0) ? hipExtAnyOrderLaunch : 0;   // experiment
 // the events ride on the dispatch itself (its start / completion signal): no marker packets of their own
 // on the queue in front of and behind the kernel
-#define FW(NL, NB, OTF, NZ, WC, HP) hipExtLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm + lds_pad, s, ev_start, ev_done, fw_flags, c->sys, ds, b, n, cog, TR, TP, w.nblk)
+#define FW(NL, NB, OTF, NZ, WC, HP) hipExtLaunchKernelGGL((k_frame_wave<NL, NB, OTF, NZ, WC, HP>), grid, blk, smm + lds_pad, s, ev_start, ev_done, 0, c->sys, ds, b, n, cog, TR, TP, w.nblk)
 #define FW_H(NL, NB, OTF, NZ, WC) do { if (hp) FW(NL, NB, OTF, NZ, WC, true); else FW(NL, NB, OTF, NZ, WC, false); } while (0)
 #define FW_NC(NL, NB, OTF)                                                                     \
   do {                                                                                          \
