@@ -121,7 +121,7 @@ struct ExtrudeRun {          // one range of environments walking through a sequ
       const bool single = ops.nops == rounds[r].nops;
       RoundNext nx;
       // (k_extrude_sg keeps a column's whole index list in registers: four entries per thread of its 512)
-      bool fuse_next = single && !c->no_extrude_sg && nsc <= 4 * 512 && dimc <= SG_MAX_N && r + 1 < nrounds && next_round(rounds[r], rounds[r + 1], nx);
+      bool fuse_next = single && !c->no_extrude_sg && nsc <= SG_U * SG_THREADS && dimc <= SG_MAX_N && r + 1 < nrounds && next_round(rounds[r], rounds[r + 1], nx);
       if (fuse_next)                             // (the next round must be one sub-round too: same class)
         for (int i = 0; i < rounds[r + 1].nops; i++) fuse_next = fuse_next && c->abclass[rounds[r + 1].layer[i]] == cls;
       float *Z = Zb[par], *ZREF = ZREFb[par];
@@ -143,7 +143,7 @@ struct ExtrudeRun {          // one range of environments walking through a sequ
         if (s != c->atm_stream) c->screens_dirty_main = true;
       }
       if (fuse_next) {
-        hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(512), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
+        hipLaunchKernelGGL(k_extrude_sg, dim3(ncol), dim3(SG_THREADS), 0, s, c->sys, ds, b, ops, NEWL, w.ldn, ZREF,
                            WS, nsp, ncol, dimc, pscale, Zb[par ^ 1], w.ldz, ZREFb[par ^ 1], nx);
         par ^= 1;
         gathered = true;

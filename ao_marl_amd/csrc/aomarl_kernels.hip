@@ -806,7 +806,11 @@ __global__ __launch_bounds__(256) void k_extrude_scatter(DevSys sys, DevState st
 #ifndef SG_EARLY
 #define SG_EARLY 1                               // 0 (A/B builds): every stencil value read back from the ring behind the barrier, as before round 6
 #endif
-__global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int env_begin, RoundOps ops,
+#ifndef SG_THREADS
+#define SG_THREADS 512                           // threads per column; SG_U stencil items per thread: ns <= SG_U * SG_THREADS
+#define SG_U 4
+#endif
+__global__ __launch_bounds__(SG_THREADS) void k_extrude_sg(DevSys sys, DevState st, int env_begin, RoundOps ops,
                                                     const float *__restrict__ NEWL, int ldn,
                                                     const float *__restrict__ ZREF, const float *__restrict__ P,
                                                     int nsplit, int ncol, int pn, float pscale,
@@ -848,11 +852,11 @@ __global__ __launch_bounds__(512) void k_extrude_sg(DevSys sys, DevState st, int
   // data that this block does not write, and the other half IS the line it writes, which it keeps in LDS: no value is
   // read back from the ring behind the barrier, one dependent round trip to memory less per launch.  Z / ZREFN are the
   // next round's buffers: the product that last read them is a whole round back.
-  constexpr int U = 4;                           // ns <= U * blockDim.x (checked on the host: AOMARL_SG_MAX_NS)
+  constexpr int U = SG_U;                        // ns <= U * blockDim.x (checked on the host: AOMARL_SG_MAX_NS)
   const float *base = st.screens + (long long)e * sys.screen_stride + L.screen_off;
-  float v[U] = {0.f, 0.f, 0.f, 0.f};
-  int rr[U] = {0, 0, 0, 0};
-  bool nw[U] = {false, false, false, false};
+  float v[U] = {};
+  int rr[U] = {};
+  bool nw[U] = {};
   float zref = 0.f;
   int zr = 0;
   bool znew = false;
